@@ -1,0 +1,227 @@
+/*
+ * rbpf.h -- C ABI of the MI355X-native Rao-Blackwellized particle filter / smoother.
+ *
+ * This is the drop-in boundary for the hot path of manonkok/Rao-Blackwellized-SLAM-smoothing.
+ * The reference has no FFI layer of its own (it is pure MATLAB); the boundary *is* the three
+ * MATLAB function signatures
+ *     src/particleFilter.m:1-3, src/particleSmoother.m:1-2,
+ *     src/particleSmootherInformationForm.m:1-2
+ * and their callback contracts.  A MEX gateway (matlab/rbpf_mex.cpp) binds
+ * exactly the entry points declared here; on machines without MATLAB the same ABI is driven by
+ * the Python ctypes host mirror in rao-blackwellized-slam-smoothing_amd/.
+ *
+ * Conventions
+ *   - All host matrices are MATLAB column-major fp64, caller-owned, never mutated.
+ *   - Function handles cannot cross the boundary; the dynModel / measModel / dynResNorm closures
+ *     of the example runners are described by an `rbpf_model` descriptor (family id + constants).
+ *   - MATLAB's global RNG stream is replaced by an `rbpf_rng` block: replay buffers (seed-exact
+ *     parity runs) or a (seed) pair for the device Philox4x32-10 generator (throughput runs).
+ *   - Every function returns an rbpf_status; RBPF_OK == 0.  No global state; a context is bound
+ *     to the HIP device that was current when it was created and owns one stream.
+ *   - Particle / time indices in trace outputs are 0-based.
+ */
+#ifndef RBPF_H_
+#define RBPF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RBPF_ABI_VERSION 1
+
+typedef enum {
+  RBPF_OK = 0,
+  RBPF_ERR_INVALID_ARG = 1,
+  RBPF_ERR_UNSUPPORTED = 2,     /* model family / option not implemented on the device path        */
+  RBPF_ERR_HIP = 3,             /* a HIP runtime call failed (rbpf_last_error has the text)         */
+  RBPF_ERR_NO_DEVICE = 4,       /* no gfx950 device visible: the product path has NO CPU fallback   */
+  RBPF_ERR_OUT_OF_MEMORY = 5,
+  RBPF_ERR_CHOL_FAILED = 6,     /* second Cholesky failure: MATLAB would throw                      *
+                                 * (particleFilter.m:147, particleSmootherInformationForm.m:228-231) */
+  RBPF_ERR_STATE = 7            /* call sequence error (e.g. advance past N_T)                      */
+} rbpf_status;
+
+/* Model families = the closures defined in the reference's example runners. */
+typedef enum {
+  /* examples/slam-dense-mag/run_dense3D_magfield.m: dynModel :301-308, measModel :265-279,
+   * dynResNorm :202-203.  nNonLin=7 (pos3+quat4), ny=3, nw=6, n_odo=7, nLin=m+3.             */
+  RBPF_MODEL_DENSE_MAG_6D = 1,
+  /* examples/slam-dense-radio/run_dense2D_withHeading.m: dynModel :75-76, dynResNorm :77,
+   * measModel :168.  nNonLin=3 (x,y,heading), ny=1, nw=1, n_odo=3, nLin=m.                    */
+  RBPF_MODEL_DENSE_RADIO_2DH = 2
+} rbpf_model_kind;
+
+typedef struct {
+  int32_t kind;          /* rbpf_model_kind                                                     */
+  int32_t m_basis;       /* number of basis functions m (tools/domain_cartesian_dx.m:43)        */
+  int32_t dim;           /* input dimension of the basis (3 for dense-mag, 2 for dense-radio)   */
+  int32_t use_dyn_res_norm; /* 1: model's dynResNorm handle; 0: additive default                *
+                             * (particleSmoother.m:175-177, isempty(dynResNorm))                */
+  const int32_t* NN;     /* [m x dim] column-major index table NN (domain_cartesian_dx.m:36-43) */
+  double L[3];           /* domain half-widths (domain_cartesian_dx.m:27-29)                    */
+} rbpf_model;
+
+typedef struct {
+  int32_t N_P;           /* particles                                                           */
+  int32_t N_T;           /* time steps = size(y,1)                                              */
+  int32_t n_nonlin;      /* size(x0_nonLin,1)                                                   */
+  int32_t n_lin;         /* size(x0_lin,1)                                                      */
+  int32_t n_y;           /* size(y,2)                                                           */
+  int32_t n_w;           /* size(Q,1)                                                           */
+  int32_t n_odo;         /* size(odometry,2)                                                    */
+  int32_t x0_lin_cols;   /* 1 or N_P          (particleFilter.m:60-64)                          */
+  int32_t q_pages;       /* size(Q,3): 1 or >= N_T-1   (particleFilter.m:75-77)                 */
+  int32_t dt_len;        /* 1 or >= N_T-1              (particleFilter.m:80-82)                 */
+  const double* odometry;/* [>=N_T-1 x n_odo], leading dimension odo_ld                         */
+  int32_t odo_ld;
+  const double* y;       /* [N_T x n_y]                                                         */
+  const double* x0_nonlin;/* [n_nonlin]                                                         */
+  const double* x0_lin;  /* [n_lin x x0_lin_cols]                                               */
+  const double* P0_lin;  /* [n_lin x n_lin]                                                     */
+  const double* Q;       /* [n_w x n_w x q_pages]                                               */
+  const double* R;       /* [n_y x n_y]                                                         */
+  const double* dt;      /* [dt_len]                                                            */
+} rbpf_problem;
+
+typedef enum { RBPF_RNG_REPLAY = 0, RBPF_RNG_PHILOX = 1 } rbpf_rng_mode;
+
+typedef struct {
+  int32_t mode;          /* rbpf_rng_mode                                                       */
+  int32_t n_iter;        /* pages available in the replay buffers (1 for the filter, N_K)       */
+  /* Replay buffers (RBPF_RNG_REPLAY), drawn by the caller in the reference's call order:
+   *   U [N_P x (N_T-1) x n_iter]      the `rand` of tools/sample.m:31 for slot i at step t
+   *                                   (for smoother iterations k>1 slot N_P-1 holds the single
+   *                                   rand of particleSmoother.m:241)
+   *   Z [n_w x N_P x (N_T-1) x n_iter] the randn's consumed by dynModel for slot i at step t
+   *   Ufin [n_iter]                   the rand of `ak = sample(w)` (particleSmoother.m:346)    */
+  const double* U;
+  const double* Z;
+  const double* Ufin;
+  uint64_t seed;         /* RBPF_RNG_PHILOX: key of the counter-based device generator          */
+} rbpf_rng;
+
+typedef struct {
+  int32_t keep_history;  /* 1: keep xn history + ancestor table (needed for traj_sample_iwmax,  *
+                          *    xn_traj and every smoother); 0: ping-pong only                   */
+  int32_t trace;         /* 1: record per-step logw / w / ancestor indices (tests)              */
+  int32_t fix_p_mean;    /* 0: reproduce quirk Q3 (particleFilter.m:228-230 overwrites P_mean)  */
+  int32_t reserved;
+  double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
+} rbpf_options;
+
+/* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */
+typedef struct {
+  double* traj_max;          /* [n_nonlin x N_T]                                                */
+  double* traj_mean;         /* [n_nonlin x N_T]                                                */
+  double* xl_max;            /* [n_lin]                                                         */
+  double* xl_mean;           /* [n_lin]                                                         */
+  double* P_max;             /* [n_lin x n_lin]                                                 */
+  double* P_mean;            /* [n_lin x n_lin]                                                 */
+  double* traj_sample_iwmax; /* [n_nonlin x N_T]   (needs keep_history)                         */
+  double* xn_traj;           /* [n_nonlin x N_P x N_T] (needs keep_history)                     */
+  /* extras (not reference outputs; used by the parity tests) */
+  double* trace_logw;        /* [N_P x N_T]        (needs trace)                                */
+  double* trace_w;           /* [N_P x N_T]        (needs trace)                                */
+  int32_t* trace_ai;         /* [N_P x N_T] 0-based, column 0 unused (needs trace)              */
+  double* final_xn;          /* [n_nonlin x N_P]                                                */
+  double* final_xl;          /* [n_lin x N_P]                                                   */
+  double* final_P;           /* [n_lin x n_lin x N_P]                                           */
+  int32_t* iw_max;           /* [1] 0-based index of the maximum-weight particle at t = N_T     */
+} rbpf_filter_out;
+
+/* Outputs of particleSmoother / particleSmootherInformationForm (particleSmoother.m:1,27-30). */
+typedef struct {
+  double* XNK;               /* [n_nonlin x N_T x N_K]                                          */
+  double* XLK;               /* [n_lin x N_K]                                                   */
+  double* PK;                /* [n_lin x n_lin x N_K]                                           */
+  /* extras for the parity tests (need trace) */
+  double* trace_logw;        /* [N_P x N_T x N_K]                                               */
+  double* trace_w;           /* [N_P x N_T x N_K]                                               */
+  int32_t* trace_ai;         /* [N_P x N_T x N_K] 0-based                                       */
+  double* trace_paNt;        /* [N_P x N_T x N_K] ancestor probabilities AI(:,t) (:240)         */
+  int32_t* trace_ak;         /* [N_K] 0-based                                                   */
+} rbpf_smoother_out;
+
+typedef struct rbpf_ctx rbpf_ctx;      /* opaque filter / smoother context (device-resident state) */
+
+/* Timing of the dominant kernel (the fused resample-gather + weight + Kalman-update stream kernel),
+ * measured with HIP events on the context's own stream.                                           */
+typedef struct {
+  double stream_kernel_ms;   /* sum of launch durations since the last reset                     */
+  int64_t stream_kernel_launches;
+  double algorithmic_bytes_per_launch; /* N_P * (2 n^2 + 2 n + 2 nNonLin) * 8         */
+} rbpf_timing;
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int rbpf_abi_version(void);
+const char* rbpf_status_string(int status);
+/* Thread-local text of the last error raised on this thread (HIP error string, argument name). */
+const char* rbpf_last_error(void);
+/* Number of visible gfx950 devices (0 when none; never touches a device).                        */
+int rbpf_device_count(void);
+
+/* ---- one-shot entry points: what the MEX gateway binds ----------------------------------------- */
+/* Replaces src/particleFilter.m:1-3 for the recognised model families (dense branch).             */
+int rbpf_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                         const rbpf_options* opt, rbpf_filter_out* out);
+/* Replaces src/particleSmoother.m:1-2 (info_form = 0) and
+ * src/particleSmootherInformationForm.m:1-2 (info_form = 1).                                      */
+int rbpf_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                           const rbpf_options* opt, int32_t N_K, int32_t info_form,
+                           rbpf_smoother_out* out);
+
+/* ---- resident-state API (what bench.py times: inputs already in HBM) --------------------------- */
+/* Uploads model, problem and RNG block to the current device and allocates the particle banks.    */
+int rbpf_filter_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                       const rbpf_options* opt, rbpf_ctx** ctx);
+/* Bytes of device memory a context for this problem needs (no device access).                     */
+int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* prob,
+                                const rbpf_options* opt, size_t* bytes);
+/* Enqueue `n_steps` time steps (particleFilter.m:100-218) on the context stream; asynchronous.    */
+int rbpf_filter_advance(rbpf_ctx* ctx, int32_t n_steps);
+/* Rewind to t = 0 (re-initialises weights / states: particleFilter.m:52-67); asynchronous.        */
+int rbpf_filter_reset(rbpf_ctx* ctx);
+/* Block until the stream is idle; reports a deferred RBPF_ERR_CHOL_FAILED.                        */
+int rbpf_sync(rbpf_ctx* ctx);
+/* Final extraction (particleFilter.m:220-233) + download of the requested outputs.                */
+int rbpf_filter_finish(rbpf_ctx* ctx, rbpf_filter_out* out);
+/* Current step index (number of steps processed).                                                 */
+int rbpf_filter_tell(const rbpf_ctx* ctx, int32_t* t);
+/* Enable (1) / disable (0) per-launch HIP-event timing of the stream kernel; read / reset it.     */
+int rbpf_timing_enable(rbpf_ctx* ctx, int32_t on);
+int rbpf_timing_read(rbpf_ctx* ctx, rbpf_timing* out, int32_t reset);
+int rbpf_destroy(rbpf_ctx* ctx);
+
+/* ---- helper kernels exposed for parity tests (a5-a8, a19 of SURVEY 8a) ------------------------- */
+/* The uniforms / normals the Philox generator hands to slot i at step t of iteration k, in replay
+ * layout (U [N_P x (N_T-1)], Z [n_w x N_P x (N_T-1)]), so a replay run can reproduce a Philox run. */
+int rbpf_philox_fill(uint64_t seed, int32_t k_iter, int32_t N_P, int32_t N_T, int32_t n_w,
+                     double* U, double* Z, double* Ufin);
+/* measModel of the family evaluated on the device: xn [n_nonlin x Npred] -> dy stored as
+ * [n_y x n_lin x Npred] (i.e. H_i contiguous per particle).  run_dense3D_magfield.m:265-279.      */
+int rbpf_meas_model(const rbpf_model* model, int32_t n_nonlin, int32_t n_pred, const double* xn,
+                    double* dy);
+/* dynModel with injected normals: xn [n_nonlin x Np], odo [n_odo], cholQ from (dt,Q),
+ * z [n_w x Np] -> xn_next [n_nonlin x Np].  run_dense3D_magfield.m:301-308.                       */
+int rbpf_dyn_model(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, int32_t n_odo,
+                   int32_t n_p, const double* xn, const double* odo, double dt, const double* Q,
+                   const double* z, double* xn_next);
+/* dynResNorm: eDyn [n_w x Np] for reference state xnk_t against xn [n_nonlin x Np]
+ * (run_dense3D_magfield.m:202-203; default additive form when model->use_dyn_res_norm == 0).      */
+int rbpf_dyn_res_norm(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, int32_t n_odo,
+                      int32_t n_p, const double* xnk_t, const double* xn, const double* odo,
+                      double dt, const double* Q, double* e_dyn);
+/* tools/sample.m:30-32 applied to n_draws uniforms: ind[j] = sum(cumsum(w) < u[j]) (0-based,
+ * clamped to N-1).                                                                                */
+int rbpf_sample(int32_t N, const double* w, int32_t n_draws, const double* u, int32_t* ind);
+/* tools/JacobianPhi3D.m:29-64: x [3 x Np] -> J [3 x 3 x m x Np].                                  */
+int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
+                        const double* lower, const double* upper, double* J);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RBPF_H_ */

@@ -1,0 +1,138 @@
+"""ctypes declarations mirroring include/rbpf.h (the C-ABI drop-in boundary)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+RBPF_OK = 0
+RBPF_ERR_INVALID_ARG = 1
+RBPF_ERR_UNSUPPORTED = 2
+RBPF_ERR_HIP = 3
+RBPF_ERR_NO_DEVICE = 4
+RBPF_ERR_OUT_OF_MEMORY = 5
+RBPF_ERR_CHOL_FAILED = 6
+RBPF_ERR_STATE = 7
+
+RBPF_MODEL_DENSE_MAG_6D = 1
+RBPF_MODEL_DENSE_RADIO_2DH = 2
+RBPF_RNG_REPLAY = 0
+RBPF_RNG_PHILOX = 1
+
+
+class rbpf_model(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("m_basis", C.c_int32), ("dim", C.c_int32), ("use_dyn_res_norm", C.c_int32),
+                ("NN", c_int32_p), ("L", C.c_double * 3)]
+
+
+class rbpf_problem(C.Structure):
+    _fields_ = [("N_P", C.c_int32), ("N_T", C.c_int32), ("n_nonlin", C.c_int32), ("n_lin", C.c_int32),
+                ("n_y", C.c_int32), ("n_w", C.c_int32), ("n_odo", C.c_int32), ("x0_lin_cols", C.c_int32),
+                ("q_pages", C.c_int32), ("dt_len", C.c_int32),
+                ("odometry", c_double_p), ("odo_ld", C.c_int32),
+                ("y", c_double_p), ("x0_nonlin", c_double_p), ("x0_lin", c_double_p), ("P0_lin", c_double_p),
+                ("Q", c_double_p), ("R", c_double_p), ("dt", c_double_p)]
+
+
+class rbpf_rng(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("n_iter", C.c_int32), ("U", c_double_p), ("Z", c_double_p),
+                ("Ufin", c_double_p), ("seed", C.c_uint64)]
+
+
+class rbpf_options(C.Structure):
+    _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
+                ("reserved", C.c_int32), ("jitter", C.c_double)]
+
+
+class rbpf_filter_out(C.Structure):
+    _fields_ = [("traj_max", c_double_p), ("traj_mean", c_double_p), ("xl_max", c_double_p), ("xl_mean", c_double_p),
+                ("P_max", c_double_p), ("P_mean", c_double_p), ("traj_sample_iwmax", c_double_p),
+                ("xn_traj", c_double_p), ("trace_logw", c_double_p), ("trace_w", c_double_p),
+                ("trace_ai", c_int32_p), ("final_xn", c_double_p), ("final_xl", c_double_p),
+                ("final_P", c_double_p), ("iw_max", c_int32_p)]
+
+
+class rbpf_smoother_out(C.Structure):
+    _fields_ = [("XNK", c_double_p), ("XLK", c_double_p), ("PK", c_double_p), ("trace_logw", c_double_p),
+                ("trace_w", c_double_p), ("trace_ai", c_int32_p), ("trace_paNt", c_double_p),
+                ("trace_ak", c_int32_p)]
+
+
+class rbpf_timing(C.Structure):
+    _fields_ = [("stream_kernel_ms", C.c_double), ("stream_kernel_launches", C.c_int64),
+                ("algorithmic_bytes_per_launch", C.c_double)]
+
+
+# every symbol include/rbpf.h declares (tests/test_abi.py checks the library exports all of them)
+EXPORTS = [
+    "rbpf_abi_version", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
+    "rbpf_particle_filter", "rbpf_particle_smoother",
+    "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
+    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
+    "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
+    "rbpf_jacobian_phi3d",
+]
+
+_lib = None
+
+
+class RBPFError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"rbpf status {status}: {msg}")
+        self.status = status
+
+
+def load_library(build_if_missing: bool = True):
+    """dlopen the in-tree HIP library.  Fails loudly when it is missing: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIBPATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RBPFError(RBPF_ERR_NO_DEVICE, f"{path} not built (run __graft_entry__.build())")
+        _build.build()
+    lib = C.CDLL(path)
+    lib.rbpf_status_string.restype = C.c_char_p
+    lib.rbpf_status_string.argtypes = [C.c_int]
+    lib.rbpf_last_error.restype = C.c_char_p
+    lib.rbpf_particle_filter.argtypes = [C.POINTER(rbpf_model), C.POINTER(rbpf_problem), C.POINTER(rbpf_rng),
+                                         C.POINTER(rbpf_options), C.POINTER(rbpf_filter_out)]
+    lib.rbpf_particle_smoother.argtypes = [C.POINTER(rbpf_model), C.POINTER(rbpf_problem), C.POINTER(rbpf_rng),
+                                           C.POINTER(rbpf_options), C.c_int32, C.c_int32,
+                                           C.POINTER(rbpf_smoother_out)]
+    lib.rbpf_filter_create.argtypes = [C.POINTER(rbpf_model), C.POINTER(rbpf_problem), C.POINTER(rbpf_rng),
+                                       C.POINTER(rbpf_options), C.POINTER(C.c_void_p)]
+    lib.rbpf_filter_workspace_bytes.argtypes = [C.POINTER(rbpf_model), C.POINTER(rbpf_problem),
+                                                C.POINTER(rbpf_options), C.POINTER(C.c_size_t)]
+    lib.rbpf_filter_advance.argtypes = [C.c_void_p, C.c_int32]
+    lib.rbpf_filter_reset.argtypes = [C.c_void_p]
+    lib.rbpf_sync.argtypes = [C.c_void_p]
+    lib.rbpf_filter_finish.argtypes = [C.c_void_p, C.POINTER(rbpf_filter_out)]
+    lib.rbpf_filter_tell.argtypes = [C.c_void_p, c_int32_p]
+    lib.rbpf_timing_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.rbpf_timing_read.argtypes = [C.c_void_p, C.POINTER(rbpf_timing), C.c_int32]
+    lib.rbpf_destroy.argtypes = [C.c_void_p]
+    lib.rbpf_philox_fill.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p,
+                                     c_double_p]
+    lib.rbpf_meas_model.argtypes = [C.POINTER(rbpf_model), C.c_int32, C.c_int32, c_double_p, c_double_p]
+    lib.rbpf_dyn_model.argtypes = [C.POINTER(rbpf_model), C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p,
+                                   c_double_p, C.c_double, c_double_p, c_double_p, c_double_p]
+    lib.rbpf_dyn_res_norm.argtypes = [C.POINTER(rbpf_model), C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_double_p,
+                                      c_double_p, c_double_p, C.c_double, c_double_p, c_double_p]
+    lib.rbpf_sample.argtypes = [C.c_int32, c_double_p, C.c_int32, c_double_p, c_int32_p]
+    lib.rbpf_jacobian_phi3d.argtypes = [C.POINTER(rbpf_model), C.c_int32, c_double_p, c_double_p, c_double_p,
+                                        c_double_p]
+    _lib = lib
+    return lib
+
+
+def check(status: int):
+    if status != RBPF_OK:
+        lib = load_library()
+        msg = (lib.rbpf_last_error() or b"").decode() or lib.rbpf_status_string(status).decode()
+        raise RBPFError(status, msg)

@@ -1,0 +1,795 @@
+// C-ABI host side of the MI355X-native RBPF (see include/rbpf.h).  Everything here is plumbing
+// around the kernels of rbpf_kernels.hip / rbpf_smoother.hip: argument validation, HBM-resident
+// state, per-step launch sequence, final extraction.  There is NO CPU compute fallback: without a
+// visible gfx950 device every entry point that needs one returns RBPF_ERR_NO_DEVICE.
+#include "../../include/rbpf.h"
+#include "rbpf_internal.hpp"
+#include "rbpf_ctx.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace rbpf {
+
+thread_local std::string g_last_error;
+
+void set_error(const std::string& s) { g_last_error = s; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+  g_last_error = buf;
+  return (e == hipErrorOutOfMemory) ? RBPF_ERR_OUT_OF_MEMORY : RBPF_ERR_HIP;
+}
+
+static bool chol_lower_host(const double* A, int n, int lda, double* Lc, int ldl) {
+  for (int j = 0; j < n; ++j) {
+    double s = A[j + (size_t)lda * j];
+    for (int k = 0; k < j; ++k) s -= Lc[j + (size_t)ldl * k] * Lc[j + (size_t)ldl * k];
+    if (!(s > 0.0)) return false;
+    const double ljj = std::sqrt(s);
+    Lc[j + (size_t)ldl * j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i + (size_t)lda * j];
+      for (int k = 0; k < j; ++k) v -= Lc[i + (size_t)ldl * k] * Lc[j + (size_t)ldl * k];
+      Lc[i + (size_t)ldl * j] = v / ljj;
+    }
+  }
+  return true;
+}
+
+// chol(dt*Q) factors per step.  For dense-mag dynModel uses the two diagonal 3x3 blocks separately
+// (run_dense3D_magfield.m:304-305) while dynResNorm uses the full 6x6 factor (:203).
+static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, std::vector<double>& blk,
+                              std::vector<double>& full, int& pages) {
+  const int nw = p->n_w;
+  const bool varying = (p->q_pages > 1) || (p->dt_len > 1);
+  pages = varying ? std::max(p->N_T - 1, 1) : 1;
+  blk.assign((size_t)pages * nw * nw, 0.0);
+  full.assign((size_t)pages * nw * nw, 0.0);
+  std::vector<double> A((size_t)nw * nw);
+  for (int t = 0; t < pages; ++t) {
+    const double dt = p->dt[p->dt_len > 1 ? t : 0];
+    const double* Q = p->Q + (size_t)(p->q_pages > 1 ? t : 0) * nw * nw;
+    for (int q = 0; q < nw * nw; ++q) A[q] = dt * Q[q];
+    double* Lb = &blk[(size_t)t * nw * nw];
+    double* Lf = &full[(size_t)t * nw * nw];
+    bool ok = true;
+    if (model->kind == RBPF_MODEL_DENSE_MAG_6D) {
+      ok = chol_lower_host(A.data(), 3, nw, Lb, nw) && chol_lower_host(A.data() + 3 + 3 * nw, 3, nw, Lb + 3 + 3 * nw, nw);
+    } else {
+      ok = chol_lower_host(A.data(), nw, nw, Lb, nw);
+    }
+    ok = ok && chol_lower_host(A.data(), nw, nw, Lf, nw);
+    if (!ok) {
+      set_error("chol(dt*Q,'lower') failed: process noise covariance must be positive definite");
+      return RBPF_ERR_CHOL_FAILED;
+    }
+  }
+  return RBPF_OK;
+}
+
+int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
+                   ModelDev& M, std::vector<int>& nn_axis_major) {
+  if (!model || !model->NN) { set_error("model / model->NN is NULL"); return RBPF_ERR_INVALID_ARG; }
+  std::memset(&M, 0, sizeof(M));
+  M.kind = model->kind;
+  M.m = model->m_basis;
+  M.dim = model->dim;
+  M.nN = nN; M.n = n; M.d = d; M.nw = nw; M.nodo = nodo;
+  M.use_dyn_res_norm = model->use_dyn_res_norm;
+  if (model->kind == RBPF_MODEL_DENSE_MAG_6D) {
+    if (model->dim != 3 || nN != 7 || d != 3 || nw != 6 || nodo != 7 || n != model->m_basis + 3) {
+      set_error("dense-mag-6D expects dim=3, nNonLin=7, ny=3, nw=6, n_odo=7, nLin=m+3");
+      return RBPF_ERR_INVALID_ARG;
+    }
+  } else if (model->kind == RBPF_MODEL_DENSE_RADIO_2DH) {
+    if (model->dim != 2 || nN != 3 || d != 1 || nw != 1 || nodo != 3 || n != model->m_basis) {
+      set_error("dense-radio-2D+heading expects dim=2, nNonLin=3, ny=1, nw=1, n_odo=3, nLin=m");
+      return RBPF_ERR_INVALID_ARG;
+    }
+  } else {
+    set_error("unknown model family");
+    return RBPF_ERR_UNSUPPORTED;
+  }
+  nn_axis_major.resize((size_t)M.m * M.dim);
+  M.ktot = 0;
+  for (int a = 0; a < M.dim; ++a) {
+    int km = 0;
+    for (int j = 0; j < M.m; ++j) {
+      const int v = model->NN[j + (size_t)M.m * a];
+      if (v < 1) { set_error("NN entries must be >= 1"); return RBPF_ERR_INVALID_ARG; }
+      nn_axis_major[(size_t)a * M.m + j] = v;
+      km = std::max(km, v);
+    }
+    M.kmax[a] = km;
+    M.ktot += km;
+    M.L[a] = model->L[a];
+    if (!(M.L[a] > 0)) { set_error("domain half-widths L must be positive"); return RBPF_ERR_INVALID_ARG; }
+  }
+  for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
+  M.jitter = jitter;
+  M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
+  return RBPF_OK;
+}
+
+static int validate_problem(const rbpf_problem* p) {
+  if (!p) { set_error("problem is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (p->N_P < 1 || p->N_T < 1) { set_error("N_P and N_T must be >= 1"); return RBPF_ERR_INVALID_ARG; }
+  if (!p->y || !p->x0_nonlin || !p->x0_lin || !p->P0_lin || !p->Q || !p->R || !p->dt) {
+    set_error("a required problem array is NULL"); return RBPF_ERR_INVALID_ARG;
+  }
+  if (p->N_T > 1 && !p->odometry) { set_error("odometry is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (p->x0_lin_cols != 1 && p->x0_lin_cols != p->N_P) { set_error("x0_lin must be n x 1 or n x N_P"); return RBPF_ERR_INVALID_ARG; }
+  if (p->q_pages != 1 && p->q_pages < p->N_T - 1) { set_error("Q must have 1 or >= N_T-1 pages"); return RBPF_ERR_INVALID_ARG; }
+  if (p->dt_len != 1 && p->dt_len < p->N_T - 1) { set_error("dt must have 1 or >= N_T-1 entries"); return RBPF_ERR_INVALID_ARG; }
+  if (p->n_nonlin > 8 || p->n_w > 8) { set_error("n_nonlin, n_w <= 8 supported"); return RBPF_ERR_UNSUPPORTED; }
+  return RBPF_OK;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return RBPF_OK;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  return RBPF_OK;
+}
+
+#define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
+
+static bool have_device() {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+static size_t bank_bytes(const Layout& L, int d, int N) {
+  return ((size_t)N * (L.szT + L.szB) + (size_t)N * 2 * d * L.ldx + (size_t)N * L.ldx) * sizeof(double);
+}
+
+int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+               bool smoother, int N_K, rbpf_ctx** out) {
+  if (!out) { set_error("ctx out pointer is NULL"); return RBPF_ERR_INVALID_ARG; }
+  *out = nullptr;
+  RB_TRY(validate_problem(prob));
+  if (!rng) { set_error("rng is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (!have_device()) { set_error("no HIP device visible: the RBPF product path has no CPU fallback"); return RBPF_ERR_NO_DEVICE; }
+  rbpf_ctx* c = new rbpf_ctx();
+  std::unique_ptr<rbpf_ctx, void (*)(rbpf_ctx*)> guard(c, [](rbpf_ctx* p) { ctx_free(p); });
+  if (opt) c->opt = *opt; else { std::memset(&c->opt, 0, sizeof(c->opt)); c->opt.keep_history = 1; }
+  if (smoother) c->opt.keep_history = 1;
+  const double jitter = (c->opt.jitter > 0) ? c->opt.jitter : (smoother ? 1e-2 : 1e-3);   // quirk Q2
+  std::vector<int> nn;
+  RB_TRY(fill_model_dev(model, prob->n_nonlin, prob->n_lin, prob->n_y, prob->n_w, prob->n_odo, prob->R, jitter, c->mdl, nn));
+  c->lay = make_layout(prob->n_lin, prob->n_y);
+  if (step_lds_bytes(c->mdl, c->lay) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
+  c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
+  c->rng_mode = rng->mode; c->seed = rng->seed;
+  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw, nodo = c->mdl.nodo;
+  const Layout& L = c->lay;
+  HIPCHK(hipGetDevice(&c->device));
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
+  // ---- model / problem constants ----
+  RB_TRY(dmalloc(&c->d_NN, nn.size()));
+  HIPCHK(hipMemcpy(c->d_NN, nn.data(), nn.size() * sizeof(int), hipMemcpyHostToDevice));
+  c->mdl.NN = c->d_NN;
+  {
+    std::vector<double> yt((size_t)T * d), od((size_t)std::max(T - 1, 1) * nodo, 0.0);
+    for (int t = 0; t < T; ++t) for (int k = 0; k < d; ++k) yt[(size_t)t * d + k] = prob->y[t + (size_t)T * k];
+    for (int t = 0; t < T - 1; ++t) for (int k = 0; k < nodo; ++k) od[(size_t)t * nodo + k] = prob->odometry[t + (size_t)prob->odo_ld * k];
+    RB_TRY(dmalloc(&c->d_y, yt.size()));
+    RB_TRY(dmalloc(&c->d_odo, od.size()));
+    HIPCHK(hipMemcpy(c->d_y, yt.data(), yt.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_odo, od.data(), od.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> blk, full;
+    RB_TRY(build_chol_factors(model, prob, blk, full, c->chol_pages));
+    RB_TRY(dmalloc(&c->d_cholQ, blk.size()));
+    RB_TRY(dmalloc(&c->d_cholQfull, full.size()));
+    HIPCHK(hipMemcpy(c->d_cholQ, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_cholQfull, full.data(), full.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  // initial state images
+  {
+    std::vector<double> x0l((size_t)prob->x0_lin_cols * L.ldx, 0.0);
+    for (int j = 0; j < prob->x0_lin_cols; ++j)
+      for (int r = 0; r < n; ++r) x0l[(size_t)j * L.ldx + r] = prob->x0_lin[r + (size_t)n * j];
+    c->x0_lin_cols = prob->x0_lin_cols;
+    RB_TRY(dmalloc(&c->d_x0l, x0l.size()));
+    HIPCHK(hipMemcpy(c->d_x0l, x0l.data(), x0l.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->h_x0n.assign(prob->x0_nonlin, prob->x0_nonlin + nN);
+    c->h_P0.assign(prob->P0_lin, prob->P0_lin + (size_t)n * n);
+    c->h_x0l.assign(prob->x0_lin, prob->x0_lin + (size_t)n * prob->x0_lin_cols);
+    c->h_R.assign(prob->R, prob->R + (size_t)d * d);
+    c->h_y.assign(prob->y, prob->y + (size_t)T * d);
+    double* tmp = nullptr;
+    RB_TRY(dmalloc(&tmp, (size_t)n * n));
+    hipError_t e = hipMemcpy(tmp, prob->P0_lin, (size_t)n * n * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      int s1 = dmalloc(&c->d_P0t, std::max<size_t>(L.szT, 1));
+      int s2 = dmalloc(&c->d_P0b, std::max<size_t>(L.szB, 1));
+      if (s1 != RBPF_OK || s2 != RBPF_OK) { hipFree(tmp); return s1 != RBPF_OK ? s1 : s2; }
+      e = launch_pack_P(L, tmp, 0, c->d_P0t, c->d_P0b, 1, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(tmp);
+    HIPCHK(e);
+  }
+  // ---- RNG block ----
+  if (rng->mode == RBPF_RNG_REPLAY) {
+    const int iters = c->N_K;
+    if (T > 1 && (!rng->U || !rng->Z)) { set_error("replay RNG needs U and Z"); return RBPF_ERR_INVALID_ARG; }
+    if (rng->n_iter < iters) { set_error("replay RNG has fewer pages than iterations"); return RBPF_ERR_INVALID_ARG; }
+    if (smoother && !rng->Ufin) { set_error("replay RNG needs Ufin for the smoother"); return RBPF_ERR_INVALID_ARG; }
+    const size_t nu = (size_t)N * std::max(T - 1, 0) * iters;
+    RB_TRY(dmalloc(&c->d_U, nu));
+    RB_TRY(dmalloc(&c->d_Z, nu * nw));
+    if (nu) {
+      HIPCHK(hipMemcpy(c->d_U, rng->U, nu * sizeof(double), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(c->d_Z, rng->Z, nu * nw * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (rng->Ufin) c->h_Ufin.assign(rng->Ufin, rng->Ufin + iters);
+  } else if (rng->mode != RBPF_RNG_PHILOX) {
+    set_error("unknown rng mode"); return RBPF_ERR_INVALID_ARG;
+  }
+  // ---- particle banks ----
+  for (int b = 0; b < 2; ++b) {
+    RB_TRY(dmalloc(&c->Pt[b], (size_t)N * L.szT));
+    RB_TRY(dmalloc(&c->Pb[b], (size_t)N * L.szB));
+    RB_TRY(dmalloc(&c->F[b], (size_t)N * 2 * d * L.ldx));
+    RB_TRY(dmalloc(&c->xl[b], (size_t)N * L.ldx));
+    HIPCHK(hipMemsetAsync(c->F[b], 0, (size_t)N * 2 * d * L.ldx * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->xl[b], 0, (size_t)N * L.ldx * sizeof(double), c->stream));
+  }
+  c->hist_slabs = c->opt.keep_history ? T : 2;
+  RB_TRY(dmalloc(&c->X, (size_t)c->hist_slabs * nN * N));
+  RB_TRY(dmalloc(&c->A, (size_t)(c->opt.keep_history ? T : 1) * N));
+  HIPCHK(hipMemsetAsync(c->A, 0, (size_t)(c->opt.keep_history ? T : 1) * N * sizeof(int), c->stream));
+  const size_t tr = c->opt.trace ? (size_t)T : 1;
+  RB_TRY(dmalloc(&c->logw, tr * N));
+  RB_TRY(dmalloc(&c->w, tr * N));
+  RB_TRY(dmalloc(&c->wc, (size_t)N));
+  RB_TRY(dmalloc(&c->traj_max, (size_t)T * nN));
+  RB_TRY(dmalloc(&c->traj_mean, (size_t)T * nN));
+  RB_TRY(dmalloc(&c->d_scal, 64));
+  RB_TRY(dmalloc(&c->d_flags, 16));
+  HIPCHK(hipMemsetAsync(c->d_flags, 0, 16 * sizeof(int), c->stream));
+  RB_TRY(ctx_reset(c));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  guard.release();
+  *out = c;
+  return RBPF_OK;
+}
+
+// fill X[0] with x0 (particleFilter.m:59) and rewind
+__global__ void fill_x0_kernel(int N, int nN, const double x0_0, const double x0_1, const double x0_2, const double x0_3,
+                               const double x0_4, const double x0_5, const double x0_6, const double x0_7, double* X0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double x0[8] = {x0_0, x0_1, x0_2, x0_3, x0_4, x0_5, x0_6, x0_7};
+  for (int c = 0; c < nN; ++c) X0[(size_t)c * N + i] = x0[c];
+}
+
+int ctx_reset(rbpf_ctx* c) {
+  double x0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < c->mdl.nN; ++k) x0[k] = c->h_x0n[k];
+  hipLaunchKernelGGL(fill_x0_kernel, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->N, c->mdl.nN, x0[0], x0[1],
+                     x0[2], x0[3], x0[4], x0[5], x0[6], x0[7], c->X);
+  HIPCHK(hipGetLastError());
+  c->t = 0;
+  c->cur = 0;
+  return RBPF_OK;
+}
+
+void ctx_free(rbpf_ctx* c) {
+  if (!c) return;
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
+  hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
+  for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
+  hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
+  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags);
+  smoother_free(c);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// One time step of particleFilter.m:100-218 / particleSmoother.m:124-341 (iteration k_iter).
+// xref != nullptr: slot N-1 is the conditioned reference trajectory (its ancestor index has
+// already been written to A_t[N-1] by the ancestor-sampling kernels).
+int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw) {
+  const int t = c->t, N = c->N, nN = c->mdl.nN, d = c->mdl.d, nw = c->mdl.nw;
+  if (t >= c->T) { set_error("advance past N_T"); return RBPF_ERR_STATE; }
+  const Layout& L = c->lay;
+  const bool hist = c->opt.keep_history != 0;
+  int* A_t = c->A + (hist ? (size_t)t * N : 0);
+  double* X_new = c->X + (size_t)(hist ? t : (t & 1)) * nN * N;
+  const double* X_old = (t == 0) ? X_new : c->X + (size_t)(hist ? t - 1 : ((t - 1) & 1)) * nN * N;
+  const size_t tr = c->opt.trace ? (size_t)t * N : 0;
+  const size_t rng_page = (size_t)k_iter * N * std::max(c->T - 1, 0);
+
+  if (t > 0 && n_draw > 0) {
+    SearchArgs s;
+    s.N = N; s.n_draw = n_draw; s.t = t; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
+    s.U = c->d_U ? c->d_U + rng_page + (size_t)(t - 1) * N : nullptr;
+    s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1;
+    HIPCHK(launch_search(s, c->stream));
+  }
+  StepArgs a;
+  a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);
+  a.ai = (t > 0) ? A_t : nullptr;
+  a.xn_old = X_old; a.xn_new = X_new;
+  const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
+  if (t == 0) {
+    a.xl_old = c->d_x0l; a.xl_old_stride = (c->x0_lin_cols > 1) ? (size_t)L.ldx : 0;
+    a.F_old = nullptr;
+    a.Pt_old = c->d_P0t; a.Pb_old = c->d_P0b; a.Pt_old_stride = 0; a.Pb_old_stride = 0;
+  } else {
+    a.xl_old = c->xl[ob]; a.xl_old_stride = (size_t)L.ldx;
+    a.F_old = c->F[ob];
+    a.Pt_old = c->Pt[ob]; a.Pb_old = c->Pb[ob]; a.Pt_old_stride = L.szT; a.Pb_old_stride = L.szB;
+  }
+  a.xl_new = c->xl[nb]; a.F_new = c->F[nb]; a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
+  a.logw = c->logw + tr;
+  a.rng_mode = c->rng_mode; a.k_iter = k_iter; a.seed = c->seed;
+  a.Z = (c->d_Z && t > 0) ? c->d_Z + (rng_page + (size_t)(t - 1) * N) * nw : nullptr;
+  a.odo = c->d_odo + (size_t)(t > 0 ? t - 1 : 0) * c->mdl.nodo;
+  a.cholQ = c->d_cholQ + (size_t)((c->chol_pages > 1 && t > 0) ? t - 1 : 0) * nw * nw;
+  a.y = c->d_y + (size_t)t * d;
+  a.xref = xref_t;
+  a.status = c->d_flags;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->timing_on) {
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, c->stream));
+  }
+  HIPCHK(launch_step(a, c->stream));
+  if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); }
+
+  NormArgs nm;
+  nm.N = N; nm.nN = nN; nm.t = t; nm.logw = c->logw + tr; nm.w = c->w + tr; nm.wc = c->wc; nm.xn = X_new;
+  nm.traj_max = c->traj_max + (size_t)t * nN; nm.traj_mean = c->traj_mean + (size_t)t * nN;
+  nm.iw_max = c->d_flags + 2; nm.lse_out = nullptr;
+  HIPCHK(launch_normalise_scan(nm, c->stream));
+  c->cur = nb;
+  c->t = t + 1;
+  return RBPF_OK;
+}
+
+int ctx_check_flags(rbpf_ctx* c) {
+  int flags[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->overflow_draws = flags[1];
+  if (flags[0] & 1) { set_error("Cholesky of the innovation covariance failed twice (matrix must be positive definite)"); return RBPF_ERR_CHOL_FAILED; }
+  if (flags[0] & 2) { set_error("Cholesky in the ancestor-weight computation failed (matrix must be positive definite)"); return RBPF_ERR_CHOL_FAILED; }
+  return RBPF_OK;
+}
+
+}  // namespace rbpf
+
+using namespace rbpf;
+
+extern "C" {
+
+int rbpf_abi_version(void) { return RBPF_ABI_VERSION; }
+
+const char* rbpf_status_string(int s) {
+  switch (s) {
+    case RBPF_OK: return "ok";
+    case RBPF_ERR_INVALID_ARG: return "invalid argument";
+    case RBPF_ERR_UNSUPPORTED: return "unsupported on the device path";
+    case RBPF_ERR_HIP: return "HIP runtime error";
+    case RBPF_ERR_NO_DEVICE: return "no gfx950 device (no CPU fallback)";
+    case RBPF_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RBPF_ERR_CHOL_FAILED: return "matrix must be positive definite";
+    case RBPF_ERR_STATE: return "invalid call sequence";
+    default: return "unknown status";
+  }
+}
+
+const char* rbpf_last_error(void) { return g_last_error.c_str(); }
+
+int rbpf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, const rbpf_options* opt, size_t* bytes) {
+  if (!model || !p || !bytes) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  const Layout L = make_layout(p->n_lin, p->n_y);
+  const bool hist = !opt || opt->keep_history;
+  const bool trace = opt && opt->trace;
+  size_t b = 2 * bank_bytes(L, p->n_y, p->N_P);
+  b += (size_t)(hist ? p->N_T : 2) * p->n_nonlin * p->N_P * sizeof(double);
+  b += (size_t)(hist ? p->N_T : 1) * p->N_P * sizeof(int);
+  b += (size_t)(trace ? 2 * p->N_T : 2) * p->N_P * sizeof(double) + (size_t)p->N_P * sizeof(double);
+  b += (L.szT + L.szB) * sizeof(double);
+  *bytes = b;
+  return RBPF_OK;
+}
+
+int rbpf_filter_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                       rbpf_ctx** ctx) {
+  return ctx_create(model, prob, rng, opt, false, 1, ctx);
+}
+
+int rbpf_filter_advance(rbpf_ctx* c, int32_t n_steps) {
+  if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N));
+  return RBPF_OK;
+}
+
+int rbpf_filter_reset(rbpf_ctx* c) {
+  if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  return ctx_reset(c);
+}
+
+int rbpf_sync(rbpf_ctx* c) {
+  if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  return ctx_check_flags(c);
+}
+
+int rbpf_filter_tell(const rbpf_ctx* c, int32_t* t) {
+  if (!c || !t) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  *t = c->t;
+  return RBPF_OK;
+}
+
+int rbpf_timing_enable(rbpf_ctx* c, int32_t on) {
+  if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
+  c->timing_on = on != 0;
+  return RBPF_OK;
+}
+
+int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
+  if (!c || !out) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double ms = 0.0;
+  for (auto& ev : c->events) {
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, ev.first, ev.second));
+    ms += f;
+  }
+  out->stream_kernel_ms = ms;
+  out->stream_kernel_launches = (int64_t)c->events.size();
+  const double n = c->mdl.n, nN = c->mdl.nN;
+  out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * 8.0;
+  if (reset) {
+    for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    c->events.clear();
+  }
+  return RBPF_OK;
+}
+
+int rbpf_destroy(rbpf_ctx* c) {
+  if (!c) return RBPF_OK;
+  hipSetDevice(c->device);
+  ctx_free(c);
+  return RBPF_OK;
+}
+
+// Final extraction: particleFilter.m:220-233
+int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
+  if (!c || !o) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  if (c->t < 1) { set_error("finish before any step"); return RBPF_ERR_STATE; }
+  RB_TRY(ctx_check_flags(c));
+  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d;
+  const int Tdone = c->t;
+  const Layout& L = c->lay;
+  const int cur = c->cur;
+  int iw = 0;
+  HIPCHK(hipMemcpy(&iw, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost));
+  if (o->iw_max) *o->iw_max = iw;
+  const size_t tr_last = c->opt.trace ? (size_t)(Tdone - 1) * N : 0;
+  const double* w_last = c->w + tr_last;
+  // traj_max / traj_mean are kept [T][nN] on the device == MATLAB [nN x T] column-major
+  if (o->traj_max) {
+    for (size_t q = 0; q < (size_t)nN * T; ++q) o->traj_max[q] = NAN;      // particleFilter.m:92
+    HIPCHK(hipMemcpy(o->traj_max, c->traj_max, (size_t)Tdone * nN * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (o->traj_mean) {
+    for (size_t q = 0; q < (size_t)nN * T; ++q) o->traj_mean[q] = NAN;
+    HIPCHK(hipMemcpy(o->traj_mean, c->traj_mean, (size_t)Tdone * nN * sizeof(double), hipMemcpyDeviceToHost));
+  }
+  if (o->xl_max) HIPCHK(hipMemcpy(o->xl_max, c->xl[cur] + (size_t)iw * L.ldx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<double> xl_mean;
+  if (o->xl_mean || o->P_mean) {
+    double* dm = nullptr;
+    RB_TRY(dmalloc(&dm, (size_t)n));
+    hipError_t e = launch_weighted_mean_xl(N, n, L.ldx, c->xl[cur], w_last, dm, c->stream);
+    xl_mean.resize(n);
+    if (e == hipSuccess) e = hipMemcpyAsync(xl_mean.data(), dm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dm);
+    HIPCHK(e);
+    if (o->xl_mean) std::memcpy(o->xl_mean, xl_mean.data(), (size_t)n * sizeof(double));
+  }
+  if (o->P_max || o->P_mean) {
+    double* dP = nullptr; int* didx = nullptr;
+    RB_TRY(dmalloc(&dP, (size_t)n * n));
+    int s2 = dmalloc(&didx, 1);
+    if (s2 != RBPF_OK) { hipFree(dP); return s2; }
+    hipError_t e = hipSuccess;
+    if (o->P_max) {
+      e = hipMemcpy(didx, &iw, sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = hipMemcpy(o->P_max, dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
+    }
+    if (e == hipSuccess && o->P_mean) {
+      if (c->opt.fix_p_mean) {
+        hipFree(dP); hipFree(didx);
+        set_error("fix_p_mean=1 (accumulated P_mean) is not implemented; the reference overwrites (quirk Q3)");
+        return RBPF_ERR_UNSUPPORTED;
+      }
+      // quirk Q3 (particleFilter.m:228-230): P_mean = w(N)*(P(:,:,N) + (xl_mean-xl(:,N))*(...)')
+      const int last = N - 1;
+      std::vector<double> Pl((size_t)n * n), xll(n);
+      double wl = 0.0;
+      e = hipMemcpy(didx, &last, sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = hipMemcpy(Pl.data(), dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(xll.data(), c->xl[cur] + (size_t)last * L.ldx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+      if (e == hipSuccess) e = hipMemcpy(&wl, w_last + last, sizeof(double), hipMemcpyDeviceToHost);
+      if (e == hipSuccess)
+        for (int cc = 0; cc < n; ++cc)
+          for (int r = 0; r < n; ++r)
+            o->P_mean[r + (size_t)n * cc] = wl * (Pl[r + (size_t)n * cc] + (xl_mean[r] - xll[r]) * (xl_mean[cc] - xll[cc]));
+    }
+    hipFree(dP); hipFree(didx);
+    HIPCHK(e);
+  }
+  if (o->traj_sample_iwmax || o->xn_traj) {
+    if (!c->opt.keep_history) { set_error("traj_sample_iwmax / xn_traj need keep_history=1"); return RBPF_ERR_STATE; }
+    if (o->traj_sample_iwmax) {
+      double* dout = nullptr; int* didx = nullptr;
+      RB_TRY(dmalloc(&dout, (size_t)nN * Tdone));
+      int s2 = dmalloc(&didx, 1);
+      if (s2 != RBPF_OK) { hipFree(dout); return s2; }
+      hipError_t e = hipMemcpy(didx, &iw, sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_backtrace(N, nN, Tdone, c->X, c->A, didx, 1, dout, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = hipMemcpy(o->traj_sample_iwmax, dout, (size_t)nN * Tdone * sizeof(double), hipMemcpyDeviceToHost);
+      hipFree(dout); hipFree(didx);
+      HIPCHK(e);
+    }
+    if (o->xn_traj) {
+      double* dout = nullptr;
+      RB_TRY(dmalloc(&dout, (size_t)nN * N * Tdone));
+      hipError_t e = launch_backtrace(N, nN, Tdone, c->X, c->A, nullptr, N, dout, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e == hipSuccess) e = hipMemcpy(o->xn_traj, dout, (size_t)nN * N * Tdone * sizeof(double), hipMemcpyDeviceToHost);
+      hipFree(dout);
+      HIPCHK(e);
+    }
+  }
+  if (o->trace_logw || o->trace_w || o->trace_ai) {
+    if (!c->opt.trace) { set_error("trace outputs need options.trace=1"); return RBPF_ERR_STATE; }
+    if (o->trace_logw) HIPCHK(hipMemcpy(o->trace_logw, c->logw, (size_t)Tdone * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (o->trace_w) HIPCHK(hipMemcpy(o->trace_w, c->w, (size_t)Tdone * N * sizeof(double), hipMemcpyDeviceToHost));
+    if (o->trace_ai) {
+      if (!c->opt.keep_history) { set_error("trace_ai needs keep_history=1"); return RBPF_ERR_STATE; }
+      HIPCHK(hipMemcpy(o->trace_ai, c->A, (size_t)Tdone * N * sizeof(int), hipMemcpyDeviceToHost));
+    }
+  }
+  if (o->final_xn) {
+    double* dout = nullptr;
+    RB_TRY(dmalloc(&dout, (size_t)nN * N));
+    const double* Xl = c->X + (size_t)(c->opt.keep_history ? Tdone - 1 : ((Tdone - 1) & 1)) * nN * N;
+    hipError_t e = launch_transpose_soa(N, nN, Xl, dout, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(o->final_xn, dout, (size_t)nN * N * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dout);
+    HIPCHK(e);
+  }
+  if (o->final_xl) {
+    double* dout = nullptr;
+    RB_TRY(dmalloc(&dout, (size_t)n * N));
+    hipError_t e = launch_gather_xl(N, n, L.ldx, c->xl[cur], dout, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(o->final_xl, dout, (size_t)n * N * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dout);
+    HIPCHK(e);
+  }
+  if (o->final_P) {
+    double* dout = nullptr;
+    RB_TRY(dmalloc(&dout, (size_t)n * n * N));
+    hipError_t e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], nullptr, N, dout, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(o->final_P, dout, (size_t)n * n * N * sizeof(double), hipMemcpyDeviceToHost);
+    hipFree(dout);
+    HIPCHK(e);
+  }
+  return RBPF_OK;
+}
+
+int rbpf_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                         rbpf_filter_out* out) {
+  rbpf_ctx* c = nullptr;
+  int s = rbpf_filter_create(model, prob, rng, opt, &c);
+  if (s != RBPF_OK) return s;
+  s = rbpf_filter_advance(c, prob->N_T);
+  if (s == RBPF_OK) s = rbpf_filter_finish(c, out);
+  rbpf_destroy(c);
+  return s;
+}
+
+// ---- helper kernels for parity tests ----------------------------------------------------------------
+int rbpf_philox_fill(uint64_t seed, int32_t k_iter, int32_t N, int32_t T, int32_t nw, double* U, double* Z, double* Ufin) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (nw > 8 || N < 1 || T < 1) { set_error("bad sizes"); return RBPF_ERR_INVALID_ARG; }
+  const size_t nu = (size_t)N * (T - 1);
+  double *dU = nullptr, *dZ = nullptr, *dF = nullptr;
+  RB_TRY(dmalloc(&dU, std::max<size_t>(nu, 1)));
+  int s = dmalloc(&dZ, std::max<size_t>(nu * nw, 1));
+  if (s == RBPF_OK) s = dmalloc(&dF, 1);
+  hipError_t e = hipSuccess;
+  if (s == RBPF_OK) {
+    e = launch_philox_fill(seed, k_iter, N, T, nw, dU, dZ, dF, 0);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && U && nu) e = hipMemcpy(U, dU, nu * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && Z && nu) e = hipMemcpy(Z, dZ, nu * nw * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && Ufin) e = hipMemcpy(Ufin, dF, sizeof(double), hipMemcpyDeviceToHost);
+  }
+  hipFree(dU); hipFree(dZ); hipFree(dF);
+  if (s != RBPF_OK) return s;
+  HIPCHK(e);
+  return RBPF_OK;
+}
+
+}  // extern "C"
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) hipFree(p); }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, std::max<size_t>(bytes, 8));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+    return RBPF_OK;
+  }
+  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+static int model_for_helpers(const rbpf_model* model, int nN, int nw, int nodo, ModelDev& M, DevBuf& nnbuf) {
+  int n = 0, d = 0;
+  if (!model) { set_error("model is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (model->kind == RBPF_MODEL_DENSE_MAG_6D) { n = model->m_basis + 3; d = 3; }
+  else if (model->kind == RBPF_MODEL_DENSE_RADIO_2DH) { n = model->m_basis; d = 1; }
+  else { set_error("unknown model family"); return RBPF_ERR_UNSUPPORTED; }
+  std::vector<int> nn;
+  RB_TRY(fill_model_dev(model, nN, n, d, nw, nodo, nullptr, 0.0, M, nn));
+  RB_TRY(nnbuf.alloc(nn.size() * sizeof(int)));
+  HIPCHK(hipMemcpy(nnbuf.p, nn.data(), nn.size() * sizeof(int), hipMemcpyHostToDevice));
+  M.NN = nnbuf.as<int>();
+  return RBPF_OK;
+}
+
+static void default_dims(const rbpf_model* model, int& nN, int& nw, int& nodo) {
+  if (model && model->kind == RBPF_MODEL_DENSE_MAG_6D) { nN = 7; nw = 6; nodo = 7; }
+  else { nN = 3; nw = 1; nodo = 3; }
+}
+
+extern "C" {
+
+int rbpf_meas_model(const rbpf_model* model, int32_t n_nonlin, int32_t n_pred, const double* xn, double* dy) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!xn || !dy || n_pred < 1) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  int nN, nw, nodo; default_dims(model, nN, nw, nodo);
+  if (n_nonlin != nN) { set_error("n_nonlin does not match the model family"); return RBPF_ERR_INVALID_ARG; }
+  ModelDev M; DevBuf nnb, dx, dd;
+  RB_TRY(model_for_helpers(model, nN, nw, nodo, M, nnb));
+  RB_TRY(dx.alloc((size_t)nN * n_pred * sizeof(double)));
+  RB_TRY(dd.alloc((size_t)M.d * M.n * n_pred * sizeof(double)));
+  HIPCHK(hipMemcpy(dx.p, xn, (size_t)nN * n_pred * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(launch_meas_model(M, n_pred, dx.as<double>(), dd.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(dy, dd.p, (size_t)M.d * M.n * n_pred * sizeof(double), hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+static int chol_for_helper(const rbpf_model* model, int nw, double dt, const double* Q, std::vector<double>& blk,
+                           std::vector<double>& full) {
+  rbpf_problem p;
+  std::memset(&p, 0, sizeof(p));
+  p.N_T = 2; p.n_w = nw; p.q_pages = 1; p.dt_len = 1; p.Q = Q; p.dt = &dt;
+  int pages = 0;
+  return build_chol_factors(model, &p, blk, full, pages);
+}
+
+int rbpf_dyn_model(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, int32_t n_odo, int32_t n_p, const double* xn,
+                   const double* odo, double dt, const double* Q, const double* z, double* xn_next) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!xn || !odo || !Q || !z || !xn_next || n_p < 1) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  int nN, nw, nodo; default_dims(model, nN, nw, nodo);
+  if (n_nonlin != nN || n_w != nw || n_odo != nodo) { set_error("dims do not match the model family"); return RBPF_ERR_INVALID_ARG; }
+  ModelDev M; DevBuf nnb, dx, dodo, dL, dz, dout;
+  RB_TRY(model_for_helpers(model, nN, nw, nodo, M, nnb));
+  std::vector<double> blk, full;
+  RB_TRY(chol_for_helper(model, nw, dt, Q, blk, full));
+  RB_TRY(dx.alloc((size_t)nN * n_p * 8)); RB_TRY(dodo.alloc((size_t)nodo * 8)); RB_TRY(dL.alloc((size_t)nw * nw * 8));
+  RB_TRY(dz.alloc((size_t)nw * n_p * 8)); RB_TRY(dout.alloc((size_t)nN * n_p * 8));
+  HIPCHK(hipMemcpy(dx.p, xn, (size_t)nN * n_p * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dodo.p, odo, (size_t)nodo * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dL.p, blk.data(), (size_t)nw * nw * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dz.p, z, (size_t)nw * n_p * 8, hipMemcpyHostToDevice));
+  HIPCHK(launch_dyn_model(M, n_p, dx.as<double>(), dodo.as<double>(), dL.as<double>(), dz.as<double>(), dout.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(xn_next, dout.p, (size_t)nN * n_p * 8, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_dyn_res_norm(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, int32_t n_odo, int32_t n_p,
+                      const double* xnk_t, const double* xn, const double* odo, double dt, const double* Q, double* e_dyn) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!xnk_t || !xn || !odo || !Q || !e_dyn || n_p < 1) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  int nN, nw, nodo; default_dims(model, nN, nw, nodo);
+  if (n_nonlin != nN || n_odo != nodo) { set_error("dims do not match the model family"); return RBPF_ERR_INVALID_ARG; }
+  if (!model->use_dyn_res_norm) nw = nN;    // additive default: residual over all non-linear states
+  if (n_w != nw) { set_error("n_w does not match"); return RBPF_ERR_INVALID_ARG; }
+  ModelDev M; DevBuf nnb, dk, dx, dodo, dL, dout;
+  RB_TRY(model_for_helpers(model, nN, model->use_dyn_res_norm ? nw : (model->kind == RBPF_MODEL_DENSE_MAG_6D ? 6 : 1), nodo, M, nnb));
+  M.nw = nw;
+  std::vector<double> Lf((size_t)nw * nw, 0.0), A((size_t)nw * nw);
+  for (int q = 0; q < nw * nw; ++q) A[q] = dt * Q[q];
+  if (!chol_lower_host(A.data(), nw, nw, Lf.data(), nw)) { set_error("chol(dt*Q) failed"); return RBPF_ERR_CHOL_FAILED; }
+  RB_TRY(dk.alloc((size_t)nN * 8)); RB_TRY(dx.alloc((size_t)nN * n_p * 8)); RB_TRY(dodo.alloc((size_t)nodo * 8));
+  RB_TRY(dL.alloc((size_t)nw * nw * 8)); RB_TRY(dout.alloc((size_t)nw * n_p * 8));
+  HIPCHK(hipMemcpy(dk.p, xnk_t, (size_t)nN * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dx.p, xn, (size_t)nN * n_p * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dodo.p, odo, (size_t)nodo * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dL.p, Lf.data(), (size_t)nw * nw * 8, hipMemcpyHostToDevice));
+  HIPCHK(launch_dyn_res_norm(M, n_p, dk.as<double>(), dx.as<double>(), dodo.as<double>(), dL.as<double>(), dout.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(e_dyn, dout.p, (size_t)nw * n_p * 8, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_sample(int32_t N, const double* w, int32_t n_draws, const double* u, int32_t* ind) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!w || !u || !ind || N < 1 || n_draws < 1) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  // reuse normalise_scan's cumsum by feeding log(w): instead run the dedicated path: upload w as
+  // already-normalised weights through logw = log(w) would re-normalise; so scan directly.
+  DevBuf dw, dwc, du, di, dlog, dx, dflag;
+  RB_TRY(dw.alloc((size_t)N * 8)); RB_TRY(dwc.alloc((size_t)N * 8)); RB_TRY(du.alloc((size_t)n_draws * 8));
+  RB_TRY(di.alloc((size_t)n_draws * 4)); RB_TRY(dflag.alloc(16));
+  HIPCHK(hipMemcpy(dw.p, w, (size_t)N * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(du.p, u, (size_t)n_draws * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dflag.p, 0, 16));
+  HIPCHK(launch_cumsum(N, dw.as<double>(), dwc.as<double>(), 0));
+  SearchArgs s;
+  s.N = N; s.n_draw = n_draws; s.t = 0; s.wc = dwc.as<double>(); s.rng_mode = 0; s.k_iter = 0; s.U = du.as<double>();
+  s.seed = 0; s.ai = di.as<int>(); s.overflow = dflag.as<int>();
+  HIPCHK(launch_search(s, 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(ind, di.p, (size_t)n_draws * 4, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x, const double* lower, const double* upper, double* J) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!model || model->kind != RBPF_MODEL_DENSE_MAG_6D || !x || !lower || !upper || !J || n_p < 1) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  ModelDev M; DevBuf nnb, dx, dlo, dup, dj;
+  RB_TRY(model_for_helpers(model, 7, 6, 7, M, nnb));
+  RB_TRY(dx.alloc((size_t)3 * n_p * 8)); RB_TRY(dlo.alloc(24)); RB_TRY(dup.alloc(24)); RB_TRY(dj.alloc((size_t)9 * M.m * n_p * 8));
+  HIPCHK(hipMemcpy(dx.p, x, (size_t)3 * n_p * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dlo.p, lower, 24, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dup.p, upper, 24, hipMemcpyHostToDevice));
+  HIPCHK(launch_jacobian_phi3d(M, n_p, dx.as<double>(), dlo.as<double>(), dup.as<double>(), dj.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(J, dj.p, (size_t)9 * M.m * n_p * 8, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+}  // extern "C"

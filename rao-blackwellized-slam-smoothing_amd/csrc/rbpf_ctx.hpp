@@ -1,0 +1,78 @@
+// Device-resident context shared by the filter and smoother host code.
+#pragma once
+#include "../../include/rbpf.h"
+#include "rbpf_internal.hpp"
+
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace rbpf {
+
+void set_error(const std::string& s);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define HIPCHK(expr)                                                          \
+  do {                                                                        \
+    hipError_t _e = (expr);                                                   \
+    if (_e != hipSuccess) return ::rbpf::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+struct SmootherState;   // rbpf_smoother.hip
+
+}  // namespace rbpf
+
+struct rbpf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  rbpf::ModelDev mdl;
+  rbpf::Layout lay;
+  rbpf_options opt;
+  int N = 0, T = 0;
+  bool smoother = false;
+  int N_K = 1;
+  int rng_mode = 0;
+  unsigned long long seed = 0;
+  int chol_pages = 1;
+  int x0_lin_cols = 1;
+  // constants
+  int* d_NN = nullptr;
+  double *d_y = nullptr, *d_odo = nullptr, *d_cholQ = nullptr, *d_cholQfull = nullptr;
+  double *d_x0l = nullptr, *d_P0t = nullptr, *d_P0b = nullptr;
+  double *d_U = nullptr, *d_Z = nullptr;
+  std::vector<double> h_x0n, h_P0, h_x0l, h_R, h_y, h_Ufin;
+  // particle banks (ping-pong)
+  double* Pt[2] = {nullptr, nullptr};
+  double* Pb[2] = {nullptr, nullptr};
+  double* F[2] = {nullptr, nullptr};
+  double* xl[2] = {nullptr, nullptr};
+  int cur = 0;
+  // history
+  int hist_slabs = 2;
+  double* X = nullptr;      // [slabs][nN][N]
+  int* A = nullptr;         // [T or 1][N]
+  double *logw = nullptr, *w = nullptr, *wc = nullptr;
+  double *traj_max = nullptr, *traj_mean = nullptr;
+  double* d_scal = nullptr;
+  int* d_flags = nullptr;   // [0] status bits, [1] clamped draws, [2] iw_max, [3..] scratch
+  int t = 0;
+  int overflow_draws = 0;
+  bool timing_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  rbpf::SmootherState* sm = nullptr;
+};
+
+namespace rbpf {
+
+int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
+                   ModelDev& M, std::vector<int>& nn_axis_major);
+int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+               bool smoother, int N_K, rbpf_ctx** out);
+int ctx_reset(rbpf_ctx* c);
+void ctx_free(rbpf_ctx* c);
+int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw);
+int ctx_check_flags(rbpf_ctx* c);
+void smoother_free(rbpf_ctx* c);
+
+}  // namespace rbpf

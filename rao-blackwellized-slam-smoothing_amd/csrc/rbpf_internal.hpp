@@ -1,0 +1,113 @@
+// Internal declarations shared by the kernel TU and the C-ABI TU.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace rbpf {
+
+constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
+constexpr int kWaves = kThreads / 64;
+constexpr int kChunkRows = 128;    // rows covered by one wave-wide 16-B-per-lane load
+
+// Model constants resident in kernel arguments (scalar registers).
+struct ModelDev {
+  int kind, m, dim;
+  int nN, n, d, nw, nodo;
+  const int* NN;       // device, [dim][m] (axis-major)
+  double L[3];
+  int kmax[3];         // largest index per axis
+  int ktot;            // kmax[0]+kmax[1]+kmax[2]
+  double R[9];         // d x d column-major
+  double jitter;
+  double logconst;     // -0.5 * d * log(2*pi)
+  int use_dyn_res_norm;
+};
+
+// HBM layout of one particle's covariance ("bank" entry).  Natural state order is kept for the
+// index space; rows are split so that the streamed part is perfectly aligned:
+//   border rows  r in [0, nb)  -> block B, row-major  B[r*ldb + c],          c in [0,n)
+//   core rows    r in [nb, n)  -> block T, column-major T[c*mc + (r - nb)],  c in [0,n)
+// with mc = 128*floor(n/128), nb = n - mc, ldb = n rounded up to even.
+struct Layout {
+  int n, nb, mc, ldb, ldx;   // ldx: padded length of per-particle vectors (xl, K, KS)
+  int CH;                    // mc / 128
+  int RS, CS, CPL;           // wave decomposition of the core stream (rows x column phases)
+  size_t szT, szB;           // elements per particle
+};
+
+struct StepArgs {
+  ModelDev mdl;
+  Layout lay;
+  int N, t, propagate;
+  const int* ai;                 // ancestors of this step (null: identity)
+  const double* xn_old; double* xn_new;     // SoA [nN][N]
+  const double* xl_old; double* xl_new;     // [N][ldx]
+  size_t xl_old_stride;                     // ldx, or 0 to broadcast x0_lin
+  const double* F_old; double* F_new;       // pending rank-d factors [N][2][d][ldx]: KS then K
+  const double* Pt_old; double* Pt_new;
+  const double* Pb_old; double* Pb_new;
+  size_t Pt_old_stride, Pb_old_stride;      // szT / szB, or 0 to broadcast P0
+  double* logw;                             // [N]
+  int rng_mode; int k_iter;
+  const double* Z;                          // replay normals of this step [N][nw]
+  unsigned long long seed;
+  const double* odo;                        // [nodo]
+  const double* cholQ;                      // [nw*nw] lower factor(s) used by dynModel
+  const double* y;                          // [d]
+  const double* xref;                       // CPF-AS: state of slot N-1 at this step (or null)
+  int* status;
+};
+
+struct NormArgs {
+  int N, nN, t;
+  const double* logw;
+  double* w;            // normalised weights out
+  double* wc;           // running sum out
+  const double* xn;     // SoA [nN][N] of this step
+  double* traj_max;     // [nN] column t (or null)
+  double* traj_mean;    // [nN] column t (or null)
+  int* iw_max;          // device scalar
+  double* lse_out;      // device scalar (or null)
+};
+
+struct SearchArgs {
+  int N, n_draw, t;
+  const double* wc;
+  int rng_mode; int k_iter;
+  const double* U;      // replay uniforms of this step [N]
+  unsigned long long seed;
+  int* ai;              // out [N]
+  int* overflow;        // device counter of clamped draws (u > wc(end))
+};
+
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay);
+Layout make_layout(int n, int d);
+
+hipError_t launch_step(const StepArgs& a, hipStream_t s);
+hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s);
+hipError_t launch_search(const SearchArgs& a, hipStream_t s);
+hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
+
+// pack / unpack between MATLAB column-major n x n images and the bank layout
+hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src_stride, double* Pt,
+                         double* Pb, int count, hipStream_t s);
+hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
+                           const int* index, int count, double* P_colmajor, hipStream_t s);
+hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
+                                   hipStream_t s);
+hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,
+                            int n_paths, double* out, hipStream_t s);
+hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,
+                              double* Ufin, hipStream_t s);
+hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s);
+hipError_t launch_dyn_model(const ModelDev& m, int np, const double* xn, const double* odo, const double* cholQ,
+                            const double* z, double* xn_next, hipStream_t s);
+hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, const double* xn,
+                               const double* odo, const double* cholQfull, double* e_dyn, hipStream_t s);
+hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, const double* lo, const double* up,
+                                 double* J, hipStream_t s);
+hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
+hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);
+
+}  // namespace rbpf

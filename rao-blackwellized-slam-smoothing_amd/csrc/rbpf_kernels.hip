@@ -1,0 +1,878 @@
+// HIP kernels of the Rao-Blackwellized particle filter hot path, written for gfx950 (MI355X).
+//
+// One particle-step of the reference (src/particleFilter.m:100-204) is
+//   resample-gather (:112-113)  ->  dynModel (:108)  ->  measModel (:124)
+//   -> importance weight (:139-150)  ->  Kalman map update (:184-198)
+// and touches the particle's n x n covariance three times.  Here the whole chain is ONE kernel that
+// reads the ancestor's covariance exactly once and writes the child's exactly once:
+//
+//   The Kalman downdate  P+ = P - (K*SS)*K'  (particleFilter.m:198) is rank-d, so it is carried as a
+//   *pending* pair of n x d factors (KS = K*SS, K) next to the stored matrix.  The next step's kernel
+//   applies it element-wise while the matrix streams through the CU, accumulates P+*H' for the new
+//   H in the same pass (lanes own rows, so no cross-lane reduction), stores P+ into the child's slot,
+//   and only then (epilogue, O(n d^2)) forms S, chol(S), logw, K, K*SS and the mean update.
+//
+// HBM traffic per particle-step = n^2 read + n^2 write (+ O(n d)): the algorithmic minimum of
+// SURVEY 8(d).  The kernel is HBM-bound (12 flop per 16 B).
+#include "rbpf_internal.hpp"
+#include "rbpf_device.hpp"
+
+namespace rbpf {
+
+// ---------------------------------------------------------------------------------------------
+// layout helpers (host + device)
+// ---------------------------------------------------------------------------------------------
+struct LdsPlan {
+  int off_HK, off_xl, off_PHt, off_parts, off_tab, off_misc, off_red, total;  // in doubles
+};
+
+__host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
+
+__host__ __device__ inline LdsPlan lds_plan(int n, int d, int ldx, int CS, int mc, int ktot) {
+  LdsPlan p;
+  int o = 0;
+  p.off_HK = o;    o += even_up(n * 2 * d);
+  p.off_xl = o;    o += ldx;
+  p.off_PHt = o;   o += d * ldx;
+  p.off_parts = o; o += CS * d * mc;
+  p.off_tab = o;   o += even_up(2 * (ktot > 0 ? ktot : 1));
+  p.off_misc = o;  o += 64;
+  p.off_red = o;   o += kWaves * 16;
+  p.total = o;
+  return p;
+}
+
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay) {
+  return (size_t)lds_plan(lay.n, m.d, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
+}
+
+Layout make_layout(int n, int d) {
+  Layout L;
+  L.n = n;
+  L.mc = (n / kChunkRows) * kChunkRows;
+  L.nb = n - L.mc;
+  L.ldb = (n + 1) & ~1;
+  L.ldx = (n + 1) & ~1;
+  L.CH = L.mc / kChunkRows;
+  // wave decomposition of the core block: RS waves along row chunks, CS column phases.
+  if (L.CH >= kWaves) { L.RS = kWaves; L.CS = 1; }
+  else if (L.CH == 3) { L.RS = 1; L.CS = kWaves; }
+  else if (L.CH == 2) { L.RS = 2; L.CS = 2; }
+  else { L.RS = 1; L.CS = kWaves; }
+  L.CPL = L.CH > 0 ? (L.CH + L.RS - 1) / L.RS : 1;
+  L.szT = (size_t)n * L.mc;
+  L.szB = (size_t)L.nb * L.ldb;
+  (void)d;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// basis / measurement model pieces shared by the step kernel and the standalone test kernels
+// ---------------------------------------------------------------------------------------------
+// sin / cos of pi*k*(x_a+L_a)/(2 L_a) for k = 1..kmax[a]  (tools/domain_cartesian_dx.m:91,154)
+__device__ inline void basis_table_entry(const ModelDev& M, int q, const double* pos, double* tabS, double* tabC) {
+  int a = 0, k = q;
+  if (k >= M.kmax[0]) { k -= M.kmax[0]; a = 1; if (k >= M.kmax[1]) { k -= M.kmax[1]; a = 2; } }
+  const double La = M.L[a];
+  const double arg = RBPF_PI * (double)(k + 1) * (pos[a] + La) / (2.0 * La);
+  double s, c;
+  sincos(arg, &s, &c);
+  tabS[q] = s;
+  tabC[q] = c;
+}
+
+// Column c of H_i (ny x nLin).
+//   dense-mag   : Rnb' * [e_c] for c<3, Rnb' * [dphi_x; dphi_y; dphi_z](j=c-3) otherwise
+//                 (examples/slam-dense-mag/run_dense3D_magfield.m:267-277,
+//                  tools/domain_cartesian_dx.m:146-170 evaluation order kept)
+//   dense-radio : phi_c(x,y) (run_dense2D_withHeading.m:168, domain_cartesian_dx.m:88-93)
+template <int D>
+__device__ inline void H_column(const ModelDev& M, int c, const double* tabS, const double* tabC, const double* Rm,
+                                double* h) {
+  if (M.kind == 1) {
+    double g[3];
+    if (c < 3) {
+      g[0] = (c == 0); g[1] = (c == 1); g[2] = (c == 2);
+    } else {
+      const int j = c - 3;
+      int base[3] = {0, M.kmax[0], M.kmax[0] + M.kmax[1]};
+      int nn[3];
+      for (int a = 0; a < 3; ++a) nn[a] = M.NN[a * M.m + j];
+      for (int di = 0; di < 3; ++di) {
+        double v = 1.0;
+        for (int a = 0; a < 3; ++a) {
+          const double La = M.L[a];
+          const int q = base[a] + nn[a] - 1;
+          if (a == di) v = v * RBPF_PI * (double)nn[a] / (2.0 * La * sqrt(La)) * tabC[q];
+          else v = v * 1.0 / sqrt(La) * tabS[q];
+        }
+        g[di] = v;
+      }
+    }
+    // (Rnb' * g)_k = sum_a Rnb(a,k) g_a
+    for (int k = 0; k < D; ++k) h[k] = Rm[0 * 3 + k] * g[0] + Rm[1 * 3 + k] * g[1] + Rm[2 * 3 + k] * g[2];
+  } else {
+    double v = 1.0;
+    int base[2] = {0, M.kmax[0]};
+    for (int a = 0; a < 2; ++a) {
+      const int nn = M.NN[a * M.m + c];
+      v = v * 1.0 / sqrt(M.L[a]) * tabS[base[a] + nn - 1];
+    }
+    h[0] = v;
+    for (int k = 1; k < D; ++k) h[k] = 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the streamed core block: lanes own rows (2 per 128-row chunk), waves walk columns
+// ---------------------------------------------------------------------------------------------
+template <int D, int CPL, int UC>
+__device__ __forceinline__ void stream_core(const double* __restrict__ src, double* __restrict__ dst,
+                                            const double* __restrict__ HK, const double* __restrict__ KSrow,
+                                            int ldx, int n, int nb, int mc, int CH, int RS, int CS, int wr, int wc,
+                                            int lane, double* __restrict__ out_acc /* [D][mc] */) {
+  double acc[CPL][2][D];
+  double ks[CPL][2][D];
+  int r0[CPL];
+  bool on[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const int ch = wr + q * RS;
+    on[q] = ch < CH;
+    r0[q] = (on[q] ? ch : 0) * kChunkRows + 2 * lane;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        acc[q][e][k] = 0.0;
+        ks[q][e][k] = KSrow ? KSrow[(size_t)k * ldx + nb + r0[q] + e] : 0.0;
+      }
+  }
+
+  int c = wc;
+  for (; c + (UC - 1) * CS < n; c += UC * CS) {
+    double2 v[UC][CPL];
+#pragma unroll
+    for (int u = 0; u < UC; ++u)
+#pragma unroll
+      for (int q = 0; q < CPL; ++q)
+        if (on[q]) v[u][q] = *reinterpret_cast<const double2*>(src + (size_t)(c + u * CS) * mc + r0[q]);
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int cc = c + u * CS;
+      double h[D], kc[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) { h[k] = HK[cc * 2 * D + k]; kc[k] = HK[cc * 2 * D + D + k]; }
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        if (!on[q]) continue;
+        double p0 = v[u][q].x, p1 = v[u][q].y;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+#pragma unroll
+        for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+        double2 o; o.x = p0; o.y = p1;
+        *reinterpret_cast<double2*>(dst + (size_t)cc * mc + r0[q]) = o;
+      }
+    }
+  }
+  for (; c < n; c += CS) {
+    double h[D], kc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { h[k] = HK[c * 2 * D + k]; kc[k] = HK[c * 2 * D + D + k]; }
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      if (!on[q]) continue;
+      const double2 vv = *reinterpret_cast<const double2*>(src + (size_t)c * mc + r0[q]);
+      double p0 = vv.x, p1 = vv.y;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+#pragma unroll
+      for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+      double2 o; o.x = p0; o.y = p1;
+      *reinterpret_cast<double2*>(dst + (size_t)c * mc + r0[q]) = o;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    if (!on[q]) continue;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      out_acc[(size_t)k * mc + r0[q]] = acc[q][0][k];
+      out_acc[(size_t)k * mc + r0[q] + 1] = acc[q][1][k];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// THE step kernel: one workgroup (4 wave64) per particle slot
+// ---------------------------------------------------------------------------------------------
+template <int D, int CPL>
+__global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
+  extern __shared__ double smem[];
+  const ModelDev& M = a.mdl;
+  const Layout& Ly = a.lay;
+  const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
+  const int N = a.N;
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const LdsPlan lp = lds_plan(n, D, ldx, Ly.CS, mc, M.ktot);
+  double* HK = smem + lp.off_HK;        // per column c: H[0..D) then Kcol[0..D)
+  double* xls = smem + lp.off_xl;
+  double* PHt = smem + lp.off_PHt;      // [D][ldx]
+  double* parts = smem + lp.off_parts;  // [CS][D][mc]
+  double* tabS = smem + lp.off_tab;
+  double* tabC = tabS + (M.ktot > 0 ? M.ktot : 1);
+  double* misc = smem + lp.off_misc;    // 0..7 xn_new, 8..16 Rnb, 20.. epilogue broadcast
+  double* red = smem + lp.off_red;
+
+  const int anc = a.ai ? a.ai[i] : i;
+  const int nN = M.nN;
+
+  // ---- A: propagate the non-linear state (one lane), stage xl and pending K into LDS (all) ----
+  if (tid == 0) {
+    double x[8], xp[8];
+    for (int c = 0; c < nN; ++c) x[c] = a.xn_old[(size_t)c * N + anc];
+    if (a.xref != nullptr && i == N - 1) {
+      for (int c = 0; c < nN; ++c) xp[c] = a.xref[c];                      // particleSmoother.m:242
+    } else if (a.propagate) {
+      double z[8];
+      if (a.rng_mode == 0) { for (int k = 0; k < M.nw; ++k) z[k] = a.Z[(size_t)i * M.nw + k]; }
+      else philox_normals(a.seed, i, a.t, a.k_iter, M.nw, z);
+      if (M.kind == 1) dyn_model_mag(x, a.odo, a.cholQ, z, xp);
+      else dyn_model_radio(x, a.odo, a.cholQ, z, xp);
+    } else {
+      for (int c = 0; c < nN; ++c) xp[c] = x[c];
+    }
+    for (int c = 0; c < nN; ++c) { a.xn_new[(size_t)c * N + i] = xp[c]; misc[c] = xp[c]; }
+    if (M.kind == 1) quat2rmat_dev(&xp[3], &misc[8]);
+  }
+  {
+    const double* xl_src = a.xl_old + (size_t)anc * a.xl_old_stride;
+    const double* Kcol = a.F_old ? a.F_old + ((size_t)anc * 2 + 1) * D * ldx : nullptr;
+    for (int c = tid; c < n; c += kThreads) {
+      xls[c] = xl_src[c];
+#pragma unroll
+      for (int k = 0; k < D; ++k) HK[c * 2 * D + D + k] = Kcol ? Kcol[(size_t)k * ldx + c] : 0.0;
+    }
+  }
+  __syncthreads();
+
+  // ---- B: per-axis sin/cos tables of the reduced-rank basis at the new position ----
+  for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
+  __syncthreads();
+
+  // ---- C: measurement Jacobian H_i, column per thread ----
+  for (int c = tid; c < n; c += kThreads) {
+    double h[D];
+    H_column<D>(M, c, tabS, tabC, &misc[8], h);
+#pragma unroll
+    for (int k = 0; k < D; ++k) HK[c * 2 * D + k] = h[k];
+  }
+  __syncthreads();
+
+  // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ H' ----
+  const double* KSrow = a.F_old ? a.F_old + ((size_t)anc * 2 + 0) * D * ldx : nullptr;
+  {
+    const int wr = wave % Ly.RS, wc = wave / Ly.RS;
+    if (mc > 0 && wc < Ly.CS) {
+      const double* src = a.Pt_old + (size_t)anc * a.Pt_old_stride;
+      double* dst = a.Pt_new + (size_t)i * Ly.szT;
+      double* out_acc = parts + (size_t)wc * D * mc;
+      stream_core<D, CPL, 4>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
+    }
+    // border rows (row-major block B): lanes walk columns, wave-reduce per row
+    for (int b = wave; b < nb; b += kWaves) {
+      const double* src = a.Pb_old + (size_t)anc * a.Pb_old_stride + (size_t)b * ldb;
+      double* dst = a.Pb_new + (size_t)i * Ly.szB + (size_t)b * ldb;
+      double ksb[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) ksb[k] = KSrow ? KSrow[(size_t)k * ldx + b] : 0.0;
+      double accb[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) accb[k] = 0.0;
+      for (int c = 2 * lane; c < ldb; c += 128) {
+        const double2 vv = *reinterpret_cast<const double2*>(src + c);
+        double p[2] = {vv.x, vv.y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cc = c + e;
+          if (cc < n) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) p[e] = fma(-ksb[k], HK[cc * 2 * D + D + k], p[e]);
+#pragma unroll
+            for (int k = 0; k < D; ++k) accb[k] = fma(p[e], HK[cc * 2 * D + k], accb[k]);
+          }
+        }
+        double2 o; o.x = p[0]; o.y = p[1];
+        *reinterpret_cast<double2*>(dst + c) = o;
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double s = wave_sum(accb[k]);
+        if (lane == 0) PHt[(size_t)k * ldx + b] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (mc > 0) {
+    // fixed-order combine of the column phases (deterministic)
+    for (int r = tid; r < mc; r += kThreads) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        double s = parts[(size_t)k * mc + r];
+        for (int w = 1; w < Ly.CS; ++w) s += parts[((size_t)w * D + k) * mc + r];
+        PHt[(size_t)k * ldx + nb + r] = s;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- E: innovation covariance S = H (P H') + R, innovation e = y - H xl ----
+  {
+    double part[D * D + D];
+#pragma unroll
+    for (int q = 0; q < D * D + D; ++q) part[q] = 0.0;
+    for (int r = tid; r < n; r += kThreads) {
+      double h[D], ph[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) { h[k] = HK[r * 2 * D + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
+      const double x = xls[r];
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+        for (int aa = 0; aa < D; ++aa) part[aa + D * bb] = fma(h[aa], ph[bb], part[aa + D * bb]);
+#pragma unroll
+      for (int aa = 0; aa < D; ++aa) part[D * D + aa] = fma(h[aa], x, part[D * D + aa]);
+    }
+#pragma unroll
+    for (int q = 0; q < D * D + D; ++q) {
+      const double s = wave_sum(part[q]);
+      if (lane == 0) red[wave * 16 + q] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double SS[D * D], e[D], cS[D * D], v[D];
+    for (int q = 0; q < D * D; ++q) {
+      double s = red[q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 16 + q];
+      SS[q] = s + M.R[q];                                                   // particleFilter.m:141
+    }
+    for (int q = 0; q < D; ++q) {
+      double s = red[D * D + q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 16 + D * D + q];
+      e[q] = a.y[q] - s;                                                    // :140
+    }
+    bool ok = chol_lower_small<D>(SS, cS);                                  // :145
+    if (!ok) {
+      double SJ[D * D];
+      for (int q = 0; q < D * D; ++q) SJ[q] = SS[q];
+      for (int q = 0; q < D; ++q) SJ[q + D * q] += M.jitter;                // :147
+      ok = chol_lower_small<D>(SJ, cS);
+    }
+    double lw;
+    if (ok) {
+      fwd_subst<D>(cS, e, v);                                               // :149
+      double sl = 0.0, vv = 0.0;
+      for (int q = 0; q < D; ++q) { sl += log(cS[q + D * q]); vv += v[q] * v[q]; }
+      lw = -sl - 0.5 * vv + M.logconst;                                     // :150
+    } else {
+      atomicOr(a.status, 1);
+      lw = nan("");
+      for (int q = 0; q < D * D; ++q) cS[q] = 0.0;
+      for (int q = 0; q < D; ++q) cS[q + D * q] = 1.0;
+    }
+    a.logw[i] = lw;
+    for (int q = 0; q < D * D; ++q) { misc[20 + q] = cS[q]; misc[30 + q] = SS[q]; }
+    for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
+  }
+  __syncthreads();
+
+  // ---- F: Kalman gain rows, mean update, new pending factors (particleFilter.m:194-198) ----
+  {
+    double cS[D * D], SS[D * D], e[D];
+#pragma unroll
+    for (int q = 0; q < D * D; ++q) { cS[q] = misc[20 + q]; SS[q] = misc[30 + q]; }
+#pragma unroll
+    for (int q = 0; q < D; ++q) e[q] = misc[40 + q];
+    double* KSn = a.F_new + ((size_t)i * 2 + 0) * D * ldx;
+    double* Kn = a.F_new + ((size_t)i * 2 + 1) * D * ldx;
+    double* xln = a.xl_new + (size_t)i * ldx;
+    for (int r = tid; r < n; r += kThreads) {
+      double ph[D], u[D], kk[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) ph[k] = PHt[(size_t)k * ldx + r];
+      fwd_subst<D>(cS, ph, u);          // (P H') / cS'
+      bwd_subst_T<D>(cS, u, kk);        // ... / cS   -> row r of K
+      double xn_ = xls[r];
+#pragma unroll
+      for (int k = 0; k < D; ++k) xn_ = fma(kk[k], e[k], xn_);              // :197
+      xln[r] = xn_;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fma(kk[k], SS[k + D * j], s);       // row r of K*SS
+        KSn[(size_t)j * ldx + r] = s;
+        Kn[(size_t)j * ldx + r] = kk[j];
+      }
+    }
+  }
+}
+
+template <int D, int CPL>
+static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
+  const size_t lds = step_lds_bytes(a.mdl, a.lay);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, CPL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((step_kernel<D, CPL>), dim3(a.N), dim3(kThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_step(const StepArgs& a, hipStream_t s) {
+  const int D = a.mdl.d, CPL = a.lay.CPL;
+  if (D == 3) {
+    if (CPL == 1) return launch_step_t<3, 1>(a, s);
+    if (CPL == 2) return launch_step_t<3, 2>(a, s);
+    if (CPL == 3) return launch_step_t<3, 3>(a, s);
+  } else if (D == 1) {
+    if (CPL == 1) return launch_step_t<1, 1>(a, s);
+    if (CPL == 2) return launch_step_t<1, 2>(a, s);
+    if (CPL == 3) return launch_step_t<1, 3>(a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight normalisation (particleFilter.m:154-161) + strict left-to-right cumsum (tools/sample.m:30)
+// one workgroup of 1024 threads
+// ---------------------------------------------------------------------------------------------
+constexpr int kNormThreads = 1024;
+constexpr int kScanChunk = 4096;
+
+__device__ inline double block_sum_1024(double v, double* sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sred[wave] = v;
+  __syncthreads();
+  double s = sred[0];
+  for (int w = 1; w < kNormThreads / 64; ++w) s += sred[w];
+  return s;
+}
+
+__device__ inline double block_max_1024(double v, double* sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if (lane == 0) sred[wave] = v;
+  __syncthreads();
+  double s = sred[0];
+  for (int w = 1; w < kNormThreads / 64; ++w) s = fmax(s, sred[w]);
+  return s;
+}
+
+__global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const NormArgs a) {
+  __shared__ double sred[16];
+  __shared__ int sidx[16];
+  __shared__ double sbuf[kScanChunk];
+  __shared__ double scarry;
+  const int tid = threadIdx.x, N = a.N;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  // c = max(logw)
+  double mx = -INFINITY;
+  for (int i = tid; i < N; i += kNormThreads) mx = fmax(mx, a.logw[i]);
+  const double c = block_max_1024(mx, sred);
+  // lse = c + log(sum(exp(logw - c)))
+  double se = 0.0;
+  for (int i = tid; i < N; i += kNormThreads) se += exp(a.logw[i] - c);
+  const double tot = block_sum_1024(se, sred);
+  const double lse = c + log(tot);
+  // w = exp(logw - lse); [~,iw_max] = max(w) (first maximum)
+  double bw = -1.0;
+  int bi = 0x7fffffff;
+  for (int i = tid; i < N; i += kNormThreads) {
+    const double wi = exp(a.logw[i] - lse);
+    a.w[i] = wi;
+    if (wi > bw) { bw = wi; bi = i; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ow = __shfl_xor(bw, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ow > bw || (ow == bw && oi < bi)) { bw = ow; bi = oi; }
+  }
+  __syncthreads();
+  if (lane == 0) { sred[wave] = bw; sidx[wave] = bi; }
+  __syncthreads();
+  double gw = sred[0];
+  int gi = sidx[0];
+  for (int w = 1; w < kNormThreads / 64; ++w)
+    if (sred[w] > gw || (sred[w] == gw && sidx[w] < gi)) { gw = sred[w]; gi = sidx[w]; }
+  if (tid == 0) {
+    *a.iw_max = gi;
+    if (a.lse_out) *a.lse_out = lse;
+  }
+  // traj_max(:,t) = xn(:,iw_max); traj_mean(:,t) = sum(xn.*w,2)
+  for (int cix = 0; cix < a.nN; ++cix) {
+    const double* xr = a.xn + (size_t)cix * N;
+    double s = 0.0;
+    for (int i = tid; i < N; i += kNormThreads) s = fma(xr[i], a.w[i], s);
+    const double tm = block_sum_1024(s, sred);
+    if (tid == 0) {
+      if (a.traj_mean) a.traj_mean[cix] = tm;
+      if (a.traj_max) a.traj_max[cix] = xr[gi];
+    }
+  }
+  // wc = cumsum(w): one lane, strict left-to-right, staged through LDS in chunks
+  if (tid == 0) scarry = 0.0;
+  __syncthreads();
+  for (int base = 0; base < N; base += kScanChunk) {
+    const int cnt = min(kScanChunk, N - base);
+    for (int j = tid; j < cnt; j += kNormThreads) sbuf[j] = a.w[base + j];
+    __syncthreads();
+    if (tid == 0) {
+      double run = scarry;
+#pragma unroll 8
+      for (int j = 0; j < cnt; ++j) { run += sbuf[j]; sbuf[j] = run; }
+      scarry = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < cnt; j += kNormThreads) a.wc[base + j] = sbuf[j];
+    __syncthreads();
+  }
+}
+
+hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(normalise_scan_kernel, dim3(1), dim3(kNormThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+// standalone strict left-to-right cumsum (tools/sample.m:30) used by rbpf_sample and the smoother
+__global__ __launch_bounds__(kNormThreads) void cumsum_kernel(int N, const double* __restrict__ w,
+                                                              double* __restrict__ wc) {
+  __shared__ double sbuf[kScanChunk];
+  __shared__ double scarry;
+  const int tid = threadIdx.x;
+  if (tid == 0) scarry = 0.0;
+  __syncthreads();
+  for (int base = 0; base < N; base += kScanChunk) {
+    const int cnt = min(kScanChunk, N - base);
+    for (int j = tid; j < cnt; j += kNormThreads) sbuf[j] = w[base + j];
+    __syncthreads();
+    if (tid == 0) {
+      double run = scarry;
+#pragma unroll 8
+      for (int j = 0; j < cnt; ++j) { run += sbuf[j]; sbuf[j] = run; }
+      scarry = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < cnt; j += kNormThreads) wc[base + j] = sbuf[j];
+    __syncthreads();
+  }
+}
+
+hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s) {
+  hipLaunchKernelGGL(cumsum_kernel, dim3(1), dim3(kNormThreads), 0, s, N, w, wc);
+  return hipGetLastError();
+}
+
+// ind = sum(wc < u) (0-based), clamped to N-1 (the reference would return N+1 -> MATLAB error)
+__global__ void search_kernel(const SearchArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_draw) return;
+  const double u = (a.rng_mode == 0) ? a.U[i] : philox_resample_uniform(a.seed, i, a.t, a.k_iter);
+  int lo = 0, hi = a.N;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.wc[mid] < u) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= a.N) { lo = a.N - 1; if (a.overflow) atomicAdd(a.overflow, 1); }
+  a.ai[i] = lo;
+}
+
+hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
+  const int nb = (a.n_draw + 255) / 256;
+  if (nb > 0) hipLaunchKernelGGL(search_kernel, dim3(nb), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack / unpack / extraction kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_P_kernel(Layout L, const double* __restrict__ P, size_t src_stride, double* __restrict__ Pt,
+                              double* __restrict__ Pb) {
+  const int p = blockIdx.x;
+  const double* src = P + (size_t)p * src_stride;
+  double* t = Pt + (size_t)p * L.szT;
+  double* b = Pb + (size_t)p * L.szB;
+  const size_t nn = (size_t)L.n * L.n;
+  for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
+    const int r = (int)(q % L.n), c = (int)(q / L.n);
+    const double v = src[q];
+    if (r < L.nb) b[(size_t)r * L.ldb + c] = v;
+    else t[(size_t)c * L.mc + (r - L.nb)] = v;
+  }
+  // zero the pad column of the border block
+  if (L.ldb > L.n)
+    for (int r = threadIdx.x; r < L.nb; r += blockDim.x) b[(size_t)r * L.ldb + L.n] = 0.0;
+}
+
+hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src_stride, double* Pt, double* Pb,
+                         int count, hipStream_t s) {
+  hipLaunchKernelGGL(pack_P_kernel, dim3(count), dim3(256), 0, s, lay, P_colmajor, src_stride, Pt, Pb);
+  return hipGetLastError();
+}
+
+// flushes the pending downdate: P(r,c) = stored(r,c) - sum_k KS(r,k) K(c,k)
+__global__ void unpack_P_kernel(Layout L, int d, const double* __restrict__ Pt, const double* __restrict__ Pb,
+                                const double* __restrict__ F, const int* __restrict__ index,
+                                double* __restrict__ P) {
+  const int p = blockIdx.x;
+  const int src = index ? index[p] : p;
+  const double* t = Pt + (size_t)src * L.szT;
+  const double* b = Pb + (size_t)src * L.szB;
+  const double* KS = F ? F + ((size_t)src * 2 + 0) * d * L.ldx : nullptr;
+  const double* K = F ? F + ((size_t)src * 2 + 1) * d * L.ldx : nullptr;
+  double* dst = P + (size_t)p * L.n * L.n;
+  const size_t nn = (size_t)L.n * L.n;
+  for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
+    const int r = (int)(q % L.n), c = (int)(q / L.n);
+    double v = (r < L.nb) ? b[(size_t)r * L.ldb + c] : t[(size_t)c * L.mc + (r - L.nb)];
+    if (F)
+      for (int k = 0; k < d; ++k) v = fma(-KS[(size_t)k * L.ldx + r], K[(size_t)k * L.ldx + c], v);
+    dst[q] = v;
+  }
+}
+
+hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
+                           const int* index, int count, double* P_colmajor, hipStream_t s) {
+  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, F, index, P_colmajor);
+  return hipGetLastError();
+}
+
+// xl_mean = sum(xl.*w,2)  (particleFilter.m:226)
+__global__ void weighted_mean_xl_kernel(int N, int n, int ldx, const double* __restrict__ xl,
+                                        const double* __restrict__ w, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double s = 0.0;
+  for (int i = 0; i < N; ++i) s = fma(xl[(size_t)i * ldx + r], w[i], s);
+  out[r] = s;
+}
+
+hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
+                                   hipStream_t s) {
+  hipLaunchKernelGGL(weighted_mean_xl_kernel, dim3((n + 63) / 64), dim3(64), 0, s, N, n, ldx, xl, w, out);
+  return hipGetLastError();
+}
+
+// Ancestral paths: the lazily evaluated equivalent of the eager history permutation
+// xn_traj(:,:,1:t-1) = xn_traj(:,ai,1:t-1)  (particleFilter.m:118).  X: [T][nN][N], A: [T][N].
+__global__ void backtrace_kernel(int N, int nN, int T, const double* __restrict__ X, const int* __restrict__ A,
+                                 const int* __restrict__ start_index, int n_paths, double* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_paths) return;
+  int j = start_index ? start_index[p] : p;
+  for (int t = T - 1; t >= 0; --t) {
+    for (int c = 0; c < nN; ++c)
+      out[c + (size_t)nN * (p + (size_t)n_paths * t)] = X[((size_t)t * nN + c) * N + j];
+    if (t > 0) j = A[(size_t)t * N + j];
+  }
+}
+
+hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,
+                            int n_paths, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(backtrace_kernel, dim3((n_paths + 63) / 64), dim3(64), 0, s, N, nN, T, X, A, start_index,
+                     n_paths, out);
+  return hipGetLastError();
+}
+
+__global__ void philox_fill_kernel(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,
+                                   double* Ufin) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0 && Ufin) *Ufin = philox_resample_uniform(seed, 0, T, k_iter);
+  if (q >= (size_t)N * (T - 1)) return;
+  const int i = (int)(q % N), t = (int)(q / N) + 1;
+  U[q] = philox_resample_uniform(seed, i, t, k_iter);
+  double z[8];
+  philox_normals(seed, i, t, k_iter, nw, z);
+  for (int k = 0; k < nw; ++k) Z[q * nw + k] = z[k];
+}
+
+hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,
+                              double* Ufin, hipStream_t s) {
+  const size_t tot = (size_t)N * (T > 1 ? T - 1 : 0);
+  const int nb = (int)((tot + 255) / 256);
+  hipLaunchKernelGGL(philox_fill_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, s, seed, k_iter, N, T, nw, U, Z, Ufin);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone model kernels (parity tests of SURVEY 8a rows a3-a8, a17, a19)
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__global__ void meas_model_kernel(ModelDev M, int npred, const double* __restrict__ xn, double* __restrict__ dy) {
+  extern __shared__ double sm[];
+  double* tabS = sm;
+  double* tabC = sm + (M.ktot > 0 ? M.ktot : 1);
+  double* misc = tabC + (M.ktot > 0 ? M.ktot : 1);
+  const int p = blockIdx.x;
+  if (threadIdx.x == 0) {
+    for (int c = 0; c < M.nN; ++c) misc[c] = xn[(size_t)p * M.nN + c];
+    if (M.kind == 1) quat2rmat_dev(&misc[3], &misc[8]);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < M.ktot; q += blockDim.x) basis_table_entry(M, q, misc, tabS, tabC);
+  __syncthreads();
+  for (int c = threadIdx.x; c < M.n; c += blockDim.x) {
+    double h[D];
+    H_column<D>(M, c, tabS, tabC, &misc[8], h);
+    for (int k = 0; k < D; ++k) dy[((size_t)p * M.n + c) * D + k] = h[k];
+  }
+}
+
+hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s) {
+  const size_t lds = (size_t)(2 * (m.ktot > 0 ? m.ktot : 1) + 32) * sizeof(double);
+  if (m.d == 3) hipLaunchKernelGGL((meas_model_kernel<3>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy);
+  else if (m.d == 1) hipLaunchKernelGGL((meas_model_kernel<1>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+__global__ void dyn_model_kernel(ModelDev M, int np, const double* __restrict__ xn, const double* __restrict__ odo,
+                                 const double* __restrict__ cholQ, const double* __restrict__ z,
+                                 double* __restrict__ xn_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  double x[8], xp[8], zz[8];
+  for (int c = 0; c < M.nN; ++c) x[c] = xn[(size_t)i * M.nN + c];
+  for (int k = 0; k < M.nw; ++k) zz[k] = z[(size_t)i * M.nw + k];
+  if (M.kind == 1) dyn_model_mag(x, odo, cholQ, zz, xp);
+  else dyn_model_radio(x, odo, cholQ, zz, xp);
+  for (int c = 0; c < M.nN; ++c) xn_next[(size_t)i * M.nN + c] = xp[c];
+}
+
+hipError_t launch_dyn_model(const ModelDev& m, int np, const double* xn, const double* odo, const double* cholQ,
+                            const double* z, double* xn_next, hipStream_t s) {
+  hipLaunchKernelGGL(dyn_model_kernel, dim3((np + 63) / 64), dim3(64), 0, s, m, np, xn, odo, cholQ, z, xn_next);
+  return hipGetLastError();
+}
+
+// eDyn = r' / chol(dt*Q,'lower'): solve x*Lq = r'  <=>  Lq' x' = r (back substitution on Lq')
+__device__ inline void dyn_res_norm_dev(const ModelDev& M, const double* xk, const double* xi, const double* odo,
+                                        const double* Lq, double* ed) {
+  double r[8];
+  const int nw = M.nw;
+  if (M.use_dyn_res_norm && M.kind == 1) {
+    // run_dense3D_magfield.m:202-203
+    for (int c = 0; c < 3; ++c) r[c] = xk[c] - xi[c] - odo[c];
+    const double oqi[4] = {odo[3], -odo[4], -odo[5], -odo[6]};
+    const double xqi[4] = {xi[3], -xi[4], -xi[5], -xi[6]};
+    double t1[4], t2[4];
+    qleft_mul(oqi, xqi, t1);
+    qleft_mul(t1, &xk[3], t2);
+    logq_dev(t2, &r[3]);
+  } else if (M.use_dyn_res_norm && M.kind == 2) {
+    r[0] = xk[2] - xi[2] - odo[2];                          // run_dense2D_withHeading.m:77
+  } else {
+    for (int c = 0; c < nw; ++c) r[c] = xk[c] - xi[c] - odo[c];   // particleSmoother.m:176
+  }
+  for (int q = nw - 1; q >= 0; --q) {
+    double s = r[q];
+    for (int k = q + 1; k < nw; ++k) s -= Lq[k + nw * q] * ed[k];
+    ed[q] = s / Lq[q + nw * q];
+  }
+}
+
+__global__ void dyn_res_norm_kernel(ModelDev M, int np, const double* __restrict__ xnk_t,
+                                    const double* __restrict__ xn, const double* __restrict__ odo,
+                                    const double* __restrict__ Lq, double* __restrict__ e_dyn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np) return;
+  double xi[8], xk[8], ed[8];
+  for (int c = 0; c < M.nN; ++c) { xi[c] = xn[(size_t)i * M.nN + c]; xk[c] = xnk_t[c]; }
+  dyn_res_norm_dev(M, xk, xi, odo, Lq, ed);
+  for (int k = 0; k < M.nw; ++k) e_dyn[(size_t)i * M.nw + k] = ed[k];
+}
+
+hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, const double* xn, const double* odo,
+                               const double* cholQfull, double* e_dyn, hipStream_t s) {
+  hipLaunchKernelGGL(dyn_res_norm_kernel, dim3((np + 63) / 64), dim3(64), 0, s, m, np, xnk_t, xn, odo, cholQfull,
+                     e_dyn);
+  return hipGetLastError();
+}
+
+// tools/JacobianPhi3D.m:29-64
+__global__ void jacobian_phi3d_kernel(ModelDev M, int np, const double* __restrict__ x, const double* __restrict__ lo,
+                                      const double* __restrict__ up, double* __restrict__ J) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)M.m * np) return;
+  const int j = (int)(q % M.m), i = (int)(q / M.m);
+  double f[3], s[3], c[3];
+  for (int d = 0; d < 3; ++d) {
+    const double jd = (double)M.NN[d * M.m + j];
+    const double ba = up[d] - lo[d];
+    f[d] = (RBPF_PI * jd) / ba;
+    const double core = RBPF_PI * jd * (x[(size_t)i * 3 + d] - lo[d]) / ba;
+    const double mult = 1.0 / sqrt(0.5 * ba);
+    double sn, cs;
+    sincos(core, &sn, &cs);
+    s[d] = sn * mult;
+    c[d] = cs * mult;
+  }
+  double* Jp = J + ((size_t)i * M.m + j) * 9;   // [3 x 3] column-major per (j,i)
+  Jp[0 + 3 * 0] = -f[0] * f[0] * s[0] * s[1] * s[2];
+  Jp[0 + 3 * 1] = f[0] * f[1] * c[0] * c[1] * s[2];
+  Jp[0 + 3 * 2] = f[0] * f[2] * c[0] * s[1] * c[2];
+  Jp[1 + 3 * 0] = f[1] * f[0] * c[0] * c[1] * s[2];
+  Jp[1 + 3 * 1] = -f[1] * f[1] * s[0] * s[1] * s[2];
+  Jp[1 + 3 * 2] = f[1] * f[2] * s[0] * c[1] * c[2];
+  Jp[2 + 3 * 0] = f[2] * f[0] * c[0] * s[1] * c[2];
+  Jp[2 + 3 * 1] = f[2] * f[1] * s[0] * c[1] * c[2];
+  Jp[2 + 3 * 2] = -f[2] * f[2] * s[0] * s[1] * s[2];
+}
+
+hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, const double* lo, const double* up,
+                                 double* J, hipStream_t s) {
+  const size_t tot = (size_t)m.m * np;
+  hipLaunchKernelGGL(jacobian_phi3d_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, m, np, x, lo, up, J);
+  return hipGetLastError();
+}
+
+// SoA [nN][N] -> MATLAB [nN x N]
+__global__ void transpose_soa_kernel(int N, int nN, const double* __restrict__ soa, double* __restrict__ aos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int c = 0; c < nN; ++c) aos[(size_t)i * nN + c] = soa[(size_t)c * N + i];
+}
+
+hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_soa_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nN, soa, aos);
+  return hipGetLastError();
+}
+
+// xl bank [N][ldx] -> MATLAB [n x N]
+__global__ void gather_xl_kernel(int N, int n, int ldx, const double* __restrict__ xl, double* __restrict__ out) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)N * n) return;
+  const int r = (int)(q % n), i = (int)(q / n);
+  out[q] = xl[(size_t)i * ldx + r];
+}
+
+hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s) {
+  const size_t tot = (size_t)N * n;
+  hipLaunchKernelGGL(gather_xl_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, N, n, ldx, xl,
+                     out_colmajor);
+  return hipGetLastError();
+}
+
+}  // namespace rbpf

@@ -1,0 +1,64 @@
+"""GPU parity: HIP particleFilter (through the C ABI) vs the numpy oracle on the same seeded inputs.
+
+Tolerances: ancestor indices bit-exact; fp64 states / weights / covariances within 1e-9 relative
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def run_both(rbpf, c):
+    ref = cases.oracle_filter(c)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    np.testing.assert_array_equal(mdl.NN, c["model"].NN.astype(np.int32))
+    np.testing.assert_allclose(P0, c["P0_lin"], rtol=1e-14)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True)
+    return ref, out
+
+
+def check_filter(ref, out):
+    traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample, xn_traj, ex = out
+    tr = ref["trace"]
+    np.testing.assert_array_equal(ex["ai"][1:], tr["ai"][1:])                  # bit-exact resample indices
+    assert ex["iw_max"] == ref["iw_max"]
+    # log-weights: compare after removing the particle-independent offset scale
+    assert np.max(np.abs(ex["logw"] - tr["logw"])) <= RTOL * max(1.0, np.max(np.abs(tr["logw"])))
+    assert rel(ex["w"], tr["w"]) <= RTOL
+    assert rel(traj_max, ref["traj_max"]) <= RTOL
+    assert rel(traj_mean, ref["traj_mean"]) <= RTOL
+    assert rel(xl_max, ref["xl_max"]) <= RTOL
+    assert rel(xl_mean, ref["xl_mean"]) <= RTOL
+    assert rel(P_max, ref["P_max"]) <= RTOL
+    assert rel(P_mean, ref["P_mean"]) <= RTOL                                   # incl. quirk Q3
+    assert rel(traj_sample, ref["traj_sample_iwmax"]) <= RTOL
+    assert rel(xn_traj, ref["xn_traj"]) <= RTOL
+    assert rel(ex["xl"], tr["xl"]) <= RTOL
+    assert rel(ex["P"], tr["P"]) <= RTOL
+    assert rel(ex["xn"], tr["xn"]) <= RTOL
+
+
+@pytest.mark.parametrize("N_P,N_T,m", [(8, 6, 16),      # n = 19  : border-only layout (mc = 0)
+                                         (12, 8, 125),    # n = 128 : one core chunk, no border
+                                         (9, 7, 130),     # n = 133 : core + 5 border rows
+                                         (8, 6, 256)])    # n = 259 : the C2 layout (2 chunks + 3 border)
+def test_dense_mag_filter_matches_oracle(rbpf, N_P, N_T, m):
+    c = cases.mag_case(N_P, N_T, m, seed=3)
+    ref, out = run_both(rbpf, c)
+    check_filter(ref, out)
+
+
+@pytest.mark.parametrize("N_P,N_T,m", [(10, 12, 32), (16, 10, 128), (7, 9, 140)])
+def test_dense_radio_filter_matches_oracle(rbpf, N_P, N_T, m):
+    c = cases.radio_case(N_P, N_T, m, seed=5)
+    ref, out = run_both(rbpf, c)
+    check_filter(ref, out)
