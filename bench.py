@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward Rao-Blackwellized particle filter throughput on synthetic
+slam-dense-mag trajectories (BASELINE.json configs[1]: N=8192, T=3000, m=256, fp64, filter only).
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one time step of particleFilter (src/particleFilter.m:100-218) over all particles:
+resample-gather, dynModel, measModel, importance weights, normalisation and the Kalman map update.
+`value` = particle-steps/s over the K timed steps with all inputs resident in HBM.  One JSON line is
+printed by rank 0.  See DESIGN.md "Measurement".
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q_MAG_DIAG = None
+
+
+def q_mag():
+    import numpy as np
+    # examples/slam-dense-mag/main.m:22
+    return np.diag(np.concatenate((10 ** 2 * np.array([0.05 ** 2, 0.05 ** 2, 0.01 ** 2]),
+                                   (np.array([0.01, 0.01, 0.3]) * np.pi / 180) ** 2)))
+
+
+THETA_MAG = [650.0, 1.2, 200.0, 10.0]                       # examples/slam-dense-mag/main.m:23
+
+
+def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
+    """Times oracle/rbpf_oracle_c.c (the plain-C restatement of src/particleFilter.m) on this host's
+    cores on a bounded sample of the same workload.  The oracle is only the thing *measured* here."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_c
+    try:
+        lib_path = oracle_c.build(native_dir=os.path.join(ROOT, "gpurun_out", "_oracle_native"))
+        flags = "-O3 -march=native -fopenmp"
+    except Exception:
+        lib_path = oracle_c.build()
+        flags = "-O3 -fopenmp"
+    cores = oracle_c.max_threads(lib_path)
+    N_s = 1024
+    Q = q_mag()
+
+    def run(T_s):
+        rs = np.random.RandomState(123)
+        rng = pkg.ReplayRNG(rs.random_sample((1, T_s - 1, N_s)), rs.standard_normal((1, T_s - 1, N_s, 6)))
+        _, secs = oracle_c.particle_filter(pkg, model, data["dx"][:T_s - 1], data["y"][:T_s], data["initState"],
+                                           x0_lin, P0, Q, R, N_s, 0.01, rng, n_threads=0, want_full=False,
+                                           lib_path=lib_path)
+        return secs
+    t_cal = run(5)
+    per_step = max(t_cal / 5.0, 1e-6)
+    T_s = int(min(300, max(8, target_s / per_step)))
+    secs = run(T_s)
+    return {"value": N_s * T_s / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"slam-dense-mag N={N_s} T={T_s} m={m} fp64, C restatement of particleFilter.m "
+                      f"(gcc {flags}, OpenMP over particles), {secs:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=8192, help="particles per GPU")
+    ap.add_argument("--m", type=int, default=256)
+    ap.add_argument("--T", type=int, default=3000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+
+    import numpy as np
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the RBPF path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+    datagen = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
+    K, W, T = args.steps, args.warmup, args.T
+    if K + W > T:
+        raise SystemExit(f"--steps + --warmup must be <= T={T}")
+    Q = q_mag()
+    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)           # data seed 1
+    model, x0_lin, P0, R = pkg.dense_mag_prior(args.m, data["LL"], THETA_MAG)
+    N_local = args.particles
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if world > 1:
+        mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
+        sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
+                                       N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world)
+    else:
+        sess = pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N_local, 0.01,
+                                 rng=pkg.PhiloxRNG(args.seed), keep_history=False)     # filter seed 1
+    sess.advance(W)
+    sess.sync()
+    sess.timing(enable=True)
+    barrier()
+    t0 = time.perf_counter()
+    sess.advance(K)
+    sess.sync()
+    barrier()
+    dt_s = time.perf_counter() - t0
+    tm = sess.timing(reset=True)
+    sess.timing(enable=False)
+    if dist is not None:
+        tt = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = float(tt.item())
+    chk = sess.finish(want=("traj_mean",))
+    if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
+        raise SystemExit("non-finite filter output")
+    sess.close()
+
+    if rank == 0:
+        n = model.nLin
+        N_total = N_local * world
+        value = N_total * K / dt_s
+        avg_ms = tm["ms"] / max(tm["launches"], 1)
+        achieved = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tr_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tr_file):
+            try:
+                rec = json.load(open(tr_file))
+                if rec.get("N_P") == N_local and rec.get("m") == args.m:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "particle-steps/s (filter)", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"slam-dense-mag N={N_total} T={T} m={args.m} (nLin={n}) fp64 filter only "
+                                   f"(BASELINE.json configs[1] x {world} GPU)",
+                       "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
+                       "filter_seed": args.seed},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "step_kernel", "avg_launch_ms": avg_ms, "launches": tm["launches"],
+                         "algorithmic_bytes_per_launch": tm["bytes_per_launch"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)
+            except Exception as exc:                                  # report, never hide
+                line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": None, "kind": "port",
+                                        "sample": f"failed: {exc}"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

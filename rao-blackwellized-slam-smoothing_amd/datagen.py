@@ -1,0 +1,113 @@
+"""Synthetic SLAM data sets for the dense model families (host-side, once per run).
+
+Product counterpart of examples/slam-dense-radio/generateData_dense.m (:181-213 bean_6D trajectory,
+:216-257 field draw in a 2000-function reduced-rank basis, :294-325 odometry noise by running
+dynModel forward) and tools/gp_rnd_scalar_potential_fast.m:42-102, scaled to an arbitrary number of
+time steps N_T by spreading the three laps over N_T points (the box, hence LL and NN, stays the
+reference's).  Implemented with per-axis sin/cos tables instead of the reference's m x d loops.
+MATLAB's randn is replaced by a seeded numpy stream; the test grid the reference also evaluates for
+plotting (:233-236) is not generated.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .host import domain_cartesian_dx, eigenval
+
+
+def _qmul(q, p):
+    """qLeft(q) * p (tools/qLeft.m:30-35)."""
+    return np.array([q[0] * p[0] - q[1] * p[1] - q[2] * p[2] - q[3] * p[3],
+                     q[1] * p[0] + q[0] * p[1] - q[3] * p[2] + q[2] * p[3],
+                     q[2] * p[0] + q[3] * p[1] + q[0] * p[2] - q[1] * p[3],
+                     q[3] * p[0] - q[2] * p[1] + q[1] * p[2] + q[0] * p[3]])
+
+
+def _expq(phi):
+    """tools/expq.m:22-31."""
+    mag = math.sqrt(float(phi[0] ** 2 + phi[1] ** 2 + phi[2] ** 2))
+    den = mag + (1.0 if mag == 0.0 else 0.0)
+    eq = np.array([math.cos(mag), phi[0] / den * math.sin(mag), phi[1] / den * math.sin(mag),
+                   phi[2] / den * math.sin(mag)])
+    return -eq if eq[0] < 0 else eq
+
+
+def _quat2rmat(q):
+    """tools/quat2rmat.m:27-33."""
+    q0, q1, q2, q3 = q
+    return np.array([[q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, 2 * q1 * q2 - 2 * q0 * q3, 2 * q1 * q3 + 2 * q0 * q2],
+                     [2 * q1 * q2 + 2 * q0 * q3, q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, 2 * q2 * q3 - 2 * q0 * q1],
+                     [2 * q1 * q3 - 2 * q0 * q2, 2 * q2 * q3 + 2 * q0 * q1, q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3]])
+
+
+def _axis_tables(NN, L, x):
+    """S[a][pt, k], C[a][pt, k]: sin / cos of pi k (x_a + L_a) / (2 L_a), k = 0..kmax_a."""
+    S, Cc = [], []
+    for a in range(NN.shape[1]):
+        k = np.arange(0, int(NN[:, a].max()) + 1, dtype=np.float64)
+        arg = np.pi * k[None, :] * (x[:, a:a + 1] + L[a]) / (2.0 * L[a])
+        S.append(np.sin(arg))
+        Cc.append(np.cos(arg))
+    return S, Cc
+
+
+def curl_free_field_draw(x, m, LL, theta, rs):
+    """Gradient-field draw of tools/gp_rnd_scalar_potential_fast.m:42-102 at points x [npts x 3]:
+    returns (df, y) = (true field, field + sqrt(sigma2) * noise)."""
+    LL = np.asarray(LL, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64) - LL.mean(axis=0)
+    L, NN = domain_cartesian_dx(m, 3, (LL.max(axis=0) - LL.min(axis=0))[None, :] / 2.0)
+    lam = eigenval(NN, L)
+    linSigma2, lengthScale, magnSigma2, sigma2 = (float(t) for t in np.asarray(theta).ravel())
+    Sse = magnSigma2 * math.sqrt(2 * math.pi) ** 3 * lengthScale ** 3 * np.exp(-lam * lengthScale ** 2 / 2)
+    foo = np.sqrt(np.concatenate(([linSigma2] * 3, Sse))) * rs.standard_normal(m + 3)
+    S, Cc = _axis_tables(NN, L, x)
+    amp = 1.0 / np.sqrt(L)
+    dfac = np.pi * NN / (2.0 * L * np.sqrt(L))                      # [m x 3]
+    s = [S[a][:, NN[:, a]] * amp[a] for a in range(3)]              # [npts x m]
+    c = [Cc[a][:, NN[:, a]] * dfac[:, a][None, :] for a in range(3)]
+    w = foo[3:]
+    df = np.column_stack(((c[0] * s[1] * s[2]) @ w + foo[0],
+                          (s[0] * c[1] * s[2]) @ w + foo[1],
+                          (s[0] * s[1] * c[2]) @ w + foo[2]))
+    y = df + math.sqrt(sigma2) * rs.standard_normal(df.shape)
+    return df, y
+
+
+def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0):
+    """generateData_dense.m 'bean_6D' scaled to N_T samples -> dict(dx, initState, y, LL, pos, quat)."""
+    rs = np.random.RandomState(seed)
+    psi = np.linspace(0.0, laps * np.pi, N_T)
+    r = a * np.sin(psi) ** 3 + a * np.cos(psi) ** 3
+    u, v = r * np.cos(psi) - 0.3, r * np.sin(psi) - 0.3
+    th = np.arctan2(np.diff(v), np.diff(u))
+    th = np.concatenate((th, th[-1:]))
+    pos = np.vstack((u, v, np.zeros_like(u)))
+    # rmat2quat of the planar rotation [c s 0; -s c 0; 0 0 1]: expq([0;0;-th]/2)  (tools/rmat2quat.m:35-36)
+    quat = np.stack([_expq(np.array([0.0, 0.0, -t / 2.0])) for t in th], axis=0)
+    pos = pos - 0.5 * (pos.min(axis=1) + pos.max(axis=1))[:, None]
+    initState = np.concatenate((pos[:, 0], quat[0]))
+    dPos = np.diff(pos.T, axis=0)
+    qc = quat[:-1] * np.array([1.0, -1.0, -1.0, -1.0])
+    dQuat = np.stack([_qmul(qc[i], quat[i + 1]) for i in range(N_T - 1)], axis=0)
+    ls = float(np.asarray(theta).ravel()[1])
+    LL = np.array([[pos[0].min() - nLL * ls, pos[1].min() - nLL * ls, -nLL * ls],
+                   [pos[0].max() + nLL * ls, pos[1].max() + nLL * ls, nLL * ls]])
+    _, yn = curl_free_field_draw(pos.T, m_sim, LL, theta, rs)
+    y = np.stack([_quat2rmat(quat[i]).T @ yn[i] for i in range(N_T)], axis=0)
+    # noisy odometry: push the truth through dynModel (run_dense3D_magfield.m:301-308)
+    Q = np.asarray(Q, dtype=np.float64)
+    Lp = np.linalg.cholesky(dt * Q[0:3, 0:3])
+    La = np.linalg.cholesky(dt * Q[3:6, 3:6])
+    x = np.zeros((N_T, 7))
+    dQn = np.zeros((N_T - 1, 4))
+    x[0] = initState
+    zo = rs.standard_normal((N_T - 1, 6))
+    for i in range(1, N_T):
+        x[i, 0:3] = x[i - 1, 0:3] + dPos[i - 1] + Lp @ zo[i - 1, 0:3]
+        dQn[i - 1] = _qmul(dQuat[i - 1], _expq(La @ zo[i - 1, 3:6]))
+        x[i, 3:7] = _qmul(x[i - 1, 3:7], dQn[i - 1])
+    dx = np.hstack((np.diff(x[:, 0:3], axis=0), dQn))
+    return dict(dx=dx, initState=initState, y=y, LL=LL, pos=pos, quat=quat)
