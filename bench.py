@@ -34,6 +34,18 @@ def q_mag():
 THETA_MAG = [650.0, 1.2, 200.0, 10.0]                       # examples/slam-dense-mag/main.m:23
 
 
+def usable_cores():
+    """Host cores this process may actually use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
     """Times oracle/rbpf_oracle_c.c (the plain-C restatement of src/particleFilter.m) on this host's
     cores on a bounded sample of the same workload.  The oracle is only the thing *measured* here."""
@@ -46,7 +58,7 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
     except Exception:
         lib_path = oracle_c.build()
         flags = "-O3 -fopenmp"
-    cores = oracle_c.max_threads(lib_path)
+    cores = usable_cores()
     N_s = 1024
     Q = q_mag()
 
@@ -54,7 +66,7 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
         rs = np.random.RandomState(123)
         rng = pkg.ReplayRNG(rs.random_sample((1, T_s - 1, N_s)), rs.standard_normal((1, T_s - 1, N_s, 6)))
         _, secs = oracle_c.particle_filter(pkg, model, data["dx"][:T_s - 1], data["y"][:T_s], data["initState"],
-                                           x0_lin, P0, Q, R, N_s, 0.01, rng, n_threads=0, want_full=False,
+                                           x0_lin, P0, Q, R, N_s, 0.01, rng, n_threads=cores, want_full=False,
                                            lib_path=lib_path)
         return secs
     t_cal = run(5)

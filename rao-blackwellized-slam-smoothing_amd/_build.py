@@ -23,9 +23,11 @@ def _stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -shared ... -> lib/librbpf_hip.so (cross-compiles without a GPU)."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, defines=None, out: str = None) -> str:
+    """hipcc --offload-arch=gfx950 -shared ... -> lib/librbpf_hip.so (cross-compiles without a GPU).
+    `defines` / `out` build a tuning variant (e.g. {"RBPF_UC": 8}) under another file name."""
+    target = out or LIBPATH
+    if out is None and not force and not _stale():
         return LIBPATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -33,15 +35,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
            "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
+    cmd += [f"-D{k}={v}" for k, v in (defines or {}).items()]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIBPATH + ".tmp"]
+    cmd += ["-o", target + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout)
-    os.replace(LIBPATH + ".tmp", LIBPATH)
-    return LIBPATH
+    os.replace(target + ".tmp", target)
+    return target
 
 
 if __name__ == "__main__":

@@ -91,7 +91,7 @@ def load_library(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIBPATH
+    path = os.environ.get("RBPF_LIB_PATH") or _build.LIBPATH     # RBPF_LIB_PATH: tuning variants only
     if not os.path.exists(path):
         if not build_if_missing:
             raise RBPFError(RBPF_ERR_NO_DEVICE, f"{path} not built (run __graft_entry__.build())")

@@ -316,7 +316,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw) {
     SearchArgs s;
     s.N = N; s.n_draw = n_draw; s.t = t; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
     s.U = c->d_U ? c->d_U + rng_page + (size_t)(t - 1) * N : nullptr;
-    s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1;
+    s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
     HIPCHK(launch_search(s, c->stream));
   }
   StepArgs a;

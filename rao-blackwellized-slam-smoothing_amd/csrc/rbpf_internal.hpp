@@ -73,6 +73,8 @@ struct NormArgs {
 
 struct SearchArgs {
   int N, n_draw, t;
+  int slot0 = 0;        // first slot drawn: slot = slot0 + i (uniform and output index)
+  int u_is_scalar = 0;  // replay: every draw uses U[0] (the `ak = sample(w)` draw)
   const double* wc;
   int rng_mode; int k_iter;
   const double* U;      // replay uniforms of this step [N]
@@ -100,7 +102,8 @@ hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A,
                             int n_paths, double* out, hipStream_t s);
 hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,
                               double* Ufin, hipStream_t s);
-hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s);
+// layout 0: dy[p][c][k] (MATLAB [ny x nLin x Npred]); layout 1: dy[p][k][c] (rows of H contiguous)
+hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s, int layout = 0);
 hipError_t launch_dyn_model(const ModelDev& m, int np, const double* xn, const double* odo, const double* cholQ,
                             const double* z, double* xn_next, hipStream_t s);
 hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, const double* xn,

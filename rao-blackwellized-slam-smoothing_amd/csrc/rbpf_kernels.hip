@@ -17,7 +17,37 @@
 #include "rbpf_internal.hpp"
 #include "rbpf_device.hpp"
 
+#include <cstdlib>
+
+#ifndef RBPF_UC
+#define RBPF_UC 8          // columns kept in flight per wave in the covariance stream
+#endif
+#ifndef RBPF_NT_LOAD
+#define RBPF_NT_LOAD 1     // 1: nontemporal loads of the streamed covariance
+#endif
+#ifndef RBPF_NT_STORE
+#define RBPF_NT_STORE 1    // 1: nontemporal stores of the streamed covariance
+#endif
+
 namespace rbpf {
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ dbl2 ld_stream(const double* p) {
+#if RBPF_NT_LOAD
+  return __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(p));
+#else
+  return *reinterpret_cast<const dbl2*>(p);
+#endif
+}
+
+__device__ __forceinline__ void st_stream(double* p, dbl2 v) {
+#if RBPF_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(p));
+#else
+  *reinterpret_cast<dbl2*>(p) = v;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // layout helpers (host + device)
@@ -59,6 +89,12 @@ Layout make_layout(int n, int d) {
   else if (L.CH == 3) { L.RS = 1; L.CS = kWaves; }
   else if (L.CH == 2) { L.RS = 2; L.CS = 2; }
   else { L.RS = 1; L.CS = kWaves; }
+  if (const char* e = getenv("RBPF_RS")) {          // tuning override: RS x CS must be <= 4
+    const int rs = atoi(e);
+    const char* e2 = getenv("RBPF_CS");
+    const int cs = e2 ? atoi(e2) : kWaves / (rs > 0 ? rs : 1);
+    if (rs >= 1 && cs >= 1 && rs * cs <= kWaves && L.CH > 0) { L.RS = rs; L.CS = cs; }
+  }
   L.CPL = L.CH > 0 ? (L.CH + L.RS - 1) / L.RS : 1;
   L.szT = (size_t)n * L.mc;
   L.szB = (size_t)L.nb * L.ldb;
@@ -151,12 +187,12 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 
   int c = wc;
   for (; c + (UC - 1) * CS < n; c += UC * CS) {
-    double2 v[UC][CPL];
+    dbl2 v[UC][CPL];
 #pragma unroll
     for (int u = 0; u < UC; ++u)
 #pragma unroll
       for (int q = 0; q < CPL; ++q)
-        if (on[q]) v[u][q] = *reinterpret_cast<const double2*>(src + (size_t)(c + u * CS) * mc + r0[q]);
+        if (on[q]) v[u][q] = ld_stream(src + (size_t)(c + u * CS) * mc + r0[q]);
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
       const int cc = c + u * CS;
@@ -171,8 +207,8 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
         for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
         for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
-        double2 o; o.x = p0; o.y = p1;
-        *reinterpret_cast<double2*>(dst + (size_t)cc * mc + r0[q]) = o;
+        dbl2 o; o.x = p0; o.y = p1;
+        st_stream(dst + (size_t)cc * mc + r0[q], o);
       }
     }
   }
@@ -183,14 +219,14 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       if (!on[q]) continue;
-      const double2 vv = *reinterpret_cast<const double2*>(src + (size_t)c * mc + r0[q]);
+      const dbl2 vv = ld_stream(src + (size_t)c * mc + r0[q]);
       double p0 = vv.x, p1 = vv.y;
 #pragma unroll
       for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
       for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
-      double2 o; o.x = p0; o.y = p1;
-      *reinterpret_cast<double2*>(dst + (size_t)c * mc + r0[q]) = o;
+      dbl2 o; o.x = p0; o.y = p1;
+      st_stream(dst + (size_t)c * mc + r0[q], o);
     }
   }
 #pragma unroll
@@ -279,7 +315,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
       const double* src = a.Pt_old + (size_t)anc * a.Pt_old_stride;
       double* dst = a.Pt_new + (size_t)i * Ly.szT;
       double* out_acc = parts + (size_t)wc * D * mc;
-      stream_core<D, CPL, 4>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
+      stream_core<D, CPL, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
@@ -479,10 +515,44 @@ __device__ inline double block_max_1024(double v, double* sred) {
   return s;
 }
 
+// Strict left-to-right running sum (bit-identical to a sequential cumsum) by one lane.  The chain of
+// dependent fp64 adds is the floor (~N x add latency); loads / stores are batched 16 wide through two
+// distinct LDS arrays so they never sit on the dependency chain.
+__device__ inline void strict_cumsum_block(int N, const double* __restrict__ w, double* __restrict__ wc,
+                                           double* __restrict__ sin_, double* __restrict__ sout, double* scarry) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  if (tid == 0) *scarry = 0.0;
+  __syncthreads();
+  for (int base = 0; base < N; base += kScanChunk) {
+    const int cnt = min(kScanChunk, N - base);
+    for (int j = tid; j < cnt; j += nthr) sin_[j] = w[base + j];
+    __syncthreads();
+    if (tid == 0) {
+      double run = *scarry;
+      int j = 0;
+      for (; j + 16 <= cnt; j += 16) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sin_[j + k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { run += v[k]; v[k] = run; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sout[j + k] = v[k];
+      }
+      for (; j < cnt; ++j) { run += sin_[j]; sout[j] = run; }
+      *scarry = run;
+    }
+    __syncthreads();
+    for (int j = tid; j < cnt; j += nthr) wc[base + j] = sout[j];
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const NormArgs a) {
   __shared__ double sred[16];
   __shared__ int sidx[16];
   __shared__ double sbuf[kScanChunk];
+  __shared__ double sbuf2[kScanChunk];
   __shared__ double scarry;
   const int tid = threadIdx.x, N = a.N;
   const int lane = tid & 63, wave = tid >> 6;
@@ -533,22 +603,7 @@ __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const Norm
     }
   }
   // wc = cumsum(w): one lane, strict left-to-right, staged through LDS in chunks
-  if (tid == 0) scarry = 0.0;
-  __syncthreads();
-  for (int base = 0; base < N; base += kScanChunk) {
-    const int cnt = min(kScanChunk, N - base);
-    for (int j = tid; j < cnt; j += kNormThreads) sbuf[j] = a.w[base + j];
-    __syncthreads();
-    if (tid == 0) {
-      double run = scarry;
-#pragma unroll 8
-      for (int j = 0; j < cnt; ++j) { run += sbuf[j]; sbuf[j] = run; }
-      scarry = run;
-    }
-    __syncthreads();
-    for (int j = tid; j < cnt; j += kNormThreads) a.wc[base + j] = sbuf[j];
-    __syncthreads();
-  }
+  strict_cumsum_block(N, a.w, a.wc, sbuf, sbuf2, &scarry);
 }
 
 hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
@@ -560,24 +615,9 @@ hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
 __global__ __launch_bounds__(kNormThreads) void cumsum_kernel(int N, const double* __restrict__ w,
                                                               double* __restrict__ wc) {
   __shared__ double sbuf[kScanChunk];
+  __shared__ double sbuf2[kScanChunk];
   __shared__ double scarry;
-  const int tid = threadIdx.x;
-  if (tid == 0) scarry = 0.0;
-  __syncthreads();
-  for (int base = 0; base < N; base += kScanChunk) {
-    const int cnt = min(kScanChunk, N - base);
-    for (int j = tid; j < cnt; j += kNormThreads) sbuf[j] = w[base + j];
-    __syncthreads();
-    if (tid == 0) {
-      double run = scarry;
-#pragma unroll 8
-      for (int j = 0; j < cnt; ++j) { run += sbuf[j]; sbuf[j] = run; }
-      scarry = run;
-    }
-    __syncthreads();
-    for (int j = tid; j < cnt; j += kNormThreads) wc[base + j] = sbuf[j];
-    __syncthreads();
-  }
+  strict_cumsum_block(N, w, wc, sbuf, sbuf2, &scarry);
 }
 
 hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s) {
@@ -587,9 +627,10 @@ hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s) {
 
 // ind = sum(wc < u) (0-based), clamped to N-1 (the reference would return N+1 -> MATLAB error)
 __global__ void search_kernel(const SearchArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_draw) return;
-  const double u = (a.rng_mode == 0) ? a.U[i] : philox_resample_uniform(a.seed, i, a.t, a.k_iter);
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= a.n_draw) return;
+  const int i = a.slot0 + i0;
+  const double u = (a.rng_mode == 0) ? a.U[a.u_is_scalar ? 0 : i] : philox_resample_uniform(a.seed, i, a.t, a.k_iter);
   int lo = 0, hi = a.N;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -720,7 +761,8 @@ hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T,
 // standalone model kernels (parity tests of SURVEY 8a rows a3-a8, a17, a19)
 // ---------------------------------------------------------------------------------------------
 template <int D>
-__global__ void meas_model_kernel(ModelDev M, int npred, const double* __restrict__ xn, double* __restrict__ dy) {
+__global__ void meas_model_kernel(ModelDev M, int npred, const double* __restrict__ xn, double* __restrict__ dy,
+                                  int layout) {
   extern __shared__ double sm[];
   double* tabS = sm;
   double* tabC = sm + (M.ktot > 0 ? M.ktot : 1);
@@ -736,14 +778,14 @@ __global__ void meas_model_kernel(ModelDev M, int npred, const double* __restric
   for (int c = threadIdx.x; c < M.n; c += blockDim.x) {
     double h[D];
     H_column<D>(M, c, tabS, tabC, &misc[8], h);
-    for (int k = 0; k < D; ++k) dy[((size_t)p * M.n + c) * D + k] = h[k];
+    for (int k = 0; k < D; ++k) dy[layout ? ((size_t)p * D + k) * M.n + c : ((size_t)p * M.n + c) * D + k] = h[k];
   }
 }
 
-hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s) {
+hipError_t launch_meas_model(const ModelDev& m, int npred, const double* xn, double* dy, hipStream_t s, int layout) {
   const size_t lds = (size_t)(2 * (m.ktot > 0 ? m.ktot : 1) + 32) * sizeof(double);
-  if (m.d == 3) hipLaunchKernelGGL((meas_model_kernel<3>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy);
-  else if (m.d == 1) hipLaunchKernelGGL((meas_model_kernel<1>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy);
+  if (m.d == 3) hipLaunchKernelGGL((meas_model_kernel<3>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy, layout);
+  else if (m.d == 1) hipLaunchKernelGGL((meas_model_kernel<1>), dim3(npred), dim3(256), lds, s, m, npred, xn, dy, layout);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

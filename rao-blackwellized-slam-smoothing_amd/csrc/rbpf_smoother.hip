@@ -1,16 +1,580 @@
-// Conditional particle filter with ancestor sampling (src/particleSmoother.m,
-// src/particleSmootherInformationForm.m) on the device.
+// Conditional particle filter with ancestor sampling (CPF-AS), iterated N_K times:
+//   src/particleSmoother.m                 (covariance-form ancestor weights, :156-245)
+//   src/particleSmootherInformationForm.m  (information-form weights, :194-254, :279-335)
+// Every time step re-uses the filter's fused step kernel (rbpf_kernels.hip); this file adds the
+// reference-trajectory machinery: ancestor weights of slot N_P, the extra information-form state
+// (Imat, ivec, halfLogDetP) and the per-iteration trajectory draw.
 #include "../../include/rbpf.h"
 #include "rbpf_internal.hpp"
 #include "rbpf_ctx.hpp"
+#include "rbpf_device.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
 
 namespace rbpf {
-struct SmootherState {};
-void smoother_free(rbpf_ctx* c) { delete c->sm; c->sm = nullptr; }
+
+struct SmootherState {
+  double* d_xnk = nullptr;      // [T][nN] reference trajectory of this iteration (row per step)
+  double* d_dyref = nullptr;    // [T][d][n] H along the reference trajectory (:120)
+  double* d_pant_log = nullptr; // [N]
+  double* d_pant = nullptr;     // [N] (or [T][N] when tracing)
+  double* d_wc2 = nullptr;      // [N]
+  double* d_Pfull = nullptr;    // cov form: [N][n*n] flushed covariances
+  double* d_G = nullptr;        // cov form: [N][Mmax*n]
+  double* d_S = nullptr;        // [N][Mmax*Mmax] (cov) / unused (info)
+  double* d_L = nullptr;        // [N][Mmax*Mmax] or [N][n*n] Cholesky factors
+  double* d_e = nullptr;        // [N][Mmax]
+  // information form
+  double* d_Imat[2] = {nullptr, nullptr};   // [N][n*n] column-major, ping-pong
+  double* d_Hb[2] = {nullptr, nullptr};     // [N][d][ldx] H used by the last update (pending Imat term)
+  double* d_ivec[2] = {nullptr, nullptr};   // [N][ldx]
+  double* d_hld[2] = {nullptr, nullptr};    // [N]
+  double* d_qf[2] = {nullptr, nullptr};     // [N] ivec' P ivec after the last update
+  double* d_ImatAdd = nullptr;  // [n*n]
+  double* d_ivecAdd = nullptr;  // [n]
+  double* d_Imat0 = nullptr;    // [n*n] diag(1./diag(P0))
+  int* d_ak = nullptr;
+  size_t Mmax = 0;
+};
+
+void smoother_free(rbpf_ctx* c) {
+  SmootherState* s = c->sm;
+  if (!s) return;
+  hipFree(s->d_xnk); hipFree(s->d_dyref); hipFree(s->d_pant_log); hipFree(s->d_pant); hipFree(s->d_wc2);
+  hipFree(s->d_Pfull); hipFree(s->d_G); hipFree(s->d_S); hipFree(s->d_L); hipFree(s->d_e);
+  for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
+  hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak);
+  delete s;
+  c->sm = nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// paNtLog(i) = log(w(i)) + logwDyn  (particleSmoother.m:175-182,232); logwMeas is added later.
+__global__ void anc_dyn_kernel(ModelDev M, int N, const double* __restrict__ xn_prev /*SoA [nN][N]*/,
+                               const double* __restrict__ xnk_t, const double* __restrict__ odo,
+                               const double* __restrict__ Lq, const double* __restrict__ w, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double xi[8], xk[8], ed[8];
+  for (int c = 0; c < M.nN; ++c) { xi[c] = xn_prev[(size_t)c * N + i]; xk[c] = xnk_t[c]; }
+  // same arithmetic as rbpf_kernels.hip::dyn_res_norm_dev (kept local: separate TU)
+  double r[8];
+  const int nw = M.nw;
+  if (M.use_dyn_res_norm && M.kind == 1) {                       // run_dense3D_magfield.m:202-203
+    for (int c = 0; c < 3; ++c) r[c] = xk[c] - xi[c] - odo[c];
+    const double oqi[4] = {odo[3], -odo[4], -odo[5], -odo[6]};
+    const double xqi[4] = {xi[3], -xi[4], -xi[5], -xi[6]};
+    double t1[4], t2[4];
+    qleft_mul(oqi, xqi, t1);
+    qleft_mul(t1, &xk[3], t2);
+    logq_dev(t2, &r[3]);
+  } else if (M.use_dyn_res_norm && M.kind == 2) {                // run_dense2D_withHeading.m:77
+    r[0] = xk[2] - xi[2] - odo[2];
+  } else {                                                       // particleSmoother.m:176
+    for (int c = 0; c < nw; ++c) r[c] = xk[c] - xi[c] - odo[c];
+  }
+  for (int q = nw - 1; q >= 0; --q) {                            // r' / Lq
+    double s = r[q];
+    for (int k = q + 1; k < nw; ++k) s -= Lq[k + nw * q] * ed[k];
+    ed[q] = s / Lq[q + nw * q];
+  }
+  double ss = 0.0;
+  for (int q = 0; q < nw; ++q) ss += ed[q] * ed[q];
+  out[i] = log(w[i]) + (-0.5 * ss);
+}
+
+// Generic strided fp64 GEMM, batched over blockIdx.z:  C = A * B  (+ diagonal blocks of Rblk)
+// element (i,k) of A at A[i*rsA + k*csA] etc.  32x32 output tile, 16x16 threads, 2x2 per thread.
+struct GemmArgs {
+  int M, N, K;
+  const double* A; long rsA, csA, bsA;
+  const double* B; long rsB, csB, bsB;
+  double* C; long rsC, csC, bsC;
+};
+
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ double As[32][33];
+  __shared__ double Bs[32][33];
+  const int bz = blockIdx.z;
+  const double* A = g.A + (size_t)bz * g.bsA;
+  const double* B = g.B + (size_t)bz * g.bsB;
+  double* C = g.C + (size_t)bz * g.bsC;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  double acc[2][2] = {{0, 0}, {0, 0}};
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    for (int q = threadIdx.x; q < 1024; q += 256) {
+      const int r = q >> 5, cc = q & 31;
+      const int ia = i0 + r, ka = k0 + cc;
+      As[r][cc] = (ia < g.M && ka < g.K) ? A[(size_t)ia * g.rsA + (size_t)ka * g.csA] : 0.0;
+      const int kb = k0 + r, jb = j0 + cc;
+      Bs[r][cc] = (kb < g.K && jb < g.N) ? B[(size_t)kb * g.rsB + (size_t)jb * g.csB] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double a0 = As[ty][k], a1 = As[ty + 16][k];
+      const double b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
+      acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
+      acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
+      if (i < g.M && j < g.N) C[(size_t)i * g.rsC + (size_t)j * g.csC] = acc[a][b];
+    }
+}
+
+static hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t s) {
+  dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, batch);
+  hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
+  return hipGetLastError();
+}
+
+// Batched dense Cholesky + forward solve, one workgroup per particle (left-looking, thread per row).
+//   MODE 0 (covariance form, particleSmoother.m:191-229):
+//     A = S_j + kron(I,R) ; rhs = ytf - dyf*xl_j ; jitter retry (:221-224);
+//     logwMeas = -sum(log(diag(cS))) - .5 v'v - numel(e)/2 log(2pi)
+//   MODE 1 (information form, particleSmootherInformationForm.m:224-236):
+//     A = Imat_j (+ pending H'R^-1 H) + ImatAddt ; rhs = ivec_j + ivecAddt ; no usable retry (quirk Q4);
+//     logwMeas = -.5 qf_j - halfLogDetP_j - sum(log(diag(cI))) + .5 v'v
+struct CholArgs {
+  int mode, Msz, d, n, ldx;
+  double* Lbuf; long ldL;           // [batch][Msz*Msz] column-major factors
+  // mode 0
+  const double* S; const double* R; const double* yf; const double* dyf; const double* xl; double jitter;
+  // mode 1
+  const double* Imat; const double* Hb; const double* Rinv; const double* ImatAdd; const double* ivec;
+  const double* ivecAdd; const double* qf; const double* hld;
+  double* pant_log;                 // += logwMeas
+  int* status;
+};
+
+__device__ inline double chol_elem(const CholArgs& a, int p, int i, int j) {
+  if (a.mode == 0) {
+    double v = a.S[(size_t)p * a.Msz * a.Msz + (size_t)i + (size_t)a.Msz * j];
+    if (i / a.d == j / a.d) v += a.R[(i % a.d) + a.d * (j % a.d)];          // kron(eye, R)
+    return v;
+  }
+  double v = a.Imat[(size_t)p * a.n * a.n + (size_t)i + (size_t)a.n * j];
+  if (a.Hb) {                                                               // pending dyi'/R*dyi (:334)
+    const double* H = a.Hb + (size_t)p * a.d * a.ldx;
+    double s = 0.0;
+    for (int aa = 0; aa < a.d; ++aa) {
+      double t = 0.0;
+      for (int bb = 0; bb < a.d; ++bb) t = fma(a.Rinv[aa + a.d * bb], H[(size_t)bb * a.ldx + j], t);
+      s = fma(H[(size_t)aa * a.ldx + i], t, s);
+    }
+    v += s;
+  }
+  return v + a.ImatAdd[(size_t)i + (size_t)a.n * j];                        // :225
+}
+
+__global__ __launch_bounds__(256) void chol_solve_kernel(CholArgs a) {
+  __shared__ double sbc[4];
+  __shared__ int sfail;
+  const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
+  double* L = a.Lbuf + (size_t)p * a.ldL;
+  constexpr int RPT = 4;                       // rows per thread: M <= 1024
+  double rhs[RPT];
+  for (int q = 0; q < RPT; ++q) {
+    const int i = tid + 256 * q;
+    rhs[q] = 0.0;
+    if (i < M) {
+      if (a.mode == 0) {
+        double s = 0.0;
+        const double* dr = a.dyf + (size_t)i * a.n;
+        const double* x = a.xl + (size_t)p * a.ldx;
+        for (int c = 0; c < a.n; ++c) s = fma(dr[c], x[c], s);
+        rhs[q] = a.yf[i] - s;                                               // particleSmoother.m:193
+      } else {
+        rhs[q] = a.ivec[(size_t)p * a.ldx + i] + a.ivecAdd[i];              // InformationForm.m:224
+      }
+    }
+  }
+  double rhs0[RPT];
+  for (int q = 0; q < RPT; ++q) rhs0[q] = rhs[q];
+  double jit = 0.0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) sfail = 0;
+    double sl = 0.0, vv = 0.0;
+    __syncthreads();
+    for (int j = 0; j < M; ++j) {
+      // column j, rows i >= j:  v_i = A(i,j) - sum_{k<j} L(i,k) L(j,k)
+      double val[RPT];
+      for (int q = 0; q < RPT; ++q) {
+        const int i = tid + 256 * q;
+        val[q] = 0.0;
+        if (i >= j && i < M) {
+          double s = chol_elem(a, p, i, j);
+          if (i == j) s += jit;
+          const double* Li = L + i;
+          const double* Lj = L + j;
+          int k = 0;
+          for (; k + 4 <= j; k += 4) {
+            const double a0 = Li[(size_t)M * k], a1 = Li[(size_t)M * (k + 1)], a2 = Li[(size_t)M * (k + 2)], a3 = Li[(size_t)M * (k + 3)];
+            const double b0 = Lj[(size_t)M * k], b1 = Lj[(size_t)M * (k + 1)], b2 = Lj[(size_t)M * (k + 2)], b3 = Lj[(size_t)M * (k + 3)];
+            s = fma(-a0, b0, s); s = fma(-a1, b1, s); s = fma(-a2, b2, s); s = fma(-a3, b3, s);
+          }
+          for (; k < j; ++k) s = fma(-Li[(size_t)M * k], Lj[(size_t)M * k], s);
+          val[q] = s;
+          if (i == j) {
+            if (!(s > 0.0)) sfail = 1;
+            const double ljj = sqrt(s);
+            sbc[0] = ljj;
+            sbc[1] = rhs[q] / ljj;            // v_j of the forward solve cS\e
+          }
+        }
+      }
+      __syncthreads();
+      if (sfail) break;
+      const double ljj = sbc[0], vj = sbc[1];
+      if (tid == 0) { sl += log(ljj); vv += vj * vj; }
+      for (int q = 0; q < RPT; ++q) {
+        const int i = tid + 256 * q;
+        if (i >= j && i < M) {
+          const double lij = (i == j) ? ljj : val[q] / ljj;
+          L[(size_t)i + (size_t)M * j] = lij;
+          if (i > j) rhs[q] = fma(-lij, vj, rhs[q]);
+        }
+      }
+      __syncthreads();
+    }
+    const int failed = sfail;
+    __syncthreads();
+    if (!failed) {
+      if (tid == 0) {
+        double lw;
+        if (a.mode == 0) lw = -sl - 0.5 * vv - 0.5 * (double)M * 1.8378770664093453;     // log(2*pi)
+        else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
+        a.pant_log[p] += lw;
+      }
+      return;
+    }
+    if (a.mode == 1 || attempt == 1) {
+      if (tid == 0) { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
+      return;
+    }
+    jit = a.jitter;                                                         // particleSmoother.m:223
+    for (int q = 0; q < RPT; ++q) rhs[q] = rhs0[q];
+  }
+}
+
+// [T][nN] row-per-step trajectory -> per-step pointer is d_xnk + t*nN.  Backtrace writes [nN x T]
+// column-major (= [T][nN] row-per-step), so no transpose is needed.
+
+// Sum over the reference trajectory (InformationForm.m:132-146), in the reference's order jj = 1..T,
+// and the per-step decrement (:194-201).  sign = +1 accumulates steps [t0,t1), -1 subtracts them.
+__global__ void info_addt_kernel(int n, int d, int t0, int t1, double sign, const double* __restrict__ dyref,
+                                 const double* __restrict__ Rinv, const double* __restrict__ y,
+                                 double* __restrict__ ImatAdd, double* __restrict__ ivecAdd) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)n * n) return;
+  const int i = (int)(q % n), j = (int)(q / n);
+  double acc = ImatAdd[q];
+  double av = (j == 0) ? ivecAdd[i] : 0.0;
+  for (int t = t0; t < t1; ++t) {
+    const double* H = dyref + (size_t)t * d * n;
+    double s = 0.0, sv = 0.0;
+    for (int a = 0; a < d; ++a) {
+      double tt = 0.0, ty = 0.0;
+      for (int b = 0; b < d; ++b) { tt = fma(Rinv[a + d * b], H[(size_t)b * n + j], tt); ty = fma(Rinv[a + d * b], y[(size_t)t * d + b], ty); }
+      s = fma(H[(size_t)a * n + i], tt, s);
+      sv = fma(H[(size_t)a * n + i], ty, sv);
+    }
+    acc += sign * s;
+    av += sign * sv;
+  }
+  ImatAdd[q] = acc;
+  if (j == 0) ivecAdd[i] = av;
+}
+
+// Imat_new(:,:,i) = Imat_old(:,:,ai(i)) + dy' / R * dy of the ancestor's last update (:170, :334)
+__global__ void imat_gather_kernel(int n, int d, int ldx, const int* __restrict__ ai, const double* __restrict__ Iold,
+                                   size_t old_stride, const double* __restrict__ Hb, const double* __restrict__ Rinv,
+                                   double* __restrict__ Inew) {
+  const int p = blockIdx.x;
+  const int a = ai ? ai[p] : p;
+  const double* src = Iold + (size_t)a * old_stride;
+  const double* H = Hb ? Hb + (size_t)a * d * ldx : nullptr;
+  double* dst = Inew + (size_t)p * n * n;
+  const size_t nn = (size_t)n * n;
+  for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
+    const int i = (int)(q % n), j = (int)(q / n);
+    double v = src[q];
+    if (H) {
+      double s = 0.0;
+      for (int aa = 0; aa < d; ++aa) {
+        double t = 0.0;
+        for (int bb = 0; bb < d; ++bb) t = fma(Rinv[aa + d * bb], H[(size_t)bb * ldx + j], t);
+        s = fma(H[(size_t)aa * ldx + i], t, s);
+      }
+      v += s;
+    }
+    dst[q] = v;
+  }
+}
+
+__global__ void gather_scalar_kernel(int N, const int* __restrict__ ai, const double* __restrict__ in, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = in[ai ? ai[i] : i];
+}
+
+__global__ void fill_kernel(size_t count, double v, double* p) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < count) p[q] = v;
+}
+
 }  // namespace rbpf
 
-extern "C" int rbpf_particle_smoother(const rbpf_model*, const rbpf_problem*, const rbpf_rng*, const rbpf_options*,
-                                      int32_t, int32_t, rbpf_smoother_out*) {
-  rbpf::set_error("smoother: not built yet");
-  return RBPF_ERR_UNSUPPORTED;
+using namespace rbpf;
+
+// information-form hooks (defined below)
+static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, double qf0, double halfLogDetR, const double* d_Rinv);
+static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv);
+static int info_pre_step(rbpf_ctx* c, int k, int t, int n_draw);
+
+#define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+  *p = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
+  return RBPF_OK;
+}
+
+static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* out) {
+  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
+  const Layout& L = c->lay;
+  hipStream_t st = c->stream;
+  SmootherState* s = new SmootherState();
+  c->sm = s;
+  if (!c->mdl.use_dyn_res_norm && nw != nN) {
+    set_error("isempty(dynResNorm): the additive default (particleSmoother.m:176) needs size(Q,1) == nNonLin");
+    return RBPF_ERR_INVALID_ARG;
+  }
+  const size_t Mmax = (size_t)d * T;
+  s->Mmax = Mmax;
+  RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
+  RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
+  RB_TRY(dmalloc(&s->d_pant_log, (size_t)N));
+  RB_TRY(dmalloc(&s->d_pant, (size_t)N * (c->opt.trace ? (size_t)T * N_K : 1)));
+  {
+    const size_t cnt = (size_t)N * (c->opt.trace ? (size_t)T * N_K : 1);
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, (double)NAN, s->d_pant);
+    HIPCHK(hipGetLastError());
+  }
+  RB_TRY(dmalloc(&s->d_wc2, (size_t)N));
+  RB_TRY(dmalloc(&s->d_ak, 4));
+  std::vector<double> Rinv((size_t)d * d), Rh(c->h_R);
+  double halfLogDetR = 0.0;
+  {  // R^-1 and 0.5*log(det(R)) via Cholesky (d <= 8)
+    std::vector<double> Lr((size_t)d * d, 0.0);
+    for (int j = 0; j < d; ++j) {
+      double sdiag = Rh[j + (size_t)d * j];
+      for (int k = 0; k < j; ++k) sdiag -= Lr[j + (size_t)d * k] * Lr[j + (size_t)d * k];
+      if (!(sdiag > 0)) { set_error("R must be positive definite"); return RBPF_ERR_CHOL_FAILED; }
+      Lr[j + (size_t)d * j] = std::sqrt(sdiag);
+      for (int i = j + 1; i < d; ++i) {
+        double v = Rh[i + (size_t)d * j];
+        for (int k = 0; k < j; ++k) v -= Lr[i + (size_t)d * k] * Lr[j + (size_t)d * k];
+        Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
+      }
+      halfLogDetR += std::log(Lr[j + (size_t)d * j]);
+    }
+    for (int col = 0; col < d; ++col) {             // solve R x = e_col
+      std::vector<double> y(d), x(d);
+      for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + (size_t)d * k] * y[k]; y[i] = v / Lr[i + (size_t)d * i]; }
+      for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + (size_t)d * i] * x[k]; x[i] = v / Lr[i + (size_t)d * i]; }
+      for (int i = 0; i < d; ++i) Rinv[i + (size_t)d * col] = x[i];
+    }
+  }
+  double *d_R = nullptr, *d_Rinv = nullptr;
+  RB_TRY(dmalloc(&d_R, (size_t)d * d));
+  RB_TRY(dmalloc(&d_Rinv, (size_t)d * d));
+  struct Guard { double* a; double* b; ~Guard() { hipFree(a); hipFree(b); } } guard{d_R, d_Rinv};
+  HIPCHK(hipMemcpy(d_R, Rh.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+
+  if (!info_form) {
+    RB_TRY(dmalloc(&s->d_Pfull, (size_t)N * n * n));
+    RB_TRY(dmalloc(&s->d_G, (size_t)N * Mmax * n));
+    RB_TRY(dmalloc(&s->d_S, (size_t)N * Mmax * Mmax));
+    RB_TRY(dmalloc(&s->d_L, (size_t)N * Mmax * Mmax));
+    if (Mmax > 1024) { set_error("covariance-form smoother supports ny*N_T <= 1024 (use the information form for long T)"); return RBPF_ERR_UNSUPPORTED; }
+  } else {
+    if (n > 1024) { set_error("information-form smoother supports nLin <= 1024"); return RBPF_ERR_UNSUPPORTED; }
+    if (c->x0_lin_cols != 1) {
+      // quirk Q5: the reference's repmat(x0_lin,1,N_P) (:109) only works for a single column
+      set_error("particleSmootherInformationForm: x0_lin must be nLin x 1 (the reference repmat's it, :109)");
+      return RBPF_ERR_INVALID_ARG;
+    }
+    for (int b = 0; b < 2; ++b) {
+      RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * n * n));
+      RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
+      RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
+      RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
+      RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
+    }
+    RB_TRY(dmalloc(&s->d_L, (size_t)N * n * n));
+    RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
+    RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
+    RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
+  }
+  // information-form initial values (quirk Q5: diagonal of P0 only, :110-115)
+  std::vector<double> ivec0(L.ldx, 0.0), Imat0((size_t)n * n, 0.0);
+  double hld0 = 0.0, qf0 = 0.0;
+  if (info_form) {
+    for (int r = 0; r < n; ++r) {
+      const double pd = c->h_P0[r + (size_t)n * r];
+      Imat0[r + (size_t)n * r] = 1.0 / pd;
+      ivec0[r] = (1.0 / pd) * c->h_x0l[r];
+      hld0 += std::log(std::sqrt(pd));
+    }
+    for (int r = 0; r < n; ++r) {                    // ivec0' * P0 * ivec0 (full P0, as :301 uses P)
+      double sacc = 0.0;
+      for (int cc = 0; cc < n; ++cc) sacc += c->h_P0[r + (size_t)n * cc] * ivec0[cc];
+      qf0 += ivec0[r] * sacc;
+    }
+    HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+  }
+
+  std::vector<double> xnk_h((size_t)nN * T);
+  for (int k = 0; k < N_K; ++k) {
+    RB_TRY(ctx_reset(c));
+    if (info_form) {
+      RB_TRY(info_begin_iteration(c, ivec0.data(), hld0, qf0, halfLogDetR, d_Rinv));
+    }
+    if (k > 0) {
+      // dy_xnk = measModel(xnk)  (:120)
+      HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, st, 1));
+      if (info_form) {                                                       // :132-146
+        HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, st));
+        HIPCHK(hipMemsetAsync(s->d_ivecAdd, 0, (size_t)n * 8, st));
+        hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, 0, T,
+                           1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+        HIPCHK(hipGetLastError());
+      }
+    }
+    for (int t = 0; t < T; ++t) {
+      const double* xref = (k > 0) ? s->d_xnk + (size_t)t * nN : nullptr;
+      int n_draw = N;
+      if (k > 0 && t > 0) {
+        n_draw = N - 1;
+        // ---- ancestor weights of the reference trajectory (Steps 9-10 of Alg. 2) ----
+        const double* X_prev = c->X + (size_t)(t - 1) * nN * N;
+        const size_t tr_prev = c->opt.trace ? (size_t)(t - 1) * N : 0;
+        const double* w_prev = c->w + tr_prev;
+        const double* Lq = c->d_cholQfull + (size_t)((c->chol_pages > 1) ? t - 1 : 0) * nw * nw;
+        hipLaunchKernelGGL(anc_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, c->mdl, N, X_prev, xref,
+                           c->d_odo + (size_t)(t - 1) * c->mdl.nodo, Lq, w_prev, s->d_pant_log);
+        HIPCHK(hipGetLastError());
+        const int cur = c->cur;
+        CholArgs ca;
+        std::memset(&ca, 0, sizeof(ca));
+        ca.d = d; ca.n = n; ca.ldx = L.ldx; ca.pant_log = s->d_pant_log; ca.status = c->d_flags;
+        if (!info_form) {
+          const int M = d * (T - t);
+          HIPCHK(launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], nullptr, N, s->d_Pfull, st));
+          const double* dyf = s->d_dyref + (size_t)t * d * n;              // [(T-t)*d x n] row-major (:163-166)
+          GemmArgs g1{M, n, n, dyf, n, 1, 0, s->d_Pfull, 1, n, (long)((size_t)n * n), s->d_G, n, 1, (long)((size_t)M * n)};
+          HIPCHK(launch_gemm(g1, N, st));                                  // G_j = dy * P_j
+          GemmArgs g2{M, M, n, s->d_G, n, 1, (long)((size_t)M * n), dyf, 1, n, 0, s->d_S, 1, M, (long)((size_t)M * M)};
+          HIPCHK(launch_gemm(g2, N, st));                                  // S_j = G_j * dy'
+          ca.mode = 0; ca.Msz = M; ca.Lbuf = s->d_L; ca.ldL = (long)((size_t)M * M);
+          ca.S = s->d_S; ca.R = d_R; ca.yf = c->d_y + (size_t)t * d; ca.dyf = dyf; ca.xl = c->xl[cur];
+          ca.jitter = c->mdl.jitter;
+        } else {
+          // the (t-1) term leaves the suffix sums (:194-201)
+          hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d,
+                             t - 1, t, -1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+          HIPCHK(hipGetLastError());
+          RB_TRY(info_fill_chol_args(c, ca, d_Rinv));
+        }
+        hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(256), 0, st, ca);
+        HIPCHK(hipGetLastError());
+        // normalise (:236-238), sample ai(N_P) (:241)
+        NormArgs nm;
+        nm.N = N; nm.nN = 0; nm.t = t; nm.logw = s->d_pant_log;
+        nm.w = s->d_pant + (c->opt.trace ? ((size_t)k * T + t) * N : 0);
+        nm.wc = s->d_wc2; nm.xn = nullptr; nm.traj_max = nullptr; nm.traj_mean = nullptr;
+        nm.iw_max = c->d_flags + 3; nm.lse_out = nullptr;
+        HIPCHK(launch_normalise_scan(nm, st));
+        SearchArgs sa;
+        sa.N = N; sa.n_draw = 1; sa.t = t; sa.wc = s->d_wc2; sa.rng_mode = c->rng_mode; sa.k_iter = k;
+        sa.slot0 = N - 1; sa.u_is_scalar = 0;
+        sa.U = c->d_U ? c->d_U + ((size_t)k * (T - 1) + (t - 1)) * N : nullptr;
+        sa.seed = c->seed; sa.ai = c->A + (size_t)t * N; sa.overflow = c->d_flags + 1;
+        HIPCHK(launch_search(sa, st));
+      }
+      if (info_form) RB_TRY(info_pre_step(c, k, t, n_draw));
+      else RB_TRY(ctx_step(c, k, xref, n_draw));
+    }
+    // ---- ak = sample(w); xnk = xn_traj(:,ak,:) (:346-354) ----
+    {
+      const size_t tr_last = c->opt.trace ? (size_t)(T - 1) * N : 0;
+      double* d_uf = c->d_scal;
+      if (c->rng_mode == RBPF_RNG_REPLAY) {
+        HIPCHK(hipMemcpyAsync(d_uf, &c->h_Ufin[k], 8, hipMemcpyHostToDevice, st));
+      }
+      SearchArgs sa;
+      sa.N = N; sa.n_draw = 1; sa.t = T; sa.wc = c->wc; sa.rng_mode = c->rng_mode; sa.k_iter = k; sa.slot0 = 0;
+      sa.U = d_uf; sa.seed = c->seed; sa.ai = s->d_ak; sa.overflow = c->d_flags + 1;
+      sa.u_is_scalar = 1;
+      HIPCHK(launch_search(sa, st));
+      (void)tr_last;
+      HIPCHK(launch_backtrace(N, nN, T, c->X, c->A, s->d_ak, 1, s->d_xnk, st));
+      int ak = 0;
+      HIPCHK(hipMemcpyAsync(&ak, s->d_ak, 4, hipMemcpyDeviceToHost, st));
+      RB_TRY(ctx_check_flags(c));
+      const int cur = c->cur;
+      if (out->XNK) HIPCHK(hipMemcpy(out->XNK + (size_t)k * nN * T, s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
+      if (out->XLK) HIPCHK(hipMemcpy(out->XLK + (size_t)k * n, c->xl[cur] + (size_t)ak * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
+      if (out->PK) {
+        double* dP = nullptr;
+        RB_TRY(dmalloc(&dP, (size_t)n * n));
+        hipError_t e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], s->d_ak, 1, dP, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(out->PK + (size_t)k * n * n, dP, (size_t)n * n * 8, hipMemcpyDeviceToHost);
+        hipFree(dP);
+        HIPCHK(e);
+      }
+      if (out->trace_ak) out->trace_ak[k] = ak;
+      if (c->opt.trace) {
+        if (out->trace_logw) HIPCHK(hipMemcpy(out->trace_logw + (size_t)k * N * T, c->logw, (size_t)N * T * 8, hipMemcpyDeviceToHost));
+        if (out->trace_w) HIPCHK(hipMemcpy(out->trace_w + (size_t)k * N * T, c->w, (size_t)N * T * 8, hipMemcpyDeviceToHost));
+        if (out->trace_ai) HIPCHK(hipMemcpy(out->trace_ai + (size_t)k * N * T, c->A, (size_t)N * T * 4, hipMemcpyDeviceToHost));
+        if (out->trace_paNt && k > 0)
+          HIPCHK(hipMemcpy(out->trace_paNt + (size_t)k * N * T, s->d_pant + (size_t)k * T * N, (size_t)N * T * 8, hipMemcpyDeviceToHost));
+      }
+    }
+  }
+  return RBPF_OK;
+}
+
+static int info_begin_iteration(rbpf_ctx*, const double*, double, double, double, const double*) { set_error("information form: not built yet"); return RBPF_ERR_UNSUPPORTED; }
+static int info_fill_chol_args(rbpf_ctx*, CholArgs&, const double*) { return RBPF_ERR_UNSUPPORTED; }
+static int info_pre_step(rbpf_ctx*, int, int, int) { return RBPF_ERR_UNSUPPORTED; }
+
+extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                                      const rbpf_options* opt, int32_t N_K, int32_t info_form, rbpf_smoother_out* out) {
+  if (!out || N_K < 1) { set_error("bad smoother arguments"); return RBPF_ERR_INVALID_ARG; }
+  rbpf_ctx* c = nullptr;
+  int st = ctx_create(model, prob, rng, opt, true, N_K, &c);
+  if (st != RBPF_OK) return st;
+  st = smoother_run(c, N_K, info_form, out);
+  if (st == RBPF_OK) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) st = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);
+  }
+  ctx_free(c);
+  return st;
 }
