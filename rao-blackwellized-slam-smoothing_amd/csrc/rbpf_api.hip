@@ -111,6 +111,18 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
     if (!(M.L[a] > 0)) { set_error("domain half-widths L must be positive"); return RBPF_ERR_INVALID_ARG; }
   }
   for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
+  if (R) {   // inv(R) and 0.5*log(det(R)) for the information-form recursions (:292,298,304)
+    double Lr[64] = {0};
+    if (d > 8 || !chol_lower_host(R, d, d, Lr, d)) { set_error("R must be positive definite"); return RBPF_ERR_CHOL_FAILED; }
+    M.halfLogDetR = 0.0;
+    for (int j = 0; j < d; ++j) M.halfLogDetR += std::log(Lr[j + d * j]);
+    for (int col = 0; col < d; ++col) {
+      double y[8], x[8];
+      for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + d * k] * y[k]; y[i] = v / Lr[i + d * i]; }
+      for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + d * i] * x[k]; x[i] = v / Lr[i + d * i]; }
+      for (int i = 0; i < d; ++i) M.Rinv[i + d * col] = x[i];
+    }
+  }
   M.jitter = jitter;
   M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
   return RBPF_OK;
@@ -165,7 +177,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   std::vector<int> nn;
   RB_TRY(fill_model_dev(model, prob->n_nonlin, prob->n_lin, prob->n_y, prob->n_w, prob->n_odo, prob->R, jitter, c->mdl, nn));
   c->lay = make_layout(prob->n_lin, prob->n_y);
-  if (step_lds_bytes(c->mdl, c->lay) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
+  if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
   c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
   c->rng_mode = rng->mode; c->seed = rng->seed;
   const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw, nodo = c->mdl.nodo;
@@ -301,7 +313,7 @@ void ctx_free(rbpf_ctx* c) {
 // One time step of particleFilter.m:100-218 / particleSmoother.m:124-341 (iteration k_iter).
 // xref != nullptr: slot N-1 is the conditioned reference trajectory (its ancestor index has
 // already been written to A_t[N-1] by the ancestor-sampling kernels).
-int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw) {
+int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const InfoStep* info) {
   const int t = c->t, N = c->N, nN = c->mdl.nN, d = c->mdl.d, nw = c->mdl.nw;
   if (t >= c->T) { set_error("advance past N_T"); return RBPF_ERR_STATE; }
   const Layout& L = c->lay;
@@ -342,6 +354,14 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw) {
   a.y = c->d_y + (size_t)t * d;
   a.xref = xref_t;
   a.status = c->d_flags;
+  a.info = info ? 1 : 0;
+  a.ivec_old = nullptr; a.ivec_old_stride = 0; a.ivec_new = nullptr; a.hld_old = nullptr; a.hld_old_stride = 0;
+  a.hld_new = nullptr; a.qf_new = nullptr; a.Hb_new = nullptr;
+  if (info) {
+    a.ivec_old = info->ivec_old; a.ivec_old_stride = info->ivec_old_stride; a.ivec_new = info->ivec_new;
+    a.hld_old = info->hld_old; a.hld_old_stride = info->hld_old_stride; a.hld_new = info->hld_new;
+    a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) {
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -422,7 +442,7 @@ int rbpf_filter_create(const rbpf_model* model, const rbpf_problem* prob, const 
 int rbpf_filter_advance(rbpf_ctx* c, int32_t n_steps) {
   if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
-  for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N));
+  for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N, nullptr));
   return RBPF_OK;
 }
 

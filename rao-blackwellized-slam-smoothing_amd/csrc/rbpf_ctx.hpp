@@ -21,6 +21,13 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 struct SmootherState;   // rbpf_smoother.hip
 
+// information-form per-step buffers handed to the step kernel
+struct InfoStep {
+  const double* ivec_old; size_t ivec_old_stride; double* ivec_new;
+  const double* hld_old; size_t hld_old_stride; double* hld_new;
+  double* qf_new; double* Hb_new;
+};
+
 }  // namespace rbpf
 
 struct rbpf_ctx {
@@ -71,7 +78,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
                bool smoother, int N_K, rbpf_ctx** out);
 int ctx_reset(rbpf_ctx* c);
 void ctx_free(rbpf_ctx* c);
-int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw);
+int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const InfoStep* info);
 int ctx_check_flags(rbpf_ctx* c);
 void smoother_free(rbpf_ctx* c);
 

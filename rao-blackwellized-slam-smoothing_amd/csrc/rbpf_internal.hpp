@@ -22,6 +22,8 @@ struct ModelDev {
   double jitter;
   double logconst;     // -0.5 * d * log(2*pi)
   int use_dyn_res_norm;
+  double Rinv[9];      // inv(R), d x d column-major
+  double halfLogDetR;  // 0.5*log(det(R))
 };
 
 // HBM layout of one particle's covariance ("bank" entry).  Natural state order is kept for the
@@ -57,6 +59,12 @@ struct StepArgs {
   const double* y;                          // [d]
   const double* xref;                       // CPF-AS: state of slot N-1 at this step (or null)
   int* status;
+  // information form (particleSmootherInformationForm.m): extra per-particle state
+  int info;
+  const double* ivec_old; size_t ivec_old_stride; double* ivec_new;   // [N][ldx]
+  const double* hld_old; size_t hld_old_stride; double* hld_new;      // halfLogDetP [N]
+  double* qf_new;                                                     // ivec'*P*ivec after the update [N]
+  double* Hb_new;                                                     // [N][d][ldx] H_i of this step
 };
 
 struct NormArgs {
@@ -83,7 +91,7 @@ struct SearchArgs {
   int* overflow;        // device counter of clamped draws (u > wc(end))
 };
 
-size_t step_lds_bytes(const ModelDev& m, const Layout& lay);
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0);
 Layout make_layout(int n, int d);
 
 hipError_t launch_step(const StepArgs& a, hipStream_t s);

@@ -58,13 +58,13 @@ struct LdsPlan {
 
 __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline LdsPlan lds_plan(int n, int d, int ldx, int CS, int mc, int ktot) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ldx, int CS, int mc, int ktot) {
   LdsPlan p;
   int o = 0;
-  p.off_HK = o;    o += even_up(n * 2 * d);
+  p.off_HK = o;    o += even_up(n * (2 * d + e));
   p.off_xl = o;    o += ldx;
-  p.off_PHt = o;   o += d * ldx;
-  p.off_parts = o; o += CS * d * mc;
+  p.off_PHt = o;   o += (d + e) * ldx;
+  p.off_parts = o; o += CS * (d + e) * mc;
   p.off_tab = o;   o += even_up(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o;  o += 64;
   p.off_red = o;   o += kWaves * 16;
@@ -72,8 +72,8 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int d, int ldx, int CS, int m
   return p;
 }
 
-size_t step_lds_bytes(const ModelDev& m, const Layout& lay) {
-  return (size_t)lds_plan(lay.n, m.d, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra) {
+  return (size_t)lds_plan(lay.n, m.d, extra, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
 }
 
 Layout make_layout(int n, int d) {
@@ -160,14 +160,17 @@ __device__ inline void H_column(const ModelDev& M, int c, const double* tabS, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// the streamed core block: lanes own rows (2 per 128-row chunk), waves walk columns
+// the streamed core block: lanes own rows (2 per 128-row chunk), waves walk columns.
+// Per column the wave needs DE = D+E right-hand-side values (H rows, then the E extra vectors of the
+// information form) and the D pending column factors; LDS record per column: [H(D) | X(E) | K(D)].
 // ---------------------------------------------------------------------------------------------
-template <int D, int CPL, int UC>
+template <int D, int E, int CPL, int UC>
 __device__ __forceinline__ void stream_core(const double* __restrict__ src, double* __restrict__ dst,
                                             const double* __restrict__ HK, const double* __restrict__ KSrow,
                                             int ldx, int n, int nb, int mc, int CH, int RS, int CS, int wr, int wc,
-                                            int lane, double* __restrict__ out_acc /* [D][mc] */) {
-  double acc[CPL][2][D];
+                                            int lane, double* __restrict__ out_acc /* [D+E][mc] */) {
+  constexpr int DE = D + E, REC = 2 * D + E;
+  double acc[CPL][2][DE];
   double ks[CPL][2][D];
   int r0[CPL];
   bool on[CPL];
@@ -177,12 +180,12 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
     on[q] = ch < CH;
     r0[q] = (on[q] ? ch : 0) * kChunkRows + 2 * lane;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        acc[q][e][k] = 0.0;
-        ks[q][e][k] = KSrow ? KSrow[(size_t)k * ldx + nb + r0[q] + e] : 0.0;
-      }
+      for (int k = 0; k < DE; ++k) acc[q][e][k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) ks[q][e][k] = KSrow ? KSrow[(size_t)k * ldx + nb + r0[q] + e] : 0.0;
+    }
   }
 
   int c = wc;
@@ -196,9 +199,11 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
       const int cc = c + u * CS;
-      double h[D], kc[D];
+      double h[DE], kc[D];
 #pragma unroll
-      for (int k = 0; k < D; ++k) { h[k] = HK[cc * 2 * D + k]; kc[k] = HK[cc * 2 * D + D + k]; }
+      for (int k = 0; k < DE; ++k) h[k] = HK[cc * REC + k];
+#pragma unroll
+      for (int k = 0; k < D; ++k) kc[k] = HK[cc * REC + DE + k];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         if (!on[q]) continue;
@@ -206,16 +211,18 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
         for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
-        for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+        for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
         dbl2 o; o.x = p0; o.y = p1;
         st_stream(dst + (size_t)cc * mc + r0[q], o);
       }
     }
   }
   for (; c < n; c += CS) {
-    double h[D], kc[D];
+    double h[DE], kc[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) { h[k] = HK[c * 2 * D + k]; kc[k] = HK[c * 2 * D + D + k]; }
+    for (int k = 0; k < DE; ++k) h[k] = HK[c * REC + k];
+#pragma unroll
+    for (int k = 0; k < D; ++k) kc[k] = HK[c * REC + DE + k];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       if (!on[q]) continue;
@@ -224,7 +231,7 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
       for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
-      for (int k = 0; k < D; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+      for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
       dbl2 o; o.x = p0; o.y = p1;
       st_stream(dst + (size_t)c * mc + r0[q], o);
     }
@@ -233,7 +240,7 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
   for (int q = 0; q < CPL; ++q) {
     if (!on[q]) continue;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
+    for (int k = 0; k < DE; ++k) {
       out_acc[(size_t)k * mc + r0[q]] = acc[q][0][k];
       out_acc[(size_t)k * mc + r0[q] + 1] = acc[q][1][k];
     }
@@ -241,22 +248,26 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 }
 
 // ---------------------------------------------------------------------------------------------
-// THE step kernel: one workgroup (4 wave64) per particle slot
+// THE step kernel: one workgroup (4 wave64) per particle slot.
+//   E = 0 : particleFilter.m:100-204 / particleSmoother.m:124-340 (covariance-form weights)
+//   E = 2 : particleSmootherInformationForm.m:274-335 -- additionally streams P*ivec and P*ivecPlus so
+//           the importance weight can be formed exactly as the reference writes it (:292-304)
 // ---------------------------------------------------------------------------------------------
-template <int D, int CPL>
+template <int D, int E, int CPL>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
+  constexpr int DE = D + E, REC = 2 * D + E;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
   const int N = a.N;
   const int i = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const LdsPlan lp = lds_plan(n, D, ldx, Ly.CS, mc, M.ktot);
-  double* HK = smem + lp.off_HK;        // per column c: H[0..D) then Kcol[0..D)
+  const LdsPlan lp = lds_plan(n, D, E, ldx, Ly.CS, mc, M.ktot);
+  double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol[0..D)
   double* xls = smem + lp.off_xl;
-  double* PHt = smem + lp.off_PHt;      // [D][ldx]
-  double* parts = smem + lp.off_parts;  // [CS][D][mc]
+  double* PHt = smem + lp.off_PHt;      // [DE][ldx]
+  double* parts = smem + lp.off_parts;  // [CS][DE][mc]
   double* tabS = smem + lp.off_tab;
   double* tabC = tabS + (M.ktot > 0 ? M.ktot : 1);
   double* misc = smem + lp.off_misc;    // 0..7 xn_new, 8..16 Rnb, 20.. epilogue broadcast
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   const int anc = a.ai ? a.ai[i] : i;
   const int nN = M.nN;
 
-  // ---- A: propagate the non-linear state (one lane), stage xl and pending K into LDS (all) ----
+  // ---- A: propagate the non-linear state (one lane), stage xl / pending K / ivec into LDS (all) ----
   if (tid == 0) {
     double x[8], xp[8];
     for (int c = 0; c < nN; ++c) x[c] = a.xn_old[(size_t)c * N + anc];
@@ -286,10 +297,12 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   {
     const double* xl_src = a.xl_old + (size_t)anc * a.xl_old_stride;
     const double* Kcol = a.F_old ? a.F_old + ((size_t)anc * 2 + 1) * D * ldx : nullptr;
+    const double* iv = (E > 0) ? a.ivec_old + (size_t)anc * a.ivec_old_stride : nullptr;
     for (int c = tid; c < n; c += kThreads) {
       xls[c] = xl_src[c];
 #pragma unroll
-      for (int k = 0; k < D; ++k) HK[c * 2 * D + D + k] = Kcol ? Kcol[(size_t)k * ldx + c] : 0.0;
+      for (int k = 0; k < D; ++k) HK[c * REC + DE + k] = Kcol ? Kcol[(size_t)k * ldx + c] : 0.0;
+      if (E > 0) HK[c * REC + D] = iv[c];
     }
   }
   __syncthreads();
@@ -298,24 +311,45 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
   __syncthreads();
 
-  // ---- C: measurement Jacobian H_i, column per thread ----
-  for (int c = tid; c < n; c += kThreads) {
-    double h[D];
-    H_column<D>(M, c, tabS, tabC, &misc[8], h);
+  // ---- C: measurement Jacobian H_i, column per thread (+ ivecPlus = ivec + dyi'/R*yt', :292) ----
+  {
+    double Riy[D];
+    if (E > 0) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) HK[c * 2 * D + k] = h[k];
+      for (int aa = 0; aa < D; ++aa) {
+        double s = 0.0;
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) s = fma(M.Rinv[aa + D * bb], a.y[bb], s);
+        Riy[aa] = s;
+      }
+    }
+    for (int c = tid; c < n; c += kThreads) {
+      double h[D];
+      H_column<D>(M, c, tabS, tabC, &misc[8], h);
+#pragma unroll
+      for (int k = 0; k < D; ++k) HK[c * REC + k] = h[k];
+      if (E > 0) {
+        double s = HK[c * REC + D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fma(h[k], Riy[k], s);
+        HK[c * REC + D + 1] = s;
+#pragma unroll
+        for (int k = 0; k < D; ++k) a.Hb_new[((size_t)i * D + k) * ldx + c] = h[k];
+        a.ivec_new[(size_t)i * ldx + c] = s;                                 // :333
+      }
+    }
   }
   __syncthreads();
 
-  // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ H' ----
+  // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ [H' X] ----
   const double* KSrow = a.F_old ? a.F_old + ((size_t)anc * 2 + 0) * D * ldx : nullptr;
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
       const double* src = a.Pt_old + (size_t)anc * a.Pt_old_stride;
       double* dst = a.Pt_new + (size_t)i * Ly.szT;
-      double* out_acc = parts + (size_t)wc * D * mc;
-      stream_core<D, CPL, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
+      double* out_acc = parts + (size_t)wc * DE * mc;
+      stream_core<D, E, CPL, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
@@ -324,27 +358,27 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
       double ksb[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) ksb[k] = KSrow ? KSrow[(size_t)k * ldx + b] : 0.0;
-      double accb[D];
+      double accb[DE];
 #pragma unroll
-      for (int k = 0; k < D; ++k) accb[k] = 0.0;
+      for (int k = 0; k < DE; ++k) accb[k] = 0.0;
       for (int c = 2 * lane; c < ldb; c += 128) {
-        const double2 vv = *reinterpret_cast<const double2*>(src + c);
+        const dbl2 vv = *reinterpret_cast<const dbl2*>(src + c);
         double p[2] = {vv.x, vv.y};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const int cc = c + e;
           if (cc < n) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) p[e] = fma(-ksb[k], HK[cc * 2 * D + D + k], p[e]);
+            for (int k = 0; k < D; ++k) p[e] = fma(-ksb[k], HK[cc * REC + DE + k], p[e]);
 #pragma unroll
-            for (int k = 0; k < D; ++k) accb[k] = fma(p[e], HK[cc * 2 * D + k], accb[k]);
+            for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], HK[cc * REC + k], accb[k]);
           }
         }
-        double2 o; o.x = p[0]; o.y = p[1];
-        *reinterpret_cast<double2*>(dst + c) = o;
+        dbl2 o; o.x = p[0]; o.y = p[1];
+        *reinterpret_cast<dbl2*>(dst + c) = o;
       }
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
+      for (int k = 0; k < DE; ++k) {
         const double s = wave_sum(accb[k]);
         if (lane == 0) PHt[(size_t)k * ldx + b] = s;
       }
@@ -355,24 +389,25 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
     // fixed-order combine of the column phases (deterministic)
     for (int r = tid; r < mc; r += kThreads) {
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
+      for (int k = 0; k < DE; ++k) {
         double s = parts[(size_t)k * mc + r];
-        for (int w = 1; w < Ly.CS; ++w) s += parts[((size_t)w * D + k) * mc + r];
+        for (int w = 1; w < Ly.CS; ++w) s += parts[((size_t)w * DE + k) * mc + r];
         PHt[(size_t)k * ldx + nb + r] = s;
       }
     }
     __syncthreads();
   }
 
-  // ---- E: innovation covariance S = H (P H') + R, innovation e = y - H xl ----
+  // ---- E: innovation covariance S = H (P H') + R, innovation e = y - H xl (+ quadratic forms) ----
+  constexpr int NRED = D * D + D + E;
   {
-    double part[D * D + D];
+    double part[NRED];
 #pragma unroll
-    for (int q = 0; q < D * D + D; ++q) part[q] = 0.0;
+    for (int q = 0; q < NRED; ++q) part[q] = 0.0;
     for (int r = tid; r < n; r += kThreads) {
       double h[D], ph[D];
 #pragma unroll
-      for (int k = 0; k < D; ++k) { h[k] = HK[r * 2 * D + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
+      for (int k = 0; k < D; ++k) { h[k] = HK[r * REC + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
       const double x = xls[r];
 #pragma unroll
       for (int bb = 0; bb < D; ++bb)
@@ -380,9 +415,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
         for (int aa = 0; aa < D; ++aa) part[aa + D * bb] = fma(h[aa], ph[bb], part[aa + D * bb]);
 #pragma unroll
       for (int aa = 0; aa < D; ++aa) part[D * D + aa] = fma(h[aa], x, part[D * D + aa]);
+      if (E > 0) {
+        // ivec'*P*ivec and ivecPlus'*P*ivecPlus (:301-303) with P = the (downdated) prior covariance
+        part[D * D + D] = fma(HK[r * REC + D], PHt[(size_t)D * ldx + r], part[D * D + D]);
+        part[D * D + D + 1] = fma(HK[r * REC + D + 1], PHt[(size_t)(D + 1) * ldx + r], part[D * D + D + 1]);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < D * D + D; ++q) {
+    for (int q = 0; q < NRED; ++q) {
       const double s = wave_sum(part[q]);
       if (lane == 0) red[wave * 16 + q] = s;
     }
@@ -407,10 +447,10 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
       for (int q = 0; q < D; ++q) SJ[q + D * q] += M.jitter;                // :147
       ok = chol_lower_small<D>(SJ, cS);
     }
-    double lw;
+    double lw = 0.0, sl = 0.0;
     if (ok) {
       fwd_subst<D>(cS, e, v);                                               // :149
-      double sl = 0.0, vv = 0.0;
+      double vv = 0.0;
       for (int q = 0; q < D; ++q) { sl += log(cS[q + D * q]); vv += v[q] * v[q]; }
       lw = -sl - 0.5 * vv + M.logconst;                                     // :150
     } else {
@@ -419,9 +459,14 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
       for (int q = 0; q < D * D; ++q) cS[q] = 0.0;
       for (int q = 0; q < D; ++q) cS[q + D * q] = 1.0;
     }
-    a.logw[i] = lw;
+    if (E == 0) a.logw[i] = lw;
     for (int q = 0; q < D * D; ++q) { misc[20 + q] = cS[q]; misc[30 + q] = SS[q]; }
     for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
+    if (E > 0) {
+      double qa = red[D * D + D], qb = red[D * D + D + 1];
+      for (int w = 1; w < kWaves; ++w) { qa += red[w * 16 + D * D + D]; qb += red[w * 16 + D * D + D + 1]; }
+      misc[44] = qa; misc[45] = qb; misc[46] = ok ? sl : nan("");
+    }
   }
   __syncthreads();
 
@@ -435,6 +480,9 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
     double* KSn = a.F_new + ((size_t)i * 2 + 0) * D * ldx;
     double* Kn = a.F_new + ((size_t)i * 2 + 1) * D * ldx;
     double* xln = a.xl_new + (size_t)i * ldx;
+    double uK[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) uK[k] = 0.0;
     for (int r = tid; r < n; r += kThreads) {
       double ph[D], u[D], kk[D];
 #pragma unroll
@@ -453,34 +501,83 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
         KSn[(size_t)j * ldx + r] = s;
         Kn[(size_t)j * ldx + r] = kk[j];
       }
+      if (E > 0) {
+        const double ip = HK[r * REC + D + 1];
+#pragma unroll
+        for (int k = 0; k < D; ++k) uK[k] = fma(ip, kk[k], uK[k]);          // ivecPlus' * K
+      }
+    }
+    if (E > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double s = wave_sum(uK[k]);
+        if (lane == 0) red[wave * 16 + k] = s;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double u[D];
+        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < kWaves; ++w) s += red[w * 16 + k]; u[k] = s; }
+        double corr = 0.0;                                                  // ivecPlus' * (K*SS*K') * ivecPlus
+        for (int bb = 0; bb < D; ++bb) {
+          double t = 0.0;
+          for (int aa = 0; aa < D; ++aa) t = fma(u[aa], SS[aa + D * bb], t);
+          corr = fma(t, u[bb], corr);
+        }
+        const double qa = misc[44], qbp = misc[45] - corr, sl = misc[46];
+        const double hld = a.hld_old[(size_t)anc * a.hld_old_stride];
+        const double hldp = -sl + M.halfLogDetR + hld;                       // :298
+        double yRy = 0.0;
+        for (int bb = 0; bb < D; ++bb) {
+          double t = 0.0;
+          for (int aa = 0; aa < D; ++aa) t = fma(a.y[aa], M.Rinv[aa + D * bb], t);
+          yRy = fma(t, a.y[bb], yRy);
+        }
+        // :301-304   (1/2*log((2*pi)^ny*det(R)) = -logconst + halfLogDetR)
+        a.logw[i] = -0.5 * qa - hld + hldp + 0.5 * qbp - 0.5 * yRy - (-M.logconst + M.halfLogDetR);
+        a.hld_new[i] = hldp;
+        a.qf_new[i] = qbp;
+      }
     }
   }
 }
 
-template <int D, int CPL>
+template <int D, int E, int CPL>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
-  const size_t lds = step_lds_bytes(a.mdl, a.lay);
+  const size_t lds = step_lds_bytes(a.mdl, a.lay, E);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, CPL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, E, CPL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((step_kernel<D, CPL>), dim3(a.N), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((step_kernel<D, E, CPL>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   const int D = a.mdl.d, CPL = a.lay.CPL;
+  if (a.info) {
+    if (D == 3) {
+      if (CPL == 1) return launch_step_t<3, 2, 1>(a, s);
+      if (CPL == 2) return launch_step_t<3, 2, 2>(a, s);
+      if (CPL == 3) return launch_step_t<3, 2, 3>(a, s);
+    } else if (D == 1) {
+      if (CPL == 1) return launch_step_t<1, 2, 1>(a, s);
+      if (CPL == 2) return launch_step_t<1, 2, 2>(a, s);
+      if (CPL == 3) return launch_step_t<1, 2, 3>(a, s);
+    }
+    return hipErrorInvalidValue;
+  }
   if (D == 3) {
-    if (CPL == 1) return launch_step_t<3, 1>(a, s);
-    if (CPL == 2) return launch_step_t<3, 2>(a, s);
-    if (CPL == 3) return launch_step_t<3, 3>(a, s);
+    if (CPL == 1) return launch_step_t<3, 0, 1>(a, s);
+    if (CPL == 2) return launch_step_t<3, 0, 2>(a, s);
+    if (CPL == 3) return launch_step_t<3, 0, 3>(a, s);
   } else if (D == 1) {
-    if (CPL == 1) return launch_step_t<1, 1>(a, s);
-    if (CPL == 2) return launch_step_t<1, 2>(a, s);
-    if (CPL == 3) return launch_step_t<1, 3>(a, s);
+    if (CPL == 1) return launch_step_t<1, 0, 1>(a, s);
+    if (CPL == 2) return launch_step_t<1, 0, 2>(a, s);
+    if (CPL == 3) return launch_step_t<1, 0, 3>(a, s);
   }
   return hipErrorInvalidValue;
 }

@@ -36,6 +36,11 @@ struct SmootherState {
   double* d_ivecAdd = nullptr;  // [n]
   double* d_Imat0 = nullptr;    // [n*n] diag(1./diag(P0))
   int* d_ak = nullptr;
+  double* d_ivec0 = nullptr;    // [ldx] initial information vector (:110)
+  double* d_hld0 = nullptr;     // [1]
+  int icur = 0;                 // ping-pong index of ivec / hld / qf / Hb
+  int imat_cur = 0;
+  bool imat_valid = false;      // false until the first gather of an iteration (Imat = Imat0)
   size_t Mmax = 0;
 };
 
@@ -45,7 +50,7 @@ void smoother_free(rbpf_ctx* c) {
   hipFree(s->d_xnk); hipFree(s->d_dyref); hipFree(s->d_pant_log); hipFree(s->d_pant); hipFree(s->d_wc2);
   hipFree(s->d_Pfull); hipFree(s->d_G); hipFree(s->d_S); hipFree(s->d_L); hipFree(s->d_e);
   for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
-  hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak);
+  hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
   delete s;
   c->sm = nullptr;
 }
@@ -150,7 +155,7 @@ struct CholArgs {
   // mode 0
   const double* S; const double* R; const double* yf; const double* dyf; const double* xl; double jitter;
   // mode 1
-  const double* Imat; const double* Hb; const double* Rinv; const double* ImatAdd; const double* ivec;
+  const double* Imat; long imat_stride; const double* Hb; const double* Rinv; const double* ImatAdd; const double* ivec;
   const double* ivecAdd; const double* qf; const double* hld;
   double* pant_log;                 // += logwMeas
   int* status;
@@ -162,7 +167,7 @@ __device__ inline double chol_elem(const CholArgs& a, int p, int i, int j) {
     if (i / a.d == j / a.d) v += a.R[(i % a.d) + a.d * (j % a.d)];          // kron(eye, R)
     return v;
   }
-  double v = a.Imat[(size_t)p * a.n * a.n + (size_t)i + (size_t)a.n * j];
+  double v = a.Imat[(size_t)p * a.imat_stride + (size_t)i + (size_t)a.n * j];
   if (a.Hb) {                                                               // pending dyi'/R*dyi (:334)
     const double* H = a.Hb + (size_t)p * a.d * a.ldx;
     double s = 0.0;
@@ -338,7 +343,7 @@ using namespace rbpf;
 // information-form hooks (defined below)
 static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, double qf0, double halfLogDetR, const double* d_Rinv);
 static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv);
-static int info_pre_step(rbpf_ctx* c, int k, int t, int n_draw);
+static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, const double* d_Rinv);
 
 #define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
 
@@ -515,8 +520,8 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         sa.seed = c->seed; sa.ai = c->A + (size_t)t * N; sa.overflow = c->d_flags + 1;
         HIPCHK(launch_search(sa, st));
       }
-      if (info_form) RB_TRY(info_pre_step(c, k, t, n_draw));
-      else RB_TRY(ctx_step(c, k, xref, n_draw));
+      if (info_form) RB_TRY(info_step(c, k, t, xref, n_draw, d_Rinv));
+      else RB_TRY(ctx_step(c, k, xref, n_draw, nullptr));
     }
     // ---- ak = sample(w); xnk = xn_traj(:,ak,:) (:346-354) ----
     {
@@ -560,9 +565,58 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   return RBPF_OK;
 }
 
-static int info_begin_iteration(rbpf_ctx*, const double*, double, double, double, const double*) { set_error("information form: not built yet"); return RBPF_ERR_UNSUPPORTED; }
-static int info_fill_chol_args(rbpf_ctx*, CholArgs&, const double*) { return RBPF_ERR_UNSUPPORTED; }
-static int info_pre_step(rbpf_ctx*, int, int, int) { return RBPF_ERR_UNSUPPORTED; }
+static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, double, double, const double*) {
+  SmootherState* s = c->sm;
+  const Layout& L = c->lay;
+  if (!s->d_ivec0) {
+    RB_TRY(dmalloc(&s->d_ivec0, (size_t)L.ldx));
+    RB_TRY(dmalloc(&s->d_hld0, 1));
+  }
+  HIPCHK(hipMemcpyAsync(s->d_ivec0, ivec0, (size_t)L.ldx * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(s->d_hld0, &hld0, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));       // host sources are stack / caller memory
+  s->icur = 0;
+  s->imat_cur = 0;
+  s->imat_valid = false;
+  return RBPF_OK;
+}
+
+static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv) {
+  SmootherState* s = c->sm;
+  const int n = c->mdl.n;
+  ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)((size_t)n * n);
+  ca.Imat = s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0;
+  ca.imat_stride = s->imat_valid ? (long)((size_t)n * n) : 0;
+  ca.Hb = s->d_Hb[s->icur]; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
+  ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
+  return RBPF_OK;
+}
+
+// One information-form time step: the fused step kernel with the extra ivec / halfLogDetP state,
+// followed (k>1) by the gather + pending update of the information matrices (:170,:186,:253,:334).
+static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, const double* d_Rinv) {
+  SmootherState* s = c->sm;
+  const int N = c->N, n = c->mdl.n, d = c->mdl.d;
+  const Layout& L = c->lay;
+  const int oc = s->icur, nc = (t == 0) ? 0 : (oc ^ 1);
+  InfoStep is;
+  if (t == 0) { is.ivec_old = s->d_ivec0; is.ivec_old_stride = 0; is.hld_old = s->d_hld0; is.hld_old_stride = 0; }
+  else { is.ivec_old = s->d_ivec[oc]; is.ivec_old_stride = (size_t)L.ldx; is.hld_old = s->d_hld[oc]; is.hld_old_stride = 1; }
+  is.ivec_new = s->d_ivec[nc]; is.hld_new = s->d_hld[nc]; is.qf_new = s->d_qf[nc]; is.Hb_new = s->d_Hb[nc];
+  RB_TRY(ctx_step(c, k, xref, n_draw, &is));
+  if (k > 0 && t > 0) {
+    const int* A_t = c->A + (size_t)t * N;
+    const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
+    hipLaunchKernelGGL(imat_gather_kernel, dim3(N), dim3(256), 0, c->stream, n, d, L.ldx, A_t,
+                       s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0, s->imat_valid ? (size_t)n * n : (size_t)0,
+                       s->d_Hb[oc], d_Rinv, s->d_Imat[ni]);
+    HIPCHK(hipGetLastError());
+    s->imat_cur = ni;
+    s->imat_valid = true;
+  }
+  s->icur = nc;
+  return RBPF_OK;
+}
 
 extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
                                       const rbpf_options* opt, int32_t N_K, int32_t info_form, rbpf_smoother_out* out) {
