@@ -113,10 +113,14 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
   for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
   if (R) {   // inv(R) and 0.5*log(det(R)) for the information-form recursions (:292,298,304)
     double Lr[64] = {0};
-    if (d > 8 || !chol_lower_host(R, d, d, Lr, d)) { set_error("R must be positive definite"); return RBPF_ERR_CHOL_FAILED; }
-    M.halfLogDetR = 0.0;
-    for (int j = 0; j < d; ++j) M.halfLogDetR += std::log(Lr[j + d * j]);
-    for (int col = 0; col < d; ++col) {
+    if (d > 8) { set_error("n_y <= 8 supported"); return RBPF_ERR_UNSUPPORTED; }
+    // Only the information-form smoother needs inv(R) / log det R; the filter accepts any R whose
+    // innovation covariance passes chol (with the jitter retry), so a failure here is not an error yet.
+    const bool pd = chol_lower_host(R, d, d, Lr, d);
+    M.halfLogDetR = pd ? 0.0 : std::nan("");
+    for (int q = 0; q < d * d; ++q) M.Rinv[q] = std::nan("");
+    for (int j = 0; pd && j < d; ++j) M.halfLogDetR += std::log(Lr[j + d * j]);
+    for (int col = 0; pd && col < d; ++col) {
       double y[8], x[8];
       for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + d * k] * y[k]; y[i] = v / Lr[i + d * i]; }
       for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + d * i] * x[k]; x[i] = v / Lr[i + d * i]; }

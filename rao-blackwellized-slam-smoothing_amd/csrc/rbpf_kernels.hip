@@ -684,6 +684,7 @@ __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const Norm
   int gi = sidx[0];
   for (int w = 1; w < kNormThreads / 64; ++w)
     if (sred[w] > gw || (sred[w] == gw && sidx[w] < gi)) { gw = sred[w]; gi = sidx[w]; }
+  if (gi < 0 || gi >= N) gi = 0;     // all weights NaN (failed chol): MATLAB's max returns index 1
   if (tid == 0) {
     *a.iw_max = gi;
     if (a.lse_out) *a.lse_out = lse;

@@ -1,0 +1,100 @@
+"""The C-ABI library loads on a CPU-only machine, exports every symbol include/rbpf.h declares, and
+the product path fails loudly (no CPU fallback) when no device is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "rbpf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rbpf_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_functions_match_export_list(rbpf):
+    assert declared_functions() == sorted(rbpf.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(rbpf):
+    lib = rbpf.load_library()
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.rbpf_abi_version() == 1
+    assert lib.rbpf_status_string(0) == b"ok"
+    assert b"positive definite" in lib.rbpf_status_string(rbpf.RBPF_ERR_CHOL_FAILED)
+
+
+def test_no_cpu_fallback_without_a_device(rbpf):
+    if rbpf.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    c = cases.radio_case(4, 3, 8, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                            c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c))
+    assert ei.value.status == rbpf.RBPF_ERR_NO_DEVICE
+    with pytest.raises(rbpf.RBPFError):
+        rbpf.sample(np.ones(4) / 4, [0.3])
+
+
+def test_arbitrary_callables_are_rejected_not_emulated(rbpf):
+    c = cases.radio_case(4, 3, 8, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleFilter(lambda *a: None, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                            c["N_P"], c["dt"])
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+    with pytest.raises(rbpf.RBPFError):                      # sparseFeatures branch: not on the device path yet
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                            c["N_P"], c["dt"], True)
+    with pytest.raises(rbpf.RBPFError):                      # InformationForm.m:77-80
+        rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"],
+                                             c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], 2, c["dt"], True)
+
+
+def test_host_side_basis_selection_matches_oracle(rbpf, oracle):
+    for m, d, LL in [(16, 3, [[-11.8, -7.4, -2.4], [11.8, 7.4, 2.4]]), (256, 3, [[-12.02, -12.02, -2.4], [12.02, 12.02, 2.4]]),
+                     (128, 2, [[-1.0, -2.5], [1.0, 2.5]]), (40, 2, [[-3.0, -3.0], [3.0, 3.0]])]:
+        L1, NN1 = rbpf.domain_cartesian_dx(m, d, LL)
+        L2, NN2 = oracle.domain_cartesian_dx(m, d, np.array(LL))
+        np.testing.assert_array_equal(NN1, NN2.astype(np.int32))
+        np.testing.assert_allclose(L1, L2, rtol=0)
+        np.testing.assert_allclose(rbpf.eigenval(NN1, L1), oracle.eigenval(NN2, L2), rtol=1e-15)
+
+
+def test_priors_match_oracle(rbpf, oracle):
+    LL = np.array([[-12.0, -11.0, -2.4], [12.0, 11.0, 2.4]])
+    _, x0a, P0a, Ra = rbpf.dense_mag_prior(64, LL, cases.THETA_MAG)
+    _, x0b, P0b, Rb = oracle.dense_mag_prior(64, LL, cases.THETA_MAG)
+    np.testing.assert_allclose(P0a, P0b, rtol=1e-14)
+    np.testing.assert_array_equal(Ra, Rb)
+    LL2 = np.array([[-1.0, -2.5], [1.0, 2.5]])
+    _, _, P0a, Ra = rbpf.dense_radio_prior(32, LL2, cases.THETA_RADIO)
+    _, _, P0b, Rb = oracle.dense_radio_prior(32, LL2, cases.THETA_RADIO)
+    np.testing.assert_allclose(P0a, P0b, rtol=1e-14)
+    np.testing.assert_array_equal(Ra, Rb)
+
+
+def test_product_datagen_matches_oracle_generator(rbpf, oracle):
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    a = dg.bean_6D(30, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=5, m_sim=80)
+    b = oracle.generate_bean_6D(30, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=5, m_sim=80)
+    for k in ("dx", "initState", "y", "LL"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-11, atol=1e-12)
+
+
+def test_replay_rng_shape_validation(rbpf):
+    c = cases.radio_case(4, 3, 8, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    bad = rbpf.ReplayRNG(np.zeros((1, 2, 3)), np.zeros((1, 2, 3, 1)))
+    with pytest.raises(ValueError):
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                            c["N_P"], c["dt"], rng=bad)

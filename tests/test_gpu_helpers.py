@@ -1,0 +1,130 @@
+"""GPU parity of the stand-alone pieces of SURVEY 8(a): sample (a2), dynModel (a3/a4), quaternion helpers through
+them (a5), basis / measModel (a7/a8), dynResNorm (a17), JacobianPhi3D (a19) -- HIP vs the numpy oracle."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_sample_is_bit_exact_including_bin_edges(rbpf, oracle):
+    rs = np.random.RandomState(3)
+    for N in (1, 7, 64, 1000, 5000):
+        w = rs.random_sample(N) ** 3
+        w[rs.random_sample(N) < 0.2] = 0.0                       # plateaus in the running sum
+        w = w / w.sum() if w.sum() > 0 else np.ones(N) / N
+        wc = np.cumsum(w)
+        u = np.concatenate((rs.random_sample(200), wc[:50], np.nextafter(wc[:50], 2.0), np.nextafter(wc[:50], -1.0),
+                            [0.0, 1e-300, wc[-1]]))
+        u = u[u <= wc[-1]]                                       # beyond wc(end) MATLAB errors; device clamps
+        want = np.array([oracle.sample(w, ui) for ui in u])
+        got = rbpf.sample(w, u)
+        np.testing.assert_array_equal(got, np.minimum(want, N - 1))
+    got = rbpf.sample(np.array([0.25, 0.25, 0.25, 0.25]), [0.9999999, 1.5])
+    np.testing.assert_array_equal(got, [3, 3])                   # u > wc(end): N+1 in MATLAB -> clamped to N
+
+
+def test_dense_mag_dynmodel(rbpf, oracle):
+    rs = np.random.RandomState(4)
+    c = cases.mag_case(4, 4, 16, seed=1)
+    mdl, *_ = cases.device_model(rbpf, c)
+    for _ in range(5):
+        q = rs.standard_normal(4)
+        xn = np.concatenate((rs.standard_normal(3), q / np.linalg.norm(q)))
+        dq = rs.standard_normal(4)
+        dx = np.concatenate((rs.standard_normal(3) * 0.1, dq / np.linalg.norm(dq)))
+        z = rs.standard_normal(6)
+        A = rs.standard_normal((6, 6))
+        Q = np.zeros((6, 6))
+        Q[:3, :3] = (A @ A.T)[:3, :3] * 1e-2
+        Q[3:, 3:] = (A @ A.T)[3:, 3:] * 1e-3                      # non-diagonal blocks exercise the 3x3 chol
+        want, _ = c["model"].dynModel(xn, dx, 0.02, Q, z)
+        got = mdl.dynModel(xn, dx, 0.02, Q, z)
+        assert rel(got, want) < 1e-13
+    # a rotation increment large enough to flip the sign in expq (expq.m:30)
+    z = np.array([0, 0, 0, 40.0, 0, 0])
+    Qb = np.diag([1e-2] * 3 + [1.0] * 3)
+    want, _ = c["model"].dynModel(xn, dx, 0.01, Qb, z)
+    assert rel(mdl.dynModel(xn, dx, 0.01, Qb, z), want) < 1e-13
+
+
+def test_dense_radio_dynmodel(rbpf, oracle):
+    rs = np.random.RandomState(5)
+    c = cases.radio_case(4, 4, 16, seed=1)
+    mdl, *_ = cases.device_model(rbpf, c)
+    xn = rs.standard_normal((3, 6))
+    z = rs.standard_normal((1, 6))
+    dx = np.array([0.1, -0.2, 0.05])
+    got = mdl.dynModel(xn, dx, 1.0, np.array([[0.09]]), z)
+    for i in range(6):
+        want, _ = c["model"].dynModel(xn[:, i], dx, 1.0, np.array([[0.09]]), z[:, i])
+        assert rel(got[:, i], want) < 1e-14
+
+
+@pytest.mark.parametrize("m", [16, 256, 512])
+def test_dense_mag_measmodel(rbpf, m):
+    c = cases.mag_case(4, 4, m, seed=2)
+    mdl, *_ = cases.device_model(rbpf, c)
+    rs = np.random.RandomState(6)
+    xn = np.zeros((7, 5))
+    xn[0:3] = rs.uniform(-1, 1, (3, 5)) * c["model"].L[:, None] * 0.9
+    q = rs.standard_normal((4, 5))
+    xn[3:7] = q / np.linalg.norm(q, axis=0)
+    want = c["model"].measModel(xn)                               # [Npred x 3 x n]
+    got = mdl.measModel(xn)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+
+
+def test_dense_radio_measmodel(rbpf):
+    c = cases.radio_case(4, 4, 128, seed=2)
+    mdl, *_ = cases.device_model(rbpf, c)
+    rs = np.random.RandomState(7)
+    xn = rs.uniform(-1, 1, (3, 9))
+    want = c["model"].measModel(xn)                               # [Npred x m] (2-D, ny = 1)
+    got = mdl.measModel(xn)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+
+
+def test_dynresnorm_both_families(rbpf):
+    rs = np.random.RandomState(8)
+    c = cases.mag_case(4, 4, 16, seed=1)
+    mdl, *_ = cases.device_model(rbpf, c)
+    for _ in range(5):
+        def rq():
+            q = rs.standard_normal(4)
+            return q / np.linalg.norm(q)
+        xk = np.concatenate((rs.standard_normal(3), rq()))
+        xi = np.concatenate((rs.standard_normal(3), rq()))
+        dx = np.concatenate((rs.standard_normal(3) * 0.1, rq()))
+        A = rs.standard_normal((6, 6))
+        Q = A @ A.T * 1e-2 + np.eye(6) * 1e-3                     # full (non-diagonal) Q: r'/L != L\r
+        want = c["model"].dynResNorm(xk, xi, dx, 0.02, Q)
+        got = mdl.dynResNorm(xk, xi, dx, 0.02, Q)
+        assert rel(got, want) < 1e-12
+    c2 = cases.radio_case(4, 4, 16, seed=1)
+    mdl2, *_ = cases.device_model(rbpf, c2)
+    want = c2["model"].dynResNorm(np.array([0.1, 0.2, 0.7]), np.array([0.0, 0.1, 0.3]), np.array([0.1, 0.0, 0.2]), 1.0,
+                                  np.array([[0.04]]))
+    got = mdl2.dynResNorm(np.array([0.1, 0.2, 0.7]), np.array([0.0, 0.1, 0.3]), np.array([0.1, 0.0, 0.2]), 1.0,
+                          np.array([[0.04]]))
+    assert rel(got, want) < 1e-14
+
+
+def test_jacobianphi3d(rbpf, oracle):
+    c = cases.mag_case(4, 4, 48, seed=3)
+    mdl, *_ = cases.device_model(rbpf, c)
+    LL = c["LL"]
+    rs = np.random.RandomState(9)
+    x = rs.uniform(-0.8, 0.8, (3, 6)) * c["model"].L[:, None]
+    want = oracle.JacobianPhi3D(x, 48, LL[0, 0], LL[1, 0], LL[0, 1], LL[1, 1], LL[0, 2], LL[1, 2], c["model"].NN)
+    got = mdl.JacobianPhi3D(x, LL[0], LL[1])
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
