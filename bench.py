@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--T", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -101,9 +102,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the RBPF path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
     datagen = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
@@ -121,7 +124,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
         sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
                                        N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world)

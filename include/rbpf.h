@@ -195,6 +195,46 @@ int rbpf_timing_enable(rbpf_ctx* ctx, int32_t on);
 int rbpf_timing_read(rbpf_ctx* ctx, rbpf_timing* out, int32_t reset);
 int rbpf_destroy(rbpf_ctx* ctx);
 
+/* ---- particle-sharded filter (one process per GPU) ----------------------------------
+ * Logical slot i of the global filter (N = world * N_P) lives on rank i / N_P.  The collectives stay
+ * outside the library (torch.distributed over RCCL in multigpu.py); the library exposes the device
+ * buffers and the kernels between them.  Per time step t >= 1 the host side does
+ *   all_gather(logw_local -> logw_gather), all_gather(xn_local -> xn_gather)
+ *   rbpf_shard_normalise_search(ctx, ai_host)     global w / cumsum / ancestors, identical on every rank
+ *   rbpf_shard_pack(ctx, idx, count)              my particles that other ranks need -> send staging
+ *   all_to_all_single(send_* -> recv_*)           only unique remote ancestors travel
+ *   rbpf_shard_step(ctx, anc_bank)                fused step kernel; remote ancestors read from recv_*
+ * and after the last step one more gather + rbpf_shard_normalise_search(ctx, NULL).                */
+typedef struct {
+  int32_t rank, world, N_local, N_global;
+  size_t szT, szB, szF, szX;   /* doubles per particle in the four bank components (Pt, Pb, F, xl)   */
+  size_t recv_capacity;        /* particles the recv region can hold                                 */
+  size_t send_capacity;        /* particles the send staging can hold                                */
+  double* logw_local;          /* [N_local]            written by the step kernel                     */
+  double* xn_local;            /* [nN][N_local]        written by the step kernel                     */
+  double* logw_gather;         /* [world][N_local]     all_gather target                             */
+  double* xn_gather;           /* [world][nN][N_local] all_gather target                             */
+  double* send_Pt; double* send_Pb; double* send_F; double* send_xl;   /* pack output                 */
+  double* recv_Pt; double* recv_Pb; double* recv_F; double* recv_xl;   /* tail of the CURRENT old bank */
+} rbpf_shard_views;
+
+int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                      const rbpf_options* opt, int32_t rank, int32_t world, rbpf_ctx** ctx);
+/* Device pointers for the collectives; recv_* change every step (ping-pong): query after each step.  */
+int rbpf_shard_views_get(rbpf_ctx* ctx, rbpf_shard_views* out);
+/* After the gathers: normalise the global weights, strict cumsum, trajectory summaries of the step just
+ * finished; if ai_host != NULL also draw the ancestors of ALL N_global slots (every rank gets the same
+ * vector, 0-based global indices) and copy them to ai_host [N_global].  Synchronises the stream.      */
+int rbpf_shard_normalise_search(rbpf_ctx* ctx, int32_t* ai_host);
+/* Gather `count` local particles (local indices idx_host, in send order) into the send staging.       */
+int rbpf_shard_pack(rbpf_ctx* ctx, const int32_t* idx_host, int32_t count);
+/* One fused step for the local slots.  anc_bank_host [N_local]: index of each slot's ancestor in the
+ * bank address space (< N_local: local particle, >= N_local: N_local + position in the recv region);
+ * NULL at t = 0.  The ancestors' non-linear states are read from xn_gather by global index.           */
+int rbpf_shard_step(rbpf_ctx* ctx, const int32_t* anc_bank_host);
+/* traj_max / traj_mean [n_nonlin x N_T] of the steps normalised so far (identical on every rank).     */
+int rbpf_shard_trajectories(rbpf_ctx* ctx, double* traj_max, double* traj_mean);
+
 /* ---- helper kernels exposed for parity tests (a5-a8, a19 of SURVEY 8a) ------------------------- */
 /* The uniforms / normals the Philox generator hands to slot i at step t of iteration k, in replay
  * layout (U [N_P x (N_T-1)], Z [n_w x N_P x (N_T-1)]), so a replay run can reproduce a Philox run. */

@@ -75,6 +75,8 @@ EXPORTS = [
     "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d",
+    "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
+    "rbpf_shard_trajectories",
 ]
 
 _lib = None

@@ -167,7 +167,7 @@ static size_t bank_bytes(const Layout& L, int d, int N) {
 }
 
 int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
-               bool smoother, int N_K, rbpf_ctx** out) {
+               bool smoother, int N_K, rbpf_ctx** out, const CreateExtras* ex) {
   if (!out) { set_error("ctx out pointer is NULL"); return RBPF_ERR_INVALID_ARG; }
   *out = nullptr;
   RB_TRY(validate_problem(prob));
@@ -183,6 +183,8 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->lay = make_layout(prob->n_lin, prob->n_y);
   if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
   c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
+  c->bank_cap = (size_t)prob->N_P + (ex ? ex->bank_extra : 0);
+  c->rng_slots = (ex && ex->rng_slots) ? ex->rng_slots : (size_t)prob->N_P;
   c->rng_mode = rng->mode; c->seed = rng->seed;
   const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw, nodo = c->mdl.nodo;
   const Layout& L = c->lay;
@@ -240,7 +242,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     if (T > 1 && (!rng->U || !rng->Z)) { set_error("replay RNG needs U and Z"); return RBPF_ERR_INVALID_ARG; }
     if (rng->n_iter < iters) { set_error("replay RNG has fewer pages than iterations"); return RBPF_ERR_INVALID_ARG; }
     if (smoother && !rng->Ufin) { set_error("replay RNG needs Ufin for the smoother"); return RBPF_ERR_INVALID_ARG; }
-    const size_t nu = (size_t)N * std::max(T - 1, 0) * iters;
+    const size_t nu = c->rng_slots * std::max(T - 1, 0) * iters;
     RB_TRY(dmalloc(&c->d_U, nu));
     RB_TRY(dmalloc(&c->d_Z, nu * nw));
     if (nu) {
@@ -253,12 +255,12 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   // ---- particle banks ----
   for (int b = 0; b < 2; ++b) {
-    RB_TRY(dmalloc(&c->Pt[b], (size_t)N * L.szT));
-    RB_TRY(dmalloc(&c->Pb[b], (size_t)N * L.szB));
-    RB_TRY(dmalloc(&c->F[b], (size_t)N * 2 * d * L.ldx));
-    RB_TRY(dmalloc(&c->xl[b], (size_t)N * L.ldx));
-    HIPCHK(hipMemsetAsync(c->F[b], 0, (size_t)N * 2 * d * L.ldx * sizeof(double), c->stream));
-    HIPCHK(hipMemsetAsync(c->xl[b], 0, (size_t)N * L.ldx * sizeof(double), c->stream));
+    RB_TRY(dmalloc(&c->Pt[b], c->bank_cap * L.szT));
+    RB_TRY(dmalloc(&c->Pb[b], c->bank_cap * L.szB));
+    RB_TRY(dmalloc(&c->F[b], c->bank_cap * 2 * d * L.ldx));
+    RB_TRY(dmalloc(&c->xl[b], c->bank_cap * L.ldx));
+    HIPCHK(hipMemsetAsync(c->F[b], 0, c->bank_cap * 2 * d * L.ldx * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->xl[b], 0, c->bank_cap * L.ldx * sizeof(double), c->stream));
   }
   c->hist_slabs = c->opt.keep_history ? T : 2;
   RB_TRY(dmalloc(&c->X, (size_t)c->hist_slabs * nN * N));
@@ -310,6 +312,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags);
   smoother_free(c);
+  shard_free(c);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -338,6 +341,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   StepArgs a;
   a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);
   a.ai = (t > 0) ? A_t : nullptr;
+  a.ai_bank = nullptr; a.slot_offset = 0; a.xn_old_stride = (size_t)N; a.xn_new_stride = (size_t)N;
   a.xn_old = X_old; a.xn_new = X_new;
   const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
   if (t == 0) {

@@ -20,6 +20,13 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
   } while (0)
 
 struct SmootherState;   // rbpf_smoother.hip
+struct ShardState;      // rbpf_shard.hip
+
+// extra capacity requested by the sharded filter
+struct CreateExtras {
+  size_t bank_extra = 0;   // particles appended to every bank (recv region of remote ancestors)
+  size_t rng_slots = 0;    // slots per step in the replay buffers (global particle count); 0: N_P
+};
 
 // information-form per-step buffers handed to the step kernel
 struct InfoStep {
@@ -68,6 +75,9 @@ struct rbpf_ctx {
   bool timing_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   rbpf::SmootherState* sm = nullptr;
+  rbpf::ShardState* sh = nullptr;
+  size_t bank_cap = 0;      // particles per bank incl. the recv region
+  size_t rng_slots = 0;     // slots per step in d_U / d_Z
 };
 
 namespace rbpf {
@@ -75,11 +85,12 @@ namespace rbpf {
 int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
                    ModelDev& M, std::vector<int>& nn_axis_major);
 int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
-               bool smoother, int N_K, rbpf_ctx** out);
+               bool smoother, int N_K, rbpf_ctx** out, const CreateExtras* ex = nullptr);
 int ctx_reset(rbpf_ctx* c);
 void ctx_free(rbpf_ctx* c);
 int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const InfoStep* info);
 int ctx_check_flags(rbpf_ctx* c);
 void smoother_free(rbpf_ctx* c);
+void shard_free(rbpf_ctx* c);
 
 }  // namespace rbpf

@@ -42,8 +42,11 @@ struct StepArgs {
   ModelDev mdl;
   Layout lay;
   int N, t, propagate;
-  const int* ai;                 // ancestors of this step (null: identity)
-  const double* xn_old; double* xn_new;     // SoA [nN][N]
+  const int* ai;                 // ancestors of this step (null: identity); index into xn_old
+  const int* ai_bank;            // ancestor index in the bank address space (null: same as ai)
+  int slot_offset;               // global id of local slot 0 (RNG counters / replay rows)
+  size_t xn_old_stride, xn_new_stride;      // component stride of the SoA state arrays
+  const double* xn_old; double* xn_new;     // SoA [nN][stride]
   const double* xl_old; double* xl_new;     // [N][ldx]
   size_t xl_old_stride;                     // ldx, or 0 to broadcast x0_lin
   const double* F_old; double* F_new;       // pending rank-d factors [N][2][d][ldx]: KS then K
@@ -119,6 +122,9 @@ hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, c
 hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, const double* lo, const double* up,
                                  double* J, hipStream_t s);
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
+hipError_t launch_unblock_soa(int world, int nN, int Nloc, const double* blocked, double* soa, hipStream_t s);
+hipError_t launch_pack_bank(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
+                            const double* F, const double* xl, double* sPt, double* sPb, double* sF, double* sxl, hipStream_t s);
 hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);
 
 }  // namespace rbpf

@@ -273,30 +273,32 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   double* misc = smem + lp.off_misc;    // 0..7 xn_new, 8..16 Rnb, 20.. epilogue broadcast
   double* red = smem + lp.off_red;
 
-  const int anc = a.ai ? a.ai[i] : i;
+  const int anc = a.ai ? a.ai[i] : i;                  // ancestor id for the non-linear state bank
+  const int ancb = a.ai_bank ? a.ai_bank[i] : anc;     // ancestor id in the map bank (local | recv region)
+  const int gslot = a.slot_offset + i;                 // global slot id (RNG stream)
   const int nN = M.nN;
 
   // ---- A: propagate the non-linear state (one lane), stage xl / pending K / ivec into LDS (all) ----
   if (tid == 0) {
     double x[8], xp[8];
-    for (int c = 0; c < nN; ++c) x[c] = a.xn_old[(size_t)c * N + anc];
+    for (int c = 0; c < nN; ++c) x[c] = a.xn_old[(size_t)c * a.xn_old_stride + anc];
     if (a.xref != nullptr && i == N - 1) {
       for (int c = 0; c < nN; ++c) xp[c] = a.xref[c];                      // particleSmoother.m:242
     } else if (a.propagate) {
       double z[8];
-      if (a.rng_mode == 0) { for (int k = 0; k < M.nw; ++k) z[k] = a.Z[(size_t)i * M.nw + k]; }
-      else philox_normals(a.seed, i, a.t, a.k_iter, M.nw, z);
+      if (a.rng_mode == 0) { for (int k = 0; k < M.nw; ++k) z[k] = a.Z[(size_t)gslot * M.nw + k]; }
+      else philox_normals(a.seed, gslot, a.t, a.k_iter, M.nw, z);
       if (M.kind == 1) dyn_model_mag(x, a.odo, a.cholQ, z, xp);
       else dyn_model_radio(x, a.odo, a.cholQ, z, xp);
     } else {
       for (int c = 0; c < nN; ++c) xp[c] = x[c];
     }
-    for (int c = 0; c < nN; ++c) { a.xn_new[(size_t)c * N + i] = xp[c]; misc[c] = xp[c]; }
+    for (int c = 0; c < nN; ++c) { a.xn_new[(size_t)c * a.xn_new_stride + i] = xp[c]; misc[c] = xp[c]; }
     if (M.kind == 1) quat2rmat_dev(&xp[3], &misc[8]);
   }
   {
-    const double* xl_src = a.xl_old + (size_t)anc * a.xl_old_stride;
-    const double* Kcol = a.F_old ? a.F_old + ((size_t)anc * 2 + 1) * D * ldx : nullptr;
+    const double* xl_src = a.xl_old + (size_t)ancb * a.xl_old_stride;
+    const double* Kcol = a.F_old ? a.F_old + ((size_t)ancb * 2 + 1) * D * ldx : nullptr;
     const double* iv = (E > 0) ? a.ivec_old + (size_t)anc * a.ivec_old_stride : nullptr;
     for (int c = tid; c < n; c += kThreads) {
       xls[c] = xl_src[c];
@@ -342,18 +344,18 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
   __syncthreads();
 
   // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ [H' X] ----
-  const double* KSrow = a.F_old ? a.F_old + ((size_t)anc * 2 + 0) * D * ldx : nullptr;
+  const double* KSrow = a.F_old ? a.F_old + ((size_t)ancb * 2 + 0) * D * ldx : nullptr;
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
-      const double* src = a.Pt_old + (size_t)anc * a.Pt_old_stride;
+      const double* src = a.Pt_old + (size_t)ancb * a.Pt_old_stride;
       double* dst = a.Pt_new + (size_t)i * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
       stream_core<D, E, CPL, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
-      const double* src = a.Pb_old + (size_t)anc * a.Pb_old_stride + (size_t)b * ldb;
+      const double* src = a.Pb_old + (size_t)ancb * a.Pb_old_stride + (size_t)b * ldb;
       double* dst = a.Pb_new + (size_t)i * Ly.szB + (size_t)b * ldb;
       double ksb[D];
 #pragma unroll
@@ -997,6 +999,48 @@ __global__ void transpose_soa_kernel(int N, int nN, const double* __restrict__ s
 
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s) {
   hipLaunchKernelGGL(transpose_soa_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nN, soa, aos);
+  return hipGetLastError();
+}
+
+// all_gather layout [world][nN][Nloc] -> SoA [nN][world*Nloc]
+__global__ void unblock_soa_kernel(int world, int nN, int Nloc, const double* __restrict__ blocked,
+                                   double* __restrict__ soa) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t tot = (size_t)world * nN * Nloc;
+  if (q >= tot) return;
+  const int i = (int)(q % Nloc);
+  const int c = (int)((q / Nloc) % nN);
+  const int r = (int)(q / ((size_t)Nloc * nN));
+  soa[(size_t)c * world * Nloc + (size_t)r * Nloc + i] = blocked[q];
+}
+
+hipError_t launch_unblock_soa(int world, int nN, int Nloc, const double* blocked, double* soa, hipStream_t s) {
+  const size_t tot = (size_t)world * nN * Nloc;
+  hipLaunchKernelGGL(unblock_soa_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, world, nN, Nloc, blocked, soa);
+  return hipGetLastError();
+}
+
+// copy the bank entries of `count` particles (Pt | Pb | F | xl) into contiguous send staging
+__global__ void pack_bank_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
+                                 const double* __restrict__ Pb, const double* __restrict__ F,
+                                 const double* __restrict__ xl, double* __restrict__ sPt, double* __restrict__ sPb,
+                                 double* __restrict__ sF, double* __restrict__ sxl) {
+  const int p = blockIdx.x;
+  const int src = idx[p];
+  const size_t szF = (size_t)2 * d * L.ldx;
+  const dbl2* a = reinterpret_cast<const dbl2*>(Pt + (size_t)src * L.szT);
+  dbl2* b = reinterpret_cast<dbl2*>(sPt + (size_t)p * L.szT);
+  for (size_t q = threadIdx.x; q < L.szT / 2; q += blockDim.x) b[q] = a[q];
+  for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) sPb[(size_t)p * L.szB + q] = Pb[(size_t)src * L.szB + q];
+  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) sF[(size_t)p * szF + q] = F[(size_t)src * szF + q];
+  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) sxl[(size_t)p * L.ldx + q] = xl[(size_t)src * L.ldx + q];
+}
+
+hipError_t launch_pack_bank(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
+                            const double* F, const double* xl, double* sPt, double* sPb, double* sF, double* sxl,
+                            hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_bank_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, sPt, sPb, sF, sxl);
   return hipGetLastError();
 }
 
