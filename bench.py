@@ -71,7 +71,7 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
         return secs
     t_cal = run(5)
     per_step = max(t_cal / 5.0, 1e-6)
-    T_s = int(min(300, max(8, target_s / per_step)))
+    T_s = int(min(1200, max(8, target_s / per_step)))
     secs = run(T_s)
     return {"value": N_s * T_s / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"slam-dense-mag N={N_s} T={T_s} m={m} fp64, C restatement of particleFilter.m "

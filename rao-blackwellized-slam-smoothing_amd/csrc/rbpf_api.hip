@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -273,6 +274,8 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   RB_TRY(dmalloc(&c->traj_max, (size_t)T * nN));
   RB_TRY(dmalloc(&c->traj_mean, (size_t)T * nN));
   RB_TRY(dmalloc(&c->d_scal, 64));
+  RB_TRY(dmalloc(&c->d_order, (size_t)N));
+  RB_TRY(dmalloc(&c->d_counts, (size_t)2 * N + 64));
   RB_TRY(dmalloc(&c->d_flags, 16));
   HIPCHK(hipMemsetAsync(c->d_flags, 0, 16 * sizeof(int), c->stream));
   RB_TRY(ctx_reset(c));
@@ -299,6 +302,7 @@ int ctx_reset(rbpf_ctx* c) {
   HIPCHK(hipGetLastError());
   c->t = 0;
   c->cur = 0;
+  c->ready_step = -1;
   return RBPF_OK;
 }
 
@@ -310,7 +314,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
-  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags);
+  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts);
   smoother_free(c);
   shard_free(c);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -331,17 +335,47 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   const size_t tr = c->opt.trace ? (size_t)t * N : 0;
   const size_t rng_page = (size_t)k_iter * N * std::max(c->T - 1, 0);
 
-  if (t > 0 && n_draw > 0) {
+  const bool pre_drawn = (c->ready_step == t);       // ancestors + order came from the fused kernel of step t-1
+  if (t > 0 && n_draw > 0 && !pre_drawn) {
     SearchArgs s;
     s.N = N; s.n_draw = n_draw; s.t = t; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
     s.U = c->d_U ? c->d_U + rng_page + (size_t)(t - 1) * N : nullptr;
     s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
+    // the weights of step t-1 were scanned in parallel: flag draws within the rounding bound of a bin edge
+    // and resolve them with the strict left-to-right cumsum (tools/sample.m:30) only then
+    s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + (c->opt.trace ? (size_t)(t - 1) * N : 0); s.wc_exact = c->wc;
     HIPCHK(launch_search(s, c->stream));
+    HIPCHK(launch_resample_fixup(s, c->stream));
   }
   StepArgs a;
   a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);
   a.ai = (t > 0) ? A_t : nullptr;
   a.ai_bank = nullptr; a.slot_offset = 0; a.xn_old_stride = (size_t)N; a.xn_new_stride = (size_t)N;
+  a.order = (pre_drawn && t > 0) ? c->d_order : nullptr;
+  {
+    static const int no_order = getenv("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only
+    static const int dbg_order = getenv("RBPF_DEBUG_ORDER") ? 1 : 0;
+    if (no_order) a.order = nullptr;
+#ifdef RBPF_STAMPS
+    if (t == 100) {
+      unsigned long long st[8];
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(st, c->d_counts + 2 * N, sizeof(st), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[rbpf stamps] normalise %.1f us, search %.1f us, order %.1f us\n", (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01);
+      fprintf(stderr, "[rbpf stamps] shader clock during the kernel: %.0f MHz\n", (double)(st[7] - st[4]) / ((st[3] - st[0]) * 0.01));
+    }
+#endif
+    if (dbg_order && a.order && (t == 5 || t == 50)) {
+      std::vector<int> ho(N), ha(N);
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(ho.data(), c->d_order, (size_t)N * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(ha.data(), A_t, (size_t)N * 4, hipMemcpyDeviceToHost));
+      long bad = 0; std::vector<char> seen(N, 0); long dup = 0;
+      for (int b = 0; b < N; ++b) { if (ho[b] < 0 || ho[b] >= N || seen[ho[b]]) ++dup; else seen[ho[b]] = 1; }
+      for (int b = 1; b < N; ++b) if (ha[ho[b]] < ha[ho[b - 1]]) ++bad;
+      fprintf(stderr, "[rbpf debug] t=%d order: %ld inversions, %ld duplicates/out-of-range; first anc %d %d %d %d\n", t, bad, dup, ha[ho[0]], ha[ho[1]], ha[ho[2]], ha[ho[3]]);
+    }
+  }
   a.xn_old = X_old; a.xn_new = X_new;
   const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
   if (t == 0) {
@@ -382,7 +416,21 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   nm.N = N; nm.nN = nN; nm.t = t; nm.logw = c->logw + tr; nm.w = c->w + tr; nm.wc = c->wc; nm.xn = X_new;
   nm.traj_max = c->traj_max + (size_t)t * nN; nm.traj_mean = c->traj_mean + (size_t)t * nN;
   nm.iw_max = c->d_flags + 2; nm.lse_out = nullptr;
-  HIPCHK(launch_normalise_scan(nm, c->stream));
+  nm.parallel_scan = 1;
+  if (c->fuse_resample && t + 1 < c->T) {
+    // filter fast path: one single-workgroup kernel normalises step t and draws step t+1's ancestors and
+    // their ancestor-sorted processing order
+    int* A_next = c->A + (hist ? (size_t)(t + 1) * N : 0);
+    SearchArgs s;
+    s.N = N; s.n_draw = N; s.t = t + 1; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
+    s.U = c->d_U ? c->d_U + rng_page + (size_t)t * N : nullptr;
+    s.seed = c->seed; s.ai = A_next; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
+    s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + tr; s.wc_exact = c->wc;
+    HIPCHK(launch_normalise_resample(nm, s, c->d_order, c->d_counts, c->stream));
+    c->ready_step = t + 1;
+  } else {
+    HIPCHK(launch_normalise_scan(nm, c->stream));
+  }
   c->cur = nb;
   c->t = t + 1;
   return RBPF_OK;
@@ -450,6 +498,7 @@ int rbpf_filter_create(const rbpf_model* model, const rbpf_problem* prob, const 
 int rbpf_filter_advance(rbpf_ctx* c, int32_t n_steps) {
   if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
+  c->fuse_resample = true;
   for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N, nullptr));
   return RBPF_OK;
 }

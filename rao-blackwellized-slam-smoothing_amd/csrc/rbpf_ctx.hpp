@@ -76,6 +76,10 @@ struct rbpf_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   rbpf::SmootherState* sm = nullptr;
   rbpf::ShardState* sh = nullptr;
+  int* d_order = nullptr;   // [N] processing order of the next step (ancestor-sorted)
+  int* d_counts = nullptr;  // [2N] counting-sort scratch
+  int ready_step = -1;      // step whose ancestors (and order) were already drawn by the fused resample kernel
+  bool fuse_resample = false;
   size_t bank_cap = 0;      // particles per bank incl. the recv region
   size_t rng_slots = 0;     // slots per step in d_U / d_Z
 };

@@ -44,6 +44,7 @@ struct StepArgs {
   int N, t, propagate;
   const int* ai;                 // ancestors of this step (null: identity); index into xn_old
   const int* ai_bank;            // ancestor index in the bank address space (null: same as ai)
+  const int* order;              // processing order: workgroup b handles slot order[b] (null: b)
   int slot_offset;               // global id of local slot 0 (RNG counters / replay rows)
   size_t xn_old_stride, xn_new_stride;      // component stride of the SoA state arrays
   const double* xn_old; double* xn_new;     // SoA [nN][stride]
@@ -80,6 +81,7 @@ struct NormArgs {
   double* traj_mean;    // [nN] column t (or null)
   int* iw_max;          // device scalar
   double* lse_out;      // device scalar (or null)
+  int parallel_scan = 0; // 1: wc holds a parallel prefix sum (searches must run in `approx` mode + fixup)
 };
 
 struct SearchArgs {
@@ -92,6 +94,10 @@ struct SearchArgs {
   unsigned long long seed;
   int* ai;              // out [N]
   int* overflow;        // device counter of clamped draws (u > wc(end))
+  int approx = 0;       // 1: wc is a parallel prefix; flag draws that fall within the rounding bound of an edge
+  int* ambiguous = nullptr;   // device counter of such draws (resolved exactly by launch_resample_fixup)
+  const double* w = nullptr;  // weights (fixup only)
+  double* wc_exact = nullptr; // scratch for the strict cumsum (fixup only; may alias wc)
 };
 
 size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0);
@@ -101,6 +107,11 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s);
 hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s);
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
+// normalise step t and, fused, draw the ancestors of step t+1 (+ their ancestor-sorted processing order)
+hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s);
+hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s);
+// exact re-draw of every slot with the strict left-to-right cumsum if any draw was flagged ambiguous
+hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s);
 
 // pack / unpack between MATLAB column-major n x n images and the bank layout
 hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src_stride, double* Pt,

@@ -22,8 +22,14 @@
 #ifndef RBPF_UC
 #define RBPF_UC 8          // columns kept in flight per wave in the covariance stream
 #endif
+#ifndef RBPF_UC2
+#define RBPF_UC2 4         // ... when a wave owns two row chunks per column
+#endif
+#ifndef RBPF_UC3
+#define RBPF_UC3 2         // ... three row chunks
+#endif
 #ifndef RBPF_NT_LOAD
-#define RBPF_NT_LOAD 1     // 1: nontemporal loads of the streamed covariance
+#define RBPF_NT_LOAD 0     // 1: nontemporal loads (defeats the Infinity-Cache reuse of sibling reads: keep 0)
 #endif
 #ifndef RBPF_NT_STORE
 #define RBPF_NT_STORE 1    // 1: nontemporal stores of the streamed covariance
@@ -87,7 +93,7 @@ Layout make_layout(int n, int d) {
   // wave decomposition of the core block: RS waves along row chunks, CS column phases.
   if (L.CH >= kWaves) { L.RS = kWaves; L.CS = 1; }
   else if (L.CH == 3) { L.RS = 1; L.CS = kWaves; }
-  else if (L.CH == 2) { L.RS = 2; L.CS = 2; }
+  else if (L.CH == 2) { L.RS = 1; L.CS = kWaves; }   // whole 2 KB columns per wave: measured 8% faster than 2x2
   else { L.RS = 1; L.CS = kWaves; }
   if (const char* e = getenv("RBPF_RS")) {          // tuning override: RS x CS must be <= 4
     const int rs = atoi(e);
@@ -95,7 +101,7 @@ Layout make_layout(int n, int d) {
     const int cs = e2 ? atoi(e2) : kWaves / (rs > 0 ? rs : 1);
     if (rs >= 1 && cs >= 1 && rs * cs <= kWaves && L.CH > 0) { L.RS = rs; L.CS = cs; }
   }
-  L.CPL = L.CH > 0 ? (L.CH + L.RS - 1) / L.RS : 1;
+  L.CPL = L.CH / L.RS;      // full rounds; the remaining CH % RS chunks go to the first waves
   L.szT = (size_t)n * L.mc;
   L.szB = (size_t)L.nb * L.ldb;
   (void)d;
@@ -167,18 +173,17 @@ __device__ inline void H_column(const ModelDev& M, int c, const double* tabS, co
 template <int D, int E, int CPL, int UC>
 __device__ __forceinline__ void stream_core(const double* __restrict__ src, double* __restrict__ dst,
                                             const double* __restrict__ HK, const double* __restrict__ KSrow,
-                                            int ldx, int n, int nb, int mc, int CH, int RS, int CS, int wr, int wc,
-                                            int lane, double* __restrict__ out_acc /* [D+E][mc] */) {
+                                            int ldx, int n, int nb, int mc, int chunk0, int chunk_stride, int CS,
+                                            int wc, int lane, double* __restrict__ out_acc /* [D+E][mc] */) {
+  // Every chunk handled here is valid (the caller decides wave-uniformly), so the loop body carries
+  // no predicates: all UC*CPL loads of a round are issued back to back and stay in flight together.
   constexpr int DE = D + E, REC = 2 * D + E;
   double acc[CPL][2][DE];
   double ks[CPL][2][D];
   int r0[CPL];
-  bool on[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
-    const int ch = wr + q * RS;
-    on[q] = ch < CH;
-    r0[q] = (on[q] ? ch : 0) * kChunkRows + 2 * lane;
+    r0[q] = (chunk0 + q * chunk_stride) * kChunkRows + 2 * lane;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
 #pragma unroll
@@ -187,6 +192,11 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
       for (int k = 0; k < D; ++k) ks[q][e][k] = KSrow ? KSrow[(size_t)k * ldx + nb + r0[q] + e] : 0.0;
     }
   }
+  const size_t colstep = (size_t)CS * mc;               // elements between two columns of this wave
+  const double* sp = src + (size_t)wc * mc;
+  double* dp = dst + (size_t)wc * mc;
+  const double* hk = HK + (size_t)wc * REC;
+  const int hkstep = CS * REC;
 
   int c = wc;
   for (; c + (UC - 1) * CS < n; c += UC * CS) {
@@ -194,51 +204,48 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
     for (int u = 0; u < UC; ++u)
 #pragma unroll
-      for (int q = 0; q < CPL; ++q)
-        if (on[q]) v[u][q] = ld_stream(src + (size_t)(c + u * CS) * mc + r0[q]);
+      for (int q = 0; q < CPL; ++q) v[u][q] = ld_stream(sp + u * colstep + r0[q]);
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
-      const int cc = c + u * CS;
       double h[DE], kc[D];
 #pragma unroll
-      for (int k = 0; k < DE; ++k) h[k] = HK[cc * REC + k];
+      for (int k = 0; k < DE; ++k) h[k] = hk[u * hkstep + k];
 #pragma unroll
-      for (int k = 0; k < D; ++k) kc[k] = HK[cc * REC + DE + k];
+      for (int k = 0; k < D; ++k) kc[k] = hk[u * hkstep + DE + k];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
-        if (!on[q]) continue;
         double p0 = v[u][q].x, p1 = v[u][q].y;
 #pragma unroll
         for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
         for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
         dbl2 o; o.x = p0; o.y = p1;
-        st_stream(dst + (size_t)cc * mc + r0[q], o);
+        st_stream(dp + u * colstep + r0[q], o);
       }
     }
+    sp += UC * colstep; dp += UC * colstep; hk += UC * hkstep;
   }
   for (; c < n; c += CS) {
     double h[DE], kc[D];
 #pragma unroll
-    for (int k = 0; k < DE; ++k) h[k] = HK[c * REC + k];
+    for (int k = 0; k < DE; ++k) h[k] = hk[k];
 #pragma unroll
-    for (int k = 0; k < D; ++k) kc[k] = HK[c * REC + DE + k];
+    for (int k = 0; k < D; ++k) kc[k] = hk[DE + k];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
-      if (!on[q]) continue;
-      const dbl2 vv = ld_stream(src + (size_t)c * mc + r0[q]);
+      const dbl2 vv = ld_stream(sp + r0[q]);
       double p0 = vv.x, p1 = vv.y;
 #pragma unroll
       for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
       for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
       dbl2 o; o.x = p0; o.y = p1;
-      st_stream(dst + (size_t)c * mc + r0[q], o);
+      st_stream(dp + r0[q], o);
     }
+    sp += colstep; dp += colstep; hk += hkstep;
   }
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
-    if (!on[q]) continue;
 #pragma unroll
     for (int k = 0; k < DE; ++k) {
       out_acc[(size_t)k * mc + r0[q]] = acc[q][0][k];
@@ -253,15 +260,20 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 //   E = 2 : particleSmootherInformationForm.m:274-335 -- additionally streams P*ivec and P*ivecPlus so
 //           the importance weight can be formed exactly as the reference writes it (:292-304)
 // ---------------------------------------------------------------------------------------------
+#ifndef RBPF_MINWAVES
+#define RBPF_MINWAVES 1     // min waves per SIMD requested from the register allocator (tuning)
+#endif
 template <int D, int E, int CPL>
-__global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
   constexpr int DE = D + E, REC = 2 * D + E;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
   const int N = a.N;
-  const int i = blockIdx.x;
+  // children are processed in ancestor order so that siblings' reads of the same covariance hit the
+  // Infinity Cache; `order` only permutes the schedule, slot i still reads / writes slot i's data
+  const int i = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LdsPlan lp = lds_plan(n, D, E, ldx, Ly.CS, mc, M.ktot);
   double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol[0..D)
@@ -351,7 +363,13 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepArgs a) {
       const double* src = a.Pt_old + (size_t)ancb * a.Pt_old_stride;
       double* dst = a.Pt_new + (size_t)i * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
-      stream_core<D, E, CPL, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, Ly.CH, Ly.RS, Ly.CS, wr, wc, lane, out_acc);
+      // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
+      // both decisions are wave-uniform, so the streaming loops are branch-free
+      if (CPL > 0)
+        stream_core<D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3))>(src, dst, HK, KSrow, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
+      const int rem = Ly.CH - CPL * Ly.RS;
+      if (wr < rem)
+        stream_core<D, E, 1, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
@@ -560,27 +578,22 @@ static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
 
 hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   const int D = a.mdl.d, CPL = a.lay.CPL;
+#define RBPF_DISPATCH(DD, EE)                                   \
+  switch (CPL) {                                                \
+    case 0: return launch_step_t<DD, EE, 0>(a, s);              \
+    case 1: return launch_step_t<DD, EE, 1>(a, s);              \
+    case 2: return launch_step_t<DD, EE, 2>(a, s);              \
+    case 3: return launch_step_t<DD, EE, 3>(a, s);              \
+    default: return hipErrorInvalidValue;                       \
+  }
   if (a.info) {
-    if (D == 3) {
-      if (CPL == 1) return launch_step_t<3, 2, 1>(a, s);
-      if (CPL == 2) return launch_step_t<3, 2, 2>(a, s);
-      if (CPL == 3) return launch_step_t<3, 2, 3>(a, s);
-    } else if (D == 1) {
-      if (CPL == 1) return launch_step_t<1, 2, 1>(a, s);
-      if (CPL == 2) return launch_step_t<1, 2, 2>(a, s);
-      if (CPL == 3) return launch_step_t<1, 2, 3>(a, s);
-    }
+    if (D == 3) { RBPF_DISPATCH(3, 2) }
+    if (D == 1) { RBPF_DISPATCH(1, 2) }
     return hipErrorInvalidValue;
   }
-  if (D == 3) {
-    if (CPL == 1) return launch_step_t<3, 0, 1>(a, s);
-    if (CPL == 2) return launch_step_t<3, 0, 2>(a, s);
-    if (CPL == 3) return launch_step_t<3, 0, 3>(a, s);
-  } else if (D == 1) {
-    if (CPL == 1) return launch_step_t<1, 0, 1>(a, s);
-    if (CPL == 2) return launch_step_t<1, 0, 2>(a, s);
-    if (CPL == 3) return launch_step_t<1, 0, 3>(a, s);
-  }
+  if (D == 3) { RBPF_DISPATCH(3, 0) }
+  if (D == 1) { RBPF_DISPATCH(1, 0) }
+#undef RBPF_DISPATCH
   return hipErrorInvalidValue;
 }
 
@@ -647,31 +660,62 @@ __device__ inline void strict_cumsum_block(int N, const double* __restrict__ w, 
   }
 }
 
-__global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const NormArgs a) {
-  __shared__ double sred[16];
-  __shared__ int sidx[16];
-  __shared__ double sbuf[kScanChunk];
-  __shared__ double sbuf2[kScanChunk];
-  __shared__ double scarry;
+// All passes below work on register batches of NB elements per thread with clamped (always in-bounds)
+// indices and selects, so the NB loads of a batch are in flight together: a lone workgroup is latency-
+// bound, and hipcc does not overlap the loads of a plain `for (i = tid; i < N; i += blockDim)` loop.
+constexpr int kNB = 8;
+
+__device__ inline void normalise_block(const NormArgs& a, double* sred, int* sidx, double* sbuf, double* sbuf2, double* scarry_p) {
   const int tid = threadIdx.x, N = a.N;
   const int lane = tid & 63, wave = tid >> 6;
+  const int step = kNormThreads * kNB;
 
-  // c = max(logw)
+  // c = max(logw)   (fmax skips NaN like MATLAB's max)
   double mx = -INFINITY;
-  for (int i = tid; i < N; i += kNormThreads) mx = fmax(mx, a.logw[i]);
+  for (int base = 0; base < N; base += step) {
+    double v[kNB];
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; v[k] = a.logw[min(i, N - 1)]; }
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; mx = fmax(mx, i < N ? v[k] : -INFINITY); }
+  }
   const double c = block_max_1024(mx, sred);
   // lse = c + log(sum(exp(logw - c)))
   double se = 0.0;
-  for (int i = tid; i < N; i += kNormThreads) se += exp(a.logw[i] - c);
+  for (int base = 0; base < N; base += step) {
+    double v[kNB];
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; v[k] = a.logw[min(i, N - 1)]; }
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; const double e = exp(v[k] - c); se += (i < N) ? e : 0.0; }
+  }
   const double tot = block_sum_1024(se, sred);
   const double lse = c + log(tot);
-  // w = exp(logw - lse); [~,iw_max] = max(w) (first maximum)
+  // w = exp(logw - lse); [~,iw_max] = max(w) (first maximum); traj_mean(:,t) = sum(xn.*w,2) -- one pass,
+  // one combined block reduction (fixed order -> deterministic)
   double bw = -1.0;
   int bi = 0x7fffffff;
-  for (int i = tid; i < N; i += kNormThreads) {
-    const double wi = exp(a.logw[i] - lse);
-    a.w[i] = wi;
-    if (wi > bw) { bw = wi; bi = i; }
+  double ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int base = 0; base < N; base += step) {
+    double v[kNB], wv[kNB];
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; v[k] = a.logw[min(i, N - 1)]; }
+#pragma unroll
+    for (int k = 0; k < kNB; ++k) {
+      const int i = base + k * kNormThreads + tid;
+      wv[k] = exp(v[k] - lse);
+      if (i < N) a.w[i] = wv[k];
+      const bool better = (i < N) && (wv[k] > bw);
+      bw = better ? wv[k] : bw;
+      bi = better ? i : bi;
+    }
+    for (int cix = 0; cix < a.nN; ++cix) {
+      double xv[kNB];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; xv[k] = a.xn[(size_t)cix * N + min(i, N - 1)]; }
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) { const int i = base + k * kNormThreads + tid; ts[cix] = (i < N) ? fma(xv[k], wv[k], ts[cix]) : ts[cix]; }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -679,8 +723,12 @@ __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const Norm
     const int oi = __shfl_xor(bi, off, 64);
     if (ow > bw || (ow == bw && oi < bi)) { bw = ow; bi = oi; }
   }
+  for (int cix = 0; cix < a.nN; ++cix) ts[cix] = wave_sum(ts[cix]);
   __syncthreads();
-  if (lane == 0) { sred[wave] = bw; sidx[wave] = bi; }
+  if (lane == 0) {
+    sred[wave] = bw; sidx[wave] = bi;
+    for (int cix = 0; cix < a.nN; ++cix) sbuf[wave * 8 + cix] = ts[cix];
+  }
   __syncthreads();
   double gw = sred[0];
   int gi = sidx[0];
@@ -691,23 +739,258 @@ __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const Norm
     *a.iw_max = gi;
     if (a.lse_out) *a.lse_out = lse;
   }
-  // traj_max(:,t) = xn(:,iw_max); traj_mean(:,t) = sum(xn.*w,2)
-  for (int cix = 0; cix < a.nN; ++cix) {
-    const double* xr = a.xn + (size_t)cix * N;
-    double s = 0.0;
-    for (int i = tid; i < N; i += kNormThreads) s = fma(xr[i], a.w[i], s);
-    const double tm = block_sum_1024(s, sred);
-    if (tid == 0) {
-      if (a.traj_mean) a.traj_mean[cix] = tm;
-      if (a.traj_max) a.traj_max[cix] = xr[gi];
+  if (tid < a.nN) {
+    double tm = sbuf[tid];
+    for (int w = 1; w < kNormThreads / 64; ++w) tm += sbuf[w * 8 + tid];
+    if (a.traj_mean) a.traj_mean[tid] = tm;
+    if (a.traj_max) a.traj_max[tid] = a.xn[(size_t)tid * N + gi];
+  }
+  __syncthreads();
+  if (!a.parallel_scan) {
+    // wc = cumsum(w): one lane, strict left-to-right, staged through LDS in chunks
+    strict_cumsum_block(N, a.w, a.wc, sbuf, sbuf2, scarry_p);
+    return;
+  }
+  // Parallel prefix sum (fixed association order -> deterministic).  It differs from the strict
+  // left-to-right cumsum of tools/sample.m:30 only by rounding; the search bounds that difference
+  // and recomputes the strict sum whenever a draw could be affected.
+  {
+    const int S = (N + kNormThreads - 1) / kNormThreads;
+    const int j0 = min(tid * S, N), j1 = min(j0 + S, N);
+    double tot = 0.0;
+    for (int jb = j0; jb < j1; jb += kNB) {
+      double v[kNB];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) v[k] = a.w[min(jb + k, N - 1)];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) tot += (jb + k < j1) ? v[k] : 0.0;
+    }
+    double inc = tot;                                   // inclusive scan of the per-thread totals
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    double exc = __shfl_up(inc, 1, 64);
+    if (lane == 0) exc = 0.0;
+    __syncthreads();
+    if (lane == 63) sred[wave] = inc;
+    __syncthreads();
+    double woff = 0.0;
+    for (int w = 0; w < wave; ++w) woff += sred[w];
+    double run = woff + exc;
+    for (int jb = j0; jb < j1; jb += kNB) {
+      double v[kNB];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k) v[k] = a.w[min(jb + k, N - 1)];
+#pragma unroll
+      for (int k = 0; k < kNB; ++k)
+        if (jb + k < j1) { run += v[k]; a.wc[jb + k] = run; }
     }
   }
-  // wc = cumsum(w): one lane, strict left-to-right, staged through LDS in chunks
-  strict_cumsum_block(N, a.w, a.wc, sbuf, sbuf2, &scarry);
+}
+
+// Lower bound of SB uniforms at once: the SB binary searches advance in lock step so that their
+// (dependent-chain) loads overlap instead of serialising.  Result = #{j : wc_j < u}.
+template <int SB>
+__device__ __forceinline__ void lower_bound_batch(const double* __restrict__ wc, int N, int rounds, const double* u,
+                                                  const bool* valid, int* out) {
+  int lo[SB], hi[SB];
+#pragma unroll
+  for (int k = 0; k < SB; ++k) { lo[k] = 0; hi[k] = valid[k] ? N : 0; }
+  for (int r = 0; r < rounds; ++r) {
+    double v[SB];
+    int mid[SB];
+#pragma unroll
+    for (int k = 0; k < SB; ++k) { mid[k] = (lo[k] + hi[k]) >> 1; v[k] = wc[min(mid[k], N - 1)]; }
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {                    // selects only: no divergent control flow
+      const bool active = lo[k] < hi[k];
+      const bool less = v[k] < u[k];
+      lo[k] = (active && less) ? mid[k] + 1 : lo[k];
+      hi[k] = (active && !less) ? mid[k] : hi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < SB; ++k) out[k] = lo[k];
+}
+
+// block-wide search of n_draw uniforms with the exact fallback inline.  One CU cannot sustain N scattered
+// 8-byte global loads per bisection round, so the bisection runs on an LDS table: the running sums
+// themselves when N <= 2*kScanChunk, otherwise the last element of every group of G consecutive sums
+// followed by a short linear count inside the one group (a single cache line for G <= 8).
+__device__ inline void search_block(const SearchArgs& a, double* sbuf, double* sbuf2, double* scarry_p, int* sflag) {
+  constexpr int SB = 8;
+  constexpr int CAP = 2 * kScanChunk;                  // sbuf and sbuf2 are one contiguous array
+  const int tid = threadIdx.x, N = a.N;
+  double* T = sbuf;
+  if (tid == 0) *sflag = 0;
+  __syncthreads();
+  const double S = (double)((N + kNormThreads - 1) / kNormThreads);
+  int G = 1;
+  while ((N + G - 1) / G > CAP) G <<= 1;
+  const int ng = (N + G - 1) / G;
+  int rounds = 1;
+  while ((1 << rounds) <= ng) ++rounds;               // ceil(log2(ng+1)) rounds settle every search
+  for (int pass = 0; pass < 2; ++pass) {
+    const double* wc = (pass == 0) ? a.wc : a.wc_exact;
+    for (int base = 0; base < ng; base += kNormThreads * SB) {
+      double v[SB];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) { const int j = base + k * kNormThreads + tid; v[k] = wc[min(min(j, ng - 1) * G + G - 1, N - 1)]; }
+#pragma unroll
+      for (int k = 0; k < SB; ++k) { const int j = base + k * kNormThreads + tid; if (j < ng) T[j] = v[k]; }
+    }
+    __syncthreads();
+    for (int base = 0; base < a.n_draw; base += kNormThreads * SB) {
+      double u[SB];
+      bool valid[SB];
+      int res[SB];
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        const int i0 = base + k * kNormThreads + tid;
+        valid[k] = i0 < a.n_draw;
+        const int i = a.slot0 + i0;
+        u[k] = !valid[k] ? 0.0
+               : (a.rng_mode == 0) ? a.U[a.u_is_scalar ? 0 : i] : philox_resample_uniform(a.seed, i, a.t, a.k_iter);
+      }
+      lower_bound_batch<SB>(T, ng, rounds, u, valid, res);          // group index (LDS)
+      double p_hi[SB], p_lo[SB];
+      if (G > 1) {                                                   // count inside the group (global)
+        for (int e = 0; e < G; ++e) {
+          double w[SB];
+#pragma unroll
+          for (int k = 0; k < SB; ++k) w[k] = wc[min(min(res[k], ng - 1) * G + e, N - 1)];
+#pragma unroll
+          for (int k = 0; k < SB; ++k) {
+            const int j = res[k] * G + e;          // res[k] still the group index in this loop
+            p_lo[k] = w[k];                        // placeholder use keeps the load live
+            if (e == 0) p_hi[k] = 0.0;
+            p_hi[k] += (res[k] < ng && j < N && w[k] < u[k]) ? 1.0 : 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SB; ++k) res[k] = (res[k] >= ng) ? N : min(res[k] * G + (int)p_hi[k], N);
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { p_hi[k] = wc[min(res[k], N - 1)]; p_lo[k] = wc[max(res[k] - 1, 0)]; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < SB; ++k) { p_hi[k] = T[min(res[k], N - 1)]; p_lo[k] = T[max(res[k] - 1, 0)]; }
+      }
+      bool amb = false;
+      int nover = 0;
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        const int lo = res[k];
+        const double tol = 1.7e-16 * ((double)lo + S + 32.0);
+        const bool a_hi = (lo < N) && (fabs(p_hi[k] - u[k]) <= tol * fabs(p_hi[k]));
+        const bool a_lo = (lo > 0) && (fabs(p_lo[k] - u[k]) <= tol * fabs(p_lo[k]));
+        amb |= valid[k] && (a_hi || a_lo);
+        nover += (valid[k] && lo >= N) ? 1 : 0;
+        res[k] = min(lo, N - 1);
+      }
+#pragma unroll
+      for (int k = 0; k < SB; ++k)
+        if (valid[k]) a.ai[a.slot0 + base + k * kNormThreads + tid] = res[k];
+      if (pass == 0 && a.approx && amb) atomicOr(sflag, 1);
+      if (pass == 0 && a.overflow && nover) atomicAdd(a.overflow, nover);
+    }
+    __syncthreads();
+    if (pass == 1 || !*sflag) break;
+    // rare: a draw within the rounding bound of a bin edge -> strict cumsum, then redo every draw exactly
+    strict_cumsum_block(N, a.w, a.wc_exact, sbuf, sbuf2, scarry_p);
+    __syncthreads();
+    if (tid == 0 && a.ambiguous) atomicAdd(a.ambiguous + 1, 1);
+  }
+}
+
+// counting sort of the slots by key (ancestor): order[] lists the slots so that equal keys are adjacent.
+// The order among equal keys is arbitrary (atomics) -- it only changes the schedule, never a result.
+__device__ inline void order_block(int n_slots, int range, const int* __restrict__ key, int* __restrict__ order,
+                                   int* __restrict__ counts_global, int* sred_i, int* lds_counts, int lds_capacity) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* counts = (range <= lds_capacity) ? lds_counts : counts_global;     // LDS atomics when the histogram fits
+  __syncthreads();
+  for (int j = tid; j < range; j += kNormThreads) counts[j] = 0;
+  __syncthreads();
+  for (int i = tid; i < n_slots; i += kNormThreads) atomicAdd(&counts[key[i]], 1);
+  __syncthreads();
+  const int S = (range + kNormThreads - 1) / kNormThreads;
+  const int j0 = min(tid * S, range), j1 = min(j0 + S, range);
+  int tot = 0;
+  for (int j = j0; j < j1; ++j) tot += __hip_atomic_load(&counts[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) sred_i[wave] = inc;
+  __syncthreads();
+  int run = inc - tot;
+  for (int w = 0; w < wave; ++w) run += sred_i[w];
+  for (int j = j0; j < j1; ++j) {
+    const int cnt = __hip_atomic_load(&counts[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&counts[j], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    run += cnt;
+  }
+  __syncthreads();
+  for (int i = tid; i < n_slots; i += kNormThreads) order[atomicAdd(&counts[key[i]], 1)] = i;
+}
+
+__global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const NormArgs a) {
+  __shared__ double sred[16];
+  __shared__ int sidx[16];
+  __shared__ double sbig[2 * kScanChunk];
+  __shared__ double scarry;
+  normalise_block(a, sred, sidx, sbig, sbig + kScanChunk, &scarry);
+}
+
+// normalise step t, then (filter fast path) draw the ancestors of step t+1 and their processing order
+__global__ __launch_bounds__(kNormThreads) void normalise_resample_kernel(const NormArgs a, const SearchArgs sa,
+                                                                          int* order, int* counts) {
+  __shared__ double sred[16];
+  __shared__ int sidx[16];
+  __shared__ double sbig[2 * kScanChunk];
+  __shared__ double scarry;
+  __shared__ int sflag;
+  double* sbuf = sbig;
+  double* sbuf2 = sbig + kScanChunk;
+#ifdef RBPF_STAMPS   // diagnostic build only: phase times (100 MHz ticks) into the tail of the counting-sort scratch
+#define RBPF_STAMP(k) if (threadIdx.x == 0) { reinterpret_cast<unsigned long long*>(counts + 2 * sa.N)[k] = __builtin_amdgcn_s_memrealtime(); reinterpret_cast<unsigned long long*>(counts + 2 * sa.N)[4 + k] = __builtin_amdgcn_s_memtime(); }
+#else
+#define RBPF_STAMP(k)
+#endif
+  RBPF_STAMP(0);
+  normalise_block(a, sred, sidx, sbuf, sbuf2, &scarry);
+  __syncthreads();
+  RBPF_STAMP(1);
+  search_block(sa, sbuf, sbuf2, &scarry, &sflag);
+  __syncthreads();
+  RBPF_STAMP(2);
+  if (order) order_block(sa.n_draw, sa.N, sa.ai, order, counts, sidx, reinterpret_cast<int*>(sbuf), 2 * kScanChunk);
+  __syncthreads();
+  RBPF_STAMP(3);
+}
+
+__global__ __launch_bounds__(kNormThreads) void order_kernel(int n_slots, int range, const int* key, int* order, int* counts) {
+  __shared__ int sidx[16];
+  __shared__ int scnt[2 * kScanChunk];
+  order_block(n_slots, range, key, order, counts, sidx, scnt, 2 * kScanChunk);
 }
 
 hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(normalise_scan_kernel, dim3(1), dim3(kNormThreads), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s) {
+  hipLaunchKernelGGL(normalise_resample_kernel, dim3(1), dim3(kNormThreads), 0, s, a, sa, order, counts);
+  return hipGetLastError();
+}
+
+hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s) {
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kNormThreads), 0, s, n_slots, range, key, order, counts);
   return hipGetLastError();
 }
 
@@ -725,7 +1008,11 @@ hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s) {
   return hipGetLastError();
 }
 
-// ind = sum(wc < u) (0-based), clamped to N-1 (the reference would return N+1 -> MATLAB error)
+// ind = sum(wc < u) (0-based), clamped to N-1 (the reference would return N+1 -> MATLAB error).
+// approx mode: wc is the parallel prefix p~.  Both p~_j and the strict cumsum wc_j approximate the
+// exact prefix S_j: |wc_j - S_j| <= (j+1) u S_j, |p~_j - S_j| <= (S + 24) u S_j (u = 2^-53), so every
+// comparison (wc_j < u) is decided by p~_j unless |p~_j - u| <= eps_j = 1.5 (j + S + 32) u p~_j.  Since
+// p~ is monotone up to rounding, only the two entries bracketing the search result can be that close.
 __global__ void search_kernel(const SearchArgs a) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   if (i0 >= a.n_draw) return;
@@ -736,8 +1023,44 @@ __global__ void search_kernel(const SearchArgs a) {
     const int mid = (lo + hi) >> 1;
     if (a.wc[mid] < u) lo = mid + 1; else hi = mid;
   }
+  if (a.approx) {
+    const double S = (double)((a.N + kNormThreads - 1) / kNormThreads);
+    bool amb = false;
+    if (lo < a.N) { const double p = a.wc[lo]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S + 32.0) * fabs(p); }
+    if (lo > 0) { const double p = a.wc[lo - 1]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S + 32.0) * fabs(p); }
+    if (amb) atomicAdd(a.ambiguous, 1);
+  }
   if (lo >= a.N) { lo = a.N - 1; if (a.overflow) atomicAdd(a.overflow, 1); }
   a.ai[i] = lo;
+}
+
+// Runs after an approx search: nothing to do unless a draw was flagged; then the strict cumsum is
+// formed (one lane, sequential) and every slot is re-drawn against it.
+__global__ __launch_bounds__(kNormThreads) void resample_fixup_kernel(const SearchArgs a) {
+  __shared__ double sbuf[kScanChunk];
+  __shared__ double sbuf2[kScanChunk];
+  __shared__ double scarry;
+  if (*a.ambiguous == 0) return;
+  strict_cumsum_block(a.N, a.w, a.wc_exact, sbuf, sbuf2, &scarry);
+  __syncthreads();
+  for (int i0 = threadIdx.x; i0 < a.n_draw; i0 += blockDim.x) {
+    const int i = a.slot0 + i0;
+    const double u = (a.rng_mode == 0) ? a.U[a.u_is_scalar ? 0 : i] : philox_resample_uniform(a.seed, i, a.t, a.k_iter);
+    int lo = 0, hi = a.N;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (a.wc_exact[mid] < u) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= a.N) lo = a.N - 1;
+    a.ai[i] = lo;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { atomicAdd(a.ambiguous + 1, 1); *a.ambiguous = 0; }   // [+1]: fallback counter (diagnostics)
+}
+
+hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(resample_fixup_kernel, dim3(1), dim3(kNormThreads), 0, s, a);
+  return hipGetLastError();
 }
 
 hipError_t launch_search(const SearchArgs& a, hipStream_t s) {

@@ -138,6 +138,7 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, int32_t* ai_host) {
   nm.N = N; nm.nN = nN; nm.t = t_done; nm.logw = s->logw_gather; nm.w = s->w_glob; nm.wc = s->wc_glob; nm.xn = s->xn_glob;
   nm.traj_max = c->traj_max + (size_t)t_done * nN; nm.traj_mean = c->traj_mean + (size_t)t_done * nN;
   nm.iw_max = c->d_flags + 2; nm.lse_out = nullptr;
+  nm.parallel_scan = 1;
   HIPCHK(launch_normalise_scan(nm, c->stream));
   s->t_norm = t_done + 1;
   if (ai_host) {
@@ -147,7 +148,9 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, int32_t* ai_host) {
     sa.u_is_scalar = 0;
     sa.U = c->d_U ? c->d_U + (size_t)(t - 1) * N : nullptr;
     sa.seed = c->seed; sa.ai = s->ai_glob; sa.overflow = c->d_flags + 1;
+    sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = s->w_glob; sa.wc_exact = s->wc_glob;
     HIPCHK(launch_search(sa, c->stream));
+    HIPCHK(launch_resample_fixup(sa, c->stream));
     HIPCHK(hipMemcpyAsync(ai_host, s->ai_glob, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(hipStreamSynchronize(c->stream));
@@ -191,6 +194,8 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host) {
     HIPCHK(hipMemcpyAsync(s->ai_bank, anc_bank_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
     a.ai = s->ai_glob + (size_t)s->rank * N;                // global ancestor ids of my slots
     a.ai_bank = s->ai_bank;
+    HIPCHK(launch_order(N, 2 * N, s->ai_bank, c->d_order, c->d_counts, c->stream));
+    a.order = c->d_order;
     a.xn_old = s->xn_glob; a.xn_old_stride = (size_t)s->Nglob;
     a.xl_old = c->xl[ob]; a.xl_old_stride = (size_t)L.ldx; a.F_old = c->F[ob];
     a.Pt_old = c->Pt[ob]; a.Pb_old = c->Pb[ob]; a.Pt_old_stride = L.szT; a.Pb_old_stride = L.szB;

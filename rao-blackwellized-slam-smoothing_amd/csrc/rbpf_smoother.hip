@@ -534,7 +534,9 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       sa.N = N; sa.n_draw = 1; sa.t = T; sa.wc = c->wc; sa.rng_mode = c->rng_mode; sa.k_iter = k; sa.slot0 = 0;
       sa.U = d_uf; sa.seed = c->seed; sa.ai = s->d_ak; sa.overflow = c->d_flags + 1;
       sa.u_is_scalar = 1;
+      sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = c->w + (c->opt.trace ? (size_t)(T - 1) * N : 0); sa.wc_exact = c->wc;
       HIPCHK(launch_search(sa, st));
+      HIPCHK(launch_resample_fixup(sa, st));
       (void)tr_last;
       HIPCHK(launch_backtrace(N, nN, T, c->X, c->A, s->d_ak, 1, s->d_xnk, st));
       int ak = 0;
