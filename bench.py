@@ -149,6 +149,7 @@ def main():
     chk = sess.finish(want=("traj_mean",))
     if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
         raise SystemExit("non-finite filter output")
+    shard_stats = getattr(sess, "stats", None)
     sess.close()
 
     if rank == 0:
@@ -179,6 +180,11 @@ def main():
                          "kernel": "step_kernel", "avg_launch_ms": avg_ms, "launches": tm["launches"],
                          "algorithmic_bytes_per_launch": tm["bytes_per_launch"]},
         }
+        if shard_stats:
+            st = dict(shard_stats)
+            ph = st.pop("phase_s", {})
+            st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 4) for k, v in ph.items()}
+            line["config"]["sharding"] = st
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)

@@ -196,42 +196,56 @@ int rbpf_timing_read(rbpf_ctx* ctx, rbpf_timing* out, int32_t reset);
 int rbpf_destroy(rbpf_ctx* ctx);
 
 /* ---- particle-sharded filter (one process per GPU) ----------------------------------
- * Logical slot i of the global filter (N = world * N_P) lives on rank i / N_P.  The collectives stay
- * outside the library (torch.distributed over RCCL in multigpu.py); the library exposes the device
+ * The global filter has N = world * N_P logical slots.  A logical slot keeps its identity (RNG stream,
+ * position in every output) but its particle may live on any rank: children are computed on the rank
+ * that already holds their ancestor's map state ("owner computes") and only the load-imbalance excess
+ * migrates.  Every rank always holds exactly N_P particles in physical slots 0..N_P-1.  The collectives
+ * stay outside the library (torch.distributed over RCCL in multigpu.py); the library exposes the device
  * buffers and the kernels between them.  Per time step t >= 1 the host side does
- *   all_gather(logw_local -> logw_gather), all_gather(xn_local -> xn_gather)
- *   rbpf_shard_normalise_search(ctx, ai_host)     global w / cumsum / ancestors, identical on every rank
- *   rbpf_shard_pack(ctx, idx, count)              my particles that other ranks need -> send staging
- *   all_to_all_single(send_* -> recv_*)           only unique remote ancestors travel
- *   rbpf_shard_step(ctx, anc_bank)                fused step kernel; remote ancestors read from recv_*
- * and after the last step one more gather + rbpf_shard_normalise_search(ctx, NULL).                */
+ *   all_gather(fwd_local -> fwd_gather)                 log-weights + non-linear states, physical order
+ *   rbpf_shard_normalise_search(ctx, perm, ai_host)     permute to logical order; global w / cumsum /
+ *                                                       ancestors -- identical on every rank
+ *   (host) placement of the new generation + exchange plan from the replicated ancestor vector
+ *   rbpf_shard_pack(ctx, idx, count)                    ancestors another rank needs -> send records
+ *   all_to_all_single(send_rec -> recv_rec)
+ *   rbpf_shard_step(ctx, anc_bank, slot_ids)            fused step kernel for my N_P physical slots
+ * and after the last step one more gather + rbpf_shard_normalise_search(ctx, perm, NULL).            */
 typedef struct {
-  int32_t rank, world, N_local, N_global;
-  size_t szT, szB, szF, szX;   /* doubles per particle in the four bank components (Pt, Pb, F, xl)   */
-  size_t recv_capacity;        /* particles the recv region can hold                                 */
-  size_t send_capacity;        /* particles the send staging can hold                                */
-  double* logw_local;          /* [N_local]            written by the step kernel                     */
-  double* xn_local;            /* [nN][N_local]        written by the step kernel                     */
-  double* logw_gather;         /* [world][N_local]     all_gather target                             */
-  double* xn_gather;           /* [world][nN][N_local] all_gather target                             */
-  double* send_Pt; double* send_Pb; double* send_F; double* send_xl;   /* pack output                 */
-  double* recv_Pt; double* recv_Pb; double* recv_F; double* recv_xl;   /* tail of the CURRENT old bank */
+  int32_t rank, world, N_local, N_global, n_nonlin;
+  size_t record_doubles;       /* doubles per exchanged particle record [Pt | Pb | F | xl]            */
+  size_t recv_capacity;        /* records the receive buffer can hold                                */
+  size_t send_capacity;        /* records the send buffer can hold                                   */
+  double* fwd_local;           /* [(n_nonlin+1)][N_local]: rows xn, last row logw (step kernel output) */
+  double* fwd_gather;          /* [world][(n_nonlin+1)][N_local] all_gather target                    */
+  double* send_rec;            /* [send_capacity][record_doubles]                                     */
+  double* recv_rec;            /* [recv_capacity][record_doubles]                                     */
 } rbpf_shard_views;
 
 int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
                       const rbpf_options* opt, int32_t rank, int32_t world, rbpf_ctx** ctx);
-/* Device pointers for the collectives; recv_* change every step (ping-pong): query after each step.  */
 int rbpf_shard_views_get(rbpf_ctx* ctx, rbpf_shard_views* out);
-/* After the gathers: normalise the global weights, strict cumsum, trajectory summaries of the step just
- * finished; if ai_host != NULL also draw the ancestors of ALL N_global slots (every rank gets the same
- * vector, 0-based global indices) and copy them to ai_host [N_global].  Synchronises the stream.      */
-int rbpf_shard_normalise_search(rbpf_ctx* ctx, int32_t* ai_host);
-/* Gather `count` local particles (local indices idx_host, in send order) into the send staging.       */
+/* After the gather: bring the forward bank into logical order (phys_of_logical_host [N_global]:
+ * rank*N_local + physical index of each logical slot; NULL = identity), normalise the global weights,
+ * cumsum, trajectory summaries of the step just finished; if ai_host != NULL also draw the ancestors of
+ * ALL N_global logical slots (0-based logical ids; the same vector on every rank) into ai_host.
+ * Synchronises the stream.                                                                          */
+int rbpf_shard_normalise_search(rbpf_ctx* ctx, const int32_t* phys_of_logical_host, int32_t* ai_host);
+/* Gather `count` local particles (physical indices idx_host, in send order) into send_rec.           */
 int rbpf_shard_pack(rbpf_ctx* ctx, const int32_t* idx_host, int32_t count);
-/* One fused step for the local slots.  anc_bank_host [N_local]: index of each slot's ancestor in the
- * bank address space (< N_local: local particle, >= N_local: N_local + position in the recv region);
- * NULL at t = 0.  The ancestors' non-linear states are read from xn_gather by global index.           */
-int rbpf_shard_step(rbpf_ctx* ctx, const int32_t* anc_bank_host);
+/* One fused step for my N_local physical slots.  slot_ids_host [N_local]: logical id of each physical
+ * slot of the NEW generation; anc_bank_host [N_local]: where its ancestor's map state is (< N_local:
+ * physical slot of the old local bank, >= N_local: N_local + record index in recv_rec).  Both NULL at
+ * t = 0 (identity placement: logical slot rank*N_local + p at physical slot p).                      */
+int rbpf_shard_step(rbpf_ctx* ctx, const int32_t* anc_bank_host, const int32_t* slot_ids_host);
+/* Device-side planner (the production path): placement of the new generation + exchange plan from the
+ * ancestors drawn by the last rbpf_shard_normalise_search, entirely on the device.  counts_host
+ * [2*world+1] receives the records to send to / receive from every rank and the number of migrating
+ * children.  Afterwards rbpf_shard_pack(ctx, NULL, n_send), rbpf_shard_step(ctx, NULL, NULL) and
+ * rbpf_shard_normalise_search(ctx, NULL, ...) use the device plan.                                      */
+int rbpf_shard_plan(rbpf_ctx* ctx, int64_t* counts_host);
+/* Test hook: this rank's view of the current device plan.                                             */
+int rbpf_shard_plan_read(rbpf_ctx* ctx, int32_t* slot_ids, int32_t* anc_bank, int32_t* send_idx,
+                         int32_t n_send, int32_t* new_gid);
 /* traj_max / traj_mean [n_nonlin x N_T] of the steps normalised so far (identical on every rank).     */
 int rbpf_shard_trajectories(rbpf_ctx* ctx, double* traj_max, double* traj_mean);
 

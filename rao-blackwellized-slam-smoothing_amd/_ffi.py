@@ -76,7 +76,7 @@ EXPORTS = [
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
-    "rbpf_shard_trajectories",
+    "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read",
 ]
 
 _lib = None

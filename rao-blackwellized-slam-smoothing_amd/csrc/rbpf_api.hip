@@ -352,6 +352,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.ai = (t > 0) ? A_t : nullptr;
   a.ai_bank = nullptr; a.slot_offset = 0; a.xn_old_stride = (size_t)N; a.xn_new_stride = (size_t)N;
   a.order = (pre_drawn && t > 0) ? c->d_order : nullptr;
+  a.slot_ids = nullptr; a.n_bank_local = 0; a.rec = nullptr; a.rec_stride = 0; a.rec_off_B = a.rec_off_F = a.rec_off_X = 0;
   {
     static const int no_order = getenv("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only
     static const int dbg_order = getenv("RBPF_DEBUG_ORDER") ? 1 : 0;

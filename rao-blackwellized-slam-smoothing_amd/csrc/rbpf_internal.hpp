@@ -45,6 +45,11 @@ struct StepArgs {
   const int* ai;                 // ancestors of this step (null: identity); index into xn_old
   const int* ai_bank;            // ancestor index in the bank address space (null: same as ai)
   const int* order;              // processing order: workgroup b handles slot order[b] (null: b)
+  const int* slot_ids;           // logical (global) id of each local slot (null: slot_offset + i); when set,
+                                 // `ai` is indexed by that logical id
+  // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
+  // `rec`, a particle-major buffer [Pt | Pb | F | xl] per record
+  int n_bank_local; const double* rec; size_t rec_stride, rec_off_B, rec_off_F, rec_off_X;
   int slot_offset;               // global id of local slot 0 (RNG counters / replay rows)
   size_t xn_old_stride, xn_new_stride;      // component stride of the SoA state arrays
   const double* xn_old; double* xn_new;     // SoA [nN][stride]
@@ -133,9 +138,10 @@ hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, c
 hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, const double* lo, const double* up,
                                  double* J, hipStream_t s);
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
-hipError_t launch_unblock_soa(int world, int nN, int Nloc, const double* blocked, double* soa, hipStream_t s);
-hipError_t launch_pack_bank(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                            const double* F, const double* xl, double* sPt, double* sPb, double* sF, double* sxl, hipStream_t s);
+hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
+                               const double* F, const double* xl, double* rec, hipStream_t s);
+hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
+                              double* logw, double* xn_soa, hipStream_t s);
 hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);
 
 }  // namespace rbpf

@@ -285,9 +285,16 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   double* misc = smem + lp.off_misc;    // 0..7 xn_new, 8..16 Rnb, 20.. epilogue broadcast
   double* red = smem + lp.off_red;
 
-  const int anc = a.ai ? a.ai[i] : i;                  // ancestor id for the non-linear state bank
-  const int ancb = a.ai_bank ? a.ai_bank[i] : anc;     // ancestor id in the map bank (local | recv region)
-  const int gslot = a.slot_offset + i;                 // global slot id (RNG stream)
+  const int gslot = a.slot_ids ? a.slot_ids[i] : a.slot_offset + i;   // logical (global) slot id: RNG stream
+  const int anc = a.ai ? a.ai[a.slot_ids ? gslot : i] : i;             // ancestor id for the non-linear state bank
+  const int ancb = a.ai_bank ? a.ai_bank[i] : anc;     // ancestor id in the map bank (local | remote records)
+  // sources of the ancestor's map state: the local bank, or a received record
+  const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;
+  const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
+  const double* srcT = remote ? recp : a.Pt_old + (size_t)ancb * a.Pt_old_stride;
+  const double* srcB = remote ? recp + a.rec_off_B : a.Pb_old + (size_t)ancb * a.Pb_old_stride;
+  const double* srcF = remote ? recp + a.rec_off_F : (a.F_old ? a.F_old + (size_t)ancb * 2 * D * ldx : nullptr);
+  const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
   const int nN = M.nN;
 
   // ---- A: propagate the non-linear state (one lane), stage xl / pending K / ivec into LDS (all) ----
@@ -309,8 +316,8 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     if (M.kind == 1) quat2rmat_dev(&xp[3], &misc[8]);
   }
   {
-    const double* xl_src = a.xl_old + (size_t)ancb * a.xl_old_stride;
-    const double* Kcol = a.F_old ? a.F_old + ((size_t)ancb * 2 + 1) * D * ldx : nullptr;
+    const double* xl_src = srcX;
+    const double* Kcol = srcF ? srcF + (size_t)D * ldx : nullptr;
     const double* iv = (E > 0) ? a.ivec_old + (size_t)anc * a.ivec_old_stride : nullptr;
     for (int c = tid; c < n; c += kThreads) {
       xls[c] = xl_src[c];
@@ -356,11 +363,11 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   __syncthreads();
 
   // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ [H' X] ----
-  const double* KSrow = a.F_old ? a.F_old + ((size_t)ancb * 2 + 0) * D * ldx : nullptr;
+  const double* KSrow = srcF;
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
-      const double* src = a.Pt_old + (size_t)ancb * a.Pt_old_stride;
+      const double* src = srcT;
       double* dst = a.Pt_new + (size_t)i * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
-      const double* src = a.Pb_old + (size_t)ancb * a.Pb_old_stride + (size_t)b * ldb;
+      const double* src = srcB + (size_t)b * ldb;
       double* dst = a.Pb_new + (size_t)i * Ly.szB + (size_t)b * ldb;
       double ksb[D];
 #pragma unroll
@@ -1325,45 +1332,49 @@ hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, h
   return hipGetLastError();
 }
 
-// all_gather layout [world][nN][Nloc] -> SoA [nN][world*Nloc]
-__global__ void unblock_soa_kernel(int world, int nN, int Nloc, const double* __restrict__ blocked,
-                                   double* __restrict__ soa) {
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t tot = (size_t)world * nN * Nloc;
-  if (q >= tot) return;
-  const int i = (int)(q % Nloc);
-  const int c = (int)((q / Nloc) % nN);
-  const int r = (int)(q / ((size_t)Nloc * nN));
-  soa[(size_t)c * world * Nloc + (size_t)r * Nloc + i] = blocked[q];
-}
-
-hipError_t launch_unblock_soa(int world, int nN, int Nloc, const double* blocked, double* soa, hipStream_t s) {
-  const size_t tot = (size_t)world * nN * Nloc;
-  hipLaunchKernelGGL(unblock_soa_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, world, nN, Nloc, blocked, soa);
-  return hipGetLastError();
-}
-
-// copy the bank entries of `count` particles (Pt | Pb | F | xl) into contiguous send staging
-__global__ void pack_bank_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
-                                 const double* __restrict__ Pb, const double* __restrict__ F,
-                                 const double* __restrict__ xl, double* __restrict__ sPt, double* __restrict__ sPb,
-                                 double* __restrict__ sF, double* __restrict__ sxl) {
+// copy the bank entries of `count` particles into particle-major records [Pt | Pb | F | xl]
+__global__ void pack_records_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
+                                    const double* __restrict__ Pb, const double* __restrict__ F,
+                                    const double* __restrict__ xl, double* __restrict__ rec) {
   const int p = blockIdx.x;
   const int src = idx[p];
   const size_t szF = (size_t)2 * d * L.ldx;
+  const size_t recsz = L.szT + L.szB + szF + L.ldx;
+  double* r = rec + (size_t)p * recsz;
   const dbl2* a = reinterpret_cast<const dbl2*>(Pt + (size_t)src * L.szT);
-  dbl2* b = reinterpret_cast<dbl2*>(sPt + (size_t)p * L.szT);
+  dbl2* b = reinterpret_cast<dbl2*>(r);
   for (size_t q = threadIdx.x; q < L.szT / 2; q += blockDim.x) b[q] = a[q];
-  for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) sPb[(size_t)p * L.szB + q] = Pb[(size_t)src * L.szB + q];
-  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) sF[(size_t)p * szF + q] = F[(size_t)src * szF + q];
-  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) sxl[(size_t)p * L.ldx + q] = xl[(size_t)src * L.ldx + q];
+  for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) r[L.szT + q] = Pb[(size_t)src * L.szB + q];
+  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[L.szT + L.szB + q] = F[(size_t)src * szF + q];
+  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[L.szT + L.szB + szF + q] = xl[(size_t)src * L.ldx + q];
 }
 
-hipError_t launch_pack_bank(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                            const double* F, const double* xl, double* sPt, double* sPb, double* sF, double* sxl,
-                            hipStream_t s) {
+hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
+                               const double* F, const double* xl, double* rec, hipStream_t s) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_bank_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, sPt, sPb, sF, sxl);
+  hipLaunchKernelGGL(pack_records_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, rec);
+  return hipGetLastError();
+}
+
+// all_gather layout [world][nN+1][Nloc] in PHYSICAL slot order (rows 0..nN-1: xn, row nN: logw) ->
+// logical order: logw[i], SoA xn[c][i], with i = logical slot id and phys_of_logical[i] = rank*Nloc + idx
+__global__ void permute_fwd_kernel(int N, int nN, int world, int Nloc, const int* __restrict__ phys_of_logical,
+                                   const double* __restrict__ fwd_gather, double* __restrict__ logw,
+                                   double* __restrict__ xn_soa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int ph = phys_of_logical ? phys_of_logical[i] : i;
+  const int r = ph / Nloc, j = ph % Nloc;
+  const double* blk = fwd_gather + (size_t)r * (nN + 1) * Nloc;
+  for (int c = 0; c < nN; ++c) xn_soa[(size_t)c * N + i] = blk[(size_t)c * Nloc + j];
+  logw[i] = blk[(size_t)nN * Nloc + j];
+  (void)world;
+}
+
+hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
+                              double* logw, double* xn_soa, hipStream_t s) {
+  hipLaunchKernelGGL(permute_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nN, world, Nloc, phys_of_logical,
+                     fwd_gather, logw, xn_soa);
   return hipGetLastError();
 }
 

@@ -1,19 +1,24 @@
 """Particle-sharded forward filter over torch.distributed (RCCL on MI355X, gloo for the CPU tests).
 
-One process per GPU.  Logical slot i of the global filter (N = world * N_local) lives on rank
-i // N_local.  Per time step:
+One process per GPU.  The global filter has N = world * N_local *logical* slots; a logical slot keeps its
+identity (RNG stream, position in the outputs) but its particle may live on any rank.  Per time step:
 
-  1. all_gather of the small forward bank: log-weights [N_local] and non-linear states [nN x N_local]
-  2. every rank normalises the GLOBAL weights and draws the GLOBAL ancestor vector with the same
-     kernels as the single-GPU path (identical on every rank, so no index exchange is needed and the
-     result equals the single-GPU run with N particles bit for bit)
-  3. all_to_all of the map state (covariance blocks, pending factors, mean) of the UNIQUE remote
-     ancestors only -- this is the one heavy message of the algorithm (reference: the gather
-     `xl = xl(:,ai); P = P(:,:,ai)`, src/particleFilter.m:112-113, when ai(i) lives on another GPU)
-  4. the fused step kernel; remote ancestors are read from the receive region behind the local bank.
+  1. ONE all_gather of the small forward bank (log-weights + non-linear states, (nN+1) x N_local doubles)
+  2. every rank normalises the GLOBAL weights and draws the GLOBAL ancestor vector with the same kernels
+     as the single-GPU path -- identical on every rank, so no index exchange is needed and the result
+     equals the single-GPU run with N particles bit for bit
+  3. placement of the new generation ("owner computes"): a child is computed on the rank that already
+     holds its ancestor's map state; only the load-imbalance excess migrates, and every rank ends up with
+     exactly N_local particles.  This is the distributed form of the reference's gather
+     `xl = xl(:,ai); P = P(:,:,ai)` (src/particleFilter.m:112-113): with static slot ownership ~(W-1)/W of
+     the covariances would cross xGMI every step; with owner-computes it is the binomial imbalance
+     (~0.4 % of the particles at W = 8 under near-uniform weights)
+  4. ONE all_to_all of whole particle records for the migrating ancestors
+  5. the fused step kernel on the N_local physical slots (placed in ancestor order, so sibling reads hit
+     the Infinity Cache exactly as in the single-GPU schedule).
 
-The exchange plan is pure numpy on the (replicated) ancestor vector, so it is unit-tested on CPU with
-gloo (tests/test_multigpu_plan.py).
+The placement / exchange plan is pure numpy on the replicated ancestor vector and is unit-tested on CPU
+with gloo (tests/test_multigpu_plan.py).
 """
 from __future__ import annotations
 
@@ -28,42 +33,97 @@ from .host import PhiloxRNG, _Problem, _dp, _ip, _rng_block
 
 
 # ------------------------------------------------------------------------------------------------
-# exchange plan (host logic, identical on every rank)
+# placement + exchange plan (host logic, identical on every rank)
 # ------------------------------------------------------------------------------------------------
 @dataclass
-class ExchangePlan:
-    send_idx: np.ndarray      # int32 local indices to pack, ordered by destination rank then index
-    send_counts: np.ndarray   # int64 [world] particles sent to each rank
-    recv_counts: np.ndarray   # int64 [world] particles received from each rank
-    anc_bank: np.ndarray      # int32 [N_local] ancestor index in [local bank | recv region]
+class GenerationPlan:
+    new_rank: np.ndarray      # int64 [N] rank that computes / holds logical slot i in the new generation
+    new_idx: np.ndarray       # int64 [N] its physical slot there
+    pair_dest: np.ndarray     # int64 [P] exchange pairs (destination rank, ...
+    pair_src: np.ndarray      # int64 [P]  ... global physical id of the ancestor), unique, sorted (dest, src)
+    migrated: int             # children computed away from their ancestor's rank
 
 
-def build_plan(ai_global: np.ndarray, rank: int, world: int, n_local: int) -> ExchangePlan:
-    """ai_global: ancestor (0-based global slot id) of every global slot, identical on all ranks.
+def _stable_argsort_small(keys, n_values):
+    """Stable argsort of non-negative integer keys < n_values.  numpy's stable sort is an O(N) radix sort for
+    16-bit keys; wider keys are split into two 16-bit passes (LSD radix)."""
+    if n_values <= 65536:
+        return np.argsort(keys.astype(np.uint16), kind="stable")
+    lo = np.argsort((keys & 0xFFFF).astype(np.uint16), kind="stable")
+    hi = np.argsort((keys[lo] >> 16).astype(np.uint16), kind="stable")
+    return lo[hi]
 
-    Receive region layout on rank g: for source ranks r = 0..world-1 (r != g) in order, the unique
-    ancestors living on r that g's slots need, ascending.  The sender derives the same lists from the
-    same vector, so both sides agree without any handshake."""
-    ai_global = np.asarray(ai_global, dtype=np.int64)
-    if ai_global.size != world * n_local:
-        raise ValueError("ai_global must have world * n_local entries")
-    owner = ai_global // n_local
-    dest = np.arange(ai_global.size, dtype=np.int64) // n_local
-    # --- what I receive: unique remote ancestors of my slots (np.unique sorts by owner, then index)
-    mine = ai_global[rank * n_local:(rank + 1) * n_local]
-    remote = np.unique(mine[mine // n_local != rank])
-    recv_counts = np.bincount(remote // n_local, minlength=world).astype(np.int64)
-    anc_bank = np.empty(n_local, dtype=np.int32)
-    local_mask = (mine // n_local) == rank
-    anc_bank[local_mask] = (mine[local_mask] - rank * n_local).astype(np.int32)
-    anc_bank[~local_mask] = (n_local + np.searchsorted(remote, mine[~local_mask])).astype(np.int32)
-    # --- what I send: for every other rank q, the unique ancestors of q's slots that live on me
-    m = (owner == rank) & (dest != rank)
-    key = np.unique(dest[m] * (world * n_local) + ai_global[m])        # sorted by destination, then index
-    send_dest = key // (world * n_local)
-    send_idx = (key % (world * n_local) - rank * n_local).astype(np.int32)
-    send_counts = np.bincount(send_dest, minlength=world).astype(np.int64)
-    return ExchangePlan(send_idx, send_counts, recv_counts, anc_bank)
+
+def plan_generation(ai, cur_rank, cur_idx, world: int, n_local: int) -> GenerationPlan:
+    """ai[i]: ancestor (logical id) of logical slot i; cur_rank/cur_idx: where every logical slot's current
+    particle lives.  Deterministic, so every rank derives the same plan from the same vector."""
+    ai = np.asarray(ai, dtype=np.int64)
+    N = world * n_local
+    if ai.size != N:
+        raise ValueError("ai must have world * n_local entries")
+    anc_gid = (np.asarray(cur_rank, dtype=np.int64) * n_local + np.asarray(cur_idx, dtype=np.int64))[ai]
+    anc_rank = anc_gid // n_local
+    load = np.bincount(anc_rank, minlength=world)
+    excess = np.maximum(load - n_local, 0)
+    deficit = np.maximum(n_local - load, 0)
+    stay_cnt = load - excess
+    # children grouped by their ancestor's rank, inside a group by ancestor slot (siblings adjacent), ties by
+    # logical id: a stable sort on the ancestor's global physical id
+    order = _stable_argsort_small(anc_gid, N)
+    grp = anc_rank[order]
+    start = np.concatenate(([0], np.cumsum(load)))[:-1]
+    pos = np.arange(N) - start[grp]
+    keep = pos < stay_cnt[grp]
+    new_rank = anc_rank.copy()
+    new_idx = np.empty(N, dtype=np.int64)
+    new_idx[order[keep]] = pos[keep]                     # stayers: position among the kept children of their rank
+    moved = order[~keep]                                 # the last `excess` children of every overloaded rank
+    receivers = np.repeat(np.arange(world), deficit)     # ranks with room, in rank order
+    new_rank[moved] = receivers
+    imp_start = np.concatenate(([0], np.cumsum(deficit)))[:-1]
+    new_idx[moved] = stay_cnt[receivers] + (np.arange(moved.size) - imp_start[receivers])
+    # one record per (destination, ancestor) pair; the moved list is ordered by source id and the receivers are
+    # non-decreasing, so equal pairs are adjacent
+    key = receivers * N + anc_gid[moved]
+    if key.size:
+        key = key[np.concatenate(([True], key[1:] != key[:-1]))]
+        key = np.sort(key)
+    return GenerationPlan(new_rank, new_idx, key // N, key % N, int(moved.size))
+
+
+@dataclass
+class RankPlan:
+    slot_ids: np.ndarray      # int32 [n_local] logical id of each physical slot of the new generation
+    anc_bank: np.ndarray      # int32 [n_local] ancestor location: < n_local local slot, else n_local + record index
+    send_idx: np.ndarray      # int32 local physical indices to pack, ordered by destination rank then index
+    send_counts: np.ndarray   # int64 [world]
+    recv_counts: np.ndarray   # int64 [world]
+
+
+def rank_view(plan: GenerationPlan, ai, cur_rank, cur_idx, rank: int, world: int, n_local: int) -> RankPlan:
+    ai = np.asarray(ai, dtype=np.int64)
+    N = world * n_local
+    mine = np.nonzero(plan.new_rank == rank)[0]
+    slot_ids = np.empty(n_local, dtype=np.int64)
+    slot_ids[plan.new_idx[mine]] = mine
+    a = ai[slot_ids]
+    a_rank = np.asarray(cur_rank, dtype=np.int64)[a]
+    a_idx = np.asarray(cur_idx, dtype=np.int64)[a]
+    anc_bank = a_idx.copy()
+    # what I receive: pairs with dest == rank, already sorted by (source rank, source slot)
+    rsel = plan.pair_dest == rank
+    recv_src = plan.pair_src[rsel]
+    recv_counts = np.bincount(recv_src // n_local, minlength=world).astype(np.int64)
+    rem = a_rank != rank
+    if rem.any():
+        anc_bank[rem] = n_local + np.searchsorted(recv_src, a_rank[rem] * n_local + a_idx[rem])
+    # what I send: pairs whose ancestor lives on me, ordered by (destination, slot)
+    ssel = (plan.pair_src // n_local) == rank
+    sd, ss = plan.pair_dest[ssel], plan.pair_src[ssel] - rank * n_local
+    o = np.lexsort((ss, sd))
+    send_counts = np.bincount(sd, minlength=world).astype(np.int64)
+    return RankPlan(slot_ids.astype(np.int32), anc_bank.astype(np.int32), ss[o].astype(np.int32), send_counts,
+                    recv_counts)
 
 
 def exchange_rows(send, recv, send_counts, recv_counts, dist):
@@ -87,29 +147,27 @@ class _DevArray:
 
 
 def _view(torch, ptr, shape, device):
-    if ptr is None or int(np.prod(shape)) == 0:
+    addr = C.cast(ptr, C.c_void_p).value
+    if not addr or int(np.prod(shape)) == 0:
         return torch.empty(tuple(int(s) for s in shape), dtype=torch.float64, device=device)
-    return torch.as_tensor(_DevArray(C.cast(ptr, C.c_void_p).value, shape), device=device)
+    return torch.as_tensor(_DevArray(addr, shape), device=device)
 
 
 class rbpf_shard_views(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("N_local", C.c_int32), ("N_global", C.c_int32),
-                ("szT", C.c_size_t), ("szB", C.c_size_t), ("szF", C.c_size_t), ("szX", C.c_size_t),
-                ("recv_capacity", C.c_size_t), ("send_capacity", C.c_size_t),
-                ("logw_local", _ffi.c_double_p), ("xn_local", _ffi.c_double_p), ("logw_gather", _ffi.c_double_p),
-                ("xn_gather", _ffi.c_double_p), ("send_Pt", _ffi.c_double_p), ("send_Pb", _ffi.c_double_p),
-                ("send_F", _ffi.c_double_p), ("send_xl", _ffi.c_double_p), ("recv_Pt", _ffi.c_double_p),
-                ("recv_Pb", _ffi.c_double_p), ("recv_F", _ffi.c_double_p), ("recv_xl", _ffi.c_double_p)]
+                ("n_nonlin", C.c_int32), ("record_doubles", C.c_size_t), ("recv_capacity", C.c_size_t),
+                ("send_capacity", C.c_size_t), ("fwd_local", _ffi.c_double_p), ("fwd_gather", _ffi.c_double_p),
+                ("send_rec", _ffi.c_double_p), ("recv_rec", _ffi.c_double_p)]
 
 
 class ShardedFilterSession:
     """Same surface as host.FilterSession (advance / sync / timing / finish / close), one rank's share.
 
     transport="device": collectives on the device buffers (RCCL; the production path).
-    transport="host"  : device -> pinned host -> gloo -> device (lets two ranks share ONE GPU in tests)."""
+    transport="host"  : device -> host -> gloo -> device (lets two ranks share ONE GPU in tests)."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
-                 transport="device"):
+                 transport="device", planner="device"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -118,14 +176,18 @@ class ShardedFilterSession:
                                                   C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
                                                   C.c_int32, C.POINTER(C.c_void_p)]),
                            ("rbpf_shard_views_get", [C.c_void_p, C.POINTER(rbpf_shard_views)]),
-                           ("rbpf_shard_normalise_search", [C.c_void_p, _ffi.c_int32_p]),
+                           ("rbpf_shard_normalise_search", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p]),
                            ("rbpf_shard_pack", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
-                           ("rbpf_shard_step", [C.c_void_p, _ffi.c_int32_p]),
+                           ("rbpf_shard_step", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p]),
+                           ("rbpf_shard_plan", [C.c_void_p, C.POINTER(C.c_int64)]),
+                           ("rbpf_shard_plan_read", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p, _ffi.c_int32_p, C.c_int32,
+                                                     _ffi.c_int32_p]),
                            ("rbpf_shard_trajectories", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p])):
             getattr(self.lib, name).argtypes = argt
         self.model, self.rank, self.world, self.transport = model, int(rank), int(world), transport
+        self.planner = planner          # "device": rbpf_shard_plan (production); "host": the numpy specification
         self.prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt)
-        # replay buffers (tests) hold all world*N_local slots; Philox streams are keyed by global slot id
+        # replay buffers (tests) hold all world*N_local slots; Philox streams are keyed by logical slot id
         self.blk, self._rng = _rng_block(rng if rng is not None else PhiloxRNG(1), self.prob.N_P * self.world,
                                          self.prob.N_T, model.nw, 1)
         self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, reserved=0, jitter=0.0)
@@ -138,71 +200,115 @@ class ShardedFilterSession:
         self.t = 0
         self.t_norm = 0
         self.ai = np.empty(self.N_global, dtype=np.int32)
-        self.stats = dict(sent_particles=0, recv_particles=0, steps=0)
-
-    # -- helpers ---------------------------------------------------------------------------------
-    def _views(self):
+        gid = np.arange(self.N_global, dtype=np.int64)
+        self.cur_rank, self.cur_idx = gid // self.N_local, gid % self.N_local
+        self.identity = True
+        self.stats = dict(migrated=0, sent_records=0, recv_records=0, steps=0)
         v = rbpf_shard_views()
         check(self.lib.rbpf_shard_views_get(self.ctx, C.byref(v)))
-        return v
+        self.v = v
+        fwd = (model.nNonLin + 1) * self.N_local
+        self.t_fwd_local = _view(torch, v.fwd_local, (fwd,), self.device)
+        self.t_fwd_gather = _view(torch, v.fwd_gather, (self.world * fwd,), self.device)
+        self.t_send = _view(torch, v.send_rec, (max(int(v.send_capacity), 1), int(v.record_doubles)), self.device) \
+            if self.world > 1 else None
+        self.t_recv = _view(torch, v.recv_rec, (max(int(v.recv_capacity), 1), int(v.record_doubles)), self.device) \
+            if self.world > 1 else None
 
-    def _gather(self, v):
+    # -- collectives -----------------------------------------------------------------------------
+    def _gather(self):
         torch, dist = self.torch, self.dist
-        nN, Nl, W = self.model.nNonLin, self.N_local, self.world
-        pairs = ((v.logw_local, v.logw_gather, Nl), (v.xn_local, v.xn_gather, nN * Nl))
-        for src_p, dst_p, cnt in pairs:
-            src = _view(torch, src_p, (cnt,), self.device)
-            dst = _view(torch, dst_p, (W * cnt,), self.device)
-            if W == 1:
-                dst.copy_(src)
-            elif self.transport == "device":
-                dist.all_gather_into_tensor(dst, src)
-            else:
-                h = torch.empty(W * cnt, dtype=torch.float64)
-                dist.all_gather_into_tensor(h, src.cpu())
-                dst.copy_(h)
+        if self.world == 1:
+            self.t_fwd_gather.copy_(self.t_fwd_local)
+        elif self.transport == "device":
+            dist.all_gather_into_tensor(self.t_fwd_gather, self.t_fwd_local)
+        else:
+            h = torch.empty(self.t_fwd_gather.shape, dtype=torch.float64)
+            dist.all_gather_into_tensor(h, self.t_fwd_local.cpu())
+            self.t_fwd_gather.copy_(h)
         torch.cuda.synchronize()
 
-    def _exchange(self, v, plan):
+    def _exchange(self, rp):
+        """rp: RankPlan (host planner) or (send_counts, recv_counts) of the device plan."""
         torch, dist = self.torch, self.dist
-        ns, nr = int(plan.send_counts.sum()), int(plan.recv_counts.sum())
-        if nr > v.recv_capacity or ns > v.send_capacity:
-            raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"exchange of {ns}/{nr} particles exceeds the staging "
-                                 f"capacity {v.send_capacity}/{v.recv_capacity}")
-        idx = np.ascontiguousarray(plan.send_idx)
-        check(self.lib.rbpf_shard_pack(self.ctx, _ip(idx), ns))
-        for sp, rp, width in ((v.send_Pt, v.recv_Pt, v.szT), (v.send_Pb, v.recv_Pb, v.szB),
-                              (v.send_F, v.recv_F, v.szF), (v.send_xl, v.recv_xl, v.szX)):
-            if width == 0:
-                continue
-            send = _view(torch, sp, (max(ns, 1), width), self.device)
-            recv = _view(torch, rp, (max(nr, 1), width), self.device)
-            if self.transport == "device":
-                exchange_rows(send, recv, plan.send_counts, plan.recv_counts, dist)
-            else:
-                hs, hr = send[:ns].cpu(), torch.empty((nr, width), dtype=torch.float64)
-                exchange_rows(hs, hr, plan.send_counts, plan.recv_counts, dist)
-                if nr:
-                    recv[:nr].copy_(hr)
+        send_counts, recv_counts = (rp.send_counts, rp.recv_counts) if isinstance(rp, RankPlan) else rp
+        ns, nr = int(send_counts.sum()), int(recv_counts.sum())
+        if nr > self.v.recv_capacity or ns > self.v.send_capacity:
+            raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"exchange of {ns}/{nr} records exceeds the buffer "
+                                 f"capacity {self.v.send_capacity}/{self.v.recv_capacity}")
+        if isinstance(rp, RankPlan):
+            idx = np.ascontiguousarray(rp.send_idx)
+            check(self.lib.rbpf_shard_pack(self.ctx, _ip(idx), ns))
+        else:
+            check(self.lib.rbpf_shard_pack(self.ctx, None, ns))
+        rp = RankPlan(None, None, None, send_counts, recv_counts)
+        if self.transport == "device":
+            exchange_rows(self.t_send, self.t_recv, rp.send_counts, rp.recv_counts, dist)
+        else:
+            width = int(self.v.record_doubles)
+            hs, hr = self.t_send[:ns].cpu(), torch.empty((nr, width), dtype=torch.float64)
+            exchange_rows(hs, hr, rp.send_counts, rp.recv_counts, dist)
+            if nr:
+                self.t_recv[:nr].copy_(hr)
         torch.cuda.synchronize()
-        self.stats["sent_particles"] += ns
-        self.stats["recv_particles"] += nr
+        self.stats["sent_records"] += ns
+        self.stats["recv_records"] += nr
+
+    def _normalise(self, want_ancestors):
+        perm = None
+        if self.planner == "device":
+            # the library keeps the placement on the device; ancestors stay there too (self.ai is only a D2H
+            # target the C side requires to trigger the draw)
+            check(self.lib.rbpf_shard_normalise_search(self.ctx, None, _ip(self.ai) if want_ancestors else None))
+            self.t_norm += 1
+            return
+        if not self.identity:
+            perm = np.ascontiguousarray((self.cur_rank * self.N_local + self.cur_idx).astype(np.int32))
+        check(self.lib.rbpf_shard_normalise_search(self.ctx, None if perm is None else _ip(perm),
+                                                   _ip(self.ai) if want_ancestors else None))
+        self.t_norm += 1
 
     # -- FilterSession surface -------------------------------------------------------------------
     def advance(self, n_steps):
+        import time
+        tm = self.stats.setdefault("phase_s", dict(gather=0.0, normalise=0.0, plan=0.0, exchange=0.0, step=0.0))
         for _ in range(int(n_steps)):
             if self.t == 0:
-                check(self.lib.rbpf_shard_step(self.ctx, None))
+                check(self.lib.rbpf_shard_step(self.ctx, None, None))
             else:
-                v = self._views()
-                self._gather(v)
-                check(self.lib.rbpf_shard_normalise_search(self.ctx, _ip(self.ai)))
-                self.t_norm += 1
-                plan = build_plan(self.ai, self.rank, self.world, self.N_local)
+                t0 = time.perf_counter()
+                self._gather()
+                t1 = time.perf_counter()
+                self._normalise(True)
+                t2 = time.perf_counter()
+                if self.planner == "device":
+                    cnt = np.zeros(2 * self.world + 1, dtype=np.int64)
+                    check(self.lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+                    t3 = time.perf_counter()
+                    if self.world > 1:
+                        self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]))
+                    t4 = time.perf_counter()
+                    check(self.lib.rbpf_shard_step(self.ctx, None, None))
+                    t5 = time.perf_counter()
+                    self.stats["migrated"] += int(cnt[2 * self.world])
+                    tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["plan"] += t3 - t2
+                    tm["exchange"] += t4 - t3; tm["step"] += t5 - t4
+                    self.t += 1
+                    self.stats["steps"] += 1
+                    continue
+                plan = plan_generation(self.ai, self.cur_rank, self.cur_idx, self.world, self.N_local)
+                rp = rank_view(plan, self.ai, self.cur_rank, self.cur_idx, self.rank, self.world, self.N_local)
+                t3 = time.perf_counter()
                 if self.world > 1:
-                    self._exchange(v, plan)
-                anc = np.ascontiguousarray(plan.anc_bank)
-                check(self.lib.rbpf_shard_step(self.ctx, _ip(anc)))
+                    self._exchange(rp)
+                t4 = time.perf_counter()
+                check(self.lib.rbpf_shard_step(self.ctx, _ip(rp.anc_bank), _ip(rp.slot_ids)))
+                t5 = time.perf_counter()
+                tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["plan"] += t3 - t2
+                tm["exchange"] += t4 - t3; tm["step"] += t5 - t4
+                self.cur_rank, self.cur_idx = plan.new_rank, plan.new_idx
+                self.identity = False
+                self.stats["migrated"] += plan.migrated
             self.t += 1
             self.stats["steps"] += 1
 
@@ -224,10 +330,8 @@ class ShardedFilterSession:
     def finish(self, want=("traj_max", "traj_mean")):
         """Normalises the last finished step and returns the global trajectory summaries."""
         if self.t_norm < self.t:
-            v = self._views()
-            self._gather(v)
-            check(self.lib.rbpf_shard_normalise_search(self.ctx, None))
-            self.t_norm += 1
+            self._gather()
+            self._normalise(False)
         nN, T = self.model.nNonLin, self.prob.N_T
         out = dict(traj_max=np.full((nN, T), np.nan, order="F"), traj_mean=np.full((nN, T), np.nan, order="F"))
         check(self.lib.rbpf_shard_trajectories(self.ctx, _dp(out["traj_max"]), _dp(out["traj_mean"])))
@@ -235,6 +339,7 @@ class ShardedFilterSession:
 
     def close(self):
         if self.ctx:
+            self.t_fwd_local = self.t_fwd_gather = self.t_send = self.t_recv = None
             self.lib.rbpf_destroy(self.ctx)
             self.ctx = C.c_void_p()
 

