@@ -108,7 +108,9 @@ typedef struct {
                           *    xn_traj and every smoother); 0: ping-pong only                   */
   int32_t trace;         /* 1: record per-step logw / w / ancestor indices (tests)              */
   int32_t fix_p_mean;    /* 0: reproduce quirk Q3 (particleFilter.m:228-230 overwrites P_mean)  */
-  int32_t reserved;
+  int32_t lazy_depth;    /* filter only: C >= 2 keeps up to C pending rank-n_y downdates on the fly and rewrites  *
+                          * the stored covariances every C-th step only (C-1 read-only steps in between);      *
+                          * 0/1: rewrite every step.  Results agree to rounding (same algebra).   max 4       */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
 } rbpf_options;
 

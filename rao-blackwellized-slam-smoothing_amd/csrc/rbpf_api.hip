@@ -182,6 +182,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   std::vector<int> nn;
   RB_TRY(fill_model_dev(model, prob->n_nonlin, prob->n_lin, prob->n_y, prob->n_w, prob->n_odo, prob->R, jitter, c->mdl, nn));
   c->lay = make_layout(prob->n_lin, prob->n_y);
+  c->lay_low = make_layout_low_regs(prob->n_lin, prob->n_y);
   if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
   c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
   c->bank_cap = (size_t)prob->N_P + (ex ? ex->bank_extra : 0);
@@ -263,6 +264,16 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     HIPCHK(hipMemsetAsync(c->F[b], 0, c->bank_cap * 2 * d * L.ldx * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->xl[b], 0, c->bank_cap * L.ldx * sizeof(double), c->stream));
   }
+  c->lazy_depth = (!smoother && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
+  if (c->lazy_depth >= 2) {
+    if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
+    if (step_lds_bytes(c->mdl, c->lay, 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    for (int b = 0; b <= c->lazy_depth; ++b) RB_TRY(dmalloc(&c->Fb[b], (size_t)N * 2 * d * L.ldx));
+    for (int b = 0; b < 2; ++b) {
+      RB_TRY(dmalloc(&c->fidx[b], (size_t)(c->lazy_depth + 1) * N));
+      RB_TRY(dmalloc(&c->base[b], (size_t)N));
+    }
+  }
   c->hist_slabs = c->opt.keep_history ? T : 2;
   RB_TRY(dmalloc(&c->X, (size_t)c->hist_slabs * nN * N));
   RB_TRY(dmalloc(&c->A, (size_t)(c->opt.keep_history ? T : 1) * N));
@@ -274,8 +285,10 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   RB_TRY(dmalloc(&c->traj_max, (size_t)T * nN));
   RB_TRY(dmalloc(&c->traj_mean, (size_t)T * nN));
   RB_TRY(dmalloc(&c->d_scal, 64));
+  RB_TRY(dmalloc(&c->d_pre_i, (size_t)N * kPreInts));
+  RB_TRY(dmalloc(&c->d_pre_d, (size_t)N * kPreDoubles));
   RB_TRY(dmalloc(&c->d_order, (size_t)N));
-  RB_TRY(dmalloc(&c->d_counts, (size_t)2 * N + 64));
+  RB_TRY(dmalloc(&c->d_counts, (size_t)2 * N + 128));
   RB_TRY(dmalloc(&c->d_flags, 16));
   HIPCHK(hipMemsetAsync(c->d_flags, 0, 16 * sizeof(int), c->stream));
   RB_TRY(ctx_reset(c));
@@ -302,6 +315,8 @@ int ctx_reset(rbpf_ctx* c) {
   HIPCHK(hipGetLastError());
   c->t = 0;
   c->cur = 0;
+  c->xcur = 0;
+  c->tcur = 0;
   c->ready_step = -1;
   return RBPF_OK;
 }
@@ -314,7 +329,9 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
-  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts);
+  for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
+  for (int b = 0; b < 2; ++b) { hipFree(c->fidx[b]); hipFree(c->base[b]); }
+  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d);
   smoother_free(c);
   shard_free(c);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -358,6 +375,12 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     static const int dbg_order = getenv("RBPF_DEBUG_ORDER") ? 1 : 0;
     if (no_order) a.order = nullptr;
 #ifdef RBPF_STAMPS
+    if (t >= 100 && t <= 103) {
+      unsigned long long ks[8];
+      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(hipMemcpy(ks, c->d_counts + 2 * N + 32, sizeof(ks), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[rbpf kstamps] step %d (prev launch): A %.1f B %.1f C %.1f D(stream) %.1f comb %.1f E %.1f F %.1f us\n", t - 1, (ks[1]-ks[0])*0.01, (ks[2]-ks[1])*0.01, (ks[3]-ks[2])*0.01, (ks[4]-ks[3])*0.01, 0.0, (ks[5]-ks[4])*0.01, (ks[6]-ks[5])*0.01);
+    }
     if (t == 100) {
       unsigned long long st[8];
       HIPCHK(hipStreamSynchronize(c->stream));
@@ -378,17 +401,44 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     }
   }
   a.xn_old = X_old; a.xn_new = X_new;
-  const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
+  const bool lazy = c->lazy_depth >= 2 && !info && !xref_t;
+  const int ob = c->cur;
+  int nb = (t == 0) ? 0 : (c->cur ^ 1);          // bank the stored covariances are written to (if at all)
+  const int xo = c->xcur, xn = (t == 0) ? 0 : (c->xcur ^ 1);
+  const int told = c->tcur, tnew = c->tcur ^ 1;
+  bool flush = true;
+  for (int q = 0; q < kMaxSets; ++q) { a.fset[q] = nullptr; a.fset_idx_old[q] = nullptr; a.fset_idx_new[q] = nullptr; }
+  a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
+  a.n_sets = (t > 0) ? 1 : 0; a.write_base = 1;
+  if (lazy) {
+    // multi-step lazy update: sets produced at steps t-ell .. t-1 are pending; every C-th step rewrites the matrices
+    const int C = c->lazy_depth, B = C + 1;
+    const int ell = (t == 0) ? 0 : ((t - 1) % C) + 1;
+    flush = (t == 0) || (ell == C);
+    a.n_sets = ell; a.write_base = flush ? 1 : 0;
+    if (ell >= 3) a.lay = c->lay_low;
+    for (int q = 0; q < ell; ++q) {
+      const int bank = (t - ell + q) % B;
+      a.fset[q] = c->Fb[bank];
+      a.fset_idx_old[q] = c->fidx[told] + (size_t)bank * N;
+      a.fset_idx_new[q] = c->fidx[tnew] + (size_t)bank * N;
+    }
+    a.fself_idx_new = c->fidx[tnew] + (size_t)(t % B) * N;
+    a.base_old = (t > 0) ? c->base[told] : nullptr;
+    a.base_new = c->base[tnew];
+    if (!flush) nb = ob;
+  }
   if (t == 0) {
     a.xl_old = c->d_x0l; a.xl_old_stride = (c->x0_lin_cols > 1) ? (size_t)L.ldx : 0;
     a.F_old = nullptr;
     a.Pt_old = c->d_P0t; a.Pb_old = c->d_P0b; a.Pt_old_stride = 0; a.Pb_old_stride = 0;
   } else {
-    a.xl_old = c->xl[ob]; a.xl_old_stride = (size_t)L.ldx;
-    a.F_old = c->F[ob];
+    a.xl_old = c->xl[xo]; a.xl_old_stride = (size_t)L.ldx;
+    a.F_old = lazy ? nullptr : c->F[ob];
     a.Pt_old = c->Pt[ob]; a.Pb_old = c->Pb[ob]; a.Pt_old_stride = L.szT; a.Pb_old_stride = L.szB;
   }
-  a.xl_new = c->xl[nb]; a.F_new = c->F[nb]; a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
+  a.xl_new = c->xl[xn]; a.F_new = lazy ? c->Fb[t % (c->lazy_depth + 1)] : c->F[nb];
+  a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
   a.logw = c->logw + tr;
   a.rng_mode = c->rng_mode; a.k_iter = k_iter; a.seed = c->seed;
   a.Z = (c->d_Z && t > 0) ? c->d_Z + (rng_page + (size_t)(t - 1) * N) * nw : nullptr;
@@ -397,6 +447,8 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.y = c->d_y + (size_t)t * d;
   a.xref = xref_t;
   a.status = c->d_flags;
+  a.stamps = reinterpret_cast<unsigned long long*>(c->d_counts + 2 * N + 32);
+  a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;
   a.info = info ? 1 : 0;
   a.ivec_old = nullptr; a.ivec_old_stride = 0; a.ivec_new = nullptr; a.hld_old = nullptr; a.hld_old_stride = 0;
   a.hld_new = nullptr; a.qf_new = nullptr; a.Hb_new = nullptr;
@@ -405,6 +457,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     a.hld_old = info->hld_old; a.hld_old_stride = info->hld_old_stride; a.hld_new = info->hld_new;
     a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
   }
+  HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) {
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -427,13 +480,35 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     s.U = c->d_U ? c->d_U + rng_page + (size_t)t * N : nullptr;
     s.seed = c->seed; s.ai = A_next; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
     s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + tr; s.wc_exact = c->wc;
-    HIPCHK(launch_normalise_resample(nm, s, c->d_order, c->d_counts, c->stream));
+    // sort key of the next step: the slot of the stored matrix each ancestor's lineage refers to
+    HIPCHK(launch_normalise_resample(nm, s, c->d_order, c->d_counts, c->stream, lazy ? c->base[tnew] : nullptr));
     c->ready_step = t + 1;
   } else {
     HIPCHK(launch_normalise_scan(nm, c->stream));
   }
   c->cur = nb;
+  c->xcur = lazy ? xn : nb;
+  if (lazy) c->tcur = tnew;
   c->t = t + 1;
+  return RBPF_OK;
+}
+
+// Flushed covariances of `count` particles (index: device list or null = 0..count-1) in MATLAB layout.
+int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out) {
+  const Layout& L = c->lay;
+  const int d = c->mdl.d, N = c->N;
+  if (c->lazy_depth < 2) {
+    HIPCHK(launch_unpack_P(L, d, c->Pt[c->cur], c->Pb[c->cur], c->t > 0 ? c->F[c->cur] : nullptr, d_index, count, d_out, c->stream));
+    return RBPF_OK;
+  }
+  const int C = c->lazy_depth, B = C + 1, t = c->t;          // state after step t-1
+  const int ell = (t == 0) ? 0 : ((t - 1) % C) + 1;
+  const double* fset[kMaxSets]; const int* fidx[kMaxSets];
+  for (int q = 0; q < ell; ++q) {
+    const int bank = (t - ell + q) % B;
+    fset[q] = c->Fb[bank]; fidx[q] = c->fidx[c->tcur] + (size_t)bank * N;
+  }
+  HIPCHK(launch_unpack_P_sets(L, d, c->Pt[c->cur], c->Pb[c->cur], ell, fset, fidx, c->base[c->tcur], d_index, count, d_out, c->stream));
   return RBPF_OK;
 }
 
@@ -565,7 +640,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
   const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d;
   const int Tdone = c->t;
   const Layout& L = c->lay;
-  const int cur = c->cur;
+  const int cur = c->xcur;          // bank of the means (== covariance bank unless the lazy update is on)
   int iw = 0;
   HIPCHK(hipMemcpy(&iw, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost));
   if (o->iw_max) *o->iw_max = iw;
@@ -601,7 +676,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
     hipError_t e = hipSuccess;
     if (o->P_max) {
       e = hipMemcpy(didx, &iw, sizeof(int), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, c->stream);
+      if (e == hipSuccess && ctx_unpack(c, didx, 1, dP) != RBPF_OK) e = hipErrorUnknown;
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       if (e == hipSuccess) e = hipMemcpy(o->P_max, dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
     }
@@ -616,7 +691,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
       std::vector<double> Pl((size_t)n * n), xll(n);
       double wl = 0.0;
       e = hipMemcpy(didx, &last, sizeof(int), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, c->stream);
+      if (e == hipSuccess && ctx_unpack(c, didx, 1, dP) != RBPF_OK) e = hipErrorUnknown;
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       if (e == hipSuccess) e = hipMemcpy(Pl.data(), dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost);
       if (e == hipSuccess) e = hipMemcpy(xll.data(), c->xl[cur] + (size_t)last * L.ldx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
@@ -684,7 +759,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
   if (o->final_P) {
     double* dout = nullptr;
     RB_TRY(dmalloc(&dout, (size_t)n * n * N));
-    hipError_t e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], nullptr, N, dout, c->stream);
+    hipError_t e = (ctx_unpack(c, nullptr, N, dout) == RBPF_OK) ? hipSuccess : hipErrorUnknown;
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(o->final_P, dout, (size_t)n * n * N * sizeof(double), hipMemcpyDeviceToHost);
     hipFree(dout);

@@ -42,6 +42,7 @@ struct rbpf_ctx {
   hipStream_t stream = nullptr;
   rbpf::ModelDev mdl;
   rbpf::Layout lay;
+  rbpf::Layout lay_low;     // same HBM layout, 2 x 2 wave decomposition (lazy variants with >= 3 pending sets)
   rbpf_options opt;
   int N = 0, T = 0;
   bool smoother = false;
@@ -61,7 +62,14 @@ struct rbpf_ctx {
   double* Pb[2] = {nullptr, nullptr};
   double* F[2] = {nullptr, nullptr};
   double* xl[2] = {nullptr, nullptr};
-  int cur = 0;
+  int cur = 0;              // bank holding the stored covariances
+  int xcur = 0;             // bank holding the means (== cur unless the multi-step lazy update is on)
+  // multi-step lazy update (filter fast path)
+  int lazy_depth = 1;
+  double* Fb[rbpf::kMaxSets + 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // factor-set banks
+  int* fidx[2] = {nullptr, nullptr};   // [lazy_depth+1][N] entry tables, ping-pong
+  int* base[2] = {nullptr, nullptr};   // [N] stored-matrix slot of every lineage, ping-pong
+  int tcur = 0;
   // history
   int hist_slabs = 2;
   double* X = nullptr;      // [slabs][nN][N]
@@ -76,6 +84,8 @@ struct rbpf_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   rbpf::SmootherState* sm = nullptr;
   rbpf::ShardState* sh = nullptr;
+  int* d_pre_i = nullptr;   // [N][kPreInts]  per-workgroup descriptors of the step kernel
+  double* d_pre_d = nullptr; // [N][kPreDoubles]
   int* d_order = nullptr;   // [N] processing order of the next step (ancestor-sorted)
   int* d_counts = nullptr;  // [2N] counting-sort scratch
   int ready_step = -1;      // step whose ancestors (and order) were already drawn by the fused resample kernel
@@ -94,6 +104,7 @@ int ctx_reset(rbpf_ctx* c);
 void ctx_free(rbpf_ctx* c);
 int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const InfoStep* info);
 int ctx_check_flags(rbpf_ctx* c);
+int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
 void shard_free(rbpf_ctx* c);
 

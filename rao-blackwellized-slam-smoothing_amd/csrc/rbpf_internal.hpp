@@ -9,6 +9,9 @@ namespace rbpf {
 constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunkRows = 128;    // rows covered by one wave-wide 16-B-per-lane load
+constexpr int kPreInts = 8;         // per-workgroup descriptor written by propagate_kernel: slot, anc, ancb, base, set idx[4]
+constexpr int kPreDoubles = 17;    // ... and xn_new[8], Rnb[9]
+constexpr int kMaxSets = 4;        // pending rank-d factor sets the step kernel can apply on the fly
 
 // Model constants resident in kernel arguments (scalar registers).
 struct ModelDev {
@@ -45,6 +48,15 @@ struct StepArgs {
   const int* ai;                 // ancestors of this step (null: identity); index into xn_old
   const int* ai_bank;            // ancestor index in the bank address space (null: same as ai)
   const int* order;              // processing order: workgroup b handles slot order[b] (null: b)
+  // multi-step lazy update.  Pending set s of particle j is entry fset_idx_old[s][j] of bank fset[s]; when
+  // fset[s] is null the legacy single set (F_old, addressed like the map bank) is used.
+  int n_sets;                    // pending sets applied on the fly (0 only at t = 0)
+  int write_base;                // 1: store the downdated matrix into the child's slot (flush); 0: light step
+  const double* fset[kMaxSets];
+  const int* fset_idx_old[kMaxSets];
+  int* fset_idx_new[kMaxSets];   // propagated entries of the surviving sets (light steps)
+  int* fself_idx_new;            // index table of the set this step produces: [i] = i
+  const int* base_old; int* base_new;   // slot of the stored matrix of each particle's lineage
   const int* slot_ids;           // logical (global) id of each local slot (null: slot_offset + i); when set,
                                  // `ai` is indexed by that logical id
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
@@ -68,6 +80,8 @@ struct StepArgs {
   const double* y;                          // [d]
   const double* xref;                       // CPF-AS: state of slot N-1 at this step (or null)
   int* status;
+  unsigned long long* stamps;               // diagnostic builds only (RBPF_STAMPS)
+  int* pre_i; double* pre_d;                // [N][kPreInts], [N][kPreDoubles] descriptors (propagate_kernel -> step_kernel)
   // information form (particleSmootherInformationForm.m): extra per-particle state
   int info;
   const double* ivec_old; size_t ivec_old_stride; double* ivec_new;   // [N][ldx]
@@ -105,15 +119,19 @@ struct SearchArgs {
   double* wc_exact = nullptr; // scratch for the strict cumsum (fixup only; may alias wc)
 };
 
-size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0);
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0, int n_sets = 1);
 Layout make_layout(int n, int d);
+Layout make_layout_low_regs(int n, int d);
 
+// dynModel for all slots (must run before launch_step of the same StepArgs)
+hipError_t launch_propagate(const StepArgs& a, hipStream_t s);
 hipError_t launch_step(const StepArgs& a, hipStream_t s);
 hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s);
 hipError_t launch_search(const SearchArgs& a, hipStream_t s);
 hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
 // normalise step t and, fused, draw the ancestors of step t+1 (+ their ancestor-sorted processing order)
-hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s);
+hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s,
+                                     const int* remap = nullptr);
 hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s);
 // exact re-draw of every slot with the strict left-to-right cumsum if any draw was flagged ambiguous
 hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s);
@@ -123,6 +141,9 @@ hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src
                          double* Pb, int count, hipStream_t s);
 hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
                            const int* index, int count, double* P_colmajor, hipStream_t s);
+hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, const double* Pb, int n_sets,
+                                const double* const* fset, const int* const* fidx, const int* base, const int* index,
+                                int count, double* P_colmajor, hipStream_t s);
 hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
                                    hipStream_t s);
 hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,

@@ -64,10 +64,10 @@ struct LdsPlan {
 
 __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ldx, int CS, int mc, int ktot) {
+__host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ns, int ldx, int CS, int mc, int ktot) {
   LdsPlan p;
   int o = 0;
-  p.off_HK = o;    o += even_up(n * (2 * d + e));
+  p.off_HK = o;    o += even_up(n * (d + e + ns * d));
   p.off_xl = o;    o += ldx;
   p.off_PHt = o;   o += (d + e) * ldx;
   p.off_parts = o; o += CS * (d + e) * mc;
@@ -78,8 +78,16 @@ __host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ldx, int CS
   return p;
 }
 
-size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra) {
-  return (size_t)lds_plan(lay.n, m.d, extra, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
+// the 2 x 2 wave decomposition (one row chunk per wave): fewer registers per lane, used by the step-kernel
+// variants that carry three or four pending factor sets
+Layout make_layout_low_regs(int n, int d) {
+  Layout L = make_layout(n, d);
+  if (L.CH == 2) { L.RS = 2; L.CS = 2; L.CPL = L.CH / L.RS; }
+  return L;
+}
+
+size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
+  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
 }
 
 Layout make_layout(int n, int d) {
@@ -170,16 +178,21 @@ __device__ inline void H_column(const ModelDev& M, int c, const double* tabS, co
 // Per column the wave needs DE = D+E right-hand-side values (H rows, then the E extra vectors of the
 // information form) and the D pending column factors; LDS record per column: [H(D) | X(E) | K(D)].
 // ---------------------------------------------------------------------------------------------
-template <int D, int E, int CPL, int UC>
+template <int NSA>
+struct SetPtrs { const double* p[NSA]; };
+
+template <int D, int E, int CPL, int UC, int NS, bool WR>
 __device__ __forceinline__ void stream_core(const double* __restrict__ src, double* __restrict__ dst,
-                                            const double* __restrict__ HK, const double* __restrict__ KSrow,
+                                            const double* __restrict__ HK, const SetPtrs<(NS > 0 ? NS : 1)> KSrows,
                                             int ldx, int n, int nb, int mc, int chunk0, int chunk_stride, int CS,
                                             int wc, int lane, double* __restrict__ out_acc /* [D+E][mc] */) {
   // Every chunk handled here is valid (the caller decides wave-uniformly), so the loop body carries
   // no predicates: all UC*CPL loads of a round are issued back to back and stay in flight together.
-  constexpr int DE = D + E, REC = 2 * D + E;
+  // NS pending rank-D factor sets are applied on the fly; WR = false (a "light" step of the multi-step
+  // lazy update) only reads the base matrix.
+  constexpr int DE = D + E, ND = NS * D, REC = DE + ND, NDA = ND > 0 ? ND : 1;
   double acc[CPL][2][DE];
-  double ks[CPL][2][D];
+  double ks[CPL][2][NDA];
   int r0[CPL];
 #pragma unroll
   for (int q = 0; q < CPL; ++q) {
@@ -189,7 +202,9 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #pragma unroll
       for (int k = 0; k < DE; ++k) acc[q][e][k] = 0.0;
 #pragma unroll
-      for (int k = 0; k < D; ++k) ks[q][e][k] = KSrow ? KSrow[(size_t)k * ldx + nb + r0[q] + e] : 0.0;
+      for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+        for (int k = 0; k < D; ++k) ks[q][e][sset * D + k] = KSrows.p[sset][(size_t)k * ldx + nb + r0[q] + e];
     }
   }
   const size_t colstep = (size_t)CS * mc;               // elements between two columns of this wave
@@ -207,40 +222,38 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
       for (int q = 0; q < CPL; ++q) v[u][q] = ld_stream(sp + u * colstep + r0[q]);
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
-      double h[DE], kc[D];
+      double h[DE], kc[NDA];
 #pragma unroll
       for (int k = 0; k < DE; ++k) h[k] = hk[u * hkstep + k];
 #pragma unroll
-      for (int k = 0; k < D; ++k) kc[k] = hk[u * hkstep + DE + k];
+      for (int k = 0; k < ND; ++k) kc[k] = hk[u * hkstep + DE + k];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         double p0 = v[u][q].x, p1 = v[u][q].y;
 #pragma unroll
-        for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+        for (int k = 0; k < ND; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
         for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
-        dbl2 o; o.x = p0; o.y = p1;
-        st_stream(dp + u * colstep + r0[q], o);
+        if (WR) { dbl2 o; o.x = p0; o.y = p1; st_stream(dp + u * colstep + r0[q], o); }
       }
     }
     sp += UC * colstep; dp += UC * colstep; hk += UC * hkstep;
   }
   for (; c < n; c += CS) {
-    double h[DE], kc[D];
+    double h[DE], kc[NDA];
 #pragma unroll
     for (int k = 0; k < DE; ++k) h[k] = hk[k];
 #pragma unroll
-    for (int k = 0; k < D; ++k) kc[k] = hk[DE + k];
+    for (int k = 0; k < ND; ++k) kc[k] = hk[DE + k];
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const dbl2 vv = ld_stream(sp + r0[q]);
       double p0 = vv.x, p1 = vv.y;
 #pragma unroll
-      for (int k = 0; k < D; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+      for (int k = 0; k < ND; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
       for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
-      dbl2 o; o.x = p0; o.y = p1;
-      st_stream(dp + r0[q], o);
+      if (WR) { dbl2 o; o.x = p0; o.y = p1; st_stream(dp + r0[q], o); }
     }
     sp += colstep; dp += colstep; hk += hkstep;
   }
@@ -255,6 +268,61 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 }
 
 // ---------------------------------------------------------------------------------------------
+// dynModel for every slot, one thread per particle (examples/slam-dense-mag/run_dense3D_magfield.m:301-308,
+// examples/slam-dense-radio/run_dense2D_withHeading.m:75-76; particleFilter.m:108).  Kept out of the step
+// kernel: there it was a single-lane serial section of 10-20 us per workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ void propagate_kernel(const StepArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;      // processing position of the step kernel
+  if (b >= a.N) return;
+  const ModelDev& M = a.mdl;
+  const int nN = M.nN;
+  const int i = a.order ? a.order[b] : b;
+  const int gslot = a.slot_ids ? a.slot_ids[i] : a.slot_offset + i;
+  const int anc = a.ai ? a.ai[a.slot_ids ? gslot : i] : i;
+  const int ancb = a.ai_bank ? a.ai_bank[i] : anc;
+  double x[8], xp[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) x[c] = (c < nN) ? a.xn_old[(size_t)c * a.xn_old_stride + anc] : 0.0;
+  if (a.xref != nullptr && i == a.N - 1) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xp[c] = (c < nN) ? a.xref[c] : 0.0;                 // particleSmoother.m:242
+  } else if (a.propagate) {
+    double z[8];
+    if (a.rng_mode == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) z[k] = (k < M.nw) ? a.Z[(size_t)gslot * M.nw + k] : 0.0;
+    } else {
+      philox_normals(a.seed, gslot, a.t, a.k_iter, M.nw, z);
+    }
+    if (M.kind == 1) dyn_model_mag(x, a.odo, a.cholQ, z, xp);
+    else dyn_model_radio(x, a.odo, a.cholQ, z, xp);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xp[c] = x[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < nN) a.xn_new[(size_t)c * a.xn_new_stride + i] = xp[c];
+  // per-workgroup descriptor: everything the step kernel would otherwise fetch through a chain of dependent
+  // scattered loads while HBM is saturated
+  int* pi = a.pre_i + (size_t)b * kPreInts;
+  pi[0] = i; pi[1] = anc; pi[2] = ancb; pi[3] = a.base_old ? a.base_old[anc] : ancb;
+#pragma unroll
+  for (int sset = 0; sset < kMaxSets; ++sset)
+    pi[4 + sset] = (sset < a.n_sets && a.fset[sset] && a.fset_idx_old[sset]) ? a.fset_idx_old[sset][anc] : ancb;
+  double* pd = a.pre_d + (size_t)b * kPreDoubles;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) pd[c] = xp[c];
+  if (M.kind == 1) quat2rmat_dev(&xp[3], &pd[8]);
+}
+
+hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(propagate_kernel, dim3((a.N + 63) / 64), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // THE step kernel: one workgroup (4 wave64) per particle slot.
 //   E = 0 : particleFilter.m:100-204 / particleSmoother.m:124-340 (covariance-form weights)
 //   E = 2 : particleSmootherInformationForm.m:274-335 -- additionally streams P*ivec and P*ivecPlus so
@@ -263,20 +331,22 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
 #ifndef RBPF_MINWAVES
 #define RBPF_MINWAVES 1     // min waves per SIMD requested from the register allocator (tuning)
 #endif
-template <int D, int E, int CPL>
+template <int D, int E, int CPL, int NS, bool WR>
 __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
-  constexpr int DE = D + E, REC = 2 * D + E;
+  constexpr int DE = D + E, ND = NS * D, REC = DE + ND, NSA = NS > 0 ? NS : 1;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
   const int N = a.N;
   // children are processed in ancestor order so that siblings' reads of the same covariance hit the
-  // Infinity Cache; `order` only permutes the schedule, slot i still reads / writes slot i's data
-  const int i = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+  // Infinity Cache; the order only permutes the schedule, slot i still reads / writes slot i's data.
+  // propagate_kernel resolved the indirections of this workgroup into one descriptor.
+  const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
+  const int i = pre_i[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const LdsPlan lp = lds_plan(n, D, E, ldx, Ly.CS, mc, M.ktot);
-  double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol[0..D)
+  const LdsPlan lp = lds_plan(n, D, E, NS, ldx, Ly.CS, mc, M.ktot);
+  double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol of every pending set [NS][D]
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;      // [DE][ldx]
   double* parts = smem + lp.off_parts;  // [CS][DE][mc]
@@ -285,53 +355,73 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   double* misc = smem + lp.off_misc;    // 0..7 xn_new, 8..16 Rnb, 20.. epilogue broadcast
   double* red = smem + lp.off_red;
 
-  const int gslot = a.slot_ids ? a.slot_ids[i] : a.slot_offset + i;   // logical (global) slot id: RNG stream
-  const int anc = a.ai ? a.ai[a.slot_ids ? gslot : i] : i;             // ancestor id for the non-linear state bank
-  const int ancb = a.ai_bank ? a.ai_bank[i] : anc;     // ancestor id in the map bank (local | remote records)
+#ifdef RBPF_STAMPS
+#define RBPF_KSTAMP(k) if (blockIdx.x == 4000 && threadIdx.x == 0 && a.stamps) a.stamps[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RBPF_KSTAMP(k)
+#endif
+  RBPF_KSTAMP(0);
+  const int anc = pre_i[1];      // ancestor id for the non-linear / information-form state banks
+  const int ancb = pre_i[2];     // ancestor id in the map bank (local | remote records)
   // sources of the ancestor's map state: the local bank, or a received record
   const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;
   const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
-  const double* srcT = remote ? recp : a.Pt_old + (size_t)ancb * a.Pt_old_stride;
-  const double* srcB = remote ? recp + a.rec_off_B : a.Pb_old + (size_t)ancb * a.Pb_old_stride;
-  const double* srcF = remote ? recp + a.rec_off_F : (a.F_old ? a.F_old + (size_t)ancb * 2 * D * ldx : nullptr);
+  // multi-step lazy update: the stored ("base") matrix of the ancestor's lineage may live in another slot
+  const int baseb = pre_i[3];
+  const double* srcT = remote ? recp : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
+  const double* srcB = remote ? recp + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
   const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
+  // pending factor sets (KS rows then K columns, [2][D][ldx] each), oldest first
+  SetPtrs<NSA> srcFs;
+#pragma unroll
+  for (int sset = 0; sset < NSA; ++sset) srcFs.p[sset] = nullptr;
+#pragma unroll
+  for (int sset = 0; sset < NS; ++sset) {
+    if (a.fset[sset]) srcFs.p[sset] = a.fset[sset] + (size_t)pre_i[4 + sset] * 2 * D * ldx;
+    else srcFs.p[sset] = remote ? recp + a.rec_off_F : a.F_old + (size_t)ancb * 2 * D * ldx;
+  }
   const int nN = M.nN;
 
-  // ---- A: propagate the non-linear state (one lane), stage xl / pending K / ivec into LDS (all) ----
-  if (tid == 0) {
-    double x[8], xp[8];
-    for (int c = 0; c < nN; ++c) x[c] = a.xn_old[(size_t)c * a.xn_old_stride + anc];
-    if (a.xref != nullptr && i == N - 1) {
-      for (int c = 0; c < nN; ++c) xp[c] = a.xref[c];                      // particleSmoother.m:242
-    } else if (a.propagate) {
-      double z[8];
-      if (a.rng_mode == 0) { for (int k = 0; k < M.nw; ++k) z[k] = a.Z[(size_t)gslot * M.nw + k]; }
-      else philox_normals(a.seed, gslot, a.t, a.k_iter, M.nw, z);
-      if (M.kind == 1) dyn_model_mag(x, a.odo, a.cholQ, z, xp);
-      else dyn_model_radio(x, a.odo, a.cholQ, z, xp);
-    } else {
-      for (int c = 0; c < nN; ++c) xp[c] = x[c];
-    }
-    for (int c = 0; c < nN; ++c) { a.xn_new[(size_t)c * a.xn_new_stride + i] = xp[c]; misc[c] = xp[c]; }
-    if (M.kind == 1) quat2rmat_dev(&xp[3], &misc[8]);
-  }
+  // ---- A: fetch the propagated non-linear state (propagate_kernel ran first), stage xl / pending K / ivec ----
+  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];   // xn_new[0..8), Rnb[8..17)
   {
+    // all loads of a pass are issued before the first LDS store (clamped indices, predicated stores): the
+    // sources are scattered small arrays, so this phase is pure latency
     const double* xl_src = srcX;
-    const double* Kcol = srcF ? srcF + (size_t)D * ldx : nullptr;
     const double* iv = (E > 0) ? a.ivec_old + (size_t)anc * a.ivec_old_stride : nullptr;
-    for (int c = tid; c < n; c += kThreads) {
-      xls[c] = xl_src[c];
+    constexpr int PB = 2;                                   // columns per thread per pass
+    for (int c0 = tid; c0 < n; c0 += PB * kThreads) {
+      double xv[PB], ivv[PB], kv[PB][ND > 0 ? ND : 1];
 #pragma unroll
-      for (int k = 0; k < D; ++k) HK[c * REC + DE + k] = Kcol ? Kcol[(size_t)k * ldx + c] : 0.0;
-      if (E > 0) HK[c * REC + D] = iv[c];
+      for (int u = 0; u < PB; ++u) {
+        const int c = min(c0 + u * kThreads, n - 1);
+        xv[u] = xl_src[c];
+        ivv[u] = (E > 0) ? iv[c] : 0.0;
+#pragma unroll
+        for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+          for (int k = 0; k < D; ++k) kv[u][sset * D + k] = srcFs.p[sset][(size_t)(D + k) * ldx + c];
+      }
+#pragma unroll
+      for (int u = 0; u < PB; ++u) {
+        const int c = c0 + u * kThreads;
+        if (c < n) {
+          xls[c] = xv[u];
+#pragma unroll
+          for (int k = 0; k < ND; ++k) HK[c * REC + DE + k] = kv[u][k];
+          if (E > 0) HK[c * REC + D] = ivv[u];
+        }
+      }
     }
   }
   __syncthreads();
 
+  RBPF_KSTAMP(1);
   // ---- B: per-axis sin/cos tables of the reduced-rank basis at the new position ----
   for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
   __syncthreads();
 
+  RBPF_KSTAMP(2);
   // ---- C: measurement Jacobian H_i, column per thread (+ ivecPlus = ivec + dyi'/R*yt', :292) ----
   {
     double Riy[D];
@@ -362,8 +452,8 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   }
   __syncthreads();
 
+  RBPF_KSTAMP(3);
   // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ [H' X] ----
-  const double* KSrow = srcF;
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
@@ -373,18 +463,20 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
       if (CPL > 0)
-        stream_core<D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3))>(src, dst, HK, KSrow, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
+        stream_core<D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
       const int rem = Ly.CH - CPL * Ly.RS;
       if (wr < rem)
-        stream_core<D, E, 1, RBPF_UC>(src, dst, HK, KSrow, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
+        stream_core<D, E, 1, RBPF_UC, NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
       const double* src = srcB + (size_t)b * ldb;
       double* dst = a.Pb_new + (size_t)i * Ly.szB + (size_t)b * ldb;
-      double ksb[D];
+      double ksb[ND > 0 ? ND : 1];
 #pragma unroll
-      for (int k = 0; k < D; ++k) ksb[k] = KSrow ? KSrow[(size_t)k * ldx + b] : 0.0;
+      for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+        for (int k = 0; k < D; ++k) ksb[sset * D + k] = srcFs.p[sset][(size_t)k * ldx + b];
       double accb[DE];
 #pragma unroll
       for (int k = 0; k < DE; ++k) accb[k] = 0.0;
@@ -396,13 +488,12 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
           const int cc = c + e;
           if (cc < n) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) p[e] = fma(-ksb[k], HK[cc * REC + DE + k], p[e]);
+            for (int k = 0; k < ND; ++k) p[e] = fma(-ksb[k], HK[cc * REC + DE + k], p[e]);
 #pragma unroll
             for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], HK[cc * REC + k], accb[k]);
           }
         }
-        dbl2 o; o.x = p[0]; o.y = p[1];
-        *reinterpret_cast<dbl2*>(dst + c) = o;
+        if (WR) { dbl2 o; o.x = p[0]; o.y = p[1]; *reinterpret_cast<dbl2*>(dst + c) = o; }
       }
 #pragma unroll
       for (int k = 0; k < DE; ++k) {
@@ -425,6 +516,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     __syncthreads();
   }
 
+  RBPF_KSTAMP(4);
   // ---- E: innovation covariance S = H (P H') + R, innovation e = y - H xl (+ quadratic forms) ----
   constexpr int NRED = D * D + D + E;
   {
@@ -497,6 +589,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   }
   __syncthreads();
 
+  RBPF_KSTAMP(5);
   // ---- F: Kalman gain rows, mean update, new pending factors (particleFilter.m:194-198) ----
   {
     double cS[D * D], SS[D * D], e[D];
@@ -506,6 +599,17 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     for (int q = 0; q < D; ++q) e[q] = misc[40 + q];
     double* KSn = a.F_new + ((size_t)i * 2 + 0) * D * ldx;
     double* Kn = a.F_new + ((size_t)i * 2 + 1) * D * ldx;
+    if (tid == 0) {
+      // lineage bookkeeping of the multi-step lazy update: where this particle's stored matrix and its
+      // surviving pending sets live (a flush makes them all obsolete)
+      if (a.base_new) a.base_new[i] = WR ? i : baseb;
+      if (!WR) {
+#pragma unroll
+        for (int sset = 0; sset < NS; ++sset)
+          if (a.fset_idx_new[sset]) a.fset_idx_new[sset][i] = pre_i[4 + sset];
+      }
+      if (a.fself_idx_new) a.fself_idx_new[i] = i;
+    }
     double* xln = a.xl_new + (size_t)i * ldx;
     double uK[D];
 #pragma unroll
@@ -567,40 +671,66 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
       }
     }
   }
+  __syncthreads();
+  RBPF_KSTAMP(6);
 }
 
-template <int D, int E, int CPL>
+template <int D, int E, int CPL, int NS, bool WR>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
-  const size_t lds = step_lds_bytes(a.mdl, a.lay, E);
+  const size_t lds = step_lds_bytes(a.mdl, a.lay, E, NS);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, E, CPL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, E, CPL, NS, WR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((step_kernel<D, E, CPL>), dim3(a.N), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((step_kernel<D, E, CPL, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_step(const StepArgs& a, hipStream_t s) {
-  const int D = a.mdl.d, CPL = a.lay.CPL;
-#define RBPF_DISPATCH(DD, EE)                                   \
-  switch (CPL) {                                                \
-    case 0: return launch_step_t<DD, EE, 0>(a, s);              \
-    case 1: return launch_step_t<DD, EE, 1>(a, s);              \
-    case 2: return launch_step_t<DD, EE, 2>(a, s);              \
-    case 3: return launch_step_t<DD, EE, 3>(a, s);              \
-    default: return hipErrorInvalidValue;                       \
+template <int D, int E, int NS, bool WR>
+static hipError_t launch_step_cpl(const StepArgs& a, hipStream_t s) {
+  switch (a.lay.CPL) {
+    case 0: return launch_step_t<D, E, 0, NS, WR>(a, s);
+    case 1: return launch_step_t<D, E, 1, NS, WR>(a, s);
+    case 2: return launch_step_t<D, E, 2, NS, WR>(a, s);
+    case 3: return launch_step_t<D, E, 3, NS, WR>(a, s);
+    default: return hipErrorInvalidValue;
   }
-  if (a.info) {
-    if (D == 3) { RBPF_DISPATCH(3, 2) }
-    if (D == 1) { RBPF_DISPATCH(1, 2) }
+}
+
+// multi-step lazy variants (filter only, E = 0): up to kMaxSets pending sets, light (read-only) or flush
+template <int D>
+static hipError_t launch_step_lazy(const StepArgs& a, hipStream_t s) {
+  if (a.lay.CPL < 1 || a.lay.CPL > 2) return hipErrorInvalidValue;
+#define RBPF_LZ(NS_, WR_) (a.lay.CPL == 1 ? launch_step_t<D, 0, 1, NS_, WR_>(a, s) : launch_step_t<D, 0, 2, NS_, WR_>(a, s))
+  if (a.write_base) {
+    switch (a.n_sets) { case 2: return RBPF_LZ(2, true); case 3: return RBPF_LZ(3, true); case 4: return RBPF_LZ(4, true); default: break; }
+  } else {
+    switch (a.n_sets) { case 1: return RBPF_LZ(1, false); case 2: return RBPF_LZ(2, false); case 3: return RBPF_LZ(3, false); default: break; }
+  }
+#undef RBPF_LZ
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_step(const StepArgs& a, hipStream_t s) {
+  const int D = a.mdl.d;
+  if (a.n_sets < 0 || a.n_sets > kMaxSets) return hipErrorInvalidValue;
+  const bool legacy = a.write_base && a.n_sets <= 1;       // one pending set, rewritten every step
+  if (!legacy) {
+    if (a.info) return hipErrorInvalidValue;
+    if (D == 3) return launch_step_lazy<3>(a, s);
+    if (D == 1) return launch_step_lazy<1>(a, s);
     return hipErrorInvalidValue;
   }
-  if (D == 3) { RBPF_DISPATCH(3, 0) }
-  if (D == 1) { RBPF_DISPATCH(1, 0) }
-#undef RBPF_DISPATCH
+  if (a.info) {
+    if (D == 3) return a.n_sets ? launch_step_cpl<3, 2, 1, true>(a, s) : launch_step_cpl<3, 2, 0, true>(a, s);
+    if (D == 1) return a.n_sets ? launch_step_cpl<1, 2, 1, true>(a, s) : launch_step_cpl<1, 2, 0, true>(a, s);
+    return hipErrorInvalidValue;
+  }
+  if (D == 3) return a.n_sets ? launch_step_cpl<3, 0, 1, true>(a, s) : launch_step_cpl<3, 0, 0, true>(a, s);
+  if (D == 1) return a.n_sets ? launch_step_cpl<1, 0, 1, true>(a, s) : launch_step_cpl<1, 0, 0, true>(a, s);
   return hipErrorInvalidValue;
 }
 
@@ -914,13 +1044,14 @@ __device__ inline void search_block(const SearchArgs& a, double* sbuf, double* s
 // counting sort of the slots by key (ancestor): order[] lists the slots so that equal keys are adjacent.
 // The order among equal keys is arbitrary (atomics) -- it only changes the schedule, never a result.
 __device__ inline void order_block(int n_slots, int range, const int* __restrict__ key, int* __restrict__ order,
-                                   int* __restrict__ counts_global, int* sred_i, int* lds_counts, int lds_capacity) {
+                                   int* __restrict__ counts_global, int* sred_i, int* lds_counts, int lds_capacity,
+                                   const int* __restrict__ remap = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* counts = (range <= lds_capacity) ? lds_counts : counts_global;     // LDS atomics when the histogram fits
   __syncthreads();
   for (int j = tid; j < range; j += kNormThreads) counts[j] = 0;
   __syncthreads();
-  for (int i = tid; i < n_slots; i += kNormThreads) atomicAdd(&counts[key[i]], 1);
+  for (int i = tid; i < n_slots; i += kNormThreads) atomicAdd(&counts[remap ? remap[key[i]] : key[i]], 1);
   __syncthreads();
   const int S = (range + kNormThreads - 1) / kNormThreads;
   const int j0 = min(tid * S, range), j1 = min(j0 + S, range);
@@ -942,7 +1073,7 @@ __device__ inline void order_block(int n_slots, int range, const int* __restrict
     run += cnt;
   }
   __syncthreads();
-  for (int i = tid; i < n_slots; i += kNormThreads) order[atomicAdd(&counts[key[i]], 1)] = i;
+  for (int i = tid; i < n_slots; i += kNormThreads) order[atomicAdd(&counts[remap ? remap[key[i]] : key[i]], 1)] = i;
 }
 
 __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const NormArgs a) {
@@ -955,7 +1086,7 @@ __global__ __launch_bounds__(kNormThreads) void normalise_scan_kernel(const Norm
 
 // normalise step t, then (filter fast path) draw the ancestors of step t+1 and their processing order
 __global__ __launch_bounds__(kNormThreads) void normalise_resample_kernel(const NormArgs a, const SearchArgs sa,
-                                                                          int* order, int* counts) {
+                                                                          int* order, int* counts, const int* remap) {
   __shared__ double sred[16];
   __shared__ int sidx[16];
   __shared__ double sbig[2 * kScanChunk];
@@ -975,7 +1106,7 @@ __global__ __launch_bounds__(kNormThreads) void normalise_resample_kernel(const 
   search_block(sa, sbuf, sbuf2, &scarry, &sflag);
   __syncthreads();
   RBPF_STAMP(2);
-  if (order) order_block(sa.n_draw, sa.N, sa.ai, order, counts, sidx, reinterpret_cast<int*>(sbuf), 2 * kScanChunk);
+  if (order) order_block(sa.n_draw, sa.N, sa.ai, order, counts, sidx, reinterpret_cast<int*>(sbuf), 2 * kScanChunk, remap);
   __syncthreads();
   RBPF_STAMP(3);
 }
@@ -991,8 +1122,9 @@ hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s) {
-  hipLaunchKernelGGL(normalise_resample_kernel, dim3(1), dim3(kNormThreads), 0, s, a, sa, order, counts);
+hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s,
+                                     const int* remap) {
+  hipLaunchKernelGGL(normalise_resample_kernel, dim3(1), dim3(kNormThreads), 0, s, a, sa, order, counts, remap);
   return hipGetLastError();
 }
 
@@ -1103,30 +1235,51 @@ hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src
   return hipGetLastError();
 }
 
-// flushes the pending downdate: P(r,c) = stored(r,c) - sum_k KS(r,k) K(c,k)
+// flushes the pending downdates: P(r,c) = stored(r,c) - sum over sets, k of KS(r,k) K(c,k)
+struct UnpackSets {
+  int n_sets;
+  const double* fset[kMaxSets];
+  const int* fidx[kMaxSets];      // entry of each particle in that bank (null: the particle's own index)
+  const int* base;                // slot of the stored matrix (null: the particle's own index)
+};
+
 __global__ void unpack_P_kernel(Layout L, int d, const double* __restrict__ Pt, const double* __restrict__ Pb,
-                                const double* __restrict__ F, const int* __restrict__ index,
-                                double* __restrict__ P) {
+                                UnpackSets us, const int* __restrict__ index, double* __restrict__ P) {
   const int p = blockIdx.x;
   const int src = index ? index[p] : p;
-  const double* t = Pt + (size_t)src * L.szT;
-  const double* b = Pb + (size_t)src * L.szB;
-  const double* KS = F ? F + ((size_t)src * 2 + 0) * d * L.ldx : nullptr;
-  const double* K = F ? F + ((size_t)src * 2 + 1) * d * L.ldx : nullptr;
+  const int bsl = us.base ? us.base[src] : src;
+  const double* t = Pt + (size_t)bsl * L.szT;
+  const double* b = Pb + (size_t)bsl * L.szB;
   double* dst = P + (size_t)p * L.n * L.n;
   const size_t nn = (size_t)L.n * L.n;
   for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
     const int r = (int)(q % L.n), c = (int)(q / L.n);
     double v = (r < L.nb) ? b[(size_t)r * L.ldb + c] : t[(size_t)c * L.mc + (r - L.nb)];
-    if (F)
-      for (int k = 0; k < d; ++k) v = fma(-KS[(size_t)k * L.ldx + r], K[(size_t)k * L.ldx + c], v);
+    for (int sset = 0; sset < us.n_sets; ++sset) {
+      const double* F = us.fset[sset] + (size_t)(us.fidx[sset] ? us.fidx[sset][src] : src) * 2 * d * L.ldx;
+      for (int k = 0; k < d; ++k) v = fma(-F[(size_t)k * L.ldx + r], F[(size_t)(d + k) * L.ldx + c], v);
+    }
     dst[q] = v;
   }
 }
 
 hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
                            const int* index, int count, double* P_colmajor, hipStream_t s) {
-  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, F, index, P_colmajor);
+  UnpackSets us;
+  us.n_sets = F ? 1 : 0; us.base = nullptr;
+  for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = nullptr; us.fidx[q] = nullptr; }
+  us.fset[0] = F;
+  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, const double* Pb, int n_sets,
+                                const double* const* fset, const int* const* fidx, const int* base, const int* index,
+                                int count, double* P_colmajor, hipStream_t s) {
+  UnpackSets us;
+  us.n_sets = n_sets; us.base = base;
+  for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = q < n_sets ? fset[q] : nullptr; us.fidx[q] = q < n_sets ? fidx[q] : nullptr; }
+  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
   return hipGetLastError();
 }
 

@@ -216,6 +216,7 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
   StepArgs a;
   std::memset(&a, 0, sizeof(a));
   a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);
+  a.n_sets = (t > 0) ? 1 : 0; a.write_base = 1;          // one pending set, rewritten every step
   a.slot_offset = s->rank * N;
   a.xn_new = s->fwd_local; a.xn_new_stride = (size_t)N;
   a.logw = s->fwd_local + (size_t)nN * N;
@@ -250,6 +251,9 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
   a.cholQ = c->d_cholQ + (size_t)((c->chol_pages > 1 && t > 0) ? t - 1 : 0) * nw * nw;
   a.y = c->d_y + (size_t)t * d;
   a.status = c->d_flags;
+  a.stamps = nullptr;
+  a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;
+  HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
   HIPCHK(launch_step(a, c->stream));

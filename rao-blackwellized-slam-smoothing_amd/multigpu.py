@@ -190,7 +190,7 @@ class ShardedFilterSession:
         # replay buffers (tests) hold all world*N_local slots; Philox streams are keyed by logical slot id
         self.blk, self._rng = _rng_block(rng if rng is not None else PhiloxRNG(1), self.prob.N_P * self.world,
                                          self.prob.N_T, model.nw, 1)
-        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, reserved=0, jitter=0.0)
+        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=0, jitter=0.0)
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         check(self.lib.rbpf_shard_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),

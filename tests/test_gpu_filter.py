@@ -16,13 +16,13 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def run_both(rbpf, c):
+def run_both(rbpf, c, lazy_depth=0):
     ref = cases.oracle_filter(c)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     np.testing.assert_array_equal(mdl.NN, c["model"].NN.astype(np.int32))
     np.testing.assert_allclose(P0, c["P0_lin"], rtol=1e-14)
     out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
-                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True)
+                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth)
     return ref, out
 
 
@@ -61,4 +61,16 @@ def test_dense_mag_filter_matches_oracle(rbpf, N_P, N_T, m):
 def test_dense_radio_filter_matches_oracle(rbpf, N_P, N_T, m):
     c = cases.radio_case(N_P, N_T, m, seed=5)
     ref, out = run_both(rbpf, c)
+    check_filter(ref, out)
+
+
+@pytest.mark.parametrize("lazy_depth", [2, 3, 4])
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 12, 11, 125), ("mag", 9, 10, 130), ("mag", 8, 9, 256),
+                                            ("radio", 16, 12, 128), ("radio", 7, 11, 140)])
+def test_multi_step_lazy_update_matches_oracle(rbpf, kind, N_P, N_T, m, lazy_depth):
+    """lazy_depth = C: the stored covariances are rewritten every C-th step only, with up to C pending rank-ny
+    downdates applied on the fly (same algebra as particleFilter.m:198 every step, so same results to rounding)."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=17)
+    ref, out = run_both(rbpf, c, lazy_depth=lazy_depth)
     check_filter(ref, out)
