@@ -78,6 +78,23 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
                       f"(gcc {flags}, OpenMP over particles), {secs:.1f} s"}
 
 
+def smoother_wallclock(pkg, datagen):
+    """Wall-clock of the two conditional particle smoothers at the reference's own dense-mag size
+    (N_P=100, T=192, m=512: run_dense3D_magfield.m:85,134; generateData_dense.m:184-187), N_K=3, device Philox."""
+    import numpy as np
+    Q = q_mag()
+    d = datagen.bean_6D(192, Q, THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = pkg.dense_mag_prior(512, d["LL"], THETA_MAG)
+    out = {"workload": "slam-dense-mag N_P=100 T=192 m=512 N_K=3 fp64 (the reference's own size)", "unit": "s"}
+    for name, f in (("information_form", pkg.particleSmootherInformationForm), ("covariance_form", pkg.particleSmoother)):
+        t0 = time.perf_counter()
+        XNK, _, _ = f(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R, 100, 3, 0.01,
+                      rng=pkg.PhiloxRNG(3))
+        out[name] = round(time.perf_counter() - t0, 3)
+        out[name + "_pos_rmse_m"] = round(float(np.sqrt(np.mean((XNK[0:3, :, -1] - d["pos"]) ** 2))), 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +104,7 @@ def main():
     ap.add_argument("--m", type=int, default=256)
     ap.add_argument("--T", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-smoother", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=3, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
@@ -191,6 +209,11 @@ def main():
             ph = st.pop("phase_s", {})
             st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 4) for k, v in ph.items()}
             line["config"]["sharding"] = st
+        if world == 1 and not args.no_smoother and not args.force_sharded:
+            try:
+                line["smoother"] = smoother_wallclock(pkg, datagen)
+            except Exception as exc:
+                line["smoother"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)

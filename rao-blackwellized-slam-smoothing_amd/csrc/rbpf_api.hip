@@ -285,6 +285,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   RB_TRY(dmalloc(&c->traj_max, (size_t)T * nN));
   RB_TRY(dmalloc(&c->traj_mean, (size_t)T * nN));
   RB_TRY(dmalloc(&c->d_scal, 64));
+  RB_TRY(dmalloc(&c->d_unext, (size_t)N));
   RB_TRY(dmalloc(&c->d_pre_i, (size_t)N * kPreInts));
   RB_TRY(dmalloc(&c->d_pre_d, (size_t)N * kPreDoubles));
   RB_TRY(dmalloc(&c->d_order, (size_t)N));
@@ -331,7 +332,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
   for (int b = 0; b < 2; ++b) { hipFree(c->fidx[b]); hipFree(c->base[b]); }
-  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d);
+  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d); hipFree(c->d_unext);
   smoother_free(c);
   shard_free(c);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -449,6 +450,8 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.status = c->d_flags;
   a.stamps = reinterpret_cast<unsigned long long*>(c->d_counts + 2 * N + 32);
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;
+  // fused fast path with the device generator: the uniforms of step t+1 are produced here, in parallel
+  a.u_next = (c->fuse_resample && c->rng_mode == RBPF_RNG_PHILOX && t + 1 < c->T) ? c->d_unext : nullptr;
   a.info = info ? 1 : 0;
   a.ivec_old = nullptr; a.ivec_old_stride = 0; a.ivec_new = nullptr; a.hld_old = nullptr; a.hld_old_stride = 0;
   a.hld_new = nullptr; a.qf_new = nullptr; a.Hb_new = nullptr;
@@ -478,6 +481,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     SearchArgs s;
     s.N = N; s.n_draw = N; s.t = t + 1; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
     s.U = c->d_U ? c->d_U + rng_page + (size_t)t * N : nullptr;
+    if (a.u_next) { s.rng_mode = RBPF_RNG_REPLAY; s.U = c->d_unext; }     // pre-drawn by propagate_kernel (same Philox values)
     s.seed = c->seed; s.ai = A_next; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
     s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + tr; s.wc_exact = c->wc;
     // sort key of the next step: the slot of the stored matrix each ancestor's lineage refers to

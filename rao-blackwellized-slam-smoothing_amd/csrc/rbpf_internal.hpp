@@ -82,6 +82,7 @@ struct StepArgs {
   int* status;
   unsigned long long* stamps;               // diagnostic builds only (RBPF_STAMPS)
   int* pre_i; double* pre_d;                // [N][kPreInts], [N][kPreDoubles] descriptors (propagate_kernel -> step_kernel)
+  double* u_next;                           // [N] out: Philox uniforms of the next step's resampling (or null)
   // information form (particleSmootherInformationForm.m): extra per-particle state
   int info;
   const double* ivec_old; size_t ivec_old_stride; double* ivec_new;   // [N][ldx]

@@ -304,6 +304,9 @@ __global__ void propagate_kernel(const StepArgs a) {
 #pragma unroll
   for (int c = 0; c < 8; ++c)
     if (c < nN) a.xn_new[(size_t)c * a.xn_new_stride + i] = xp[c];
+  // next step's resampling uniforms (tools/sample.m:31) for this slot: off the critical path here, the
+  // single-workgroup resample kernel then just loads them
+  if (a.u_next) a.u_next[gslot] = philox_resample_uniform(a.seed, gslot, a.t + 1, a.k_iter);
   // per-workgroup descriptor: everything the step kernel would otherwise fetch through a chain of dependent
   // scattered loads while HBM is saturated
   int* pi = a.pre_i + (size_t)b * kPreInts;

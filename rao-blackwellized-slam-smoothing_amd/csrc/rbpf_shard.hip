@@ -252,7 +252,7 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
   a.y = c->d_y + (size_t)t * d;
   a.status = c->d_flags;
   a.stamps = nullptr;
-  a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;
+  a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d; a.u_next = nullptr;
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }

@@ -27,7 +27,7 @@ for name, lib, env_extra in variants:
     if lib:
         env["RBPF_LIB_PATH"] = lib
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "20",
-                        "--no-cpu-baseline"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                        "--no-cpu-baseline --no-smoother"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(f"{name:24s} FAILED: {r.stderr[-300:]}")
