@@ -240,9 +240,10 @@ int rbpf_shard_pack(rbpf_ctx* ctx, const int32_t* idx_host, int32_t count);
  * t = 0 (identity placement: logical slot rank*N_local + p at physical slot p).                      */
 int rbpf_shard_step(rbpf_ctx* ctx, const int32_t* anc_bank_host, const int32_t* slot_ids_host);
 /* Device-side planner (the production path): placement of the new generation + exchange plan from the
- * ancestors drawn by the last rbpf_shard_normalise_search, entirely on the device.  counts_host
- * [2*world+1] receives the records to send to / receive from every rank and the number of migrating
- * children.  Afterwards rbpf_shard_pack(ctx, NULL, n_send), rbpf_shard_step(ctx, NULL, NULL) and
+  * ancestors drawn by the last rbpf_shard_normalise_search, entirely on the device.  counts_host
+ * [2*world+2] receives the records to send to / receive from every rank, the number of migrating
+ * children, and the first record of recv_rec this step's exchange must write to (records persist across
+ * the read-only steps of a lazy cycle).  Afterwards rbpf_shard_pack(ctx, NULL, n_send), rbpf_shard_step(ctx, NULL, NULL) and
  * rbpf_shard_normalise_search(ctx, NULL, ...) use the device plan.                                      */
 int rbpf_shard_plan(rbpf_ctx* ctx, int64_t* counts_host);
 /* Test hook: this rank's view of the current device plan.                                             */

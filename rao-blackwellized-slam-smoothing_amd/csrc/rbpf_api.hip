@@ -268,7 +268,10 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
     if (step_lds_bytes(c->mdl, c->lay, 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
-    for (int b = 0; b <= c->lazy_depth; ++b) RB_TRY(dmalloc(&c->Fb[b], (size_t)N * 2 * d * L.ldx));
+    for (int b = 0; b <= c->lazy_depth; ++b) {            // entry N of every bank stays zero (fresh lineages)
+      RB_TRY(dmalloc(&c->Fb[b], (size_t)(N + 1) * 2 * d * L.ldx));
+      HIPCHK(hipMemsetAsync(c->Fb[b], 0, (size_t)(N + 1) * 2 * d * L.ldx * sizeof(double), c->stream));
+    }
     for (int b = 0; b < 2; ++b) {
       RB_TRY(dmalloc(&c->fidx[b], (size_t)(c->lazy_depth + 1) * N));
       RB_TRY(dmalloc(&c->base[b], (size_t)N));
@@ -370,6 +373,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.ai = (t > 0) ? A_t : nullptr;
   a.ai_bank = nullptr; a.slot_offset = 0; a.xn_old_stride = (size_t)N; a.xn_new_stride = (size_t)N;
   a.order = (pre_drawn && t > 0) ? c->d_order : nullptr;
+  a.zero_set_idx = N;
   a.slot_ids = nullptr; a.n_bank_local = 0; a.rec = nullptr; a.rec_stride = 0; a.rec_off_B = a.rec_off_F = a.rec_off_X = 0;
   {
     static const int no_order = getenv("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only

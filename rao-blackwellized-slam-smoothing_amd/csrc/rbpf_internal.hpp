@@ -62,6 +62,7 @@ struct StepArgs {
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
   // `rec`, a particle-major buffer [Pt | Pb | F | xl] per record
   int n_bank_local; const double* rec; size_t rec_stride, rec_off_B, rec_off_F, rec_off_X;
+  int zero_set_idx;              // entry of every factor-set bank that holds zeros (fresh lineages)
   int slot_offset;               // global id of local slot 0 (RNG counters / replay rows)
   size_t xn_old_stride, xn_new_stride;      // component stride of the SoA state arrays
   const double* xn_old; double* xn_new;     // SoA [nN][stride]
@@ -162,6 +163,10 @@ hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, con
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
                                const double* F, const double* xl, double* rec, hipStream_t s);
+hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx, int count, const double* Pt,
+                                       const double* Pb, int n_sets, const double* const* fset, const int* const* fidx,
+                                       const int* base, int n_bank_local, const double* rec, size_t rec_stride,
+                                       const double* xl, double* out, hipStream_t s);
 hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
                               double* logw, double* xn_soa, hipStream_t s);
 hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);

@@ -310,10 +310,19 @@ __global__ void propagate_kernel(const StepArgs a) {
   // per-workgroup descriptor: everything the step kernel would otherwise fetch through a chain of dependent
   // scattered loads while HBM is saturated
   int* pi = a.pre_i + (size_t)b * kPreInts;
-  pi[0] = i; pi[1] = anc; pi[2] = ancb; pi[3] = a.base_old ? a.base_old[anc] : ancb;
+  // lineage tables are indexed by the ancestor's slot in the local banks (== anc on one GPU; the bank index
+  // in the sharded filter).  A migrated child (ancb in the record region) starts a fresh lineage: its record
+  // holds the ancestor's matrix with every pending set already applied, so the old sets map to the zero entry.
+  const bool imported = a.rec != nullptr && ancb >= a.n_bank_local;
+  const int tix = a.slot_ids ? ancb : anc;
+  pi[0] = i; pi[1] = anc; pi[2] = ancb;
+  pi[3] = imported ? ancb : (a.base_old ? a.base_old[tix] : ancb);
 #pragma unroll
-  for (int sset = 0; sset < kMaxSets; ++sset)
-    pi[4 + sset] = (sset < a.n_sets && a.fset[sset] && a.fset_idx_old[sset]) ? a.fset_idx_old[sset][anc] : ancb;
+  for (int sset = 0; sset < kMaxSets; ++sset) {
+    int v = ancb;
+    if (sset < a.n_sets && a.fset[sset]) v = imported ? a.zero_set_idx : (a.fset_idx_old[sset] ? a.fset_idx_old[sset][tix] : ancb);
+    pi[4 + sset] = v;
+  }
   double* pd = a.pre_d + (size_t)b * kPreDoubles;
 #pragma unroll
   for (int c = 0; c < 8; ++c) pd[c] = xp[c];
@@ -367,12 +376,14 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   const int anc = pre_i[1];      // ancestor id for the non-linear / information-form state banks
   const int ancb = pre_i[2];     // ancestor id in the map bank (local | remote records)
   // sources of the ancestor's map state: the local bank, or a received record
-  const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;
+  const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;          // mean / legacy factors in a record
   const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
   // multi-step lazy update: the stored ("base") matrix of the ancestor's lineage may live in another slot
   const int baseb = pre_i[3];
-  const double* srcT = remote ? recp : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
-  const double* srcB = remote ? recp + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
+  const bool remoteP = a.rec != nullptr && baseb >= a.n_bank_local;        // stored matrix in a (persisting) record
+  const double* recP = remoteP ? a.rec + (size_t)(baseb - a.n_bank_local) * a.rec_stride : nullptr;
+  const double* srcT = remoteP ? recP : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
+  const double* srcB = remoteP ? recP + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
   const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
   // pending factor sets (KS rows then K columns, [2][D][ldx] each), oldest first
   SetPtrs<NSA> srcFs;
@@ -1503,6 +1514,61 @@ __global__ void pack_records_kernel(Layout L, int d, const int* __restrict__ idx
   for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) r[L.szT + q] = Pb[(size_t)src * L.szB + q];
   for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[L.szT + L.szB + q] = F[(size_t)src * szF + q];
   for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[L.szT + L.szB + szF + q] = xl[(size_t)src * L.ldx + q];
+}
+
+// Same records, but with the lineage's pending factor sets applied while packing (sharded filter with the
+// multi-step lazy update): the receiver gets a plain matrix and starts a fresh lineage.
+struct PackSets {
+  int n_sets, n_bank_local;
+  const double* fset[kMaxSets];
+  const int* fidx[kMaxSets];
+  const int* base;
+  const double* rec; size_t rec_stride;       // bases of previously imported lineages live in the record buffer
+};
+
+__global__ void pack_records_flushed_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
+                                            const double* __restrict__ Pb, PackSets ps, const double* __restrict__ xl,
+                                            double* __restrict__ out) {
+  const int p = blockIdx.x;
+  const int src = idx[p];
+  const size_t szF = (size_t)2 * d * L.ldx;
+  const size_t recsz = L.szT + L.szB + szF + L.ldx;
+  double* r = out + (size_t)p * recsz;
+  const int bsl = ps.base ? ps.base[src] : src;
+  const bool inrec = ps.rec != nullptr && bsl >= ps.n_bank_local;
+  const double* t = inrec ? ps.rec + (size_t)(bsl - ps.n_bank_local) * ps.rec_stride : Pt + (size_t)bsl * L.szT;
+  const double* b = inrec ? ps.rec + (size_t)(bsl - ps.n_bank_local) * ps.rec_stride + L.szT : Pb + (size_t)bsl * L.szB;
+  const double* F[kMaxSets];
+  for (int s = 0; s < ps.n_sets; ++s) F[s] = ps.fset[s] + (size_t)(ps.fidx[s] ? ps.fidx[s][src] : src) * szF;
+  for (size_t q = threadIdx.x; q < L.szT; q += blockDim.x) {
+    const int c = (int)(q / L.mc), rr = L.nb + (int)(q % L.mc);
+    double v = t[q];
+    for (int s = 0; s < ps.n_sets; ++s)
+      for (int k = 0; k < d; ++k) v = fma(-F[s][(size_t)k * L.ldx + rr], F[s][(size_t)(d + k) * L.ldx + c], v);
+    r[q] = v;
+  }
+  for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) {
+    const int rr = (int)(q / L.ldb), c = (int)(q % L.ldb);
+    double v = b[q];
+    if (c < L.n)
+      for (int s = 0; s < ps.n_sets; ++s)
+        for (int k = 0; k < d; ++k) v = fma(-F[s][(size_t)k * L.ldx + rr], F[s][(size_t)(d + k) * L.ldx + c], v);
+    r[L.szT + q] = v;
+  }
+  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[L.szT + L.szB + q] = 0.0;
+  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[L.szT + L.szB + szF + q] = xl[(size_t)src * L.ldx + q];
+}
+
+hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx, int count, const double* Pt,
+                                       const double* Pb, int n_sets, const double* const* fset, const int* const* fidx,
+                                       const int* base, int n_bank_local, const double* rec, size_t rec_stride,
+                                       const double* xl, double* out, hipStream_t s) {
+  if (count <= 0) return hipSuccess;
+  PackSets ps;
+  ps.n_sets = n_sets; ps.n_bank_local = n_bank_local; ps.base = base; ps.rec = rec; ps.rec_stride = rec_stride;
+  for (int q = 0; q < kMaxSets; ++q) { ps.fset[q] = q < n_sets ? fset[q] : nullptr; ps.fidx[q] = q < n_sets ? fidx[q] : nullptr; }
+  hipLaunchKernelGGL(pack_records_flushed_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, ps, xl, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,

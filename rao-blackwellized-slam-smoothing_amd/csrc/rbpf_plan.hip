@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kPlanThreads) void plan_pairs_kernel(int world, int
   if (tid == 0) counts_out[2 * world] = M;
 }
 
-__global__ void plan_finish_kernel(int nl, int me, const PlanScalars* __restrict__ ps, const int* __restrict__ mv_child,
+__global__ void plan_finish_kernel(int nl, int me, int rec_off, const PlanScalars* __restrict__ ps, const int* __restrict__ mv_child,
                                    const int* __restrict__ mv_src, const int* __restrict__ mv_q, const int* __restrict__ pref,
                                    const int* __restrict__ new_gid, int* __restrict__ anc_bank, int* __restrict__ send_idx) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,7 +151,7 @@ __global__ void plan_finish_kernel(int nl, int me, const PlanScalars* __restrict
   if (mv_q[j] == me) {
     const int lo = ps->imp_start[me];
     const int base = lo > 0 ? pref[lo - 1] : 0;
-    anc_bank[new_gid[mv_child[j]] - me * nl] = nl + (pref[j] - 1 - base);
+    anc_bank[new_gid[mv_child[j]] - me * nl] = nl + rec_off + (pref[j] - 1 - base);
   }
   if (first && mv_src[j] / nl == me) {
     const int lo = ps->mv_off[me];
@@ -161,7 +161,7 @@ __global__ void plan_finish_kernel(int nl, int me, const PlanScalars* __restrict
 }
 
 hipError_t plan_run(const PlanBuffers& b, int N, int world, int nl, int me, const int* ai, const int* cur_gid,
-                    hipStream_t s) {
+                    int rec_off, hipStream_t s) {
   hipError_t e;
   if ((e = hipMemsetAsync(b.counts, 0, (size_t)(N + 1) * sizeof(int), s)) != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.fill, 0, (size_t)N * sizeof(int), s)) != hipSuccess) return e;
@@ -175,7 +175,7 @@ hipError_t plan_run(const PlanBuffers& b, int N, int world, int nl, int me, cons
   hipLaunchKernelGGL(plan_pairs_kernel, dim3(1), dim3(kPlanThreads), 0, s, world, me, b.scalars, b.mv_src, b.mv_q, b.pref,
                      b.counts_dev);
   // M is only known on the device: launch enough threads for the worst case (every child moves)
-  hipLaunchKernelGGL(plan_finish_kernel, dim3(nb), dim3(256), 0, s, nl, me, b.scalars, b.mv_child, b.mv_src, b.mv_q, b.pref,
+  hipLaunchKernelGGL(plan_finish_kernel, dim3(nb), dim3(256), 0, s, nl, me, rec_off, b.scalars, b.mv_child, b.mv_src, b.mv_q, b.pref,
                      b.new_gid, b.anc_bank, b.send_idx);
   return hipGetLastError();
 }

@@ -21,7 +21,8 @@ struct PlanBuffers {
   long long* counts_dev;                 // [2*world + 1]: send counts, recv counts, migrated
 };
 
+// rec_off: first free record of the (persisting) receive buffer; imports get bank index nl + rec_off + position
 hipError_t plan_run(const PlanBuffers& b, int N, int world, int nl, int me, const int* ai, const int* cur_gid,
-                    hipStream_t s);
+                    int rec_off, hipStream_t s);
 
 }  // namespace rbpf

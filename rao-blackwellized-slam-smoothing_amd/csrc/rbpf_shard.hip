@@ -41,6 +41,9 @@ struct ShardState {
   bool plan_ready = false;         // a device plan for the next step exists
   long long* counts_pin = nullptr; // pinned host copy of [send counts | recv counts | migrated]
   int last_send_total = 0;
+  // multi-step lazy update: received records persist until the next flush (imported lineages use them as base)
+  int rec_used = 0;                // records currently alive in recv_rec
+  int plan_recv = 0;               // records the pending plan will append
 };
 
 void shard_free(rbpf_ctx* c) {
@@ -195,8 +198,18 @@ int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
     idx = s->pack_idx;
   }
   const int ob = c->cur;
-  HIPCHK(launch_pack_records(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], c->F[ob], c->xl[ob], s->send_rec,
-                             c->stream));
+  if (c->lazy_depth >= 2) {
+    // state after step t-1: ell pending sets per lineage; apply them while packing
+    const int C = c->lazy_depth, B = C + 1, t = c->t, N = s->Nloc;
+    const int ell = (t == 0) ? 0 : ((t - 1) % C) + 1;
+    const double* fset[kMaxSets]; const int* fidx[kMaxSets];
+    for (int q = 0; q < ell; ++q) { const int bank = (t - ell + q) % B; fset[q] = c->Fb[bank]; fidx[q] = c->fidx[c->tcur] + (size_t)bank * N; }
+    HIPCHK(launch_pack_records_flushed(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], ell, fset, fidx, c->base[c->tcur], N,
+                                       s->recv_rec, s->recsz, c->xl[c->xcur], s->send_rec, c->stream));
+  } else {
+    HIPCHK(launch_pack_records(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], c->F[ob], c->xl[ob], s->send_rec,
+                               c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
   return RBPF_OK;
 }
@@ -220,7 +233,31 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
   a.slot_offset = s->rank * N;
   a.xn_new = s->fwd_local; a.xn_new_stride = (size_t)N;
   a.logw = s->fwd_local + (size_t)nN * N;
-  const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
+  const bool lazy = c->lazy_depth >= 2;
+  if (lazy && t > 0 && !dev_plan) { set_error("lazy_depth >= 2 in the sharded filter needs the device planner"); return RBPF_ERR_UNSUPPORTED; }
+  const int ob = c->cur;
+  int nb = (t == 0) ? 0 : (c->cur ^ 1);
+  const int xo = c->xcur, xn = (t == 0) ? 0 : (c->xcur ^ 1);
+  const int told = c->tcur, tnew = c->tcur ^ 1;
+  bool flush = true;
+  a.zero_set_idx = N;
+  if (lazy) {
+    const int C = c->lazy_depth, B = C + 1;
+    const int ell = (t == 0) ? 0 : ((t - 1) % C) + 1;
+    flush = (t == 0) || (ell == C);
+    a.n_sets = ell; a.write_base = flush ? 1 : 0;
+    if (ell >= 3) a.lay = c->lay_low;
+    for (int q = 0; q < ell; ++q) {
+      const int bank = (t - ell + q) % B;
+      a.fset[q] = c->Fb[bank];
+      a.fset_idx_old[q] = c->fidx[told] + (size_t)bank * N;
+      a.fset_idx_new[q] = c->fidx[tnew] + (size_t)bank * N;
+    }
+    a.fself_idx_new = c->fidx[tnew] + (size_t)(t % B) * N;
+    a.base_old = (t > 0) ? c->base[told] : nullptr;
+    a.base_new = c->base[tnew];
+    if (!flush) nb = ob;
+  }
   if (t == 0) {
     a.xn_old = c->X; a.xn_old_stride = (size_t)N;           // filled with x0 by ctx_reset
     a.xl_old = c->d_x0l; a.xl_old_stride = 0; a.F_old = nullptr;
@@ -237,14 +274,15 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
     }
     a.ai = s->ai_glob;                                       // indexed by logical slot id
     a.xn_old = s->xn_glob; a.xn_old_stride = (size_t)s->Nglob;
-    a.xl_old = c->xl[ob]; a.xl_old_stride = (size_t)L.ldx; a.F_old = c->F[ob];
+    a.xl_old = c->xl[xo]; a.xl_old_stride = (size_t)L.ldx; a.F_old = lazy ? nullptr : c->F[ob];
     a.Pt_old = c->Pt[ob]; a.Pb_old = c->Pb[ob]; a.Pt_old_stride = L.szT; a.Pb_old_stride = L.szB;
     a.n_bank_local = N;
     a.rec = s->recv_rec; a.rec_stride = s->recsz;
     a.rec_off_B = L.szT; a.rec_off_F = L.szT + L.szB; a.rec_off_X = L.szT + L.szB + (size_t)2 * d * L.ldx;
     // the host places the new generation in ancestor order, so physical order is already cache-friendly
   }
-  a.xl_new = c->xl[nb]; a.F_new = c->F[nb]; a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
+  a.xl_new = c->xl[xn]; a.F_new = lazy ? c->Fb[t % (c->lazy_depth + 1)] : c->F[nb];
+  a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
   a.rng_mode = c->rng_mode; a.k_iter = 0; a.seed = c->seed;
   a.Z = (c->d_Z && t > 0) ? c->d_Z + (size_t)(t - 1) * s->Nglob * nw : nullptr;
   a.odo = c->d_odo + (size_t)(t > 0 ? t - 1 : 0) * c->mdl.nodo;
@@ -265,7 +303,14 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
     s->placed = true;
     s->plan_ready = false;
   }
+  if (lazy) {
+    // records received for this step stay alive (imported lineages keep them as base) until the next flush
+    s->rec_used = flush ? 0 : s->rec_used + s->plan_recv;
+    s->plan_recv = 0;
+    c->tcur = tnew;
+  }
   c->cur = nb;
+  c->xcur = lazy ? xn : nb;
   c->t = t + 1;
   return RBPF_OK;
 }
@@ -279,10 +324,15 @@ int rbpf_shard_plan(rbpf_ctx* c, int64_t* counts_host) {
   ShardState* s = c->sh;
   if (c->t < 1 || s->t_norm < c->t) { set_error("plan needs the ancestors of the next step (normalise_search first)"); return RBPF_ERR_STATE; }
   s->pb.new_gid = s->gid_buf[s->gid_cur ^ 1];
-  HIPCHK(plan_run(s->pb, s->Nglob, s->world, s->Nloc, s->rank, s->ai_glob, s->placed ? s->cur_gid : nullptr, c->stream));
+  const int rec_off = (c->lazy_depth >= 2) ? s->rec_used : 0;
+  HIPCHK(plan_run(s->pb, s->Nglob, s->world, s->Nloc, s->rank, s->ai_glob, s->placed ? s->cur_gid : nullptr, rec_off, c->stream));
   HIPCHK(hipMemcpyAsync(s->counts_pin, s->pb.counts_dev, ((size_t)2 * s->world + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (int q = 0; q < 2 * s->world + 1; ++q) counts_host[q] = (int64_t)s->counts_pin[q];
+  counts_host[2 * s->world + 1] = rec_off;                 // first record of recv_rec the exchange may write
+  s->plan_recv = 0;
+  for (int q = 0; q < s->world; ++q) s->plan_recv += (int)s->counts_pin[s->world + q];
+  if ((size_t)(rec_off + s->plan_recv) > s->recv_cap) { set_error("receive buffer too small for the records alive in this lazy cycle"); return RBPF_ERR_OUT_OF_MEMORY; }
   s->plan_ready = true;
   return RBPF_OK;
 }

@@ -167,7 +167,7 @@ class ShardedFilterSession:
     transport="host"  : device -> host -> gloo -> device (lets two ranks share ONE GPU in tests)."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
-                 transport="device", planner="device"):
+                 transport="device", planner="device", lazy_depth=0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -190,7 +190,9 @@ class ShardedFilterSession:
         # replay buffers (tests) hold all world*N_local slots; Philox streams are keyed by logical slot id
         self.blk, self._rng = _rng_block(rng if rng is not None else PhiloxRNG(1), self.prob.N_P * self.world,
                                          self.prob.N_T, model.nw, 1)
-        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=0, jitter=0.0)
+        if lazy_depth >= 2 and planner != "device":
+            raise ValueError("lazy_depth >= 2 needs planner='device'")
+        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0)
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         check(self.lib.rbpf_shard_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),
@@ -228,12 +230,13 @@ class ShardedFilterSession:
             self.t_fwd_gather.copy_(h)
         torch.cuda.synchronize()
 
-    def _exchange(self, rp):
-        """rp: RankPlan (host planner) or (send_counts, recv_counts) of the device plan."""
+    def _exchange(self, rp, recv_off=0):
+        """rp: RankPlan (host planner) or (send_counts, recv_counts) of the device plan.  recv_off: first record of
+        the receive buffer this exchange writes (records persist during a lazy cycle)."""
         torch, dist = self.torch, self.dist
         send_counts, recv_counts = (rp.send_counts, rp.recv_counts) if isinstance(rp, RankPlan) else rp
         ns, nr = int(send_counts.sum()), int(recv_counts.sum())
-        if nr > self.v.recv_capacity or ns > self.v.send_capacity:
+        if recv_off + nr > self.v.recv_capacity or ns > self.v.send_capacity:
             raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"exchange of {ns}/{nr} records exceeds the buffer "
                                  f"capacity {self.v.send_capacity}/{self.v.recv_capacity}")
         if isinstance(rp, RankPlan):
@@ -242,14 +245,15 @@ class ShardedFilterSession:
         else:
             check(self.lib.rbpf_shard_pack(self.ctx, None, ns))
         rp = RankPlan(None, None, None, send_counts, recv_counts)
+        t_recv = self.t_recv[recv_off:]
         if self.transport == "device":
-            exchange_rows(self.t_send, self.t_recv, rp.send_counts, rp.recv_counts, dist)
+            exchange_rows(self.t_send, t_recv, rp.send_counts, rp.recv_counts, dist)
         else:
             width = int(self.v.record_doubles)
             hs, hr = self.t_send[:ns].cpu(), torch.empty((nr, width), dtype=torch.float64)
             exchange_rows(hs, hr, rp.send_counts, rp.recv_counts, dist)
             if nr:
-                self.t_recv[:nr].copy_(hr)
+                t_recv[:nr].copy_(hr)
         torch.cuda.synchronize()
         self.stats["sent_records"] += ns
         self.stats["recv_records"] += nr
@@ -282,11 +286,11 @@ class ShardedFilterSession:
                 self._normalise(True)
                 t2 = time.perf_counter()
                 if self.planner == "device":
-                    cnt = np.zeros(2 * self.world + 1, dtype=np.int64)
+                    cnt = np.zeros(2 * self.world + 2, dtype=np.int64)
                     check(self.lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
                     t3 = time.perf_counter()
                     if self.world > 1:
-                        self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]))
+                        self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]), int(cnt[2 * self.world + 1]))
                     t4 = time.perf_counter()
                     check(self.lib.rbpf_shard_step(self.ctx, None, None))
                     t5 = time.perf_counter()
