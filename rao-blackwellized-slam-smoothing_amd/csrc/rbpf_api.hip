@@ -288,6 +288,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   RB_TRY(dmalloc(&c->traj_max, (size_t)T * nN));
   RB_TRY(dmalloc(&c->traj_mean, (size_t)T * nN));
   RB_TRY(dmalloc(&c->d_scal, 64));
+  RB_TRY(dmalloc(&c->d_rs, resample_scratch_doubles(std::max<size_t>((size_t)N, c->rng_slots))));
   RB_TRY(dmalloc(&c->d_unext, (size_t)N));
   RB_TRY(dmalloc(&c->d_pre_i, (size_t)N * kPreInts));
   RB_TRY(dmalloc(&c->d_pre_d, (size_t)N * kPreDoubles));
@@ -335,7 +336,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
   for (int b = 0; b < 2; ++b) { hipFree(c->fidx[b]); hipFree(c->base[b]); }
-  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d); hipFree(c->d_unext);
+  hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d); hipFree(c->d_unext); hipFree(c->d_rs);
   smoother_free(c);
   shard_free(c);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -489,8 +490,13 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     s.seed = c->seed; s.ai = A_next; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
     s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + tr; s.wc_exact = c->wc;
     // sort key of the next step: the slot of the stored matrix each ancestor's lineage refers to
-    HIPCHK(launch_normalise_resample(nm, s, c->d_order, c->d_counts, c->stream, lazy ? c->base[tnew] : nullptr));
+    if (N > kSingleWgResampleMaxN)
+      HIPCHK(launch_resample_pipeline(nm, &s, c->d_order, c->d_counts, lazy ? c->base[tnew] : nullptr, c->d_rs, c->stream));
+    else
+      HIPCHK(launch_normalise_resample(nm, s, c->d_order, c->d_counts, c->stream, lazy ? c->base[tnew] : nullptr));
     c->ready_step = t + 1;
+  } else if (N > kSingleWgResampleMaxN) {
+    HIPCHK(launch_resample_pipeline(nm, nullptr, nullptr, nullptr, nullptr, c->d_rs, c->stream));
   } else {
     HIPCHK(launch_normalise_scan(nm, c->stream));
   }

@@ -84,6 +84,7 @@ struct rbpf_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   rbpf::SmootherState* sm = nullptr;
   rbpf::ShardState* sh = nullptr;
+  double* d_rs = nullptr;    // scratch of the multi-workgroup resample pipeline
   double* d_unext = nullptr; // [N] Philox resampling uniforms of the next step (written by propagate_kernel)
   int* d_pre_i = nullptr;   // [N][kPreInts]  per-workgroup descriptors of the step kernel
   double* d_pre_d = nullptr; // [N][kPreDoubles]

@@ -115,6 +115,7 @@ struct SearchArgs {
   unsigned long long seed;
   int* ai;              // out [N]
   int* overflow;        // device counter of clamped draws (u > wc(end))
+  int scan_depth = 0;   // extra summation depth of the parallel prefix beyond the element index (0: N/1024 + 32)
   int approx = 0;       // 1: wc is a parallel prefix; flag draws that fall within the rounding bound of an edge
   int* ambiguous = nullptr;   // device counter of such draws (resolved exactly by launch_resample_fixup)
   const double* w = nullptr;  // weights (fixup only)
@@ -135,6 +136,11 @@ hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
 hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s,
                                      const int* remap = nullptr);
 hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s);
+// multi-workgroup equivalent for large N (rbpf_resample.hip); sa may be null (normalise only)
+size_t resample_scratch_doubles(int N);
+hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, int* order, int* counts, const int* remap,
+                                    double* scratch, hipStream_t s);
+constexpr int kSingleWgResampleMaxN = 8192;   // above this the multi-workgroup pipeline is used
 // exact re-draw of every slot with the strict left-to-right cumsum if any draw was flagged ambiguous
 hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s);
 

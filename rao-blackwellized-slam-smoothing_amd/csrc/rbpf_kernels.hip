@@ -1177,10 +1177,10 @@ __global__ void search_kernel(const SearchArgs a) {
     if (a.wc[mid] < u) lo = mid + 1; else hi = mid;
   }
   if (a.approx) {
-    const double S = (double)((a.N + kNormThreads - 1) / kNormThreads);
+    const double S = a.scan_depth > 0 ? (double)a.scan_depth : (double)((a.N + kNormThreads - 1) / kNormThreads) + 32.0;
     bool amb = false;
-    if (lo < a.N) { const double p = a.wc[lo]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S + 32.0) * fabs(p); }
-    if (lo > 0) { const double p = a.wc[lo - 1]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S + 32.0) * fabs(p); }
+    if (lo < a.N) { const double p = a.wc[lo]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S) * fabs(p); }
+    if (lo > 0) { const double p = a.wc[lo - 1]; amb |= fabs(p - u) <= 1.7e-16 * ((double)lo + S) * fabs(p); }
     if (amb) atomicAdd(a.ambiguous, 1);
   }
   if (lo >= a.N) { lo = a.N - 1; if (a.overflow) atomicAdd(a.overflow, 1); }

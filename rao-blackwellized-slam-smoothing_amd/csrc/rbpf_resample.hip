@@ -1,0 +1,222 @@
+// Multi-workgroup weight normalisation + resampling for large particle counts (the single-workgroup
+// normalise_resample_kernel of rbpf_kernels.hip is latency-bound: 75 us at N = 8192 but 1.3 ms at N = 65536).
+// Same semantics (particleFilter.m:154-161, tools/sample.m:30-32): every reduction and the prefix sum use a
+// fixed two-level order (1024-element blocks, then the block partials in index order), so results are
+// deterministic and identical on every rank; the running sum is again only an approximation of the strict
+// left-to-right cumsum, certified per draw by search_kernel and repaired by resample_fixup_kernel.
+#include "rbpf_internal.hpp"
+#include "rbpf_device.hpp"
+
+namespace rbpf {
+
+constexpr int kRB = 1024;     // elements (= threads) per block
+
+__device__ inline double blk_sum(double v, double* sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) sred[wave] = v;
+  __syncthreads();
+  double s = sred[0];
+  for (int w = 1; w < kRB / 64; ++w) s += sred[w];
+  return s;
+}
+
+__device__ inline double blk_max(double v, double* sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+  __syncthreads();
+  if (lane == 0) sred[wave] = v;
+  __syncthreads();
+  double s = sred[0];
+  for (int w = 1; w < kRB / 64; ++w) s = fmax(s, sred[w]);
+  return s;
+}
+
+__global__ __launch_bounds__(kRB) void rs_max_kernel(int N, const double* __restrict__ logw, double* __restrict__ pmax) {
+  __shared__ double sred[16];
+  const int i = blockIdx.x * kRB + threadIdx.x;
+  const double m = blk_max(i < N ? logw[i] : -INFINITY, sred);
+  if (threadIdx.x == 0) pmax[blockIdx.x] = m;
+}
+
+__device__ inline double global_max(const double* pmax, int B, double* sred) {
+  double m = -INFINITY;
+  for (int b = threadIdx.x; b < B; b += kRB) m = fmax(m, pmax[b]);
+  return blk_max(m, sred);
+}
+
+__global__ __launch_bounds__(kRB) void rs_sumexp_kernel(int N, int B, const double* __restrict__ logw,
+                                                        const double* __restrict__ pmax, double* __restrict__ psum) {
+  __shared__ double sred[16];
+  const double c = global_max(pmax, B, sred);
+  const int i = blockIdx.x * kRB + threadIdx.x;
+  const double s = blk_sum(i < N ? exp(logw[i] - c) : 0.0, sred);
+  if (threadIdx.x == 0) psum[blockIdx.x] = s;
+}
+
+// w, per-block first-maximum / weighted state sums / local inclusive prefix of w
+__global__ __launch_bounds__(kRB) void rs_weights_kernel(NormArgs a, int B, const double* __restrict__ pmax,
+                                                         const double* __restrict__ psum, double* __restrict__ btot,
+                                                         double* __restrict__ bparts /* [B][10] */) {
+  __shared__ double sred[16];
+  __shared__ int sidx[16];
+  __shared__ double sbc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, N = a.N;
+  const double c = global_max(pmax, B, sred);
+  if (tid == 0) { double t = 0.0; for (int b = 0; b < B; ++b) t += psum[b]; sbc = c + log(t); }   // fixed order
+  __syncthreads();
+  const double lse = sbc;
+  const int i = blockIdx.x * kRB + tid;
+  const double wi = (i < N) ? exp(a.logw[i] - lse) : 0.0;
+  if (i < N) a.w[i] = wi;
+  // first maximum of the block
+  double bw = (i < N) ? wi : -1.0;
+  int bi = (i < N) ? i : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ow = __shfl_xor(bw, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ow > bw || (ow == bw && oi < bi)) { bw = ow; bi = oi; }
+  }
+  __syncthreads();
+  if (lane == 0) { sred[wave] = bw; sidx[wave] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    double gw = sred[0]; int gi = sidx[0];
+    for (int w = 1; w < kRB / 64; ++w) if (sred[w] > gw || (sred[w] == gw && sidx[w] < gi)) { gw = sred[w]; gi = sidx[w]; }
+    bparts[blockIdx.x * 10 + 0] = gw;
+    bparts[blockIdx.x * 10 + 1] = (double)gi;
+  }
+  for (int cix = 0; cix < a.nN; ++cix) {
+    const double s = blk_sum((i < N) ? a.xn[(size_t)cix * N + i] * wi : 0.0, sred);
+    if (tid == 0) bparts[blockIdx.x * 10 + 2 + cix] = s;
+  }
+  // local inclusive prefix (wave scan + wave offsets in order)
+  double inc = wi;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  __syncthreads();
+  if (lane == 63) sred[wave] = inc;
+  __syncthreads();
+  double woff = 0.0;
+  for (int w = 0; w < wave; ++w) woff += sred[w];
+  const double lp = woff + inc;
+  if (i < N) a.wc[i] = lp;
+  if (tid == kRB - 1) btot[blockIdx.x] = lp;
+}
+
+__global__ __launch_bounds__(kRB) void rs_offsets_kernel(NormArgs a, int B, const double* __restrict__ btot,
+                                                         const double* __restrict__ bparts) {
+  __shared__ double sb[1024];                           // block totals (B <= 1024)
+  __shared__ double sp[16][10];
+  __shared__ double soff;
+  const int tid = threadIdx.x, N = a.N;
+  for (int b = tid; b < B; b += kRB) sb[b] = btot[b];   // parallel loads, then an in-order sum from LDS
+  __syncthreads();
+  if (tid == 0) { double t = 0.0; for (int b = 0; b < (int)blockIdx.x; ++b) t += sb[b]; soff = t; }
+  __syncthreads();
+  const int i = blockIdx.x * kRB + tid;
+  if (i < N && blockIdx.x > 0) a.wc[i] = soff + a.wc[i];
+  if (blockIdx.x == 0) {
+    // global first maximum and weighted state sums from the per-block partials, in block order
+    if (tid < 2 + a.nN) {
+      const int q = tid;
+      if (q >= 2) {
+        double t = 0.0;
+        for (int b = 0; b < B; ++b) t += bparts[b * 10 + q];
+        sp[0][q] = t;
+      }
+    }
+    if (tid == 0) {
+      double gw = bparts[0]; int gi = (int)bparts[1];
+      for (int b = 1; b < B; ++b) { const double w = bparts[b * 10]; const int ix = (int)bparts[b * 10 + 1]; if (w > gw || (w == gw && ix < gi)) { gw = w; gi = ix; } }
+      if (gi < 0 || gi >= N) gi = 0;
+      *a.iw_max = gi;
+      sp[1][0] = (double)gi;
+    }
+    __syncthreads();
+    if (tid >= 2 && tid < 2 + a.nN) {
+      const int cix = tid - 2, gi = (int)sp[1][0];
+      if (a.traj_mean) a.traj_mean[cix] = sp[0][tid];
+      if (a.traj_max) a.traj_max[cix] = a.xn[(size_t)cix * N + gi];
+    }
+  }
+}
+
+// counting sort of the slots by (remapped) ancestor: histogram, single-workgroup scan, scatter
+__global__ void rs_hist_kernel(int N, const int* __restrict__ key, const int* __restrict__ remap, int* __restrict__ counts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) atomicAdd(&counts[remap ? remap[key[i]] : key[i]], 1);
+}
+
+__global__ __launch_bounds__(kRB) void rs_scan_kernel(int N, int* __restrict__ counts) {
+  __shared__ int swave[kRB / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int S = (N + kRB - 1) / kRB;
+  const int j0 = min(tid * S, N), j1 = min(j0 + S, N);
+  constexpr int NBATCH = 8;                            // loads in flight per thread (a lone workgroup is latency-bound)
+  int tot = 0;
+  for (int jb = j0; jb < j1; jb += NBATCH) {
+    int v[NBATCH];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) v[k] = counts[min(jb + k, N - 1)];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) tot += (jb + k < j1) ? v[k] : 0;
+  }
+  int inc = tot;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off, 64); if (lane >= off) inc += o; }
+  if (lane == 63) swave[wave] = inc;
+  __syncthreads();
+  int run = inc - tot;
+  for (int w = 0; w < wave; ++w) run += swave[w];
+  for (int jb = j0; jb < j1; jb += NBATCH) {
+    int v[NBATCH];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) v[k] = counts[min(jb + k, N - 1)];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k)
+      if (jb + k < j1) { counts[jb + k] = run; run += v[k]; }
+  }
+}
+
+__global__ void rs_scatter_kernel(int N, const int* __restrict__ key, const int* __restrict__ remap, int* __restrict__ counts,
+                                  int* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) order[atomicAdd(&counts[remap ? remap[key[i]] : key[i]], 1)] = i;
+}
+
+// scratch: doubles [pmax B | psum B | btot B | bparts 10 B], B = ceil(N/1024)
+size_t resample_scratch_doubles(int N) { return (size_t)13 * ((N + kRB - 1) / kRB) + 16; }
+
+hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, int* order, int* counts, const int* remap,
+                                    double* scratch, hipStream_t s) {
+  const int N = nm.N, B = (N + kRB - 1) / kRB;
+  double* pmax = scratch; double* psum = pmax + B; double* btot = psum + B; double* bparts = btot + B;
+  hipLaunchKernelGGL(rs_max_kernel, dim3(B), dim3(kRB), 0, s, N, nm.logw, pmax);
+  hipLaunchKernelGGL(rs_sumexp_kernel, dim3(B), dim3(kRB), 0, s, N, B, nm.logw, pmax, psum);
+  hipLaunchKernelGGL(rs_weights_kernel, dim3(B), dim3(kRB), 0, s, nm, B, pmax, psum, btot, bparts);
+  hipLaunchKernelGGL(rs_offsets_kernel, dim3(B), dim3(kRB), 0, s, nm, B, btot, bparts);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !sa) return e;
+  SearchArgs q = *sa;
+  q.scan_depth = B + 32;
+  if ((e = launch_search(q, s)) != hipSuccess) return e;
+  if (q.approx && (e = launch_resample_fixup(q, s)) != hipSuccess) return e;
+  if (order) {
+    if ((e = hipMemsetAsync(counts, 0, (size_t)N * sizeof(int), s)) != hipSuccess) return e;
+    const int nb = (q.n_draw + 255) / 256;
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(256), 0, s, q.n_draw, q.ai, remap, counts);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRB), 0, s, N, counts);
+    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(256), 0, s, q.n_draw, q.ai, remap, counts, order);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace rbpf

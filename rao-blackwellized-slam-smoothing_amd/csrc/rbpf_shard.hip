@@ -176,8 +176,11 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* 
     sa.U = c->d_U ? c->d_U + (size_t)(t - 1) * N : nullptr;
     sa.seed = c->seed; sa.ai = s->ai_glob; sa.overflow = c->d_flags + 1;
     sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = s->w_glob; sa.wc_exact = s->wc_glob;
-    HIPCHK(launch_normalise_resample(nm, sa, nullptr, nullptr, c->stream));
+    if (N > kSingleWgResampleMaxN) HIPCHK(launch_resample_pipeline(nm, &sa, nullptr, nullptr, nullptr, c->d_rs, c->stream));
+    else HIPCHK(launch_normalise_resample(nm, sa, nullptr, nullptr, c->stream));
     HIPCHK(hipMemcpyAsync(ai_host, s->ai_glob, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  } else if (N > kSingleWgResampleMaxN) {
+    HIPCHK(launch_resample_pipeline(nm, nullptr, nullptr, nullptr, nullptr, c->d_rs, c->stream));
   } else {
     HIPCHK(launch_normalise_scan(nm, c->stream));
   }

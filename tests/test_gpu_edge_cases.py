@@ -128,3 +128,19 @@ def test_properties_at_benchmark_size(rbpf):
     assert ev2.min() > -1e-8 * np.max(np.abs(np.diag(P0)))
     q = a["traj_mean"][3:7]
     assert np.all(np.abs(np.linalg.norm(q, axis=0) - 1.0) < 0.05)  # linear quaternion mean (quirk Q8) stays near unit
+
+
+@pytest.mark.parametrize("kind", ["radio", "mag"])
+def test_large_particle_count_uses_the_multi_workgroup_resample_pipeline(rbpf, kind):
+    """N_P > 8192 switches normalisation / resampling to the multi-workgroup pipeline (rbpf_resample.hip);
+    indices must still equal the strict-cumsum semantics of tools/sample.m bit for bit."""
+    N = 9000
+    c = cases.radio_case(N, 4, 16, seed=21) if kind == "radio" else cases.mag_case(N, 3, 16, seed=22)
+    ref = cases.oracle_filter(c)
+    out = run_filter(rbpf, c)
+    ex = out[8]
+    np.testing.assert_array_equal(ex["ai"][1:], ref["trace"]["ai"][1:])
+    assert ex["iw_max"] == ref["iw_max"]
+    assert rel(ex["w"], ref["trace"]["w"]) <= RTOL
+    assert rel(out[1], ref["traj_mean"]) <= RTOL
+    assert rel(out[4], ref["P_max"]) <= RTOL
