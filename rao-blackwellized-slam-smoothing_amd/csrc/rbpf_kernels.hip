@@ -1257,23 +1257,28 @@ struct UnpackSets {
   const int* base;                // slot of the stored matrix (null: the particle's own index)
 };
 
-__global__ void unpack_P_kernel(Layout L, int d, const double* __restrict__ Pt, const double* __restrict__ Pb,
-                                UnpackSets us, const int* __restrict__ index, double* __restrict__ P) {
+// grid (count, ceil(n / 16)): a workgroup expands 16 columns of one particle
+constexpr int kUnpackCols = 16;
+__global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const double* __restrict__ Pt,
+                                                       const double* __restrict__ Pb, UnpackSets us,
+                                                       const int* __restrict__ index, double* __restrict__ P) {
   const int p = blockIdx.x;
   const int src = index ? index[p] : p;
   const int bsl = us.base ? us.base[src] : src;
   const double* t = Pt + (size_t)bsl * L.szT;
   const double* b = Pb + (size_t)bsl * L.szB;
   double* dst = P + (size_t)p * L.n * L.n;
-  const size_t nn = (size_t)L.n * L.n;
-  for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
-    const int r = (int)(q % L.n), c = (int)(q / L.n);
-    double v = (r < L.nb) ? b[(size_t)r * L.ldb + c] : t[(size_t)c * L.mc + (r - L.nb)];
-    for (int sset = 0; sset < us.n_sets; ++sset) {
-      const double* F = us.fset[sset] + (size_t)(us.fidx[sset] ? us.fidx[sset][src] : src) * 2 * d * L.ldx;
-      for (int k = 0; k < d; ++k) v = fma(-F[(size_t)k * L.ldx + r], F[(size_t)(d + k) * L.ldx + c], v);
+  const int c0 = blockIdx.y * kUnpackCols, c1 = min(L.n, c0 + kUnpackCols);
+  const double* F[kMaxSets];
+  for (int sset = 0; sset < kMaxSets; ++sset)
+    F[sset] = sset < us.n_sets ? us.fset[sset] + (size_t)(us.fidx[sset] ? us.fidx[sset][src] : src) * 2 * d * L.ldx : nullptr;
+  for (int r = threadIdx.x; r < L.n; r += 256) {
+    for (int c = c0; c < c1; ++c) {
+      double v = (r < L.nb) ? b[(size_t)r * L.ldb + c] : t[(size_t)c * L.mc + (r - L.nb)];
+      for (int sset = 0; sset < us.n_sets; ++sset)
+        for (int k = 0; k < d; ++k) v = fma(-F[sset][(size_t)k * L.ldx + r], F[sset][(size_t)(d + k) * L.ldx + c], v);
+      dst[(size_t)c * L.n + r] = v;
     }
-    dst[q] = v;
   }
 }
 
@@ -1283,7 +1288,7 @@ hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const dou
   us.n_sets = F ? 1 : 0; us.base = nullptr;
   for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = nullptr; us.fidx[q] = nullptr; }
   us.fset[0] = F;
-  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
+  hipLaunchKernelGGL(unpack_P_kernel, dim3(count, (lay.n + kUnpackCols - 1) / kUnpackCols), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
   return hipGetLastError();
 }
 
@@ -1293,7 +1298,7 @@ hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, cons
   UnpackSets us;
   us.n_sets = n_sets; us.base = base;
   for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = q < n_sets ? fset[q] : nullptr; us.fidx[q] = q < n_sets ? fidx[q] : nullptr; }
-  hipLaunchKernelGGL(unpack_P_kernel, dim3(count), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
+  hipLaunchKernelGGL(unpack_P_kernel, dim3(count, (lay.n + kUnpackCols - 1) / kUnpackCols), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
   return hipGetLastError();
 }
 

@@ -161,104 +161,325 @@ struct CholArgs {
   int* status;
 };
 
-__device__ inline double chol_elem(const CholArgs& a, int p, int i, int j) {
-  if (a.mode == 0) {
-    double v = a.S[(size_t)p * a.Msz * a.Msz + (size_t)i + (size_t)a.Msz * j];
-    if (i / a.d == j / a.d) v += a.R[(i % a.d) + a.d * (j % a.d)];          // kron(eye, R)
-    return v;
-  }
-  double v = a.Imat[(size_t)p * a.imat_stride + (size_t)i + (size_t)a.n * j];
-  if (a.Hb) {                                                               // pending dyi'/R*dyi (:334)
-    const double* H = a.Hb + (size_t)p * a.d * a.ldx;
-    double s = 0.0;
-    for (int aa = 0; aa < a.d; ++aa) {
-      double t = 0.0;
-      for (int bb = 0; bb < a.d; ++bb) t = fma(a.Rinv[aa + a.d * bb], H[(size_t)bb * a.ldx + j], t);
-      s = fma(H[(size_t)aa * a.ldx + i], t, s);
-    }
-    v += s;
-  }
-  return v + a.ImatAdd[(size_t)i + (size_t)a.n * j];                        // :225
+// Blocked left-looking Cholesky on the fp64 matrix cores, one workgroup (16 waves) per particle.
+//
+// The matrix is augmented with the right-hand side as row M ([A rhs; rhs' *]): row M of its factor is (cS \ rhs)',
+// so the forward solve comes with the factorisation.  Rows are padded to RT = ceil((M+1)/16) tiles of 16.
+//
+// Factor storage ("fragment order"): for row tile rt and column group kg (4 columns) the 64 values
+// L(16 rt + r, 4 kg + kk) sit contiguously at ((kg * RT + rt) * 64 + kk * 16 + r) -- exactly the lane order of the
+// A/B operand of v_mfma_f64_16x16x4_f64 (lane l: row/col l & 15, k = l >> 4), so one operand is one 512 B load.
+//
+// Column block jt (16 columns):
+//   1. every wave owns up to 4 row tiles rt >= jt and accumulates  W' = panel * tile'  over the columns k < 16 jt
+//      (A operand = the fragment of tile jt, B operand = the fragment of its own tile; result layout
+//      W'[c = (l >> 4) + 4 reg][r = l & 15]), then  V' = A' - W';
+//   2. wave 0 factors the 16 x 16 diagonal tile in registers (lane = row, v_readlane broadcasts) and inverts it;
+//   3. the other tiles need X = V * Ld^-T, i.e. X' = Ld^-1 * V': the accumulator registers ARE the B operand of
+//      that product (k = 4 s + (l >> 4) is register s), so it is 4 more MFMAs per tile with no data movement;
+//      X' leaves in fragment order with one coalesced store per register.
+// The triangular solve uses the explicit inverse of the 16 x 16 diagonal tile (error ~ eps * cond of that tile).
+constexpr int kCholThreads = 1024;               // 16 waves; M + 1 <= 1024 rows -> <= 64 row tiles, <= 4 per wave
+typedef double v4d __attribute__((ext_vector_type(4)));
+#ifdef RBPF_CHOL_STAMPS                          // tuning aid: per-phase clocks of workgroup 0, printed from the device
+#define CSTAMP(k) do { __syncthreads(); if (tid == 0) { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } } while (0)
+#else
+#define CSTAMP(k) do { } while (0)
+#endif
+
+__device__ inline double readlane_f64(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__global__ __launch_bounds__(256) void chol_solve_kernel(CholArgs a) {
-  __shared__ double sbc[4];
-  __shared__ int sfail;
+// acc[s] -= panel(jt) * tile(rt[s])' over the column groups [0, nkg); nkg is a multiple of 4.
+template <int NT>
+__device__ inline void chol_panel_product(const double* __restrict__ Lt, int RT, int jt, const int (&rt)[4], int nkg,
+                                          int lane, v4d (&acc)[4]) {
+  const size_t gs = (size_t)RT * 64;             // stride between column groups
+  const double* pa = Lt + (size_t)jt * 64 + lane;
+  const double* pb[NT];
+#pragma unroll
+  for (int s = 0; s < NT; ++s) pb[s] = Lt + (size_t)rt[s] * 64 + lane;
+  double a0[4], b0[NT][4], a1[4], b1[NT][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    a0[u] = -pa[gs * u];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) b0[s][u] = pb[s][gs * u];
+  }
+  for (int kg = 0; kg < nkg; kg += 8) {
+    const int k1 = min(kg + 4, nkg - 4), k2 = min(kg + 8, nkg - 4);       // clamped: loads stay in range, branch-free
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a1[u] = -pa[gs * (k1 + u)];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) b1[s][u] = pb[s][gs * (k1 + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[s][u], acc[s], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0[u] = -pa[gs * (k2 + u)];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) b0[s][u] = pb[s][gs * (k2 + u)];
+    }
+    if (kg + 4 < nkg) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < NT; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[s][u], acc[s], 0, 0, 0);
+    }
+  }
+}
+
+// Elements (i, j0 + cg + 4 q), q = 0..3, of the augmented matrix [A rhs; rhs' *] (lower triangle, everything else
+// 0).  All loads are unconditional (clamped indices) and issued together; Hs / RH hold the pending measurement
+// term of the information form (H and R^-1 H of this particle) in LDS.
+template <int MODE>
+__device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, int M, const double* rhs_s,
+                                      const double* Hs, const double* RH, double jit, v4d& out) {
+  const int ic = min(i, M - 1);
+  double v[4];
+  int j[4], jc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { j[q] = jb + 4 * q; jc[q] = min(j[q], M - 1); }
+  if (MODE == 0) {
+    const int* dv = reinterpret_cast<const int*>(Hs);                        // (index / d) << 3 | index % d
+    const int di = dv[ic];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = a.S[(size_t)p * M * M + (size_t)ic + (size_t)M * jc[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dj = dv[jc[q]];
+      const double rr = a.R[(di & 7) + a.d * (dj & 7)];                      // kron(eye, R)
+      v[q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
+    }
+  } else {
+    double ad[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = a.Imat[(size_t)p * a.imat_stride + (size_t)ic + (size_t)a.n * jc[q]];
+      ad[q] = a.ImatAdd[(size_t)ic + (size_t)a.n * jc[q]];
+    }
+    if (Hs) {                                                                // pending dyi'/R*dyi (:334)
+      for (int aa = 0; aa < a.d; ++aa) {
+        const double h = Hs[aa * M + ic];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fma(h, RH[aa * M + jc[q]], v[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += ad[q];                               // :225
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (i == j[q]) v[q] += jit;
+    if (i == M) v[q] = rhs_s[jc[q]];
+    out[q] = (j[q] < M && i <= M && i >= j[q]) ? v[q] : 0.0;
+  }
+}
+
+// acc[s] = A'(tile rt[s], block jt) - panel(jt) * tile(rt[s])' for the NT tiles of this wave
+template <int NT, int MODE>
+__device__ inline void chol_block_front(const CholArgs& a, int p, const double* __restrict__ Lt, int RT, int jt,
+                                        const int (&rt)[4], int M, const double* rhs_s, const double* Hs,
+                                        const double* RH, double jit, int lane, v4d (&acc)[4]) {
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+    chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 16 * jt + (lane >> 4), M, rhs_s, Hs, RH, jit, acc[s]);
+  if (jt > 0) chol_panel_product<NT>(Lt, RT, jt, rt, 4 * jt, lane, acc);
+}
+
+// sqrt(x) and 1/sqrt(x) from v_rsq_f64 + two coupled Newton steps (the library sqrt + divide pair is ~4x longer and
+// sits on the serial path of the diagonal-tile factorisation)
+__device__ inline void sqrt_rsqrt(double x, double& g, double& rinv) {
+  const double y = __builtin_amdgcn_rsq(x);
+  g = x * y;
+  double h = 0.5 * y;
+  double r = fma(-g, h, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  r = fma(-g, h, 0.5);
+  g = fma(g, r, g); h = fma(h, r, h);
+  const double dd = fma(-g, g, x);
+  g = fma(dd, h, g);
+  rinv = h + h;
+}
+
+__global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a) {
+  extern __shared__ double csm[];
   const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
-  double* L = a.Lbuf + (size_t)p * a.ldL;
-  constexpr int RPT = 4;                       // rows per thread: M <= 1024
-  double rhs[RPT];
-  for (int q = 0; q < RPT; ++q) {
-    const int i = tid + 256 * q;
-    rhs[q] = 0.0;
-    if (i < M) {
-      if (a.mode == 0) {
-        double s = 0.0;
-        const double* dr = a.dyf + (size_t)i * a.n;
-        const double* x = a.xl + (size_t)p * a.ldx;
-        for (int c = 0; c < a.n; ++c) s = fma(dr[c], x[c], s);
-        rhs[q] = a.yf[i] - s;                                               // particleSmoother.m:193
-      } else {
-        rhs[q] = a.ivec[(size_t)p * a.ldx + i] + a.ivecAdd[i];              // InformationForm.m:224
+  const int lane = tid & 63, wv = tid >> 6;
+  const int RT = (M + 1 + 15) >> 4;
+  double* Lt = a.Lbuf + (size_t)p * a.ldL;       // fragment order, (16 RT)^2 doubles
+  double* Dg = csm;                               // [16][16] diagonal tile, Dg[c][r]
+  double* LinvT = Dg + 256;                       // [16][16] LinvT[cc][c] = inv(Ld)(c, cc)
+  double* red = LinvT + 256;                      // [32] reduction scratch
+  double* rhs_s = red + 32;                       // [M]
+  int& sfail = *reinterpret_cast<int*>(rhs_s + M);
+  const bool pend = (a.mode == 1 && a.Hb != nullptr);
+  double* Hs = (pend || a.mode == 0) ? rhs_s + M + 2 : nullptr;   // [d][M] H of this particle (mode 0: int index table)
+  double* RH = pend ? Hs + (size_t)a.d * M : nullptr;   // [d][M]  R^-1 H
+#ifdef RBPF_CHOL_STAMPS
+  long long cst[6] = {0, 0, 0, 0, 0, 0}, clast = clock64();
+#endif
+  for (int i = tid; i < M; i += kCholThreads) {
+    double r;
+    if (a.mode == 0) {
+      double s = 0.0;
+      const double* dr = a.dyf + (size_t)i * a.n;
+      const double* x = a.xl + (size_t)p * a.ldx;
+      for (int c = 0; c < a.n; ++c) s = fma(dr[c], x[c], s);
+      r = a.yf[i] - s;                                                      // particleSmoother.m:193
+    } else {
+      r = a.ivec[(size_t)p * a.ldx + i] + a.ivecAdd[i];                     // InformationForm.m:224
+    }
+    rhs_s[i] = r;
+    if (a.mode == 0) reinterpret_cast<int*>(Hs)[i] = ((i / a.d) << 3) | (i % a.d);
+    if (pend) {
+      const double* H = a.Hb + (size_t)p * a.d * a.ldx;
+      for (int aa = 0; aa < a.d; ++aa) {
+        double t = 0.0;
+        for (int bb = 0; bb < a.d; ++bb) t = fma(a.Rinv[aa + a.d * bb], H[(size_t)bb * a.ldx + i], t);
+        Hs[aa * M + i] = H[(size_t)aa * a.ldx + i];
+        RH[aa * M + i] = t;
       }
     }
   }
-  double rhs0[RPT];
-  for (int q = 0; q < RPT; ++q) rhs0[q] = rhs[q];
+  const int cr = lane & 15, cg = lane >> 4;       // my row within a tile / my column group within a block
   double jit = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (tid == 0) sfail = 0;
-    double sl = 0.0, vv = 0.0;
     __syncthreads();
-    for (int j = 0; j < M; ++j) {
-      // column j, rows i >= j:  v_i = A(i,j) - sum_{k<j} L(i,k) L(j,k)
-      double val[RPT];
-      for (int q = 0; q < RPT; ++q) {
-        const int i = tid + 256 * q;
-        val[q] = 0.0;
-        if (i >= j && i < M) {
-          double s = chol_elem(a, p, i, j);
-          if (i == j) s += jit;
-          const double* Li = L + i;
-          const double* Lj = L + j;
-          int k = 0;
-          for (; k + 4 <= j; k += 4) {
-            const double a0 = Li[(size_t)M * k], a1 = Li[(size_t)M * (k + 1)], a2 = Li[(size_t)M * (k + 2)], a3 = Li[(size_t)M * (k + 3)];
-            const double b0 = Lj[(size_t)M * k], b1 = Lj[(size_t)M * (k + 1)], b2 = Lj[(size_t)M * (k + 2)], b3 = Lj[(size_t)M * (k + 3)];
-            s = fma(-a0, b0, s); s = fma(-a1, b1, s); s = fma(-a2, b2, s); s = fma(-a3, b3, s);
+    for (int jt = 0; 16 * jt < M; ++jt) {
+      const int j0 = 16 * jt;
+      int rt[4], nt = 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int t = jt + wv + 16 * s;
+        rt[s] = min(t, RT - 1);
+        nt += (t < RT) ? 1 : 0;
+      }
+      v4d acc[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+      const int fsel = nt ? nt + 4 * a.mode : 0;  // wave-uniform
+      switch (fsel) {
+        case 1: chol_block_front<1, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 2: chol_block_front<2, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 3: chol_block_front<3, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 4: chol_block_front<4, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 5: chol_block_front<1, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 6: chol_block_front<2, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 7: chol_block_front<3, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 8: chol_block_front<4, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        default: break;
+      }
+      CSTAMP(0);
+      // diagonal tile: wave 0, slot 0
+      if (wv == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Dg[(cg + 4 * q) * 16 + cr] = acc[0][q];
+        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
+        __builtin_amdgcn_wave_barrier();
+        double row[16], inv[16];
+        const int r = lane & 15;                  // lanes >= 16 mirror lanes 0..15 (results unused)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) row[c] = Dg[c * 16 + r];
+        bool bad = false;
+        double dinv_r = 1.0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double piv = readlane_f64(row[c], c);
+          if (j0 + c >= M) piv = 1.0;             // augmented / padding columns: nothing below them matters
+          bad |= !(piv > 0.0);
+          double ljj, rinv;
+          sqrt_rsqrt(piv, ljj, rinv);
+          row[c] = (r == c) ? ljj : ((r > c) ? row[c] * rinv : 0.0);
+          if (r == c) dinv_r = rinv;
+#pragma unroll
+          for (int cc = c + 1; cc < 16; ++cc) {
+            const double lcc = readlane_f64(row[c], cc);                     // Ld(cc, c)
+            if (cc <= r) row[cc] = fma(-row[c], lcc, row[cc]);
           }
-          for (; k < j; ++k) s = fma(-Li[(size_t)M * k], Lj[(size_t)M * k], s);
-          val[q] = s;
-          if (i == j) {
-            if (!(s > 0.0)) sfail = 1;
-            const double ljj = sqrt(s);
-            sbc[0] = ljj;
-            sbc[1] = rhs[q] / ljj;            // v_j of the forward solve cS\e
+        }
+        // inv(Ld): row r of the inverse, rows finished in order (forward substitution, :0 <= cc <= r)
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) inv[cc] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          // row k is final once rows < k were folded in: inv(k, cc) = (delta - sum) / Ld(k,k)
+#pragma unroll
+          for (int cc = 0; cc <= k; ++cc) {
+            double fin = ((cc == k) ? 1.0 : 0.0) - inv[cc];
+            fin *= dinv_r;
+            if (r == k) inv[cc] = fin;
+            const double b = readlane_f64(inv[cc], k);                       // inv(k, cc)
+            if (r > k) inv[cc] = fma(row[k], b, inv[cc]);                    // running sum_k Ld(r,k) inv(k,cc)
           }
+        }
+        if (lane < 16) {
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            LinvT[c * 16 + r] = (c <= r) ? inv[c] : 0.0;
+            Lt[((size_t)(4 * jt + (c >> 2)) * RT + jt) * 64 + (c & 3) * 16 + r] = row[c];
+          }
+          if (bad && lane == 0) sfail = 1;
         }
       }
       __syncthreads();
+      CSTAMP(2);
       if (sfail) break;
-      const double ljj = sbc[0], vj = sbc[1];
-      if (tid == 0) { sl += log(ljj); vv += vj * vj; }
-      for (int q = 0; q < RPT; ++q) {
-        const int i = tid + 256 * q;
-        if (i >= j && i < M) {
-          const double lij = (i == j) ? ljj : val[q] / ljj;
-          L[(size_t)i + (size_t)M * j] = lij;
-          if (i > j) rhs[q] = fma(-lij, vj, rhs[q]);
+      // X' = inv(Ld) * V' for the tiles below the diagonal
+      {
+        double af[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) af[q] = LinvT[64 * q + lane];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (s < nt && !(wv == 0 && s == 0)) {
+            v4d x = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x = __builtin_amdgcn_mfma_f64_16x16x4f64(af[q], acc[s][q], x, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lt[((size_t)(4 * jt + q) * RT + rt[s]) * 64 + lane] = x[q];
+          }
         }
       }
-      __syncthreads();
+      __syncthreads();                            // the block's columns are visible to the next panel product
+      CSTAMP(3);
     }
+    __syncthreads();
     const int failed = sfail;
     __syncthreads();
     if (!failed) {
+      // sum(log(diag(cS))) and v'v
+      double sl = 0.0, vv = 0.0;
+      for (int j = tid; j < M; j += kCholThreads) {
+        const size_t col = (size_t)(j >> 2) * RT * 64 + (size_t)(j & 3) * 16;
+        const double dj = Lt[col + (size_t)(j >> 4) * 64 + (j & 15)];
+        const double vj = Lt[col + (size_t)(M >> 4) * 64 + (M & 15)];
+        sl += log(dj);
+        vv = fma(vj, vj, vv);
+      }
+      sl = wave_sum(sl); vv = wave_sum(vv);
+      if (lane == 0) { red[wv] = sl; red[16 + wv] = vv; }
+      __syncthreads();
       if (tid == 0) {
+        sl = 0.0; vv = 0.0;
+        for (int w = 0; w < 16; ++w) { sl += red[w]; vv += red[16 + w]; }
         double lw;
         if (a.mode == 0) lw = -sl - 0.5 * vv - 0.5 * (double)M * 1.8378770664093453;     // log(2*pi)
         else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
         a.pant_log[p] += lw;
+#ifdef RBPF_CHOL_STAMPS
+        cst[4] = clock64() - clast;
+        if (p == 0 && M >= 500) printf("chol M=%d mode=%d clocks: product %lld elem %lld diag %lld solve %lld tail %lld\n", M, a.mode, cst[0], cst[1], cst[2], cst[3], cst[4]);
+#endif
       }
       return;
     }
@@ -267,9 +488,11 @@ __global__ __launch_bounds__(256) void chol_solve_kernel(CholArgs a) {
       return;
     }
     jit = a.jitter;                                                         // particleSmoother.m:223
-    for (int q = 0; q < RPT; ++q) rhs[q] = rhs0[q];
   }
 }
+
+static size_t chol_lds_bytes(int M, int d) { return ((size_t)256 + 256 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double); }
+static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 1 + 15) / 16); return mp * mp; }
 
 // [T][nN] row-per-step trajectory -> per-step pointer is d_xnk + t*nN.  Backtrace writes [nN x T]
 // column-major (= [T][nN] row-per-step), so no transpose is needed.
@@ -301,28 +524,35 @@ __global__ void info_addt_kernel(int n, int d, int t0, int t1, double sign, cons
 }
 
 // Imat_new(:,:,i) = Imat_old(:,:,ai(i)) + dy' / R * dy of the ancestor's last update (:170, :334)
-__global__ void imat_gather_kernel(int n, int d, int ldx, const int* __restrict__ ai, const double* __restrict__ Iold,
-                                   size_t old_stride, const double* __restrict__ Hb, const double* __restrict__ Rinv,
-                                   double* __restrict__ Inew) {
+// grid (N_P, ceil(n / 16)): a workgroup copies 16 columns; the rows of a thread are the same for every column, so the
+// H(:, row) factors are read once and R^-1 H(:, col) is wave-uniform.
+constexpr int kGatherCols = 16;
+__global__ __launch_bounds__(256) void imat_gather_kernel(int n, int d, int ldx, const int* __restrict__ ai,
+                                                          const double* __restrict__ Iold, size_t old_stride,
+                                                          const double* __restrict__ Hb, const double* __restrict__ Rinv,
+                                                          double* __restrict__ Inew) {
   const int p = blockIdx.x;
   const int a = ai ? ai[p] : p;
   const double* src = Iold + (size_t)a * old_stride;
   const double* H = Hb ? Hb + (size_t)a * d * ldx : nullptr;
   double* dst = Inew + (size_t)p * n * n;
-  const size_t nn = (size_t)n * n;
-  for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
-    const int i = (int)(q % n), j = (int)(q / n);
-    double v = src[q];
-    if (H) {
-      double s = 0.0;
-      for (int aa = 0; aa < d; ++aa) {
-        double t = 0.0;
-        for (int bb = 0; bb < d; ++bb) t = fma(Rinv[aa + d * bb], H[(size_t)bb * ldx + j], t);
-        s = fma(H[(size_t)aa * ldx + i], t, s);
+  const int c0 = blockIdx.y * kGatherCols, c1 = min(n, c0 + kGatherCols);
+  for (int r = threadIdx.x; r < n; r += 256) {
+    double hr[8];
+    for (int aa = 0; aa < 8; ++aa) hr[aa] = (H && aa < d) ? H[(size_t)aa * ldx + r] : 0.0;
+    for (int c = c0; c < c1; ++c) {
+      double v = src[(size_t)c * n + r];
+      if (H) {
+        double s = 0.0;
+        for (int aa = 0; aa < d; ++aa) {
+          double t = 0.0;
+          for (int bb = 0; bb < d; ++bb) t = fma(Rinv[aa + d * bb], H[(size_t)bb * ldx + c], t);
+          s = fma(hr[aa], t, s);
+        }
+        v += s;
       }
-      v += s;
+      dst[(size_t)c * n + r] = v;
     }
-    dst[q] = v;
   }
 }
 
@@ -413,10 +643,10 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     RB_TRY(dmalloc(&s->d_Pfull, (size_t)N * n * n));
     RB_TRY(dmalloc(&s->d_G, (size_t)N * Mmax * n));
     RB_TRY(dmalloc(&s->d_S, (size_t)N * Mmax * Mmax));
-    RB_TRY(dmalloc(&s->d_L, (size_t)N * Mmax * Mmax));
-    if (Mmax > 1024) { set_error("covariance-form smoother supports ny*N_T <= 1024 (use the information form for long T)"); return RBPF_ERR_UNSUPPORTED; }
+    RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles((int)Mmax)));
+    if (Mmax > 1023) { set_error("covariance-form smoother supports ny*N_T <= 1023 (use the information form for long T)"); return RBPF_ERR_UNSUPPORTED; }
   } else {
-    if (n > 1024) { set_error("information-form smoother supports nLin <= 1024"); return RBPF_ERR_UNSUPPORTED; }
+    if (n > 1023) { set_error("information-form smoother supports nLin <= 1023"); return RBPF_ERR_UNSUPPORTED; }
     if (c->x0_lin_cols != 1) {
       // quirk Q5: the reference's repmat(x0_lin,1,N_P) (:109) only works for a single column
       set_error("particleSmootherInformationForm: x0_lin must be nLin x 1 (the reference repmat's it, :109)");
@@ -429,7 +659,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
       RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
     }
-    RB_TRY(dmalloc(&s->d_L, (size_t)N * n * n));
+    RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles(n)));
     RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
     RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
     RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
@@ -494,7 +724,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           HIPCHK(launch_gemm(g1, N, st));                                  // G_j = dy * P_j
           GemmArgs g2{M, M, n, s->d_G, n, 1, (long)((size_t)M * n), dyf, 1, n, 0, s->d_S, 1, M, (long)((size_t)M * M)};
           HIPCHK(launch_gemm(g2, N, st));                                  // S_j = G_j * dy'
-          ca.mode = 0; ca.Msz = M; ca.Lbuf = s->d_L; ca.ldL = (long)((size_t)M * M);
+          ca.mode = 0; ca.Msz = M; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(M);
           ca.S = s->d_S; ca.R = d_R; ca.yf = c->d_y + (size_t)t * d; ca.dyf = dyf; ca.xl = c->xl[cur];
           ca.jitter = c->mdl.jitter;
         } else {
@@ -504,7 +734,11 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           HIPCHK(hipGetLastError());
           RB_TRY(info_fill_chol_args(c, ca, d_Rinv));
         }
-        hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(256), 0, st, ca);
+        {
+          static bool attr = false;
+          if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+          hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(kCholThreads), chol_lds_bytes(ca.Msz, ca.mode == 1 ? d : 0), st, ca);
+        }
         HIPCHK(hipGetLastError());
         // normalise (:236-238), sample ai(N_P) (:241)
         NormArgs nm;
@@ -586,7 +820,7 @@ static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, d
 static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv) {
   SmootherState* s = c->sm;
   const int n = c->mdl.n;
-  ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)((size_t)n * n);
+  ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
   ca.Imat = s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0;
   ca.imat_stride = s->imat_valid ? (long)((size_t)n * n) : 0;
   ca.Hb = s->d_Hb[s->icur]; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
@@ -609,7 +843,7 @@ static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, 
   if (k > 0 && t > 0) {
     const int* A_t = c->A + (size_t)t * N;
     const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
-    hipLaunchKernelGGL(imat_gather_kernel, dim3(N), dim3(256), 0, c->stream, n, d, L.ldx, A_t,
+    hipLaunchKernelGGL(imat_gather_kernel, dim3(N, (n + kGatherCols - 1) / kGatherCols), dim3(256), 0, c->stream, n, d, L.ldx, A_t,
                        s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0, s->imat_valid ? (size_t)n * n : (size_t)0,
                        s->d_Hb[oc], d_Rinv, s->d_Imat[ni]);
     HIPCHK(hipGetLastError());
