@@ -92,8 +92,10 @@ __global__ void anc_dyn_kernel(ModelDev M, int N, const double* __restrict__ xn_
   out[i] = log(w[i]) + (-0.5 * ss);
 }
 
-// Generic strided fp64 GEMM, batched over blockIdx.z:  C = A * B  (+ diagonal blocks of Rblk)
-// element (i,k) of A at A[i*rsA + k*csA] etc.  32x32 output tile, 16x16 threads, 2x2 per thread.
+// Generic strided fp64 GEMM on the matrix cores, batched over blockIdx.z:  C = A * B.
+// Element (i,k) of A at A[i*rsA + k*csA] etc.  64 x 64 output tile per workgroup, 4 waves of 32 x 32
+// (2 x 2 v_mfma_f64_16x16x4 tiles); 16-deep slices of A and B go through LDS k-major so that an MFMA operand
+// (lane l: row/col l & 15, k = l >> 4) is a conflict-free read, whichever stride of the source is the unit one.
 struct GemmArgs {
   int M, N, K;
   const double* A; long rsA, csA, bsA;
@@ -101,43 +103,83 @@ struct GemmArgs {
   double* C; long rsC, csC, bsC;
 };
 
+typedef double gemm_v4d __attribute__((ext_vector_type(4)));
+constexpr int kGemmTile = 64, kGemmK = 16;
+
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ double As[32][33];
-  __shared__ double Bs[32][33];
+  __shared__ double As[kGemmK][kGemmTile + 1];   // As[k][i]
+  __shared__ double Bs[kGemmK][kGemmTile + 1];   // Bs[k][j]
   const int bz = blockIdx.z;
   const double* A = g.A + (size_t)bz * g.bsA;
   const double* B = g.B + (size_t)bz * g.bsB;
   double* C = g.C + (size_t)bz * g.bsC;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  double acc[2][2] = {{0, 0}, {0, 0}};
-  for (int k0 = 0; k0 < g.K; k0 += 32) {
-    for (int q = threadIdx.x; q < 1024; q += 256) {
-      const int r = q >> 5, cc = q & 31;
-      const int ia = i0 + r, ka = k0 + cc;
-      As[r][cc] = (ia < g.M && ka < g.K) ? A[(size_t)ia * g.rsA + (size_t)ka * g.csA] : 0.0;
-      const int kb = k0 + r, jb = j0 + cc;
-      Bs[r][cc] = (kb < g.K && jb < g.N) ? B[(size_t)kb * g.rsB + (size_t)jb * g.csB] : 0.0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i0 = blockIdx.y * kGemmTile, j0 = blockIdx.x * kGemmTile;
+  const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
+  const bool a_kfast = (g.csA == 1), b_kfast = (g.rsB == 1);
+  gemm_v4d acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = (gemm_v4d){0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < g.K; k0 += kGemmK) {
+    double av[4], bv[4];
+    int ak[4], ai[4], bk[4], bj[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = tid + 256 * e;
+      ak[e] = a_kfast ? (q & 15) : (q >> 6);
+      ai[e] = a_kfast ? (q >> 4) : (q & 63);
+      bk[e] = b_kfast ? (q & 15) : (q >> 6);
+      bj[e] = b_kfast ? (q >> 4) : (q & 63);
+      const int ia = min(i0 + ai[e], g.M - 1), ka = min(k0 + ak[e], g.K - 1);
+      const int jb = min(j0 + bj[e], g.N - 1), kb = min(k0 + bk[e], g.K - 1);
+      av[e] = A[(size_t)ia * g.rsA + (size_t)ka * g.csA];
+      bv[e] = B[(size_t)kb * g.rsB + (size_t)jb * g.csB];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      As[ak[e]][ai[e]] = (k0 + ak[e] < g.K) ? av[e] : 0.0;                 // rows/cols past the edge are never stored
+      Bs[bk[e]][bj[e]] = (k0 + bk[e] < g.K) ? bv[e] : 0.0;
     }
     __syncthreads();
-#pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-      const double a0 = As[ty][k], a1 = As[ty + 16][k];
-      const double b0 = Bs[k][tx], b1 = Bs[k][tx + 16];
-      acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
-      acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+#pragma unroll
+    for (int ks = 0; ks < kGemmK / 4; ++ks) {
+      double a[2], b[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        a[x] = As[4 * ks + (lane >> 4)][wi + 16 * x + (lane & 15)];
+        b[x] = Bs[4 * ks + (lane >> 4)][wj + 16 * x + (lane & 15)];
+      }
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
     }
     __syncthreads();
   }
-  for (int a = 0; a < 2; ++a)
-    for (int b = 0; b < 2; ++b) {
-      const int i = i0 + ty + 16 * a, j = j0 + tx + 16 * b;
-      if (i < g.M && j < g.N) C[(size_t)i * g.rsC + (size_t)j * g.csC] = acc[a][b];
-    }
+  // result layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi + 16 * x + (lane >> 4) + 4 * r, j = j0 + wj + 16 * y + (lane & 15);
+        if (i < g.M && j < g.N) C[(size_t)i * g.rsC + (size_t)j * g.csC] = acc[x][y][r];
+      }
 }
 
-static hipError_t launch_gemm(const GemmArgs& g, int batch, hipStream_t s) {
-  dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, batch);
+static hipError_t launch_gemm(const GemmArgs& g0, int batch, hipStream_t s) {
+  GemmArgs g = g0;
+  if (g0.rsC == 1 && g0.csC != 1) {
+    // the lanes of a result tile run along its column index: compute C' = B' * A' so that they run along the unit stride
+    g.M = g0.N; g.N = g0.M;
+    g.A = g0.B; g.rsA = g0.csB; g.csA = g0.rsB; g.bsA = g0.bsB;
+    g.B = g0.A; g.rsB = g0.csA; g.csB = g0.rsA; g.bsB = g0.bsA;
+    g.rsC = g0.csC; g.csC = g0.rsC;
+  }
+  dim3 grid((g.N + kGemmTile - 1) / kGemmTile, (g.M + kGemmTile - 1) / kGemmTile, batch);
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
   return hipGetLastError();
 }
