@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-smoother", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=3, help="rewrite the covariances every C-th step only (0/1: every step)")
+    ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     args = ap.parse_args()
 
@@ -150,7 +151,8 @@ def main():
                                        lazy_depth=args.lazy_depth)
     else:
         sess = pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N_local, 0.01,
-                                 rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=args.lazy_depth)     # filter seed 1
+                                 rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=args.lazy_depth,
+                                 inplace=args.inplace)     # filter seed 1
     sess.advance(W)
     sess.sync()
     sess.timing(enable=True)
@@ -194,7 +196,7 @@ def main():
             "config": {"workload": f"slam-dense-mag N={N_total} T={T} m={args.m} (nLin={n}) fp64 filter only "
                                    f"(BASELINE.json configs[1] x {world} GPU)",
                        "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
-                       "lazy_depth": args.lazy_depth,
+                       "lazy_depth": args.lazy_depth, "inplace": args.inplace,
                        "filter_seed": args.seed},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 1
+#define RBPF_ABI_VERSION 2
 
 typedef enum {
   RBPF_OK = 0,
@@ -112,6 +112,12 @@ typedef struct {
                           * the stored covariances every C-th step only (C-1 read-only steps in between);      *
                           * 0/1: rewrite every step.  Results agree to rounding (same algebra).   max 4       */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
+  int32_t inplace;       /* filter with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
+                          * every flush (the first child of a stored matrix overwrites it after its siblings    *
+                          * were written to dead slots) instead of ping-pong banks -- halves the memory, same    *
+                          * results bit for bit.  0: automatic (when two banks do not fit the device), 1: on,    *
+                          * -1: off                                                                              */
+  int32_t reserved_;
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */

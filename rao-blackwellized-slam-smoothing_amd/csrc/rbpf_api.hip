@@ -256,15 +256,31 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     set_error("unknown rng mode"); return RBPF_ERR_INVALID_ARG;
   }
   // ---- particle banks ----
+  c->lazy_depth = (!smoother && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
+  {
+    // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
+    const bool can = !smoother && !ex && c->lazy_depth >= 2;
+    if (c->opt.inplace > 0 && !can) { set_error("inplace=1 needs the unsharded filter with lazy_depth >= 2"); return RBPF_ERR_UNSUPPORTED; }
+    c->inplace = c->opt.inplace > 0;
+    if (c->opt.inplace == 0 && can) {
+      size_t fr = 0, tot = 0;
+      HIPCHK(hipMemGetInfo(&fr, &tot));
+      const size_t two = 2 * c->bank_cap * (L.szT + L.szB) * sizeof(double);
+      c->inplace = (double)two > 0.85 * (double)fr;
+    }
+  }
   for (int b = 0; b < 2; ++b) {
-    RB_TRY(dmalloc(&c->Pt[b], c->bank_cap * L.szT));
-    RB_TRY(dmalloc(&c->Pb[b], c->bank_cap * L.szB));
+    if (b == 1 && c->inplace) { c->Pt[1] = c->Pt[0]; c->Pb[1] = c->Pb[0]; }
+    else {
+      RB_TRY(dmalloc(&c->Pt[b], c->bank_cap * L.szT));
+      RB_TRY(dmalloc(&c->Pb[b], c->bank_cap * L.szB));
+    }
     RB_TRY(dmalloc(&c->F[b], c->bank_cap * 2 * d * L.ldx));
     RB_TRY(dmalloc(&c->xl[b], c->bank_cap * L.ldx));
     HIPCHK(hipMemsetAsync(c->F[b], 0, c->bank_cap * 2 * d * L.ldx * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->xl[b], 0, c->bank_cap * L.ldx * sizeof(double), c->stream));
   }
-  c->lazy_depth = (!smoother && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
+  if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
     if (step_lds_bytes(c->mdl, c->lay, 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
@@ -332,6 +348,8 @@ void ctx_free(rbpf_ctx* c) {
   for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
+  if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
+  hipFree(c->d_ip);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
@@ -415,6 +433,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   bool flush = true;
   for (int q = 0; q < kMaxSets; ++q) { a.fset[q] = nullptr; a.fset_idx_old[q] = nullptr; a.fset_idx_new[q] = nullptr; }
   a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
+  a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1;
   a.n_sets = (t > 0) ? 1 : 0; a.write_base = 1;
   if (lazy) {
     // multi-step lazy update: sets produced at steps t-ell .. t-1 are pending; every C-th step rewrites the matrices
@@ -465,13 +484,27 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     a.hld_old = info->hld_old; a.hld_old_stride = info->hld_old_stride; a.hld_new = info->hld_new;
     a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
   }
+  const bool two_phase = c->inplace && lazy && flush && t > 0;
+  if (two_phase) {
+    // single-bank flush: siblings move to dead entries first (launch 0), then the first child of every stored
+    // matrix overwrites it (launch 1); the plan comes from the ancestor-sorted order of the fused resample kernel
+    if (!a.order) { set_error("in-place flush without a processing order"); return RBPF_ERR_STATE; }
+    int* dst = c->d_ip; int* ph = c->d_ip + N;
+    HIPCHK(launch_inplace_plan(N, a.order, A_t, c->base[told], dst, ph, c->d_ip + 2 * (size_t)N, c->stream));
+    a.dst_slot = dst; a.phase_of = ph;
+  }
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) {
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));
   }
-  HIPCHK(launch_step(a, c->stream));
+  if (two_phase) {
+    a.phase = 0; HIPCHK(launch_step(a, c->stream));
+    a.phase = 1; HIPCHK(launch_step(a, c->stream));
+  } else {
+    HIPCHK(launch_step(a, c->stream));
+  }
   if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); }
 
   NormArgs nm;
@@ -572,6 +605,7 @@ int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, 
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;
   size_t b = 2 * bank_bytes(L, p->n_y, p->N_P);
+  if (opt && opt->inplace > 0) b -= (size_t)p->N_P * (L.szT + L.szB) * sizeof(double);   // one covariance bank
   b += (size_t)(hist ? p->N_T : 2) * p->n_nonlin * p->N_P * sizeof(double);
   b += (size_t)(hist ? p->N_T : 1) * p->N_P * sizeof(int);
   b += (size_t)(trace ? 2 * p->N_T : 2) * p->N_P * sizeof(double) + (size_t)p->N_P * sizeof(double);

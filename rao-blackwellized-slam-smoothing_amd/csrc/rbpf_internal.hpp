@@ -9,7 +9,8 @@ namespace rbpf {
 constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunkRows = 128;    // rows covered by one wave-wide 16-B-per-lane load
-constexpr int kPreInts = 8;         // per-workgroup descriptor written by propagate_kernel: slot, anc, ancb, base, set idx[4]
+constexpr int kPreInts = 12;        // per-workgroup descriptor written by propagate_kernel: slot, anc, ancb, base, set idx[4],
+                                    // destination slot of the stored matrix, flush phase, 2 x pad
 constexpr int kPreDoubles = 17;    // ... and xn_new[8], Rnb[9]
 constexpr int kMaxSets = 4;        // pending rank-d factor sets the step kernel can apply on the fly
 
@@ -57,6 +58,10 @@ struct StepArgs {
   int* fset_idx_new[kMaxSets];   // propagated entries of the surviving sets (light steps)
   int* fself_idx_new;            // index table of the set this step produces: [i] = i
   const int* base_old; int* base_new;   // slot of the stored matrix of each particle's lineage
+  // single-bank ("in place") flush: the rewritten matrix of slot i goes to bank entry dst_slot[i] (null: i) and the
+  // launch only processes the slots whose phase_of[i] equals `phase` (phase < 0: all).  Phase 0 = children that move
+  // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.
+  const int* dst_slot; const int* phase_of; int phase;
   const int* slot_ids;           // logical (global) id of each local slot (null: slot_offset + i); when set,
                                  // `ai` is indexed by that logical id
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
@@ -136,6 +141,10 @@ hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
 hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s,
                                      const int* remap = nullptr);
 hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s);
+// plan of a single-bank flush: order [N] lists the slots sorted by the entry base[ai[.]] of their ancestor's stored
+// matrix.  dst [N] / phase [N] out; scratch: 3 N ints.
+hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase,
+                               int* scratch, hipStream_t s);
 // multi-workgroup equivalent for large N (rbpf_resample.hip); sa may be null (normalise only)
 size_t resample_scratch_doubles(int N);
 hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, int* order, int* counts, const int* remap,

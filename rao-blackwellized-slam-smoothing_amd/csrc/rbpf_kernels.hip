@@ -323,6 +323,8 @@ __global__ void propagate_kernel(const StepArgs a) {
     if (sset < a.n_sets && a.fset[sset]) v = imported ? a.zero_set_idx : (a.fset_idx_old[sset] ? a.fset_idx_old[sset][tix] : ancb);
     pi[4 + sset] = v;
   }
+  pi[8] = a.dst_slot ? a.dst_slot[i] : i;
+  pi[9] = a.phase_of ? a.phase_of[i] : 0;
   double* pd = a.pre_d + (size_t)b * kPreDoubles;
 #pragma unroll
   for (int c = 0; c < 8; ++c) pd[c] = xp[c];
@@ -355,7 +357,9 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   // Infinity Cache; the order only permutes the schedule, slot i still reads / writes slot i's data.
   // propagate_kernel resolved the indirections of this workgroup into one descriptor.
   const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
+  if (WR && a.phase >= 0 && pre_i[9] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
+  const int dslot = WR ? pre_i[8] : i;                         // bank entry the rewritten matrix goes to
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LdsPlan lp = lds_plan(n, D, E, NS, ldx, Ly.CS, mc, M.ktot);
   double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol of every pending set [NS][D]
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
       const double* src = srcT;
-      double* dst = a.Pt_new + (size_t)i * Ly.szT;
+      double* dst = a.Pt_new + (size_t)dslot * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
       const double* src = srcB + (size_t)b * ldb;
-      double* dst = a.Pb_new + (size_t)i * Ly.szB + (size_t)b * ldb;
+      double* dst = a.Pb_new + (size_t)dslot * Ly.szB + (size_t)b * ldb;
       double ksb[ND > 0 ? ND : 1];
 #pragma unroll
       for (int sset = 0; sset < NS; ++sset)
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     if (tid == 0) {
       // lineage bookkeeping of the multi-step lazy update: where this particle's stored matrix and its
       // surviving pending sets live (a flush makes them all obsolete)
-      if (a.base_new) a.base_new[i] = WR ? i : baseb;
+      if (a.base_new) a.base_new[i] = WR ? dslot : baseb;
       if (!WR) {
 #pragma unroll
         for (int sset = 0; sset < NS; ++sset)

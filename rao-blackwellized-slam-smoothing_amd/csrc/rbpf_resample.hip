@@ -219,4 +219,45 @@ hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, in
   return e;
 }
 
+// ---- plan of a single-bank ("in place") flush ---------------------------------------------------------------
+// Every stored matrix with children keeps its bank entry for its first child (in the ancestor-sorted processing
+// order); the other children take the entries no child refers to, the k-th of them the k-th free entry.
+__global__ void ip_mark_kernel(int N, const int* __restrict__ ai, const int* __restrict__ base, int* __restrict__ has,
+                               int* __restrict__ nzp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { const int s = base[ai[i]]; has[s] = 1; nzp[s] = 1; }
+}
+
+__global__ void ip_free_kernel(int N, const int* __restrict__ has, const int* __restrict__ nzp, int* __restrict__ freelist) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < N && !has[f]) freelist[f - nzp[f]] = f;
+}
+
+__global__ void ip_assign_kernel(int N, const int* __restrict__ order, const int* __restrict__ ai, const int* __restrict__ base,
+                                 const int* __restrict__ nzp, const int* __restrict__ freelist, int* __restrict__ dst,
+                                 int* __restrict__ phase) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int i = order[b];
+  const int s = base[ai[i]];
+  const int prev = (b > 0) ? base[ai[order[b - 1]]] : -1;
+  const bool first = (s != prev);
+  // children before position b that are not the first of their matrix: b - (#matrices with children below s) - 1
+  dst[i] = first ? s : freelist[b - nzp[s] - 1];
+  phase[i] = first ? 1 : 0;
+}
+
+hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
+                               hipStream_t s) {
+  int* has = scratch; int* nzp = scratch + N; int* freelist = scratch + 2 * (size_t)N;
+  hipError_t e = hipMemsetAsync(scratch, 0, (size_t)2 * N * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(ip_mark_kernel, dim3(nb), dim3(256), 0, s, N, ai, base, has, nzp);
+  hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRB), 0, s, N, nzp);          // exclusive prefix of the flags
+  hipLaunchKernelGGL(ip_free_kernel, dim3(nb), dim3(256), 0, s, N, has, nzp, freelist);
+  hipLaunchKernelGGL(ip_assign_kernel, dim3(nb), dim3(256), 0, s, N, order, ai, base, nzp, freelist, dst, phase);
+  return hipGetLastError();
+}
+
 }  // namespace rbpf

@@ -333,7 +333,7 @@ def _recognise(dynModel, measModel, dynResNorm=None):
 # ------------------------------------------------------------------------------------------------
 def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, *, rng=None, trace=False,
-                   want_xn_traj=True, extras=False, lazy_depth=0):
+                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended."""
@@ -344,7 +344,7 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, 1)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=0,
-                            lazy_depth=int(lazy_depth), jitter=0.0)
+                            lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace))
     mdesc = model.descriptor()
     nN, n, N, T = model.nNonLin, model.nLin, prob.N_P, prob.N_T
 
@@ -478,13 +478,13 @@ class FilterSession:
     """Thin RAII wrapper over rbpf_filter_create / advance / sync / timing / destroy."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng=None, keep_history=False,
-                 trace=False, lazy_depth=0):
+                 trace=False, lazy_depth=0, inplace=0):
         self.lib = load_library()
         self.model = model
         self.prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
         self.blk, self._rng = _rng_block(rng, self.prob.N_P, self.prob.N_T, model.nw, 1)
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=1 if trace else 0, fix_p_mean=0,
-                                     lazy_depth=int(lazy_depth), jitter=0.0)
+                                     lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         check(self.lib.rbpf_filter_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),

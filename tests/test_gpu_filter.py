@@ -16,13 +16,14 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def run_both(rbpf, c, lazy_depth=0):
+def run_both(rbpf, c, lazy_depth=0, inplace=0):
     ref = cases.oracle_filter(c)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     np.testing.assert_array_equal(mdl.NN, c["model"].NN.astype(np.int32))
     np.testing.assert_allclose(P0, c["P0_lin"], rtol=1e-14)
     out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
-                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth)
+                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth,
+                              inplace=inplace)
     return ref, out
 
 
@@ -74,3 +75,20 @@ def test_multi_step_lazy_update_matches_oracle(rbpf, kind, N_P, N_T, m, lazy_dep
     c = mk(N_P, N_T, m, seed=17)
     ref, out = run_both(rbpf, c, lazy_depth=lazy_depth)
     check_filter(ref, out)
+
+
+@pytest.mark.parametrize("lazy_depth", [2, 3])
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 24, 14, 125), ("mag", 300, 9, 130), ("radio", 33, 13, 128)])
+def test_single_bank_inplace_flush_is_bit_identical(rbpf, kind, N_P, N_T, m, lazy_depth):
+    """inplace=1: ONE covariance bank; at a flush the siblings of every stored matrix are written to dead entries
+    first and its first child then overwrites it (two launches of the step kernel).  Only the placement of the
+    matrices in the bank changes, so every output equals the ping-pong run bit for bit (and the oracle to 1e-9)."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=23)
+    ref, out1 = run_both(rbpf, c, lazy_depth=lazy_depth, inplace=1)
+    check_filter(ref, out1)
+    _, out0 = run_both(rbpf, c, lazy_depth=lazy_depth, inplace=-1)
+    for a, b in zip(out1[:8], out0[:8]):
+        np.testing.assert_array_equal(a, b)
+    for k in ("ai", "logw", "w", "xl", "P", "xn"):
+        np.testing.assert_array_equal(out1[8][k], out0[8][k])
