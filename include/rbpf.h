@@ -258,6 +258,42 @@ int rbpf_shard_plan_read(rbpf_ctx* ctx, int32_t* slot_ids, int32_t* anc_bank, in
 /* traj_max / traj_mean [n_nonlin x N_T] of the steps normalised so far (identical on every rank).     */
 int rbpf_shard_trajectories(rbpf_ctx* ctx, double* traj_max, double* traj_mean);
 
+/* ---- particle-sharded information-form smoother ---------------------------------
+ * particleSmootherInformationForm.m with the N = world * N_P particles of every CPF-AS iteration sharded like the
+ * filter above.  The extra information-form state (ivec, Imat, halfLogDetP) travels in the particle records.
+ * The ancestor weights of the reference trajectory (:205-240) are computed on the rank that holds each particle,
+ * all-gathered (N doubles) and normalised / sampled identically on every rank.  Results equal the single-GPU
+ * rbpf_particle_smoother(info_form = 1) with N particles bit for bit.  Per iteration k the host side does
+ *   rbpf_shard_smoother_begin(ctx, k)
+ *   t = 0: rbpf_shard_smoother_step(ctx)
+ *   t > 0: all_gather(fwd_local -> fwd_gather); rbpf_shard_smoother_normalise(ctx, 1)
+ *          k > 0: rbpf_shard_smoother_anc_weights(ctx); all_gather(anc_local -> anc_gather);
+ *                 rbpf_shard_smoother_anc_sample(ctx)
+ *          rbpf_shard_plan; rbpf_shard_pack; all_to_all_single(send_rec -> recv_rec); rbpf_shard_smoother_step(ctx)
+ *   all_gather; rbpf_shard_smoother_normalise(ctx, 0); rbpf_shard_smoother_end(ctx, ...)                       */
+typedef struct {
+  double* anc_local;           /* [N_local] ancestor log-weights of my particles (physical order)          */
+  double* anc_gather;          /* [world][N_local] all_gather target                                      */
+} rbpf_shard_smoother_views;
+
+int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
+                               const rbpf_options* opt, int32_t N_K, int32_t rank, int32_t world, rbpf_ctx** ctx);
+int rbpf_shard_smoother_views_get(rbpf_ctx* ctx, rbpf_shard_smoother_views* out);
+/* Start of iteration k (0-based): rewind; k > 0: H along the reference trajectory + suffix sums (:120,:132-146). */
+int rbpf_shard_smoother_begin(rbpf_ctx* ctx, int32_t k);
+/* Global weights of the finished step; want_draw: ancestors of the ordinary slots of the next one (:160-166).   */
+int rbpf_shard_smoother_normalise(rbpf_ctx* ctx, int32_t want_draw);
+/* k > 0, t > 0: ancestor log-weights of my particles -> anc_local (:205-240).  Synchronises.                     */
+int rbpf_shard_smoother_anc_weights(rbpf_ctx* ctx);
+/* After the all_gather of anc_local: normalise (:243-245) and draw ai(N_P) (:248).                                */
+int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx);
+/* One information-form time step of my particles (:256-335), using the plan of rbpf_shard_plan for t > 0.        */
+int rbpf_shard_smoother_step(rbpf_ctx* ctx);
+/* End of iteration (:346-354): ak = sample(w), new reference trajectory -> XNK_k [n_nonlin x N_T] (every rank);
+ * XLK_k [n_lin], PK_k [n_lin x n_lin] are filled by the rank that holds particle ak (*owner_rank), zero elsewhere. */
+int rbpf_shard_smoother_end(rbpf_ctx* ctx, double* XNK_k, double* XLK_k, double* PK_k, int32_t* ak,
+                            int32_t* owner_rank);
+
 /* ---- helper kernels exposed for parity tests (a5-a8, a19 of SURVEY 8a) ------------------------- */
 /* The uniforms / normals the Philox generator hands to slot i at step t of iteration k, in replay
  * layout (U [N_P x (N_T-1)], Z [n_w x N_P x (N_T-1)]), so a replay run can reproduce a Philox run. */

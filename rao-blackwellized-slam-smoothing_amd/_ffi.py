@@ -77,6 +77,9 @@ EXPORTS = [
     "rbpf_jacobian_phi3d",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
     "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read",
+    "rbpf_shard_smoother_create", "rbpf_shard_smoother_views_get", "rbpf_shard_smoother_begin",
+    "rbpf_shard_smoother_normalise", "rbpf_shard_smoother_anc_weights", "rbpf_shard_smoother_anc_sample",
+    "rbpf_shard_smoother_step", "rbpf_shard_smoother_end",
 ]
 
 _lib = None

@@ -394,6 +394,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.order = (pre_drawn && t > 0) ? c->d_order : nullptr;
   a.zero_set_idx = N;
   a.slot_ids = nullptr; a.n_bank_local = 0; a.rec = nullptr; a.rec_stride = 0; a.rec_off_B = a.rec_off_F = a.rec_off_X = 0;
+  a.rec_off_I = a.rec_off_hld = 0;
   {
     static const int no_order = getenv("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only
     static const int dbg_order = getenv("RBPF_DEBUG_ORDER") ? 1 : 0;
@@ -470,7 +471,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.odo = c->d_odo + (size_t)(t > 0 ? t - 1 : 0) * c->mdl.nodo;
   a.cholQ = c->d_cholQ + (size_t)((c->chol_pages > 1 && t > 0) ? t - 1 : 0) * nw * nw;
   a.y = c->d_y + (size_t)t * d;
-  a.xref = xref_t;
+  a.xref = xref_t; a.xref_gslot = N - 1;
   a.status = c->d_flags;
   a.stamps = reinterpret_cast<unsigned long long*>(c->d_counts + 2 * N + 32);
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;

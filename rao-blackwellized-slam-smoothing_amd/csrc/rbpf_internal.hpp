@@ -67,6 +67,7 @@ struct StepArgs {
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
   // `rec`, a particle-major buffer [Pt | Pb | F | xl] per record
   int n_bank_local; const double* rec; size_t rec_stride, rec_off_B, rec_off_F, rec_off_X;
+  size_t rec_off_I, rec_off_hld;            // information form: ivec [ldx] and halfLogDetP of a record (sharded smoother)
   int zero_set_idx;              // entry of every factor-set bank that holds zeros (fresh lineages)
   int slot_offset;               // global id of local slot 0 (RNG counters / replay rows)
   size_t xn_old_stride, xn_new_stride;      // component stride of the SoA state arrays
@@ -84,7 +85,8 @@ struct StepArgs {
   const double* odo;                        // [nodo]
   const double* cholQ;                      // [nw*nw] lower factor(s) used by dynModel
   const double* y;                          // [d]
-  const double* xref;                       // CPF-AS: state of slot N-1 at this step (or null)
+  const double* xref;                       // CPF-AS: state of the reference slot at this step (or null)
+  int xref_gslot;                           // logical id of the reference slot (N_P - 1 of the global filter)
   int* status;
   unsigned long long* stamps;               // diagnostic builds only (RBPF_STAMPS)
   int* pre_i; double* pre_d;                // [N][kPreInts], [N][kPreDoubles] descriptors (propagate_kernel -> step_kernel)
@@ -177,7 +179,7 @@ hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, con
                                  double* J, hipStream_t s);
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                               const double* F, const double* xl, double* rec, hipStream_t s);
+                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride = 0);
 hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx, int count, const double* Pt,
                                        const double* Pb, int n_sets, const double* const* fset, const int* const* fidx,
                                        const int* base, int n_bank_local, const double* rec, size_t rec_stride,

@@ -284,7 +284,7 @@ __global__ void propagate_kernel(const StepArgs a) {
   double x[8], xp[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) x[c] = (c < nN) ? a.xn_old[(size_t)c * a.xn_old_stride + anc] : 0.0;
-  if (a.xref != nullptr && i == a.N - 1) {
+  if (a.xref != nullptr && gslot == a.xref_gslot) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) xp[c] = (c < nN) ? a.xref[c] : 0.0;                 // particleSmoother.m:242
   } else if (a.propagate) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     // all loads of a pass are issued before the first LDS store (clamped indices, predicated stores): the
     // sources are scattered small arrays, so this phase is pure latency
     const double* xl_src = srcX;
-    const double* iv = (E > 0) ? a.ivec_old + (size_t)anc * a.ivec_old_stride : nullptr;
+    const double* iv = (E > 0) ? (remote ? recp + a.rec_off_I : a.ivec_old + (size_t)ancb * a.ivec_old_stride) : nullptr;
     constexpr int PB = 2;                                   // columns per thread per pass
     for (int c0 = tid; c0 < n; c0 += PB * kThreads) {
       double xv[PB], ivv[PB], kv[PB][ND > 0 ? ND : 1];
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
           corr = fma(t, u[bb], corr);
         }
         const double qa = misc[44], qbp = misc[45] - corr, sl = misc[46];
-        const double hld = a.hld_old[(size_t)anc * a.hld_old_stride];
+        const double hld = remote ? recp[a.rec_off_hld] : a.hld_old[(size_t)ancb * a.hld_old_stride];
         const double hldp = -sl + M.halfLogDetR + hld;                       // :298
         double yRy = 0.0;
         for (int bb = 0; bb < D; ++bb) {
@@ -1511,11 +1511,11 @@ hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, h
 // copy the bank entries of `count` particles into particle-major records [Pt | Pb | F | xl]
 __global__ void pack_records_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
                                     const double* __restrict__ Pb, const double* __restrict__ F,
-                                    const double* __restrict__ xl, double* __restrict__ rec) {
+                                    const double* __restrict__ xl, double* __restrict__ rec, size_t rec_stride) {
   const int p = blockIdx.x;
   const int src = idx[p];
   const size_t szF = (size_t)2 * d * L.ldx;
-  const size_t recsz = L.szT + L.szB + szF + L.ldx;
+  const size_t recsz = rec_stride ? rec_stride : L.szT + L.szB + szF + L.ldx;
   double* r = rec + (size_t)p * recsz;
   const dbl2* a = reinterpret_cast<const dbl2*>(Pt + (size_t)src * L.szT);
   dbl2* b = reinterpret_cast<dbl2*>(r);
@@ -1581,9 +1581,9 @@ hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx,
 }
 
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                               const double* F, const double* xl, double* rec, hipStream_t s) {
+                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_records_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, rec);
+  hipLaunchKernelGGL(pack_records_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, rec, rec_stride);
   return hipGetLastError();
 }
 

@@ -8,43 +8,13 @@
 #include "rbpf_internal.hpp"
 #include "rbpf_ctx.hpp"
 #include "rbpf_plan.hpp"
+#include "rbpf_shard_state.hpp"
 
 #include <algorithm>
 #include <cstring>
 #include <vector>
 
 namespace rbpf {
-
-struct ShardState {
-  int rank = 0, world = 1, Nloc = 0, Nglob = 0;
-  size_t recsz = 0, recv_cap = 0, send_cap = 0;
-  double* fwd_local = nullptr;     // [(nN+1)][Nloc]
-  double* fwd_gather = nullptr;    // [world][(nN+1)][Nloc]
-  double* logw_glob = nullptr;     // [Nglob] logical order
-  double* xn_glob = nullptr;       // SoA [nN][Nglob] logical order
-  double* w_glob = nullptr;        // [Nglob]
-  double* wc_glob = nullptr;       // [Nglob]
-  int* ai_glob = nullptr;          // [Nglob] ancestors by logical id
-  int* perm = nullptr;             // [Nglob] phys_of_logical
-  int* ai_bank = nullptr;          // [Nloc]
-  int* slot_ids = nullptr;         // [Nloc]
-  int* pack_idx = nullptr;         // [send_cap]
-  double* send_rec = nullptr;
-  double* recv_rec = nullptr;
-  int t_norm = 0;                  // steps normalised so far
-  // device-side planner state
-  PlanBuffers pb{};
-  int* cur_gid = nullptr;          // [Nglob] location of every logical slot's current particle (null: identity)
-  int* gid_buf[2] = {nullptr, nullptr};
-  int gid_cur = 0;
-  bool placed = false;             // false until the first planned generation (identity placement)
-  bool plan_ready = false;         // a device plan for the next step exists
-  long long* counts_pin = nullptr; // pinned host copy of [send counts | recv counts | migrated]
-  int last_send_total = 0;
-  // multi-step lazy update: received records persist until the next flush (imported lineages use them as base)
-  int rec_used = 0;                // records currently alive in recv_rec
-  int plan_recv = 0;               // records the pending plan will append
-};
 
 void shard_free(rbpf_ctx* c) {
   ShardState* s = c->sh;
@@ -56,6 +26,8 @@ void shard_free(rbpf_ctx* c) {
   hipFree(s->pb.order); hipFree(s->pb.mv_child); hipFree(s->pb.mv_src); hipFree(s->pb.mv_q); hipFree(s->pb.pref);
   hipFree(s->pb.slot_ids); hipFree(s->pb.anc_bank); hipFree(s->pb.send_idx); hipFree(s->pb.scalars); hipFree(s->pb.counts_dev);
   hipFree(s->gid_buf[0]); hipFree(s->gid_buf[1]);
+  hipFree(s->Xhist); hipFree(s->Ahist); hipFree(s->anc_local); hipFree(s->anc_gather); hipFree(s->anc_glob);
+  hipFree(s->anc_w); hipFree(s->anc_wc); hipFree(s->w_local); hipFree(s->ident_bank);
   if (s->counts_pin) hipHostFree(s->counts_pin);
   delete s;
   c->sh = nullptr;
@@ -76,10 +48,8 @@ static int dmalloc(T** p, size_t count) {
   return RBPF_OK;
 }
 
-extern "C" {
-
-int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
-                      int32_t rank, int32_t world, rbpf_ctx** out) {
+int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                            int32_t rank, int32_t world, bool smoother, int N_K, rbpf_ctx** out) {
   if (!prob || !out || world < 1 || rank < 0 || rank >= world) { set_error("bad shard arguments"); return RBPF_ERR_INVALID_ARG; }
   if (prob->x0_lin_cols != 1) { set_error("sharded filter: x0_lin must be nLin x 1"); return RBPF_ERR_UNSUPPORTED; }
   const size_t Nloc = (size_t)prob->N_P;
@@ -90,14 +60,27 @@ int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const r
   if (opt) o = *opt; else std::memset(&o, 0, sizeof(o));
   o.keep_history = 0;
   o.trace = 0;
+  if (smoother) o.lazy_depth = 0;
   rbpf_ctx* c = nullptr;
-  RB_TRY(ctx_create(model, prob, rng, &o, false, 1, &c, &ex));
+  RB_TRY(ctx_create(model, prob, rng, &o, smoother, N_K, &c, &ex));
   ShardState* s = new ShardState();
   c->sh = s;
   s->rank = rank; s->world = world; s->Nloc = (int)Nloc; s->Nglob = (int)(Nloc * world);
   const Layout& L = c->lay;
   const int nN = c->mdl.nN, d = c->mdl.d;
   s->recsz = L.szT + L.szB + (size_t)2 * d * L.ldx + L.ldx;
+  s->recsz_base = s->recsz;
+  s->smoother = smoother;
+  if (smoother) {
+    // information part of a record: [ivec ldx | halfLogDetP, pad | pending H d*ldx | Imat n*n], 16-byte aligned
+    const size_t n = (size_t)c->mdl.n;
+    s->rec_off_I = s->recsz_base;
+    s->rec_off_hld = s->rec_off_I + L.ldx;
+    s->rec_off_Hb = s->rec_off_hld + 2;
+    s->rec_off_Imat = s->rec_off_Hb + (size_t)d * L.ldx;
+    s->recsz = s->rec_off_Imat + n * n;
+    s->recsz += s->recsz & 1;
+  }
   if (world > 1) {
     // A rank receives at most one record per physical slot (N_local); it may have to send its particles to
     // every other rank ((world-1)*N_local records in the degenerate case).  Take the worst case when it fits
@@ -136,9 +119,23 @@ int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const r
     A(dmalloc(&s->gid_buf[0], Ng)); A(dmalloc(&s->gid_buf[1], Ng));
     if (st == RBPF_OK && hipHostMalloc((void**)&s->counts_pin, ((size_t)2 * world + 1) * sizeof(long long)) != hipSuccess) st = RBPF_ERR_OUT_OF_MEMORY;
   }
+  if (smoother) {
+    const size_t Ng = (size_t)s->Nglob, T = (size_t)prob->N_T;
+    A(dmalloc(&s->Xhist, T * nN * Ng)); A(dmalloc(&s->Ahist, T * Ng));
+    A(dmalloc(&s->anc_local, Nloc)); A(dmalloc(&s->anc_gather, Ng)); A(dmalloc(&s->anc_glob, Ng));
+    A(dmalloc(&s->anc_w, Ng)); A(dmalloc(&s->anc_wc, Ng)); A(dmalloc(&s->w_local, Nloc)); A(dmalloc(&s->ident_bank, Nloc));
+    if (st == RBPF_OK && hipMemset(s->Ahist, 0, T * Ng * sizeof(int)) != hipSuccess) st = RBPF_ERR_HIP;
+  }
   if (st != RBPF_OK) { ctx_free(c); return st; }
   *out = c;
   return RBPF_OK;
+}
+
+extern "C" {
+
+int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                      int32_t rank, int32_t world, rbpf_ctx** out) {
+  return shard_create_impl(model, prob, rng, opt, rank, world, false, 1, out);
 }
 
 int rbpf_shard_views_get(rbpf_ctx* c, rbpf_shard_views* v) {
@@ -152,6 +149,12 @@ int rbpf_shard_views_get(rbpf_ctx* c, rbpf_shard_views* v) {
 
 int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host) {
   if (!c || !c->sh) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  return shard_normalise_impl(c, perm_host, ai_host, 0, c->sh->Nglob);
+}
+
+}  // extern "C"
+
+int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host, int k_iter, int n_draw) {
   HIPCHK(hipSetDevice(c->device));
   ShardState* s = c->sh;
   const int nN = c->mdl.nN, N = s->Nglob;
@@ -171,9 +174,9 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* 
   if (ai_host) {
     const int t = c->t;                        // the step about to run
     SearchArgs sa;
-    sa.N = N; sa.n_draw = N; sa.t = t; sa.wc = s->wc_glob; sa.rng_mode = c->rng_mode; sa.k_iter = 0; sa.slot0 = 0;
+    sa.N = N; sa.n_draw = n_draw; sa.t = t; sa.wc = s->wc_glob; sa.rng_mode = c->rng_mode; sa.k_iter = k_iter; sa.slot0 = 0;
     sa.u_is_scalar = 0;
-    sa.U = c->d_U ? c->d_U + (size_t)(t - 1) * N : nullptr;
+    sa.U = c->d_U ? c->d_U + ((size_t)k_iter * std::max(c->T - 1, 0) + (size_t)(t - 1)) * N : nullptr;
     sa.seed = c->seed; sa.ai = s->ai_glob; sa.overflow = c->d_flags + 1;
     sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = s->w_glob; sa.wc_exact = s->wc_glob;
     if (N > kSingleWgResampleMaxN) HIPCHK(launch_resample_pipeline(nm, &sa, nullptr, nullptr, nullptr, c->d_rs, c->stream));
@@ -184,10 +187,17 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* 
   } else {
     HIPCHK(launch_normalise_scan(nm, c->stream));
   }
+  if (s->Xhist) {       // smoother: keep every step's states / ancestors (logical order) for the trajectory draw
+    HIPCHK(hipMemcpyAsync(s->Xhist + (size_t)t_done * nN * N, s->xn_glob, (size_t)nN * N * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    if (ai_host && c->t < c->T)
+      HIPCHK(hipMemcpyAsync(s->Ahist + (size_t)c->t * N, s->ai_glob, (size_t)n_draw * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+  }
   s->t_norm = t_done + 1;
   HIPCHK(hipStreamSynchronize(c->stream));
   return RBPF_OK;
 }
+
+extern "C" {
 
 int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
   if (!c || !c->sh || count < 0) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
@@ -211,14 +221,23 @@ int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
                                        s->recv_rec, s->recsz, c->xl[c->xcur], s->send_rec, c->stream));
   } else {
     HIPCHK(launch_pack_records(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], c->F[ob], c->xl[ob], s->send_rec,
-                               c->stream));
+                               c->stream, s->recsz));
   }
+  if (s->smoother) RB_TRY(shard_smoother_pack_info(c, idx, count));
   HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
   return RBPF_OK;
 }
 
 int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* slot_ids_host) {
   if (!c || !c->sh) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  if (c->sh->smoother) { set_error("smoother context: use rbpf_shard_smoother_step"); return RBPF_ERR_STATE; }
+  return shard_step_impl(c, anc_bank_host, slot_ids_host, 0, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* slot_ids_host, int k_iter,
+                          const double* xref_t, const InfoStep* info) {
   HIPCHK(hipSetDevice(c->device));
   ShardState* s = c->sh;
   const int t = c->t, N = s->Nloc, nN = c->mdl.nN, d = c->mdl.d, nw = c->mdl.nw;
@@ -282,12 +301,21 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
     a.n_bank_local = N;
     a.rec = s->recv_rec; a.rec_stride = s->recsz;
     a.rec_off_B = L.szT; a.rec_off_F = L.szT + L.szB; a.rec_off_X = L.szT + L.szB + (size_t)2 * d * L.ldx;
+    a.rec_off_I = s->rec_off_I; a.rec_off_hld = s->rec_off_hld;
     // the host places the new generation in ancestor order, so physical order is already cache-friendly
   }
   a.xl_new = c->xl[xn]; a.F_new = lazy ? c->Fb[t % (c->lazy_depth + 1)] : c->F[nb];
   a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
-  a.rng_mode = c->rng_mode; a.k_iter = 0; a.seed = c->seed;
-  a.Z = (c->d_Z && t > 0) ? c->d_Z + (size_t)(t - 1) * s->Nglob * nw : nullptr;
+  a.rng_mode = c->rng_mode; a.k_iter = k_iter; a.seed = c->seed;
+  a.Z = (c->d_Z && t > 0) ? c->d_Z + ((size_t)k_iter * std::max(c->T - 1, 0) + (size_t)(t - 1)) * s->Nglob * nw : nullptr;
+  a.xref = xref_t; a.xref_gslot = s->Nglob - 1;
+  a.info = info ? 1 : 0;
+  if (info) {
+    if (lazy) { set_error("the information form has no lazy update"); return RBPF_ERR_UNSUPPORTED; }
+    a.ivec_old = info->ivec_old; a.ivec_old_stride = info->ivec_old_stride; a.ivec_new = info->ivec_new;
+    a.hld_old = info->hld_old; a.hld_old_stride = info->hld_old_stride; a.hld_new = info->hld_new;
+    a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
+  }
   a.odo = c->d_odo + (size_t)(t > 0 ? t - 1 : 0) * c->mdl.nodo;
   a.cholQ = c->d_cholQ + (size_t)((c->chol_pages > 1 && t > 0) ? t - 1 : 0) * nw * nw;
   a.y = c->d_y + (size_t)t * d;
@@ -317,6 +345,8 @@ int rbpf_shard_step(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
   c->t = t + 1;
   return RBPF_OK;
 }
+
+extern "C" {
 
 // Device-side placement + exchange plan for the step about to run, from the ancestors drawn by the last
 // rbpf_shard_normalise_search.  counts_host [2*world+1]: records to send to / receive from each rank, then the

@@ -8,6 +8,7 @@
 #include "rbpf_internal.hpp"
 #include "rbpf_ctx.hpp"
 #include "rbpf_device.hpp"
+#include "rbpf_shard_state.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -42,6 +43,11 @@ struct SmootherState {
   int imat_cur = 0;
   bool imat_valid = false;      // false until the first gather of an iteration (Imat = Imat0)
   size_t Mmax = 0;
+  // sharded information-form smoother
+  double* d_Rinv = nullptr;     // [d*d]
+  std::vector<double> h_ivec0;  // [ldx]
+  double hld0 = 0.0;
+  std::vector<int> h_ai;        // [Nglob] D2H target of the global ancestor draw
 };
 
 void smoother_free(rbpf_ctx* c) {
@@ -51,6 +57,7 @@ void smoother_free(rbpf_ctx* c) {
   hipFree(s->d_Pfull); hipFree(s->d_G); hipFree(s->d_S); hipFree(s->d_L); hipFree(s->d_e);
   for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
   hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
+  hipFree(s->d_Rinv);
   delete s;
   c->sm = nullptr;
 }
@@ -572,11 +579,16 @@ constexpr int kGatherCols = 16;
 __global__ __launch_bounds__(256) void imat_gather_kernel(int n, int d, int ldx, const int* __restrict__ ai,
                                                           const double* __restrict__ Iold, size_t old_stride,
                                                           const double* __restrict__ Hb, const double* __restrict__ Rinv,
-                                                          double* __restrict__ Inew) {
+                                                          double* __restrict__ Inew, int n_bank_local,
+                                                          const double* __restrict__ rec, size_t rec_stride,
+                                                          size_t rec_off_Imat, size_t rec_off_Hb) {
   const int p = blockIdx.x;
   const int a = ai ? ai[p] : p;
-  const double* src = Iold + (size_t)a * old_stride;
-  const double* H = Hb ? Hb + (size_t)a * d * ldx : nullptr;
+  // sharded smoother: an ancestor index >= n_bank_local refers to a received record (rbpf_shard_state.hpp)
+  const bool remote = rec != nullptr && a >= n_bank_local;
+  const double* recp = remote ? rec + (size_t)(a - n_bank_local) * rec_stride : nullptr;
+  const double* src = remote ? recp + rec_off_Imat : Iold + (size_t)a * old_stride;
+  const double* H = remote ? recp + rec_off_Hb : (Hb ? Hb + (size_t)a * d * ldx : nullptr);
   double* dst = Inew + (size_t)p * n * n;
   const int c0 = blockIdx.y * kGatherCols, c1 = min(n, c0 + kGatherCols);
   for (int r = threadIdx.x; r < n; r += 256) {
@@ -608,6 +620,34 @@ __global__ void fill_kernel(size_t count, double v, double* p) {
   if (q < count) p[q] = v;
 }
 
+// sharded smoother: information part of the send records [ivec | halfLogDetP | pending H | Imat] of the particles idx[.]
+__global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, const int* __restrict__ idx,
+                                                        const double* __restrict__ ivec, const double* __restrict__ hld,
+                                                        const double* __restrict__ Hb, const double* __restrict__ Imat,
+                                                        size_t imat_stride, double* __restrict__ rec, size_t rec_stride,
+                                                        size_t off_I, size_t off_hld, size_t off_Hb, size_t off_Imat) {
+  const int p = blockIdx.x, src = idx[p];
+  double* r = rec + (size_t)p * rec_stride;
+  if (blockIdx.y == 0) {
+    for (int q = threadIdx.x; q < ldx; q += blockDim.x) r[off_I + q] = ivec[(size_t)src * ldx + q];
+    for (int q = threadIdx.x; q < d * ldx; q += blockDim.x) r[off_Hb + q] = Hb[(size_t)src * d * ldx + q];
+    if (threadIdx.x == 0) { r[off_hld] = hld[src]; r[off_hld + 1] = 0.0; }
+  }
+  if (Imat) {
+    const size_t nn = (size_t)n * n, per = (nn + gridDim.y - 1) / gridDim.y;
+    const size_t q0 = (size_t)blockIdx.y * per, q1 = q0 + per < nn ? q0 + per : nn;
+    const double* im = Imat + (size_t)src * imat_stride;
+    for (size_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) r[off_Imat + q] = im[q];
+  }
+}
+
+// w_local[p] = w_glob[logical id of physical slot p]
+__global__ void gather_w_local_kernel(int Nloc, int slot0, const int* __restrict__ slot_ids, const double* __restrict__ w_glob,
+                                      double* __restrict__ w_local) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < Nloc) w_local[p] = w_glob[slot_ids ? slot_ids[p] : slot0 + p];
+}
+
 }  // namespace rbpf
 
 using namespace rbpf;
@@ -626,6 +666,43 @@ static int dmalloc(T** p, size_t count) {
   hipError_t e = hipMalloc((void**)p, count * sizeof(T));
   if (e != hipSuccess) return hip_fail(e, "hipMalloc", __FILE__, __LINE__);
   return RBPF_OK;
+}
+
+// R^-1 and 0.5*log(det(R)) via Cholesky (d <= 8)
+static int invert_R(const std::vector<double>& Rh, int d, std::vector<double>& Rinv, double& halfLogDetR) {
+  halfLogDetR = 0.0;
+  std::vector<double> Lr((size_t)d * d, 0.0);
+  for (int j = 0; j < d; ++j) {
+    double sdiag = Rh[j + (size_t)d * j];
+    for (int k = 0; k < j; ++k) sdiag -= Lr[j + (size_t)d * k] * Lr[j + (size_t)d * k];
+    if (!(sdiag > 0)) { set_error("R must be positive definite"); return RBPF_ERR_CHOL_FAILED; }
+    Lr[j + (size_t)d * j] = std::sqrt(sdiag);
+    for (int i = j + 1; i < d; ++i) {
+      double v = Rh[i + (size_t)d * j];
+      for (int k = 0; k < j; ++k) v -= Lr[i + (size_t)d * k] * Lr[j + (size_t)d * k];
+      Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
+    }
+    halfLogDetR += std::log(Lr[j + (size_t)d * j]);
+  }
+  for (int col = 0; col < d; ++col) {             // solve R x = e_col
+    std::vector<double> y(d), x(d);
+    for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + (size_t)d * k] * y[k]; y[i] = v / Lr[i + (size_t)d * i]; }
+    for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + (size_t)d * i] * x[k]; x[i] = v / Lr[i + (size_t)d * i]; }
+    for (int i = 0; i < d; ++i) Rinv[i + (size_t)d * col] = x[i];
+  }
+  return RBPF_OK;
+}
+
+// information-form initial values (quirk Q5: diagonal of P0 only, particleSmootherInformationForm.m:110-115)
+static void info_initial_values(rbpf_ctx* c, std::vector<double>& ivec0, std::vector<double>& Imat0, double& hld0) {
+  const int n = c->mdl.n;
+  hld0 = 0.0;
+  for (int r = 0; r < n; ++r) {
+    const double pd = c->h_P0[r + (size_t)n * r];
+    Imat0[r + (size_t)n * r] = 1.0 / pd;
+    ivec0[r] = (1.0 / pd) * c->h_x0l[r];
+    hld0 += std::log(std::sqrt(pd));
+  }
 }
 
 static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* out) {
@@ -653,27 +730,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   RB_TRY(dmalloc(&s->d_ak, 4));
   std::vector<double> Rinv((size_t)d * d), Rh(c->h_R);
   double halfLogDetR = 0.0;
-  {  // R^-1 and 0.5*log(det(R)) via Cholesky (d <= 8)
-    std::vector<double> Lr((size_t)d * d, 0.0);
-    for (int j = 0; j < d; ++j) {
-      double sdiag = Rh[j + (size_t)d * j];
-      for (int k = 0; k < j; ++k) sdiag -= Lr[j + (size_t)d * k] * Lr[j + (size_t)d * k];
-      if (!(sdiag > 0)) { set_error("R must be positive definite"); return RBPF_ERR_CHOL_FAILED; }
-      Lr[j + (size_t)d * j] = std::sqrt(sdiag);
-      for (int i = j + 1; i < d; ++i) {
-        double v = Rh[i + (size_t)d * j];
-        for (int k = 0; k < j; ++k) v -= Lr[i + (size_t)d * k] * Lr[j + (size_t)d * k];
-        Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
-      }
-      halfLogDetR += std::log(Lr[j + (size_t)d * j]);
-    }
-    for (int col = 0; col < d; ++col) {             // solve R x = e_col
-      std::vector<double> y(d), x(d);
-      for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + (size_t)d * k] * y[k]; y[i] = v / Lr[i + (size_t)d * i]; }
-      for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + (size_t)d * i] * x[k]; x[i] = v / Lr[i + (size_t)d * i]; }
-      for (int i = 0; i < d; ++i) Rinv[i + (size_t)d * col] = x[i];
-    }
-  }
+  RB_TRY(invert_R(Rh, d, Rinv, halfLogDetR));
   double *d_R = nullptr, *d_Rinv = nullptr;
   RB_TRY(dmalloc(&d_R, (size_t)d * d));
   RB_TRY(dmalloc(&d_Rinv, (size_t)d * d));
@@ -710,12 +767,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   std::vector<double> ivec0(L.ldx, 0.0), Imat0((size_t)n * n, 0.0);
   double hld0 = 0.0, qf0 = 0.0;
   if (info_form) {
-    for (int r = 0; r < n; ++r) {
-      const double pd = c->h_P0[r + (size_t)n * r];
-      Imat0[r + (size_t)n * r] = 1.0 / pd;
-      ivec0[r] = (1.0 / pd) * c->h_x0l[r];
-      hld0 += std::log(std::sqrt(pd));
-    }
+    info_initial_values(c, ivec0, Imat0, hld0);
     for (int r = 0; r < n; ++r) {                    // ivec0' * P0 * ivec0 (full P0, as :301 uses P)
       double sacc = 0.0;
       for (int cc = 0; cc < n; ++cc) sacc += c->h_P0[r + (size_t)n * cc] * ivec0[cc];
@@ -887,7 +939,7 @@ static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, 
     const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
     hipLaunchKernelGGL(imat_gather_kernel, dim3(N, (n + kGatherCols - 1) / kGatherCols), dim3(256), 0, c->stream, n, d, L.ldx, A_t,
                        s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0, s->imat_valid ? (size_t)n * n : (size_t)0,
-                       s->d_Hb[oc], d_Rinv, s->d_Imat[ni]);
+                       s->d_Hb[oc], d_Rinv, s->d_Imat[ni], 0, nullptr, 0, 0, 0);
     HIPCHK(hipGetLastError());
     s->imat_cur = ni;
     s->imat_valid = true;
@@ -910,3 +962,253 @@ extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_proble
   ctx_free(c);
   return st;
 }
+
+// =============================================================================================================
+// Particle-sharded information-form smoother: one process per GPU, collectives issued by the host
+// mirror (multigpu.py) between these calls.  Every rank keeps N_local particles with their extra information-form
+// state; the ancestor weights of the reference trajectory (particleSmootherInformationForm.m:205-247) are computed
+// on the rank that holds each particle, all-gathered (N doubles), and normalised / sampled identically on every
+// rank, so a W-rank run equals the single-GPU smoother with N = W * N_local particles bit for bit.
+// =============================================================================================================
+int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  if (!s || !sh || count <= 0) return RBPF_OK;
+  const int n = c->mdl.n, d = c->mdl.d;
+  const Layout& L = c->lay;
+  const bool with_imat = sh->k_iter > 0;                     // iteration 1 never reads Imat (:157: k > 1 only)
+  const double* im = with_imat ? (s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0) : nullptr;
+  const size_t stride = s->imat_valid ? (size_t)n * n : 0;
+  hipLaunchKernelGGL(pack_info_kernel, dim3(count, with_imat ? 8 : 1), dim3(256), 0, c->stream, n, d, L.ldx, d_idx,
+                     s->d_ivec[s->icur], s->d_hld[s->icur], s->d_Hb[s->icur], im, stride, sh->send_rec, sh->recsz,
+                     sh->rec_off_I, sh->rec_off_hld, sh->rec_off_Hb, sh->rec_off_Imat);
+  HIPCHK(hipGetLastError());
+  return RBPF_OK;
+}
+
+extern "C" {
+
+int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                               int32_t N_K, int32_t rank, int32_t world, rbpf_ctx** out) {
+  if (N_K < 1 || !out) { set_error("bad smoother arguments"); return RBPF_ERR_INVALID_ARG; }
+  rbpf_ctx* c = nullptr;
+  RB_TRY(shard_create_impl(model, prob, rng, opt, rank, world, true, N_K, &c));
+  std::unique_ptr<rbpf_ctx, void (*)(rbpf_ctx*)> guard(c, [](rbpf_ctx* p) { ctx_free(p); });
+  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
+  const Layout& L = c->lay;
+  if (!c->mdl.use_dyn_res_norm && nw != nN) {
+    set_error("isempty(dynResNorm): the additive default (particleSmoother.m:176) needs size(Q,1) == nNonLin");
+    return RBPF_ERR_INVALID_ARG;
+  }
+  if (n > 1023) { set_error("information-form smoother supports nLin <= 1023"); return RBPF_ERR_UNSUPPORTED; }
+  SmootherState* s = new SmootherState();
+  c->sm = s;
+  RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
+  RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
+  RB_TRY(dmalloc(&s->d_ak, 4));
+  for (int b = 0; b < 2; ++b) {
+    RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * n * n));
+    RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
+    RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
+    RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
+    RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
+  }
+  RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles(n)));
+  RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
+  RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
+  RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
+  RB_TRY(dmalloc(&s->d_Rinv, (size_t)d * d));
+  std::vector<double> Rinv((size_t)d * d), Imat0((size_t)n * n, 0.0);
+  double halfLogDetR = 0.0;
+  RB_TRY(invert_R(c->h_R, d, Rinv, halfLogDetR));
+  s->h_ivec0.assign(L.ldx, 0.0);
+  info_initial_values(c, s->h_ivec0, Imat0, s->hld0);
+  HIPCHK(hipMemcpy(s->d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+  s->h_ai.assign((size_t)c->sh->Nglob, 0);
+  guard.release();
+  *out = c;
+  return RBPF_OK;
+}
+
+int rbpf_shard_smoother_views_get(rbpf_ctx* c, rbpf_shard_smoother_views* v) {
+  if (!c || !c->sh || !c->sm || !v) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  v->anc_local = c->sh->anc_local; v->anc_gather = c->sh->anc_gather;
+  return RBPF_OK;
+}
+
+// Start of CPF-AS iteration k (particleSmootherInformationForm.m:96-146): rewind, information-form initial values,
+// and for k > 1 the measurement Jacobians along the reference trajectory with their suffix sums.
+int rbpf_shard_smoother_begin(rbpf_ctx* c, int32_t k) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  if (k < 0 || k >= c->N_K) { set_error("iteration out of range"); return RBPF_ERR_INVALID_ARG; }
+  const int T = c->T, n = c->mdl.n, d = c->mdl.d;
+  RB_TRY(ctx_reset(c));
+  sh->t_norm = 0; sh->placed = false; sh->plan_ready = false; sh->gid_cur = 0; sh->cur_gid = nullptr;
+  sh->rec_used = 0; sh->plan_recv = 0; sh->k_iter = k;
+  RB_TRY(info_begin_iteration(c, s->h_ivec0.data(), s->hld0, 0.0, 0.0, s->d_Rinv));
+  if (k > 0) {
+    HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, c->stream, 1));           // :120
+    HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, c->stream));
+    HIPCHK(hipMemsetAsync(s->d_ivecAdd, 0, (size_t)n * 8, c->stream));
+    hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, c->stream, n, d, 0, T,
+                       1.0, s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);   // :132-146
+    HIPCHK(hipGetLastError());
+  }
+  return RBPF_OK;
+}
+
+// After the all_gather of the forward bank: global weights of the finished step and (want_draw) the ancestors of the
+// ordinary slots of the next one -- N - 1 of them when slot N - 1 carries the reference trajectory (:160-166).
+int rbpf_shard_smoother_normalise(rbpf_ctx* c, int32_t want_draw) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  ShardState* sh = c->sh;
+  const int n_draw = (sh->k_iter > 0) ? sh->Nglob - 1 : sh->Nglob;
+  return shard_normalise_impl(c, nullptr, want_draw ? c->sm->h_ai.data() : nullptr, sh->k_iter, n_draw);
+}
+
+// k > 1, t > 1: ancestor log-weights of my particles against the reference state of the step about to run
+// (:205-240) -> anc_local [N_local] (physical order).  Synchronises: the all_gather follows.
+int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  const int t = c->t, k = sh->k_iter, N = sh->Nloc, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
+  if (k < 1 || t < 1 || t >= c->T || sh->t_norm < t) { set_error("ancestor weights need k > 0, t > 0 and the normalised weights of step t-1"); return RBPF_ERR_STATE; }
+  hipStream_t st = c->stream;
+  const double* xref = s->d_xnk + (size_t)t * nN;
+  hipLaunchKernelGGL(gather_w_local_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, sh->rank * N,
+                     sh->placed ? sh->pb.slot_ids : nullptr, sh->w_glob, sh->w_local);
+  const double* Lq = c->d_cholQfull + (size_t)((c->chol_pages > 1) ? t - 1 : 0) * nw * nw;
+  hipLaunchKernelGGL(anc_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, c->mdl, N, sh->fwd_local, xref,
+                     c->d_odo + (size_t)(t - 1) * c->mdl.nodo, Lq, sh->w_local, sh->anc_local);
+  // the (t-1) term leaves the suffix sums (:194-201)
+  hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, t - 1, t, -1.0,
+                     s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+  HIPCHK(hipGetLastError());
+  CholArgs ca;
+  std::memset(&ca, 0, sizeof(ca));
+  ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
+  RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv));
+  {
+    static bool attr = false;
+    if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
+    hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(kCholThreads), chol_lds_bytes(ca.Msz, d), st, ca);
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  return RBPF_OK;
+}
+
+// After the all_gather of anc_local: normalise the global ancestor probabilities (:243-245) and draw ai(N_P) (:248).
+int rbpf_shard_smoother_anc_sample(rbpf_ctx* c) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  ShardState* sh = c->sh;
+  const int t = c->t, k = sh->k_iter, N = sh->Nglob;
+  hipStream_t st = c->stream;
+  HIPCHK(launch_permute_fwd(N, 0, sh->world, sh->Nloc, sh->placed ? sh->cur_gid : nullptr, sh->anc_gather, sh->anc_glob, nullptr, st));
+  NormArgs nm;
+  nm.N = N; nm.nN = 0; nm.t = t; nm.logw = sh->anc_glob; nm.w = sh->anc_w; nm.wc = sh->anc_wc; nm.xn = nullptr;
+  nm.traj_max = nullptr; nm.traj_mean = nullptr; nm.iw_max = c->d_flags + 3; nm.lse_out = nullptr;
+  HIPCHK(launch_normalise_scan(nm, st));
+  SearchArgs sa;
+  sa.N = N; sa.n_draw = 1; sa.t = t; sa.wc = sh->anc_wc; sa.rng_mode = c->rng_mode; sa.k_iter = k;
+  sa.slot0 = N - 1; sa.u_is_scalar = 0;
+  sa.U = c->d_U ? c->d_U + ((size_t)k * (c->T - 1) + (t - 1)) * N : nullptr;
+  sa.seed = c->seed; sa.ai = sh->ai_glob; sa.overflow = c->d_flags + 1;
+  HIPCHK(launch_search(sa, st));
+  HIPCHK(hipMemcpyAsync(sh->Ahist + (size_t)t * N + (N - 1), sh->ai_glob + (N - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return RBPF_OK;
+}
+
+// One information-form time step of my N_local particles (device plan of rbpf_shard_plan; nothing to plan at t = 0).
+int rbpf_shard_smoother_step(rbpf_ctx* c) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  const int t = c->t, k = sh->k_iter, N = sh->Nloc, n = c->mdl.n, d = c->mdl.d, nN = c->mdl.nN;
+  const Layout& L = c->lay;
+  const double* xref = (k > 0) ? s->d_xnk + (size_t)t * nN : nullptr;
+  const int oc = s->icur, nc = (t == 0) ? 0 : (oc ^ 1);
+  InfoStep is;
+  if (t == 0) { is.ivec_old = s->d_ivec0; is.ivec_old_stride = 0; is.hld_old = s->d_hld0; is.hld_old_stride = 0; }
+  else { is.ivec_old = s->d_ivec[oc]; is.ivec_old_stride = (size_t)L.ldx; is.hld_old = s->d_hld[oc]; is.hld_old_stride = 1; }
+  is.ivec_new = s->d_ivec[nc]; is.hld_new = s->d_hld[nc]; is.qf_new = s->d_qf[nc]; is.Hb_new = s->d_Hb[nc];
+  RB_TRY(shard_step_impl(c, nullptr, nullptr, k, xref, &is));
+  if (k > 0 && t > 0) {
+    const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
+    hipLaunchKernelGGL(imat_gather_kernel, dim3(N, (n + kGatherCols - 1) / kGatherCols), dim3(256), 0, c->stream, n, d, L.ldx,
+                       sh->pb.anc_bank, s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0,
+                       s->imat_valid ? (size_t)n * n : (size_t)0, s->d_Hb[oc], s->d_Rinv, s->d_Imat[ni], N, sh->recv_rec,
+                       sh->recsz, sh->rec_off_Imat, sh->rec_off_Hb);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));      // recv_rec is rewritten by the next exchange
+    s->imat_cur = ni;
+    s->imat_valid = true;
+  }
+  s->icur = nc;
+  return RBPF_OK;
+}
+
+// End of iteration k (:346-354), after the last step was gathered and normalised: ak = sample(w), the new reference
+// trajectory (identical on every rank) into XNK_k [nN x T]; XLK_k [n] / PK_k [n x n] are written by the rank that
+// holds particle ak (owner_rank) and zero-filled elsewhere.
+int rbpf_shard_smoother_end(rbpf_ctx* c, double* XNK_k, double* XLK_k, double* PK_k, int32_t* ak_out, int32_t* owner_rank) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  const int T = c->T, k = sh->k_iter, N = sh->Nglob, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d;
+  const Layout& L = c->lay;
+  hipStream_t st = c->stream;
+  if (c->t != T || sh->t_norm != T) { set_error("iteration not finished (run all steps, then gather + normalise)"); return RBPF_ERR_STATE; }
+  double* d_uf = c->d_scal;
+  if (c->rng_mode == RBPF_RNG_REPLAY) HIPCHK(hipMemcpyAsync(d_uf, &c->h_Ufin[k], 8, hipMemcpyHostToDevice, st));
+  SearchArgs sa;
+  sa.N = N; sa.n_draw = 1; sa.t = T; sa.wc = sh->wc_glob; sa.rng_mode = c->rng_mode; sa.k_iter = k; sa.slot0 = 0;
+  sa.U = d_uf; sa.seed = c->seed; sa.ai = s->d_ak; sa.overflow = c->d_flags + 1; sa.u_is_scalar = 1;
+  sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = sh->w_glob; sa.wc_exact = sh->wc_glob;
+  if (N > kSingleWgResampleMaxN) sa.scan_depth = (N + 1023) / 1024 + 32;
+  HIPCHK(launch_search(sa, st));
+  HIPCHK(launch_resample_fixup(sa, st));
+  HIPCHK(launch_backtrace(N, nN, T, sh->Xhist, sh->Ahist, s->d_ak, 1, s->d_xnk, st));
+  int ak = 0;
+  HIPCHK(hipMemcpyAsync(&ak, s->d_ak, 4, hipMemcpyDeviceToHost, st));
+  RB_TRY(ctx_check_flags(c));
+  int gid = ak;
+  if (sh->placed) HIPCHK(hipMemcpy(&gid, sh->cur_gid + ak, 4, hipMemcpyDeviceToHost));
+  const int owner = gid / sh->Nloc, idx = gid % sh->Nloc;
+  if (ak_out) *ak_out = ak;
+  if (owner_rank) *owner_rank = owner;
+  if (XNK_k) HIPCHK(hipMemcpy(XNK_k, s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
+  const int cur = c->cur;
+  if (XLK_k) {
+    std::memset(XLK_k, 0, (size_t)n * 8);
+    if (owner == sh->rank) HIPCHK(hipMemcpy(XLK_k, c->xl[cur] + (size_t)idx * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
+  }
+  if (PK_k) {
+    std::memset(PK_k, 0, (size_t)n * n * 8);
+    if (owner == sh->rank) {
+      double* dP = nullptr; int* didx = nullptr;
+      RB_TRY(dmalloc(&dP, (size_t)n * n));
+      int s2 = dmalloc(&didx, 1);
+      if (s2 != RBPF_OK) { hipFree(dP); return s2; }
+      hipError_t e = hipMemcpy(didx, &idx, 4, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess) e = hipMemcpy(PK_k, dP, (size_t)n * n * 8, hipMemcpyDeviceToHost);
+      hipFree(dP); hipFree(didx);
+      HIPCHK(e);
+    }
+  }
+  return RBPF_OK;
+}
+
+}  // extern "C"

@@ -111,3 +111,63 @@ def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0):
         x[i, 3:7] = _qmul(x[i - 1, 3:7], dQn[i - 1])
     dx = np.hstack((np.diff(x[:, 0:3], axis=0), dQn))
     return dict(dx=dx, initState=initState, y=y, LL=LL, pos=pos, quat=quat)
+
+
+def scalar_field_draw(x, m, LL, theta, rs):
+    """Scalar-field draw of tools/gp_rnd_SE1D_fast.m:44-85 at points x [npts x 2]: returns (f, y)."""
+    LL = np.asarray(LL, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64) - LL.mean(axis=0)
+    L, NN = domain_cartesian_dx(m, 2, (LL.max(axis=0) - LL.min(axis=0))[None, :] / 2.0)
+    lam = eigenval(NN, L)
+    lengthScale, magnSigma2, sigma2 = (float(t) for t in np.asarray(theta).ravel())
+    k = magnSigma2 * math.sqrt(2 * math.pi) ** 2 * lengthScale ** 2 * np.exp(-lam * lengthScale ** 2 / 2)
+    foo = np.sqrt(k) * rs.standard_normal(m)
+    noise = rs.standard_normal(x.shape[0])
+    S, _ = _axis_tables(NN, L, x)
+    amp = 1.0 / np.sqrt(L)
+    f = ((S[0][:, NN[:, 0]] * amp[0]) * (S[1][:, NN[:, 1]] * amp[1])) @ foo
+    return f, f + math.sqrt(sigma2) * noise
+
+
+def radio_Q(N_T, traj="line_3D"):
+    """Time-varying heading noise of run_dense2D_withHeading.m:69-73 (line) / :83-86 (square), [1 x 1 x N_T]."""
+    Q = 1e-6 * np.ones(N_T)
+    if traj == "line_3D":
+        Q[N_T // 2 - 1] = 0.3 ** 2
+    else:
+        for j in range(3):
+            Q[N_T // 4 + (N_T // 4) * j - 1] = 0.1 ** 2
+    return Q.reshape(1, 1, N_T)
+
+
+def planar_heading(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=4, traj="line_3D"):
+    """generateData_dense.m 'line_3D' (:113-132) / 'square_3D' (:101-112) with N = N_T points, scalar field
+    (:258-290), odometry noise on the heading by running dynModel forward (:310-323;
+    run_dense2D_withHeading.m:75-76) -> dict(dx, initState, y [N_T x 1], LL, pos)."""
+    rs = np.random.RandomState(seed)
+    N = int(N_T)
+    if traj == "line_3D":
+        pos = np.vstack((np.zeros(N), np.concatenate((np.linspace(0, 3, N // 2), np.linspace(3, 0, N - N // 2)))))
+    elif traj == "square_3D":
+        q = N // 4
+        pos = np.vstack((np.concatenate((np.zeros(q), np.linspace(0, 2, q), 2 * np.ones(q), np.linspace(2, 0, N - 3 * q))),
+                         np.concatenate((np.linspace(0, 2, q), 2 * np.ones(q), np.linspace(2, 0, q), np.zeros(N - 3 * q)))))
+    else:
+        raise ValueError("traj must be 'line_3D' or 'square_3D'")
+    pos = pos - pos.mean(axis=1, keepdims=True)
+    initState = np.concatenate((pos[:, 0], [0.0]))
+    dx = np.hstack((np.diff(pos.T, axis=0), np.zeros((N - 1, 1))))
+    ls = float(np.asarray(theta).ravel()[0])
+    LL = np.array([[pos[0].min() - nLL * ls, pos[1].min() - nLL * ls],
+                   [pos[0].max() + nLL * ls, pos[1].max() + nLL * ls]])
+    _, y = scalar_field_draw(pos.T, m_sim, LL, theta, rs)
+    Q = np.asarray(Q, dtype=np.float64).reshape(1, 1, -1)
+    dtv = np.broadcast_to(np.asarray(dt, dtype=np.float64).ravel(), (1,)) if np.ndim(dt) == 0 else np.asarray(dt)
+    zo = rs.standard_normal(N - 1)
+    th = np.zeros(N)
+    for i in range(1, N):
+        q = Q[0, 0, (i - 1) if Q.shape[2] > 1 else 0]
+        h = dtv[(i - 1) if dtv.size > 1 else 0]
+        th[i] = th[i - 1] + dx[i - 1, 2] + math.sqrt(h * q) * zo[i - 1]
+    dxn = np.hstack((dx[:, 0:2], np.diff(th)[:, None]))                    # :319
+    return dict(dx=dxn, initState=initState, y=y.reshape(-1, 1), LL=LL, pos=pos)

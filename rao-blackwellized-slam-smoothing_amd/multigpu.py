@@ -189,14 +189,13 @@ class ShardedFilterSession:
         self.prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt)
         # replay buffers (tests) hold all world*N_local slots; Philox streams are keyed by logical slot id
         self.blk, self._rng = _rng_block(rng if rng is not None else PhiloxRNG(1), self.prob.N_P * self.world,
-                                         self.prob.N_T, model.nw, 1)
+                                         self.prob.N_T, model.nw, self._n_iter())
         if lazy_depth >= 2 and planner != "device":
             raise ValueError("lazy_depth >= 2 needs planner='device'")
         self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0)
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
-        check(self.lib.rbpf_shard_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),
-                                         C.byref(self.opt), self.rank, self.world, C.byref(self.ctx)))
+        self._create()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.N_local, self.N_global = self.prob.N_P, self.prob.N_P * self.world
         self.t = 0
@@ -216,6 +215,13 @@ class ShardedFilterSession:
             if self.world > 1 else None
         self.t_recv = _view(torch, v.recv_rec, (max(int(v.recv_capacity), 1), int(v.record_doubles)), self.device) \
             if self.world > 1 else None
+
+    def _n_iter(self):
+        return 1
+
+    def _create(self):
+        check(self.lib.rbpf_shard_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),
+                                         C.byref(self.opt), self.rank, self.world, C.byref(self.ctx)))
 
     # -- collectives -----------------------------------------------------------------------------
     def _gather(self):
@@ -352,3 +358,125 @@ class ShardedFilterSession:
 
     def __exit__(self, *a):
         self.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# particle-sharded information-form smoother
+# ------------------------------------------------------------------------------------------------
+class rbpf_shard_smoother_views(C.Structure):
+    _fields_ = [("anc_local", _ffi.c_double_p), ("anc_gather", _ffi.c_double_p)]
+
+
+class ShardedSmootherSession(ShardedFilterSession):
+    """src/particleSmootherInformationForm.m with the N = world * N_local particles of every CPF-AS iteration sharded
+    over the ranks (one process per GPU).  On top of the filter's collectives every step of an iteration k > 1 adds
+    one all_gather of N ancestor log-weights (:205-240 are evaluated where each particle lives); the information
+    state (ivec, Imat, halfLogDetP) migrates inside the particle records.  run() returns the reference's outputs
+    (XNK [nN x T x N_K], XLK [n x N_K], PK [n x n x N_K]) on every rank, equal to the single-GPU smoother with N
+    particles bit for bit."""
+
+    def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
+                 transport="device"):
+        self.N_K = int(N_K)
+        lib = load_library()
+        for name, argt in (("rbpf_shard_smoother_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
+                                                           C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
+                                                           C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+                           ("rbpf_shard_smoother_views_get", [C.c_void_p, C.POINTER(rbpf_shard_smoother_views)]),
+                           ("rbpf_shard_smoother_begin", [C.c_void_p, C.c_int32]),
+                           ("rbpf_shard_smoother_normalise", [C.c_void_p, C.c_int32]),
+                           ("rbpf_shard_smoother_anc_weights", [C.c_void_p]),
+                           ("rbpf_shard_smoother_anc_sample", [C.c_void_p]),
+                           ("rbpf_shard_smoother_step", [C.c_void_p]),
+                           ("rbpf_shard_smoother_end", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p, _ffi.c_double_p,
+                                                        _ffi.c_int32_p, _ffi.c_int32_p])):
+            getattr(lib, name).argtypes = argt
+        super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
+                         transport=transport, planner="device", lazy_depth=0)
+        sv = rbpf_shard_smoother_views()
+        check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
+        self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)
+        self.t_anc_gather = _view(self.torch, sv.anc_gather, (self.N_global,), self.device)
+
+    def _n_iter(self):
+        return self.N_K
+
+    def _create(self):
+        check(self.lib.rbpf_shard_smoother_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),
+                                                  C.byref(self.opt), self.N_K, self.rank, self.world, C.byref(self.ctx)))
+
+    def _gather_anc(self):
+        torch, dist = self.torch, self.dist
+        if self.world == 1:
+            self.t_anc_gather.copy_(self.t_anc_local)
+        elif self.transport == "device":
+            dist.all_gather_into_tensor(self.t_anc_gather, self.t_anc_local)
+        else:
+            h = torch.empty(self.t_anc_gather.shape, dtype=torch.float64)
+            dist.all_gather_into_tensor(h, self.t_anc_local.cpu())
+            self.t_anc_gather.copy_(h)
+        torch.cuda.synchronize()
+
+    def advance(self, n_steps):
+        raise NotImplementedError("use run()")
+
+    def run(self, progress=None):
+        import time
+        lib, T, W = self.lib, self.prob.N_T, self.world
+        nN, n = self.model.nNonLin, self.model.nLin
+        XNK = np.zeros((nN, T, self.N_K), order="F")
+        XLK = np.zeros((n, self.N_K), order="F")
+        PK = np.zeros((n, n, self.N_K), order="F")
+        self.aks = []
+        tm = self.stats.setdefault("phase_s", dict(gather=0.0, normalise=0.0, anc=0.0, plan=0.0, exchange=0.0, step=0.0))
+        for k in range(self.N_K):
+            check(lib.rbpf_shard_smoother_begin(self.ctx, k))
+            for t in range(T):
+                if t == 0:
+                    check(lib.rbpf_shard_smoother_step(self.ctx))
+                    continue
+                t0 = time.perf_counter()
+                self._gather()
+                t1 = time.perf_counter()
+                check(lib.rbpf_shard_smoother_normalise(self.ctx, 1))
+                t2 = time.perf_counter()
+                if k > 0:
+                    check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
+                    self._gather_anc()
+                    check(lib.rbpf_shard_smoother_anc_sample(self.ctx))
+                t3 = time.perf_counter()
+                cnt = np.zeros(2 * W + 2, dtype=np.int64)
+                check(lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+                t4 = time.perf_counter()
+                if W > 1:
+                    self._exchange((cnt[:W], cnt[W:2 * W]), int(cnt[2 * W + 1]))
+                t5 = time.perf_counter()
+                check(lib.rbpf_shard_smoother_step(self.ctx))
+                t6 = time.perf_counter()
+                tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["anc"] += t3 - t2; tm["plan"] += t4 - t3
+                tm["exchange"] += t5 - t4; tm["step"] += t6 - t5
+                self.stats["migrated"] += int(cnt[2 * W])
+                self.stats["steps"] += 1
+            self._gather()
+            check(lib.rbpf_shard_smoother_normalise(self.ctx, 0))
+            xnk = np.zeros((nN, T), order="F")
+            xlk = np.zeros(n)
+            pk = np.zeros((n, n), order="F")
+            ak, owner = C.c_int32(0), C.c_int32(0)
+            check(lib.rbpf_shard_smoother_end(self.ctx, _dp(xnk), _dp(xlk), _dp(pk), C.byref(ak), C.byref(owner)))
+            if W > 1:                                      # the owner's rows reach every rank (zeros elsewhere)
+                buf = self.torch.from_numpy(np.concatenate((xlk, pk.ravel(order="F"))))
+                if self.transport == "device":
+                    buf = buf.to(self.device)
+                self.dist.all_reduce(buf)
+                buf = buf.cpu().numpy()
+                xlk, pk = buf[:n], buf[n:].reshape((n, n), order="F")
+            XNK[:, :, k], XLK[:, k], PK[:, :, k] = xnk, xlk, pk
+            self.aks.append(int(ak.value))
+            if progress:
+                progress(k)
+        return XNK, XLK, PK
+
+    def close(self):
+        self.t_anc_local = self.t_anc_gather = None
+        super().close()

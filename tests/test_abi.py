@@ -91,6 +91,19 @@ def test_product_datagen_matches_oracle_generator(rbpf, oracle):
         np.testing.assert_allclose(a[k], b[k], rtol=1e-11, atol=1e-12)
 
 
+@pytest.mark.parametrize("traj,N_T", [("line_3D", 32), ("square_3D", 48)])
+def test_product_radio_datagen_matches_oracle_generator(rbpf, oracle, traj, N_T):
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    Q = dg.radio_Q(N_T, traj)
+    if traj == "line_3D":
+        np.testing.assert_array_equal(Q, cases.radio_case(2, N_T, 8)["Q"])
+    a = dg.planar_heading(N_T, Q, cases.THETA_RADIO, 1.0, seed=7, m_sim=90, nLL=4, traj=traj)
+    b = oracle.generate_line_3D(N_T, Q, cases.THETA_RADIO, 1.0, seed=7, m_sim=90, nLL=4, traj=traj)
+    for k in ("dx", "initState", "y", "LL"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-11, atol=1e-12)
+
+
 def test_replay_rng_shape_validation(rbpf):
     c = cases.radio_case(4, 3, 8, seed=1)
     mdl, x0, P0, R = cases.device_model(rbpf, c)

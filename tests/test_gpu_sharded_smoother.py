@@ -1,0 +1,99 @@
+"""GPU: the particle-sharded information-form smoother equals the single-GPU smoother with N = world * N_local
+particles bit for bit (and the oracle to 1e-9).  Two ranks share the box's one GPU over the host/gloo transport; a
+world-size-1 RCCL group exercises the device transport."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _case(kind, N, T, m, N_K):
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    return mk(N, T, m, seed=31, N_K=N_K)
+
+
+def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q):
+    import importlib
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        rbpf = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+        mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
+        c = _case(kind, world * n_local, T, m, N_K)
+        mdl, x0, P0, R = cases.device_model(rbpf, c)
+        s = mg.ShardedSmootherSession(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, n_local, N_K, c["dt"],
+                                      rng=cases.device_rng(rbpf, c), rank=rank, world=world, transport=transport)
+        XNK, XLK, PK = s.run()
+        stats = dict(s.stats)
+        aks = list(s.aks)
+        s.close()
+        q.put((rank, XNK, XLK, PK, aks, stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, backend, transport, kind, n_local, T, m, N_K):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, kind, n_local, T, m, N_K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+def _single(rbpf, kind, N, T, m, N_K):
+    c = _case(kind, N, T, m, N_K)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    out = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"],
+                                               x0, P0, c["Q"], R, N, N_K, c["dt"], rng=cases.device_rng(rbpf, c), extras=True)
+    return c, out
+
+
+@pytest.mark.parametrize("kind,n_local,T,m,N_K", [("mag", 12, 8, 130, 3), ("mag", 40, 7, 16, 3), ("radio", 24, 10, 128, 3)])
+def test_two_ranks_equal_single_gpu_smoother(rbpf, kind, n_local, T, m, N_K):
+    res = _run(2, "gloo", "host", kind, n_local, T, m, N_K)
+    c, ref = _single(rbpf, kind, 2 * n_local, T, m, N_K)
+    for rank, XNK, XLK, PK, aks, stats in res:                 # every rank returns the full outputs
+        np.testing.assert_array_equal(np.asarray(aks), ref[3]["ak"])
+        np.testing.assert_array_equal(XNK, ref[0])             # bit for bit
+        np.testing.assert_array_equal(XLK, ref[1])
+        np.testing.assert_array_equal(PK, ref[2])
+    assert res[0][5]["migrated"] > 0                           # particle records (incl. Imat) did cross ranks
+    # and the oracle (same replayed random numbers)
+    orc = cases.oracle_smoother(c, info_form=True)
+    np.testing.assert_allclose(res[0][1], orc["XNK"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(res[0][2], orc["XLK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["XLK"])))
+    np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
+
+
+def test_world_size_one_rccl_smoother(rbpf):
+    kind, n_local, T, m, N_K = "mag", 20, 6, 130, 2
+    res = _run(1, "nccl", "device", kind, n_local, T, m, N_K)
+    _, ref = _single(rbpf, kind, n_local, T, m, N_K)
+    np.testing.assert_array_equal(res[0][1], ref[0])
+    np.testing.assert_array_equal(res[0][2], ref[1])
+    np.testing.assert_array_equal(res[0][3], ref[2])
