@@ -206,6 +206,11 @@ struct CholArgs {
   // mode 1
   const double* Imat; long imat_stride; const double* Hb; const double* Rinv; const double* ImatAdd; const double* ivec;
   const double* ivecAdd; const double* qf; const double* hld;
+  // mode 1, fused gather (:170,:253,:334): the particle's information matrix is its ancestor's stored matrix (bank entry
+  // imat_anc[p], or a received record when the index is >= n_bank_local) plus its own last update; the sum is stored
+  // as the particle's matrix (ImatOut) while it is loaded for the factorisation
+  const int* imat_anc; double* ImatOut;
+  int n_bank_local; const double* rec; size_t rec_stride, rec_off_Imat;
   double* pant_log;                 // += logwMeas
   int* status;
 };
@@ -310,17 +315,27 @@ __device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, i
     }
   } else {
     double ad[4];
+    const double* src = a.Imat + (size_t)p * a.imat_stride;                  // p: the ancestor's entry (resolved by the caller)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      v[q] = a.Imat[(size_t)p * a.imat_stride + (size_t)ic + (size_t)a.n * jc[q]];
+      v[q] = src[(size_t)ic + (size_t)a.n * jc[q]];
       ad[q] = a.ImatAdd[(size_t)ic + (size_t)a.n * jc[q]];
     }
-    if (Hs) {                                                                // pending dyi'/R*dyi (:334)
+    if (Hs) {                                                                // + dyi'/R*dyi of the last update (:334)
+      double sacc[4] = {0.0, 0.0, 0.0, 0.0};
       for (int aa = 0; aa < a.d; ++aa) {
         const double h = Hs[aa * M + ic];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fma(h, RH[aa * M + jc[q]], v[q]);
+        for (int q = 0; q < 4; ++q) sacc[q] = fma(h, RH[aa * M + jc[q]], sacc[q]);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += sacc[q];
+    }
+    if (a.ImatOut && i < M) {                                                // Imat(:,:,i) of the new generation
+      double* dst = a.ImatOut + (size_t)blockIdx.x * a.n * a.n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (j[q] < M) __builtin_nontemporal_store(v[q], &dst[(size_t)i + (size_t)a.n * j[q]]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] += ad[q];                               // :225
@@ -359,9 +374,18 @@ __device__ inline void sqrt_rsqrt(double x, double& g, double& rinv) {
   rinv = h + h;
 }
 
-__global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a) {
+__global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in) {
   extern __shared__ double csm[];
+  CholArgs a = a_in;
   const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
+  if (a.mode == 1) {
+    // source of the stored information matrix: my own entry, my ancestor's entry, or a received record
+    const int src = a.imat_anc ? a.imat_anc[p] : p;
+    const bool remote = a.rec != nullptr && src >= a.n_bank_local;
+    a.Imat = remote ? a.rec + (size_t)(src - a.n_bank_local) * a.rec_stride + a.rec_off_Imat
+                    : a.Imat + (size_t)src * a.imat_stride;
+    a.imat_stride = 0;
+  }
   const int lane = tid & 63, wv = tid >> 6;
   const int RT = (M + 1 + 15) >> 4;
   double* Lt = a.Lbuf + (size_t)p * a.ldL;       // fragment order, (16 RT)^2 doubles
@@ -572,44 +596,6 @@ __global__ void info_addt_kernel(int n, int d, int t0, int t1, double sign, cons
   if (j == 0) ivecAdd[i] = av;
 }
 
-// Imat_new(:,:,i) = Imat_old(:,:,ai(i)) + dy' / R * dy of the ancestor's last update (:170, :334)
-// grid (N_P, ceil(n / 16)): a workgroup copies 16 columns; the rows of a thread are the same for every column, so the
-// H(:, row) factors are read once and R^-1 H(:, col) is wave-uniform.
-constexpr int kGatherCols = 16;
-__global__ __launch_bounds__(256) void imat_gather_kernel(int n, int d, int ldx, const int* __restrict__ ai,
-                                                          const double* __restrict__ Iold, size_t old_stride,
-                                                          const double* __restrict__ Hb, const double* __restrict__ Rinv,
-                                                          double* __restrict__ Inew, int n_bank_local,
-                                                          const double* __restrict__ rec, size_t rec_stride,
-                                                          size_t rec_off_Imat, size_t rec_off_Hb) {
-  const int p = blockIdx.x;
-  const int a = ai ? ai[p] : p;
-  // sharded smoother: an ancestor index >= n_bank_local refers to a received record (rbpf_shard_state.hpp)
-  const bool remote = rec != nullptr && a >= n_bank_local;
-  const double* recp = remote ? rec + (size_t)(a - n_bank_local) * rec_stride : nullptr;
-  const double* src = remote ? recp + rec_off_Imat : Iold + (size_t)a * old_stride;
-  const double* H = remote ? recp + rec_off_Hb : (Hb ? Hb + (size_t)a * d * ldx : nullptr);
-  double* dst = Inew + (size_t)p * n * n;
-  const int c0 = blockIdx.y * kGatherCols, c1 = min(n, c0 + kGatherCols);
-  for (int r = threadIdx.x; r < n; r += 256) {
-    double hr[8];
-    for (int aa = 0; aa < 8; ++aa) hr[aa] = (H && aa < d) ? H[(size_t)aa * ldx + r] : 0.0;
-    for (int c = c0; c < c1; ++c) {
-      double v = src[(size_t)c * n + r];
-      if (H) {
-        double s = 0.0;
-        for (int aa = 0; aa < d; ++aa) {
-          double t = 0.0;
-          for (int bb = 0; bb < d; ++bb) t = fma(Rinv[aa + d * bb], H[(size_t)bb * ldx + c], t);
-          s = fma(hr[aa], t, s);
-        }
-        v += s;
-      }
-      dst[(size_t)c * n + r] = v;
-    }
-  }
-}
-
 __global__ void gather_scalar_kernel(int N, const int* __restrict__ ai, const double* __restrict__ in, double* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) out[i] = in[ai ? ai[i] : i];
@@ -654,7 +640,7 @@ using namespace rbpf;
 
 // information-form hooks (defined below)
 static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, double qf0, double halfLogDetR, const double* d_Rinv);
-static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv);
+static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv, const int* anc);
 static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, const double* d_Rinv);
 
 #define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
@@ -826,7 +812,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d,
                              t - 1, t, -1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
           HIPCHK(hipGetLastError());
-          RB_TRY(info_fill_chol_args(c, ca, d_Rinv));
+          RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
         }
         {
           static bool attr = false;
@@ -911,14 +897,23 @@ static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, d
   return RBPF_OK;
 }
 
-static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv) {
+// Arguments of the information-form ancestor-weight factorisation of the step about to run (t >= 1).  The kernel
+// also forms the information matrices of the current generation, Imat(:,:,i) = Imat(:,:,ai(i)) + dyi'/R*dyi
+// (:170,:253,:334), from the previous generation's bank (entry anc[i]; generation 0 starts from Imat0) and stores
+// them into the other bank: the gather `Imat = Imat(:,:,ai)` costs one extra write instead of a copy kernel.
+static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv, const int* anc) {
   SmootherState* s = c->sm;
   const int n = c->mdl.n;
+  const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
   ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
   ca.Imat = s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0;
   ca.imat_stride = s->imat_valid ? (long)((size_t)n * n) : 0;
+  ca.imat_anc = s->imat_valid ? anc : nullptr;
+  ca.ImatOut = s->d_Imat[ni];
   ca.Hb = s->d_Hb[s->icur]; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
   ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
+  s->imat_cur = ni;                 // after the launch the new bank is the current one
+  s->imat_valid = true;
   return RBPF_OK;
 }
 
@@ -934,16 +929,7 @@ static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, 
   else { is.ivec_old = s->d_ivec[oc]; is.ivec_old_stride = (size_t)L.ldx; is.hld_old = s->d_hld[oc]; is.hld_old_stride = 1; }
   is.ivec_new = s->d_ivec[nc]; is.hld_new = s->d_hld[nc]; is.qf_new = s->d_qf[nc]; is.Hb_new = s->d_Hb[nc];
   RB_TRY(ctx_step(c, k, xref, n_draw, &is));
-  if (k > 0 && t > 0) {
-    const int* A_t = c->A + (size_t)t * N;
-    const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
-    hipLaunchKernelGGL(imat_gather_kernel, dim3(N, (n + kGatherCols - 1) / kGatherCols), dim3(256), 0, c->stream, n, d, L.ldx, A_t,
-                       s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0, s->imat_valid ? (size_t)n * n : (size_t)0,
-                       s->d_Hb[oc], d_Rinv, s->d_Imat[ni], 0, nullptr, 0, 0, 0);
-    HIPCHK(hipGetLastError());
-    s->imat_cur = ni;
-    s->imat_valid = true;
-  }
+  (void)N; (void)n; (void)d; (void)d_Rinv;
   s->icur = nc;
   return RBPF_OK;
 }
@@ -976,9 +962,12 @@ int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
   if (!s || !sh || count <= 0) return RBPF_OK;
   const int n = c->mdl.n, d = c->mdl.d;
   const Layout& L = c->lay;
-  const bool with_imat = sh->k_iter > 0;                     // iteration 1 never reads Imat (:157: k > 1 only)
-  const double* im = with_imat ? (s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0) : nullptr;
-  const size_t stride = s->imat_valid ? (size_t)n * n : 0;
+  // iteration 1 never reads Imat (:157: k > 1 only); later the ancestor-weight factorisation of this step has just
+  // stored the matrices of the current generation (own updates included), so the records carry them complete
+  const bool with_imat = sh->k_iter > 0;
+  if (with_imat && !s->imat_valid) { set_error("pack before the ancestor weights of this step"); return RBPF_ERR_STATE; }
+  const double* im = with_imat ? s->d_Imat[s->imat_cur] : nullptr;
+  const size_t stride = (size_t)n * n;
   hipLaunchKernelGGL(pack_info_kernel, dim3(count, with_imat ? 8 : 1), dim3(256), 0, c->stream, n, d, L.ldx, d_idx,
                      s->d_ivec[s->icur], s->d_hld[s->icur], s->d_Hb[s->icur], im, stride, sh->send_rec, sh->recsz,
                      sh->rec_off_I, sh->rec_off_hld, sh->rec_off_Hb, sh->rec_off_Imat);
@@ -1093,7 +1082,8 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   CholArgs ca;
   std::memset(&ca, 0, sizeof(ca));
   ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
-  RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv));
+  RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv, sh->pb.anc_bank));     // plan of the step that made this generation
+  ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
   {
     static bool attr = false;
     if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
@@ -1142,17 +1132,7 @@ int rbpf_shard_smoother_step(rbpf_ctx* c) {
   else { is.ivec_old = s->d_ivec[oc]; is.ivec_old_stride = (size_t)L.ldx; is.hld_old = s->d_hld[oc]; is.hld_old_stride = 1; }
   is.ivec_new = s->d_ivec[nc]; is.hld_new = s->d_hld[nc]; is.qf_new = s->d_qf[nc]; is.Hb_new = s->d_Hb[nc];
   RB_TRY(shard_step_impl(c, nullptr, nullptr, k, xref, &is));
-  if (k > 0 && t > 0) {
-    const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
-    hipLaunchKernelGGL(imat_gather_kernel, dim3(N, (n + kGatherCols - 1) / kGatherCols), dim3(256), 0, c->stream, n, d, L.ldx,
-                       sh->pb.anc_bank, s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0,
-                       s->imat_valid ? (size_t)n * n : (size_t)0, s->d_Hb[oc], s->d_Rinv, s->d_Imat[ni], N, sh->recv_rec,
-                       sh->recsz, sh->rec_off_Imat, sh->rec_off_Hb);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(c->stream));      // recv_rec is rewritten by the next exchange
-    s->imat_cur = ni;
-    s->imat_valid = true;
-  }
+  (void)N; (void)n; (void)d;
   s->icur = nc;
   return RBPF_OK;
 }
