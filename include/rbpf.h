@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 2
+#define RBPF_ABI_VERSION 3
 
 typedef enum {
   RBPF_OK = 0,
@@ -51,7 +51,12 @@ typedef enum {
   RBPF_MODEL_DENSE_MAG_6D = 1,
   /* examples/slam-dense-radio/run_dense2D_withHeading.m: dynModel :75-76, dynResNorm :77,
    * measModel :168.  nNonLin=3 (x,y,heading), ny=1, nw=1, n_odo=3, nLin=m.                    */
-  RBPF_MODEL_DENSE_RADIO_2DH = 2
+  RBPF_MODEL_DENSE_RADIO_2DH = 2,
+  /* examples/slam-sparse-visual: dynModel pfslam.m:81 (xn + dx' + sqrt(dt*Q)*randn, element-wise sqrt), measModel
+   * pfslam.m:82 -> measurement.m:32-84 (1-D pinhole camera, point landmarks), dynResNorm = [] (psslam.m:119).
+   * sparseFeatures = true: per-particle EKF linearisation, NaN in y = not observed (particleFilter.m:127-137,
+   * 165-181).  nNonLin=3 (x,y,heading), ny = m_basis landmarks, nw=3, n_odo=3, nLin = 2*m_basis.              */
+  RBPF_MODEL_SPARSE_VISUAL_2D = 3
 } rbpf_model_kind;
 
 typedef struct {
@@ -60,8 +65,10 @@ typedef struct {
   int32_t dim;           /* input dimension of the basis (3 for dense-mag, 2 for dense-radio)   */
   int32_t use_dyn_res_norm; /* 1: model's dynResNorm handle; 0: additive default                *
                              * (particleSmoother.m:175-177, isempty(dynResNorm))                */
-  const int32_t* NN;     /* [m x dim] column-major index table NN (domain_cartesian_dx.m:36-43) */
+  const int32_t* NN;     /* [m x dim] column-major index table NN (domain_cartesian_dx.m:36-43); NULL for   *
+                          * RBPF_MODEL_SPARSE_VISUAL_2D                                                       */
   double L[3];           /* domain half-widths (domain_cartesian_dx.m:27-29)                    */
+  double cam[3];         /* RBPF_MODEL_SPARSE_VISUAL_2D: f, fp, fw (load_data.m:58-60)          */
 } rbpf_model;
 
 typedef struct {

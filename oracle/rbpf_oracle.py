@@ -383,6 +383,52 @@ class DenseRadioModel:
         return mrdivide_row(r, Lq)
 
 
+@dataclass
+class SparseVisualModel:
+    """examples/slam-sparse-visual closures (pfslam.m:81-82, psslam.m:91-92): 2-D pose (x, y, heading), nLand point
+    landmarks seen by a 1-D pinhole camera (measurement.m:32-84); sparseFeatures = true, dynResNorm = []."""
+    f: float = 1.5            # load_data.m:58-60
+    fp: float = 0.0
+    fw: float = 1.0
+    nLand: int = 20
+    nNonLin: int = 3
+    nw: int = 3
+    sparse: bool = True
+    dynResNorm = None
+
+    @property
+    def ny(self):
+        return self.nLand
+
+    @property
+    def nLin(self):
+        return 2 * self.nLand
+
+    def dynModel(self, xn, dx, dt, Q, z):
+        """pfslam.m:81: xn + dx' + sqrt(dt*Q)*randn(3,1) -- sqrt is ELEMENT-wise."""
+        xn = np.asarray(xn, dtype=np.float64).ravel()
+        dx = np.asarray(dx, dtype=np.float64).ravel()
+        return xn + dx + np.sqrt(dt * np.atleast_2d(Q)) @ np.asarray(z, dtype=np.float64).ravel(), None
+
+    def measModel(self, xn, xl):
+        """measurement([xn(1:3); xl], f, fp, fw, true) (measurement.m:32-84) -> (yhat [nLand], dy [nLand x 2 nLand])."""
+        xn = np.asarray(xn, dtype=np.float64).ravel()
+        mp = np.asarray(xl, dtype=np.float64).reshape(-1, 2).T           # reshape(x(4:end),2,[])  (:43)
+        p, th = xn[0:2], xn[2]
+        Rm = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])   # :35
+        K = np.array([[self.f, self.fp], [0.0, 1.0]])                    # :46
+        u = K @ np.hstack((Rm.T, (-Rm.T @ p)[:, None])) @ np.vstack((mp, np.ones((1, mp.shape[1]))))   # :49
+        y = u[0] / u[1]                                                  # :52
+        div = (mp[1] * math.cos(th) - p[1] * math.cos(th) - mp[0] * math.sin(th) + p[0] * math.sin(th)) ** 2   # :61
+        dym1 = (self.f * (mp[1] - p[1])) / div                           # :74
+        dym2 = -(self.f * (mp[0] - p[0])) / div                          # :77
+        dy = np.zeros((mp.shape[1], 2 * mp.shape[1]))
+        idx = np.arange(mp.shape[1])
+        dy[idx, 2 * idx] = dym1                                          # :80
+        dy[idx, 2 * idx + 1] = dym2                                      # :81
+        return y, dy                                                     # onlyLin (:84-86)
+
+
 def mrdivide_row(r, Lq):
     """MATLAB `r' / Lq` for a row vector: solve x*Lq = r'  <=>  Lq' x' = r."""
     return np.linalg.solve(Lq.T, np.asarray(r, dtype=np.float64).ravel())
@@ -474,6 +520,38 @@ def _kalman_update(yt, dyt, xl_i, P_i, R, jitter):
     return xl_i + K @ e, P_i - K @ SS @ K.T, yhat, cS
 
 
+def _sparse_innovation(model, yt, xn_i, xl_i, P_i, R):
+    """particleFilter.m:129-137: EKF linearisation, innovation and its covariance restricted to the observed outputs."""
+    yhat, dy = model.measModel(xn_i, xl_i)
+    e = yt - yhat
+    SS = dy @ P_i @ dy.T + R
+    ind = ~np.isnan(yt)
+    return e[ind], SS[np.ix_(ind, ind)], dy, ind, yhat
+
+
+def _sparse_logw(model, yt, xn_i, xl_i, P_i, R, jitter):
+    """particleFilter.m:129-150 (sparse branch)."""
+    e, SS, _, _, _ = _sparse_innovation(model, yt, xn_i, xl_i, P_i, R)
+    if e.size == 0:
+        return 0.0
+    cS = _chol_lower_with_jitter(SS, jitter)
+    v = np.linalg.solve(cS, e)
+    return -np.sum(np.log(np.diag(cS))) - 0.5 * (v @ v) - 0.5 * e.size * LOG2PI
+
+
+def _sparse_update(model, yt, xn_i, xl_i, P_i, R, jitter):
+    """particleFilter.m:165-181,197-198 (sparse branch)."""
+    e, SS, dy, ind, yhat = _sparse_innovation(model, yt, xn_i, xl_i, P_i, R)
+    if e.size == 0:
+        return xl_i.copy(), P_i.copy(), yhat
+    cS = _chol_lower_with_jitter(SS, jitter)
+    dyo = dy[ind, :]
+    M = np.linalg.solve(cS, dyo).T                                   # dy(ind,:)'/cS'
+    M = np.linalg.solve(cS.T, M.T).T                                 # (.)/cS
+    K = P_i @ M
+    return xl_i + K @ e, P_i - K @ SS @ K.T, yhat
+
+
 def _normalise(logw):
     """particleFilter.m:154-156."""
     c = np.max(logw)
@@ -486,14 +564,13 @@ def _normalise(logw):
 # --------------------------------------------------------------------------------------
 def particleFilter(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng: ReplayRNG,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, trace=False):
-    """src/particleFilter.m:1-234 for the dense (sparseFeatures=false) branch.
+    """src/particleFilter.m:1-234 (dense branch, and the sparseFeatures EKF branch :127-137,165-181 for models
+    whose measModel(xn_i, xl_i) returns (yhat, dy)).
 
     `model` supplies dynModel / measModel (the reference passes them as handles).
     Returns a dict with the 8 reference outputs (same shapes) and, if trace, per-step
     `ai` [T x N] (0-based, row 0 unused), `logw`, `w` [T x N] and final `xl`, `P`.
     """
-    if sparseFeatures:
-        raise NotImplementedError("sparseFeatures branch: SURVEY 8(f2), not on the hot path")
     y = np.atleast_2d(np.asarray(y, dtype=np.float64))
     odometry = np.atleast_2d(np.asarray(odometry, dtype=np.float64))
     x0_nonLin = np.asarray(x0_nonLin, dtype=np.float64).ravel()
@@ -536,9 +613,13 @@ def particleFilter(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
             xn_traj[:, :, t] = xn                                  # :117
             xn_traj[:, :, :t] = xn_traj[:, ai, :t]                 # :118
         yt = y[t, :]                                               # :122
-        dy = model.measModel(xn)                                   # :124
+        if not sparseFeatures:
+            dy = model.measModel(xn)                               # :124
         for i in range(N_P):                                       # :126-151
-            logw[i] = _importance_logw(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
+            if sparseFeatures:
+                logw[i] = _sparse_logw(model, yt, xn[:, i], xl[:, i], P[:, :, i], R, jitter)
+            else:
+                logw[i] = _importance_logw(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
         w = _normalise(logw)                                       # :154-156
         iw_max = int(np.argmax(w))                                 # :159 (first maximum)
         traj_max[:, t] = xn[:, iw_max]                             # :160
@@ -550,7 +631,10 @@ def particleFilter(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
         xl = xl.copy()
         P = P.copy()
         for i in range(N_P):                                       # :164-204
-            xl[:, i], P[:, :, i], yhat, _ = _kalman_update(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
+            if sparseFeatures:
+                xl[:, i], P[:, :, i], yhat = _sparse_update(model, yt, xn[:, i], xl[:, i], P[:, :, i], R, jitter)
+            else:
+                xl[:, i], P[:, :, i], yhat, _ = _kalman_update(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
             if i == iw_max:
                 yhattraj[:, t] = yhat                              # :201-203
         if makePlots is not None:                                  # :215-217
@@ -587,9 +671,7 @@ def _default_dyn_res_norm(xnkt, xni, odo, dt, Q):
 def particleSmoother(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt, rng: ReplayRNG,
                      sparseFeatures=False, makePlots: Optional[Callable] = None,
                      use_dynResNorm=True, trace=False):
-    """src/particleSmoother.m:1-367 (dense branch)."""
-    if sparseFeatures:
-        raise NotImplementedError("sparseFeatures branch: SURVEY 8(f2)")
+    """src/particleSmoother.m:1-367 (dense branch, and the sparseFeatures branch :194-217,267-277,306-321)."""
     y = np.atleast_2d(np.asarray(y, dtype=np.float64))
     odometry = np.atleast_2d(np.asarray(odometry, dtype=np.float64))
     x0_nonLin = np.asarray(x0_nonLin, dtype=np.float64).ravel()
@@ -626,7 +708,7 @@ def particleSmoother(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N
         if k != 0:
             xn_traj[:, N_P - 1, :] = xnk                           # :112
         xn_traj[:, :, 0] = xn                                      # :116
-        if k != 0:
+        if k != 0 and not sparseFeatures:
             dy_xnk = model.measModel(xnk)                          # :120  [T x ny x n] or [T x n]
 
         for t in range(N_T):                                       # :124
@@ -649,23 +731,45 @@ def particleSmoother(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N
                     P_pred[:, :, i] = P[:, :, ai[i]]
                 else:
                     paNtLog = np.zeros(N_P)                        # :159
-                    dyf = dy_xnk[t:N_T]                            # :163
-                    if dyf.ndim == 3:                              # :164-166 -> [(ny*(T-t)) x n], time-major
-                        dyf = dyf.reshape(ny * (N_T - t), nLin)
                     xnkt = xnk[:, t]                               # :170
-                    ytf = y[t:, :].reshape(ny * (N_T - t))         # :192
-                    Rbig = np.kron(np.eye(N_T - t), R)             # :191
+                    if not sparseFeatures:
+                        dyf = dy_xnk[t:N_T]                        # :163
+                        if dyf.ndim == 3:                          # :164-166 -> [(ny*(T-t)) x n], time-major
+                            dyf = dyf.reshape(ny * (N_T - t), nLin)
+                        ytf = y[t:, :].reshape(ny * (N_T - t))     # :192
+                        Rbig = np.kron(np.eye(N_T - t), R)         # :191
                     for i in range(N_P):                           # :171-233
                         if dyn_res is None:
                             eDyn = _default_dyn_res_norm(xnkt, xn[:, i], odometry[t - 1, :], dt[t - 1], Q[:, :, t - 1])
                         else:
                             eDyn = dyn_res(xnkt, xn[:, i], odometry[t - 1, :], dt[t - 1], Q[:, :, t - 1])
                         logwDyn = -0.5 * float(eDyn @ eDyn)         # :182
-                        SS = dyf @ P[:, :, i] @ dyf.T + Rbig       # :191
-                        e = ytf - dyf @ xl[:, i]                   # :193
-                        cS = _chol_lower_with_jitter(SS, jitter)   # :221-224
-                        v = np.linalg.solve(cS, e)
-                        logwMeas = -np.sum(np.log(np.diag(cS))) - 0.5 * (v @ v) - e.size / 2.0 * LOG2PI  # :229
+                        if not sparseFeatures:
+                            SS = dyf @ P[:, :, i] @ dyf.T + Rbig   # :191
+                            e = ytf - dyf @ xl[:, i]               # :193
+                        else:                                      # :194-217: future observations, linearised at xl_i
+                            es, dys, inds = [], [], []
+                            for ti in range(t, N_T):
+                                yti = y[ti, :]
+                                ind = ~np.isnan(yti)
+                                yhat_i, dyi = model.measModel(xnk[:, ti], xl[:, i])
+                                es.append((yti - yhat_i)[ind])
+                                dys.append(dyi[ind, :])
+                                inds.append(np.nonzero(ind)[0])
+                            e = np.concatenate(es)
+                            dyf = np.vstack(dys)
+                            RS = np.zeros((e.size, e.size))
+                            o = 0
+                            for idx in inds:                       # blkdiag(RS, R(ind,ind))  (:211)
+                                RS[o:o + idx.size, o:o + idx.size] = R[np.ix_(idx, idx)]
+                                o += idx.size
+                            SS = dyf @ P[:, :, i] @ dyf.T + RS     # :215
+                        if e.size:
+                            cS = _chol_lower_with_jitter(SS, jitter)   # :221-224
+                            v = np.linalg.solve(cS, e)
+                            logwMeas = -np.sum(np.log(np.diag(cS))) - 0.5 * (v @ v) - e.size / 2.0 * LOG2PI  # :229
+                        else:
+                            logwMeas = 0.0
                         paNtLog[i] = math.log(w[i]) + logwDyn + logwMeas if w[i] > 0 else -np.inf   # :232
                     paNt = _normalise(paNtLog)                     # :236-238
                     if trace:
@@ -680,16 +784,23 @@ def particleSmoother(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N
                 xn_traj[:, :, :t] = xn_traj[:, ai, :t]             # :257
 
             yt = y[t, :]
-            dy = model.measModel(xn)                               # :264
+            if not sparseFeatures:
+                dy = model.measModel(xn)                           # :264
             for i in range(N_P):                                   # :266-294
-                logw[i] = _importance_logw(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
+                if sparseFeatures:
+                    logw[i] = _sparse_logw(model, yt, xn[:, i], xl[:, i], P[:, :, i], R, jitter)
+                else:
+                    logw[i] = _importance_logw(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
             w = _normalise(logw)                                   # :300-302
             if trace:
                 tr["ai"][k, t] = ai
                 tr["logw"][k, t] = logw
                 tr["w"][k, t] = w
             for i in range(N_P):                                   # :305-340
-                xl[:, i], P[:, :, i], _, _ = _kalman_update(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
+                if sparseFeatures:
+                    xl[:, i], P[:, :, i], _ = _sparse_update(model, yt, xn[:, i], xl[:, i], P[:, :, i], R, jitter)
+                else:
+                    xl[:, i], P[:, :, i], _, _ = _kalman_update(yt, _dy_of(dy, i), xl[:, i], P[:, :, i], R, jitter)
 
         ak = sample(w, rng.Ufin[k])                                # :346
         xnk = xn_traj[:, ak, :].copy()                             # :347

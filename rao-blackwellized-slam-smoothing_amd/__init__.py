@@ -11,7 +11,7 @@ from ._ffi import (RBPFError, load_library, EXPORTS,                  # noqa: F4
                    RBPF_OK, RBPF_ERR_INVALID_ARG, RBPF_ERR_UNSUPPORTED, RBPF_ERR_HIP, RBPF_ERR_NO_DEVICE,
                    RBPF_ERR_OUT_OF_MEMORY, RBPF_ERR_CHOL_FAILED, RBPF_ERR_STATE)
 from .host import (particleFilter, particleSmoother, particleSmootherInformationForm,   # noqa: F401
-                   DenseMagModel, DenseRadioModel, dense_mag_prior, dense_radio_prior,
+                   DenseMagModel, DenseRadioModel, SparseVisualModel, dense_mag_prior, dense_radio_prior,
                    domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample)
 
 

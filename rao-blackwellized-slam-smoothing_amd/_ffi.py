@@ -20,13 +20,14 @@ RBPF_ERR_STATE = 7
 
 RBPF_MODEL_DENSE_MAG_6D = 1
 RBPF_MODEL_DENSE_RADIO_2DH = 2
+RBPF_MODEL_SPARSE_VISUAL_2D = 3
 RBPF_RNG_REPLAY = 0
 RBPF_RNG_PHILOX = 1
 
 
 class rbpf_model(C.Structure):
     _fields_ = [("kind", C.c_int32), ("m_basis", C.c_int32), ("dim", C.c_int32), ("use_dyn_res_norm", C.c_int32),
-                ("NN", c_int32_p), ("L", C.c_double * 3)]
+                ("NN", c_int32_p), ("L", C.c_double * 3), ("cam", C.c_double * 3)]
 
 
 class rbpf_problem(C.Structure):

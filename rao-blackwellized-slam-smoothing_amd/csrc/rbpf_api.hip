@@ -5,6 +5,7 @@
 #include "../../include/rbpf.h"
 #include "rbpf_internal.hpp"
 #include "rbpf_ctx.hpp"
+#include "rbpf_sparse.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -61,6 +62,8 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
     bool ok = true;
     if (model->kind == RBPF_MODEL_DENSE_MAG_6D) {
       ok = chol_lower_host(A.data(), 3, nw, Lb, nw) && chol_lower_host(A.data() + 3 + 3 * nw, 3, nw, Lb + 3 + 3 * nw, nw);
+    } else if (model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
+      for (int q = 0; q < nw * nw; ++q) Lb[q] = std::sqrt(A[q]);         // sqrt(dt*Q), element-wise (pfslam.m:81)
     } else {
       ok = chol_lower_host(A.data(), nw, nw, Lb, nw);
     }
@@ -75,7 +78,7 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
 
 int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
                    ModelDev& M, std::vector<int>& nn_axis_major) {
-  if (!model || !model->NN) { set_error("model / model->NN is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (!model || (!model->NN && model->kind != RBPF_MODEL_SPARSE_VISUAL_2D)) { set_error("model / model->NN is NULL"); return RBPF_ERR_INVALID_ARG; }
   std::memset(&M, 0, sizeof(M));
   M.kind = model->kind;
   M.m = model->m_basis;
@@ -92,6 +95,18 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
       set_error("dense-radio-2D+heading expects dim=2, nNonLin=3, ny=1, nw=1, n_odo=3, nLin=m");
       return RBPF_ERR_INVALID_ARG;
     }
+  } else if (model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
+    if (nN != 3 || nw != 3 || nodo != 3 || d != model->m_basis || n != 2 * model->m_basis || d < 1 || d > 32) {
+      set_error("sparse-visual-2D expects nNonLin=3, nw=3, n_odo=3, ny = landmarks <= 32, nLin = 2*landmarks");
+      return RBPF_ERR_INVALID_ARG;
+    }
+    for (int q = 0; q < 3; ++q) M.cam[q] = model->cam[q];
+    if (!(M.cam[0] != 0.0)) { set_error("sparse-visual-2D: focal length cam[0] must be non-zero"); return RBPF_ERR_INVALID_ARG; }
+    M.dim = 2;
+    M.jitter = jitter;
+    M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
+    nn_axis_major.clear();
+    return RBPF_OK;                       // R lives in device memory (ModelDev::Rdev, set by ctx_create)
   } else {
     set_error("unknown model family");
     return RBPF_ERR_UNSUPPORTED;
@@ -183,7 +198,11 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   RB_TRY(fill_model_dev(model, prob->n_nonlin, prob->n_lin, prob->n_y, prob->n_w, prob->n_odo, prob->R, jitter, c->mdl, nn));
   c->lay = make_layout(prob->n_lin, prob->n_y);
   c->lay_low = make_layout_low_regs(prob->n_lin, prob->n_y);
-  if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
+  const bool sparse = model->kind == RBPF_MODEL_SPARSE_VISUAL_2D;
+  if (sparse) {
+    if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }
+    if (ex) { set_error("the sparseFeatures branch is not sharded"); return RBPF_ERR_UNSUPPORTED; }
+  } else if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
   c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
   c->bank_cap = (size_t)prob->N_P + (ex ? ex->bank_extra : 0);
   c->rng_slots = (ex && ex->rng_slots) ? ex->rng_slots : (size_t)prob->N_P;
@@ -195,8 +214,13 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
 
   // ---- model / problem constants ----
   RB_TRY(dmalloc(&c->d_NN, nn.size()));
-  HIPCHK(hipMemcpy(c->d_NN, nn.data(), nn.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!nn.empty()) HIPCHK(hipMemcpy(c->d_NN, nn.data(), nn.size() * sizeof(int), hipMemcpyHostToDevice));
   c->mdl.NN = c->d_NN;
+  if (sparse) {
+    RB_TRY(dmalloc(&c->d_R, (size_t)d * d));
+    HIPCHK(hipMemcpy(c->d_R, prob->R, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice));
+    c->mdl.Rdev = c->d_R;
+  }
   {
     std::vector<double> yt((size_t)T * d), od((size_t)std::max(T - 1, 1) * nodo, 0.0);
     for (int t = 0; t < T; ++t) for (int k = 0; k < d; ++k) yt[(size_t)t * d + k] = prob->y[t + (size_t)T * k];
@@ -256,7 +280,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     set_error("unknown rng mode"); return RBPF_ERR_INVALID_ARG;
   }
   // ---- particle banks ----
-  c->lazy_depth = (!smoother && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
+  c->lazy_depth = (!smoother && !sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     const bool can = !smoother && !ex && c->lazy_depth >= 2;
@@ -346,6 +370,7 @@ void ctx_free(rbpf_ctx* c) {
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+  hipFree(c->d_R);
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
@@ -386,6 +411,42 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + (c->opt.trace ? (size_t)(t - 1) * N : 0); s.wc_exact = c->wc;
     HIPCHK(launch_search(s, c->stream));
     HIPCHK(launch_resample_fixup(s, c->stream));
+  }
+  if (c->mdl.kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
+    // sparseFeatures branch: one small kernel does gather, dynModel, EKF weight and update (rbpf_sparse.hip);
+    // the update is applied at once, so the pending-factor banks stay zero
+    if (info) { set_error("This code has only been implemented for dense features"); return RBPF_ERR_UNSUPPORTED; }
+    const int ob = c->cur, nb = (t == 0) ? 0 : (c->cur ^ 1);
+    SparseStepArgs sa;
+    sa.N = N; sa.t = t; sa.n = c->mdl.n; sa.d = d; sa.nN = nN; sa.nw = nw; sa.ldx = L.ldx; sa.ldb = L.ldb; sa.propagate = (t > 0);
+    sa.szB = L.szB; sa.f = c->mdl.cam[0]; sa.fp = c->mdl.cam[1];
+    sa.ai = (t > 0) ? A_t : nullptr;
+    sa.xn_old = X_old; sa.xn_old_stride = (size_t)N; sa.xn_new = X_new; sa.xn_new_stride = (size_t)N;
+    if (t == 0) {
+      sa.xl_old = c->d_x0l; sa.xl_old_stride = (c->x0_lin_cols > 1) ? (size_t)L.ldx : 0;
+      sa.Pb_old = c->d_P0b; sa.Pb_old_stride = 0;
+    } else {
+      sa.xl_old = c->xl[ob]; sa.xl_old_stride = (size_t)L.ldx;
+      sa.Pb_old = c->Pb[ob]; sa.Pb_old_stride = L.szB;
+    }
+    sa.xl_new = c->xl[nb]; sa.Pb_new = c->Pb[nb];
+    sa.y = c->d_y + (size_t)t * d; sa.R = c->d_R;
+    sa.odo = c->d_odo + (size_t)(t > 0 ? t - 1 : 0) * c->mdl.nodo;
+    sa.Ssqrt = c->d_cholQ + (size_t)((c->chol_pages > 1 && t > 0) ? t - 1 : 0) * nw * nw;
+    sa.rng_mode = c->rng_mode; sa.k_iter = k_iter; sa.seed = c->seed;
+    sa.Z = (c->d_Z && t > 0) ? c->d_Z + (rng_page + (size_t)(t - 1) * N) * nw : nullptr;
+    sa.xref = xref_t; sa.jitter = c->mdl.jitter; sa.logw = c->logw + tr; sa.status = c->d_flags;
+    HIPCHK(launch_sparse_step(sa, c->stream));
+    NormArgs nm;
+    nm.N = N; nm.nN = nN; nm.t = t; nm.logw = c->logw + tr; nm.w = c->w + tr; nm.wc = c->wc; nm.xn = X_new;
+    nm.traj_max = c->traj_max + (size_t)t * nN; nm.traj_mean = c->traj_mean + (size_t)t * nN;
+    nm.iw_max = c->d_flags + 2; nm.lse_out = nullptr;
+    nm.parallel_scan = 1;
+    if (N > kSingleWgResampleMaxN) HIPCHK(launch_resample_pipeline(nm, nullptr, nullptr, nullptr, nullptr, c->d_rs, c->stream));
+    else HIPCHK(launch_normalise_scan(nm, c->stream));
+    c->cur = nb; c->xcur = nb;
+    c->t = t + 1;
+    return RBPF_OK;
   }
   StepArgs a;
   a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);

@@ -55,6 +55,7 @@ struct rbpf_ctx {
   int* d_NN = nullptr;
   double *d_y = nullptr, *d_odo = nullptr, *d_cholQ = nullptr, *d_cholQfull = nullptr;
   double *d_x0l = nullptr, *d_P0t = nullptr, *d_P0b = nullptr;
+  double* d_R = nullptr;    // sparse-visual family: R [d x d]
   double *d_U = nullptr, *d_Z = nullptr;
   std::vector<double> h_x0n, h_P0, h_x0l, h_R, h_y, h_Ufin;
   // particle banks (ping-pong)

@@ -28,6 +28,8 @@ struct ModelDev {
   int use_dyn_res_norm;
   double Rinv[9];      // inv(R), d x d column-major
   double halfLogDetR;  // 0.5*log(det(R))
+  double cam[3];       // sparse-visual family: f, fp, fw
+  const double* Rdev;  // sparse-visual family: full R [d x d] in device memory (d may exceed 3)
 };
 
 // HBM layout of one particle's covariance ("bank" entry).  Natural state order is kept for the

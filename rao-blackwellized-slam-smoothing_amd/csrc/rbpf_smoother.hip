@@ -9,6 +9,7 @@
 #include "rbpf_ctx.hpp"
 #include "rbpf_device.hpp"
 #include "rbpf_shard_state.hpp"
+#include "rbpf_sparse.hpp"
 
 #include <cmath>
 #include <cstring>
@@ -203,6 +204,7 @@ struct CholArgs {
   double* Lbuf; long ldL;           // [batch][Msz*Msz] column-major factors
   // mode 0
   const double* S; const double* R; const double* yf; const double* dyf; const double* xl; double jitter;
+  const double* rhs;                // mode 0, sparse branch: innovation given directly [batch][Msz]; R == null: S complete
   // mode 1
   const double* Imat; long imat_stride; const double* Hb; const double* Rinv; const double* ImatAdd; const double* ivec;
   const double* ivecAdd; const double* qf; const double* hld;
@@ -307,11 +309,13 @@ __device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, i
     const int di = dv[ic];
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = a.S[(size_t)p * M * M + (size_t)ic + (size_t)M * jc[q]];
+    if (a.R) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int dj = dv[jc[q]];
-      const double rr = a.R[(di & 7) + a.d * (dj & 7)];                      // kron(eye, R)
-      v[q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
+      for (int q = 0; q < 4; ++q) {
+        const int dj = dv[jc[q]];
+        const double rr = a.R[(di & 7) + a.d * (dj & 7)];                    // kron(eye, R)
+        v[q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
+      }
     }
   } else {
     double ad[4];
@@ -402,7 +406,9 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
 #endif
   for (int i = tid; i < M; i += kCholThreads) {
     double r;
-    if (a.mode == 0) {
+    if (a.mode == 0 && a.rhs) {
+      r = a.rhs[(size_t)p * M + i];                                         // particleSmoother.m:207-208 (sparse branch)
+    } else if (a.mode == 0) {
       double s = 0.0;
       const double* dr = a.dyf + (size_t)i * a.n;
       const double* x = a.xl + (size_t)p * a.ldx;
@@ -724,7 +730,32 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   HIPCHK(hipMemcpy(d_R, Rh.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
 
-  if (!info_form) {
+  const bool sparse = c->mdl.kind == RBPF_MODEL_SPARSE_VISUAL_2D;
+  std::vector<int> pair_t, pair_j, pair_off((size_t)T + 1, 0);
+  int *d_pair_t = nullptr, *d_pair_j = nullptr;
+  struct PairGuard { int** a; int** b; ~PairGuard() { hipFree(*a); hipFree(*b); } } pair_guard{&d_pair_t, &d_pair_j};
+  if (sparse) {
+    if (info_form) { set_error("This code has only been implemented for dense features"); return RBPF_ERR_UNSUPPORTED; }   // InformationForm.m:77-80
+    // observed (time, output) pairs, time-major: the future observations of step t are the suffix from pair_off[t]
+    for (int ti = 0; ti < T; ++ti) {
+      pair_off[ti] = (int)pair_t.size();
+      for (int j = 0; j < d; ++j)
+        if (!std::isnan(c->h_y[ti + (size_t)T * j])) { pair_t.push_back(ti); pair_j.push_back(j); }
+    }
+    pair_off[T] = (int)pair_t.size();
+    const size_t Ms = (T > 1) ? (size_t)(pair_off[T] - pair_off[1]) : 0;
+    if (Ms > 1023) { set_error("sparse smoother: more than 1023 future observations (particleSmoother.m:197-212 stacks them all)"); return RBPF_ERR_UNSUPPORTED; }
+    s->Mmax = Ms;
+    RB_TRY(dmalloc(&d_pair_t, pair_t.size()));
+    RB_TRY(dmalloc(&d_pair_j, pair_j.size()));
+    if (!pair_t.empty()) {
+      HIPCHK(hipMemcpy(d_pair_t, pair_t.data(), pair_t.size() * sizeof(int), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d_pair_j, pair_j.data(), pair_j.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
+    RB_TRY(dmalloc(&s->d_S, (size_t)N * Ms * Ms));
+    RB_TRY(dmalloc(&s->d_e, (size_t)N * Ms));
+    RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles((int)Ms)));
+  } else if (!info_form) {
     RB_TRY(dmalloc(&s->d_Pfull, (size_t)N * n * n));
     RB_TRY(dmalloc(&s->d_G, (size_t)N * Mmax * n));
     RB_TRY(dmalloc(&s->d_S, (size_t)N * Mmax * Mmax));
@@ -768,7 +799,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     if (info_form) {
       RB_TRY(info_begin_iteration(c, ivec0.data(), hld0, qf0, halfLogDetR, d_Rinv));
     }
-    if (k > 0) {
+    if (k > 0 && !sparse) {
       // dy_xnk = measModel(xnk)  (:120)
       HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, st, 1));
       if (info_form) {                                                       // :132-146
@@ -796,7 +827,18 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         CholArgs ca;
         std::memset(&ca, 0, sizeof(ca));
         ca.d = d; ca.n = n; ca.ldx = L.ldx; ca.pant_log = s->d_pant_log; ca.status = c->d_flags;
-        if (!info_form) {
+        bool skip_chol = false;
+        if (sparse) {
+          const int M = pair_off[T] - pair_off[t];
+          skip_chol = (M == 0);                                            // no future observation: logwMeas = 0
+          SparseAncArgs aa;
+          aa.n = n; aa.d = d; aa.nN = nN; aa.ldx = L.ldx; aa.ldb = L.ldb; aa.M = M; aa.off = pair_off[t]; aa.szB = L.szB;
+          aa.f = c->mdl.cam[0]; aa.fp = c->mdl.cam[1]; aa.pair_t = d_pair_t; aa.pair_j = d_pair_j; aa.xnk = s->d_xnk;
+          aa.y = c->d_y; aa.xl = c->xl[cur]; aa.Pb = c->Pb[cur]; aa.R = c->d_R; aa.rhs = s->d_e; aa.S = s->d_S;
+          HIPCHK(launch_sparse_anc(aa, N, st));
+          ca.mode = 0; ca.Msz = M; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(M);
+          ca.S = s->d_S; ca.R = nullptr; ca.rhs = s->d_e; ca.jitter = c->mdl.jitter;
+        } else if (!info_form) {
           const int M = d * (T - t);
           HIPCHK(launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], nullptr, N, s->d_Pfull, st));
           const double* dyf = s->d_dyref + (size_t)t * d * n;              // [(T-t)*d x n] row-major (:163-166)
@@ -814,7 +856,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           HIPCHK(hipGetLastError());
           RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
         }
-        {
+        if (!skip_chol) {
           static bool attr = false;
           if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
           hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(kCholThreads), chol_lds_bytes(ca.Msz, ca.mode == 1 ? d : 0), st, ca);

@@ -171,3 +171,31 @@ def planar_heading(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=4, traj="line_3D")
         th[i] = th[i - 1] + dx[i - 1, 2] + math.sqrt(h * q) * zo[i - 1]
     dxn = np.hstack((dx[:, 0:2], np.diff(th)[:, None]))                    # :319
     return dict(dx=dxn, initState=initState, y=y.reshape(-1, 1), LL=LL, pos=pos)
+
+
+def sparse_visual_load(mat_path, seed=42, posVar=0.04 ** 2, posBias=0.01, angleVar=(0.001 ** 2) ** 2, obsStd=0.01,
+                       guessMapVar=1.0, initMapVar=4.0 ** 2, noiseVar=0.1 ** 2, N_P=100, N_T=None):
+    """examples/slam-sparse-visual/load_data.m:55-89 + the problem set-up of pfslam.m:84-94 on the reference's data file
+    `curve-x2.mat` (the only data fixture the reference ships): noisy odometry u from the true path, noisy observations
+    Y = Yclean + 0.01*randn (NaN = landmark not in view), per-particle initial maps, priors and noise covariances.
+    MATLAB's randn stream is replaced by a seeded numpy stream.  N_T: use only the first N_T steps.
+    -> dict(model args for particleFilter / particleSmoother, plus ground truth)."""
+    import scipy.io as sio
+    d = sio.loadmat(mat_path)
+    rs = np.random.RandomState(seed)
+    p, th, mp = d["p"], d["th"].ravel(), d["map"]
+    Yclean = d["Yclean"]
+    T = p.shape[1] if N_T is None else int(N_T)
+    p, th, Yclean = p[:, :T], th[:T], Yclean[:, :T]
+    dPos = np.diff(p, axis=1)                                                 # :71
+    dTheta = np.diff(np.unwrap(th))                                           # :72
+    u = np.vstack((dPos, dTheta[None, :])).T                                  # :75
+    u[:, 0:2] = u[:, 0:2] + math.sqrt(posVar) * rs.standard_normal((T - 1, 2)) + posBias    # :78
+    u[:, 2] = u[:, 2] + math.sqrt(angleVar) * rs.standard_normal(T - 1)       # :79
+    Y = Yclean + obsStd * rs.standard_normal(Yclean.shape)                    # :82
+    nLand = mp.shape[1]
+    x0_lin = mp.T.reshape(-1)[:, None] + math.sqrt(guessMapVar) * rs.standard_normal((2 * nLand, N_P))   # pfslam.m:91
+    return dict(odometry=u, y=Y.T, x0_nonLin=np.concatenate((p[:, 0], th[:1])), x0_lin=x0_lin,
+                P0_lin=initMapVar * np.eye(2 * nLand), Q=np.diag([0.1 ** 2, 0.1 ** 2, 0.001 ** 2]),
+                R=noiseVar * np.eye(nLand), dt=1.0, N_P=N_P, nLand=nLand, map=mp, groundTruth=np.vstack((p, th[None, :])),
+                cam=(1.5, 0.0, 1.0))

@@ -175,6 +175,46 @@ class DenseRadioModel(_ModelFamily):
         return self.m
 
 
+class SparseVisualModel(_ModelFamily):
+    """examples/slam-sparse-visual: planar pose (x, y, heading), nLand point landmarks seen by a 1-D pinhole camera.
+    dynModel pfslam.m:81 (xn + dx' + sqrt(dt*Q)*randn, element-wise sqrt), measModel pfslam.m:82 ->
+    measurement.m:32-84 ([yhat, dy] = measModel(xn_i, xl_i)), dynResNorm = [] (psslam.m:118-119).
+    Runs with sparseFeatures=true (per-particle EKF linearisation, NaN in y = not observed)."""
+    kind = _ffi.RBPF_MODEL_SPARSE_VISUAL_2D
+    nNonLin, nw, n_odo, dim = 3, 3, 3, 2
+    sparse = True
+
+    def __init__(self, nLand, f=1.5, fp=0.0, fw=1.0):                         # camera: load_data.m:58-60
+        self.nLand, self.f, self.fp, self.fw = int(nLand), float(f), float(fp), float(fw)
+        self.NN = np.zeros((self.nLand, 2), dtype=np.int32)
+        self.L = np.ones(2)
+        self.dynModel = _Handle(self, "dynModel")
+        self.measModel = _Handle(self, "measModel")
+        self.dynResNorm = None                                                # psslam.m passes []
+
+    @property
+    def m(self):
+        return self.nLand
+
+    @property
+    def ny(self):
+        return self.nLand
+
+    @property
+    def nLin(self):
+        return 2 * self.nLand
+
+    def descriptor(self, use_dyn_res_norm=False):
+        d = _ffi.rbpf_model()
+        d.kind, d.m_basis, d.dim, d.use_dyn_res_norm = self.kind, self.nLand, 2, 0
+        d.NN = None
+        d.cam[0], d.cam[1], d.cam[2] = self.f, self.fp, self.fw
+        return d
+
+    def _evaluate(self, role, *args):
+        raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "the sparse-visual closures are only evaluated inside the estimators")
+
+
 def dense_mag_prior(m, LL, theta):
     """GP prior of run_dense3D_magfield.m:83-107,122-131 -> (model, x0_lin, P0_lin, R)."""
     L, NN = domain_cartesian_dx(m, 3, LL)
@@ -313,6 +353,13 @@ class _Problem:
         self.c = p
 
 
+def _check_sparse_flag(model, sparseFeatures):
+    """sparseFeatures selects the measModel calling convention (particleFilter.m:123-129): it has to match the family."""
+    if bool(sparseFeatures) != bool(getattr(model, "sparse", False)):
+        raise RBPFError(_ffi.RBPF_ERR_INVALID_ARG,
+                        "sparseFeatures=%s does not match the measurement model of %s" % (bool(sparseFeatures), type(model).__name__))
+
+
 def _recognise(dynModel, measModel, dynResNorm=None):
     """Map handles to a model family (the MATLAB wrappers do the same on func2str)."""
     mdl = getattr(dynModel, "model", None)
@@ -337,9 +384,8 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended."""
-    if sparseFeatures:
-        raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "sparseFeatures=true (EKF branch) is not on the device path yet")
     model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
+    _check_sparse_flag(model, sparseFeatures)
     lib = load_library()
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, 1)
@@ -411,8 +457,8 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "This code has only been implemented for dense features")
-        raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "sparseFeatures=true (EKF branch) is not on the device path yet")
     model, use_drn = _recognise(dynModel, measModel, dynResNorm)
+    _check_sparse_flag(model, sparseFeatures)
     lib = load_library()
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     N_K = int(N_K)

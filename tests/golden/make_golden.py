@@ -43,7 +43,19 @@ def save_smoother(name, c, info_form):
                         paNt=tr["paNt"], ak=tr["ak"], XNK=r["XNK"], XLK=r["XLK"], PK=r["PK"])
 
 
+def save_sparse(name, c):
+    """slam-sparse-visual on the reference's data file curve-x2.mat (sparseFeatures branch): filter and smoother."""
+    r = cases.oracle_filter(c)
+    sm = cases.oracle_smoother(c, False)
+    np.savez_compressed(os.path.join(HERE, name), N_P=c["N_P"], N_T=c["y"].shape[0], N_K=c["N_K"], y=c["y"],
+                        odometry=c["odometry"], filter_ai=r["trace"]["ai"], filter_w=r["trace"]["w"],
+                        filter_traj_mean=r["traj_mean"], filter_xl_mean=r["xl_mean"], filter_P_max=r["P_max"],
+                        smoother_ak=sm["trace"]["ak"], smoother_ai=sm["trace"]["ai"], smoother_XNK=sm["XNK"],
+                        smoother_XLK=sm["XLK"])
+
+
 if __name__ == "__main__":
+    save_sparse("sparse_curve_n40.npz", cases.sparse_curve_case(None, 10, 30, N_K=3))
     save_filter("filter_mag_n19.npz", cases.mag_case(8, 8, 16, seed=31))
     save_filter("filter_mag_n133.npz", cases.mag_case(6, 6, 130, seed=32))
     save_filter("filter_radio_n32.npz", cases.radio_case(12, 10, 32, seed=33))

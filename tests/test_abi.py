@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rbpf):
     lib = rbpf.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rbpf_abi_version() == 2
+    assert lib.rbpf_abi_version() == 3
     assert lib.rbpf_status_string(0) == b"ok"
     assert b"positive definite" in lib.rbpf_status_string(rbpf.RBPF_ERR_CHOL_FAILED)
 
@@ -111,3 +111,20 @@ def test_replay_rng_shape_validation(rbpf):
     with pytest.raises(ValueError):
         rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
                             c["N_P"], c["dt"], rng=bad)
+
+
+def test_procrustes_recovers_a_similarity_transform(rbpf):
+    """metrics.procrustes (MATLAB `procrustes`, used by calc_rmses.m:37) recovers scale, rotation and translation."""
+    import importlib
+    mt = importlib.import_module(rbpf.__name__ + ".metrics")
+    rs = np.random.RandomState(0)
+    Y = rs.standard_normal((20, 2))
+    th = 0.7
+    T = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    X = 1.7 * Y @ T + np.array([3.0, -2.0])
+    d, Z, tr = mt.procrustes(X, Y)
+    assert d < 1e-12 and abs(tr["b"] - 1.7) < 1e-12
+    np.testing.assert_allclose(Z, X, atol=1e-12)
+    np.testing.assert_allclose(tr["T"], T, atol=1e-12)
+    rp, rm = mt.calc_rmses(X, Y, X[:5], Y[:5])
+    assert rp < 1e-12 and rm < 1e-12
