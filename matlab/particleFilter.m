@@ -7,8 +7,10 @@ function [traj_max,traj_mean,xl_max,xl_mean,P_max,P_mean,traj_sample_iwmax,xn_tr
 % rng(s,'twister') reproduces the reference run.  UNTESTED here: no MATLAB in the build image.
   if nargin < 12 || isempty(sparseFeatures), sparseFeatures = false; end
   if nargin < 13, makePlots = []; end %#ok<NASGU>
-  if sparseFeatures, error('rbpf:unsupported', 'sparseFeatures branch is not on the device path yet'); end
   desc = rbpf_descriptor(dynModel, measModel);
+  if logical(sparseFeatures) ~= (desc.kind == 3)
+    error('rbpf:usage', 'sparseFeatures must be true for (and only for) the sparse-visual family');
+  end
   N_T = size(y,1); nw = size(Q,1);
   U = zeros(N_P, max(N_T-1,0)); Z = zeros(nw, N_P, max(N_T-1,0));
   for t = 1:N_T-1

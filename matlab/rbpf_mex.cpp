@@ -24,6 +24,14 @@ static rbpf_model model_from(const mxArray* d, std::vector<int32_t>& nn) {
   rbpf_model m;
   std::memset(&m, 0, sizeof(m));
   m.kind = (int32_t)mxGetScalar(mxGetField(d, 0, "kind"));
+  if (m.kind == RBPF_MODEL_SPARSE_VISUAL_2D) {                 // examples/slam-sparse-visual: camera f, fp, fw
+    m.m_basis = (int32_t)mxGetScalar(mxGetField(d, 0, "nLand"));
+    m.dim = 2;
+    const double* cam = mxGetPr(mxGetField(d, 0, "cam"));
+    for (int a = 0; a < 3; ++a) m.cam[a] = cam[a];
+    m.use_dyn_res_norm = 0;                                    // psslam.m passes dynResNorm = []
+    return m;
+  }
   const mxArray* NN = mxGetField(d, 0, "NN");
   m.m_basis = (int32_t)mxGetM(NN);
   m.dim = (int32_t)mxGetN(NN);

@@ -1,8 +1,10 @@
 function [XNK,XLK,PK] = rbpf_smoother_common(info_form, dynModel,measModel,dynResNorm,odometry,y,x0_nonLin,x0_lin,P0_lin,Q,R,N_P,N_K,dt,sparse)
 % Shared marshalling of the two smoother wrappers.  UNTESTED here: no MATLAB in the build image.
-  if sparse, error('rbpf:unsupported', 'sparseFeatures branch is not on the device path yet'); end
   f = functions(dynModel);
   desc = f.workspace{1}.rbpf_desc;
+  if logical(sparse) ~= (desc.kind == 3)
+    error('rbpf:usage', 'sparseFeatures must be true for (and only for) the sparse-visual family');
+  end
   desc.use_dyn_res_norm = ~isempty(dynResNorm);
   N_T = size(y,1); nw = size(Q,1);
   U = zeros(N_P, max(N_T-1,0), N_K); Z = zeros(nw, N_P, max(N_T-1,0), N_K); Ufin = zeros(N_K,1);
