@@ -11,7 +11,9 @@
 #include "rbpf_shard_state.hpp"
 #include "rbpf_sparse.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -235,7 +237,7 @@ struct CholArgs {
 //      that product (k = 4 s + (l >> 4) is register s), so it is 4 more MFMAs per tile with no data movement;
 //      X' leaves in fragment order with one coalesced store per register.
 // The triangular solve uses the explicit inverse of the 16 x 16 diagonal tile (error ~ eps * cond of that tile).
-constexpr int kCholThreads = 1024;               // 16 waves; M + 1 <= 1024 rows -> <= 64 row tiles, <= 4 per wave
+constexpr int kCholThreads = 1024;               // at most 16 waves; M + 1 <= 1024 rows -> <= 64 row tiles, <= 4 per wave
 typedef double v4d __attribute__((ext_vector_type(4)));
 #ifdef RBPF_CHOL_STAMPS                          // tuning aid: per-phase clocks of workgroup 0, printed from the device
 #define CSTAMP(k) do { __syncthreads(); if (tid == 0) { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } } while (0)
@@ -378,7 +380,12 @@ __device__ inline void sqrt_rsqrt(double x, double& g, double& rinv) {
   rinv = h + h;
 }
 
-__global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in) {
+// W waves per workgroup (4, 8 or 16): the smallest that keeps <= 4 row tiles per wave.  A small matrix then leaves room
+// for several workgroups per CU, whose single-wave diagonal-tile sections and barriers overlap (a 16-wave workgroup owns
+// the whole register file: at n = 128 seven of its waves had no tile and every CU waited on one particle's serial chain).
+template <int W>
+__global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
+  constexpr int kThreadsW = W * 64;
   extern __shared__ double csm[];
   CholArgs a = a_in;
   const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
 #ifdef RBPF_CHOL_STAMPS
   long long cst[6] = {0, 0, 0, 0, 0, 0}, clast = clock64();
 #endif
-  for (int i = tid; i < M; i += kCholThreads) {
+  for (int i = tid; i < M; i += kThreadsW) {
     double r;
     if (a.mode == 0 && a.rhs) {
       r = a.rhs[(size_t)p * M + i];                                         // particleSmoother.m:207-208 (sparse branch)
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
       int rt[4], nt = 0;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int t = jt + wv + 16 * s;
+        const int t = jt + wv + W * s;
         rt[s] = min(t, RT - 1);
         nt += (t < RT) ? 1 : 0;
       }
@@ -538,7 +545,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
     if (!failed) {
       // sum(log(diag(cS))) and v'v
       double sl = 0.0, vv = 0.0;
-      for (int j = tid; j < M; j += kCholThreads) {
+      for (int j = tid; j < M; j += kThreadsW) {
         const size_t col = (size_t)(j >> 2) * RT * 64 + (size_t)(j & 3) * 16;
         const double dj = Lt[col + (size_t)(j >> 4) * 64 + (j & 15)];
         const double vj = Lt[col + (size_t)(M >> 4) * 64 + (M & 15)];
@@ -550,7 +557,7 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
       __syncthreads();
       if (tid == 0) {
         sl = 0.0; vv = 0.0;
-        for (int w = 0; w < 16; ++w) { sl += red[w]; vv += red[16 + w]; }
+        for (int w = 0; w < W; ++w) { sl += red[w]; vv += red[16 + w]; }
         double lw;
         if (a.mode == 0) lw = -sl - 0.5 * vv - 0.5 * (double)M * 1.8378770664093453;     // log(2*pi)
         else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
@@ -571,6 +578,30 @@ __global__ __launch_bounds__(kCholThreads) void chol_solve_kernel(CholArgs a_in)
 }
 
 static size_t chol_lds_bytes(int M, int d) { return ((size_t)256 + 256 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double); }
+template <int W>
+static hipError_t launch_chol_w(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(chol_solve_kernel<W>, dim3(batch), dim3(W * 64), lds, st, ca);
+  return hipGetLastError();
+}
+
+// batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0)
+static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
+  static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
+  const int RT = (ca.Msz + 1 + 15) >> 4;
+  int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
+  if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
+  const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
+  if (W == 4) return launch_chol_w<4>(ca, batch, lds, st);
+  if (W == 8) return launch_chol_w<8>(ca, batch, lds, st);
+  return launch_chol_w<16>(ca, batch, lds, st);
+}
+
 static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 1 + 15) / 16); return mp * mp; }
 
 // [T][nN] row-per-step trajectory -> per-step pointer is d_xnk + t*nN.  Backtrace writes [nN x T]
@@ -856,11 +887,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           HIPCHK(hipGetLastError());
           RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
         }
-        if (!skip_chol) {
-          static bool attr = false;
-          if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-          hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(kCholThreads), chol_lds_bytes(ca.Msz, ca.mode == 1 ? d : 0), st, ca);
-        }
+        if (!skip_chol) HIPCHK(launch_chol(ca, N, ca.mode == 1 ? d : 0, st));
         HIPCHK(hipGetLastError());
         // normalise (:236-238), sample ai(N_P) (:241)
         NormArgs nm;
@@ -1126,11 +1153,7 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
   RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv, sh->pb.anc_bank));     // plan of the step that made this generation
   ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
-  {
-    static bool attr = false;
-    if (!attr) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; }
-    hipLaunchKernelGGL(chol_solve_kernel, dim3(N), dim3(kCholThreads), chol_lds_bytes(ca.Msz, d), st, ca);
-  }
+  HIPCHK(launch_chol(ca, N, d, st));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   return RBPF_OK;
