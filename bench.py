@@ -95,6 +95,63 @@ def smoother_wallclock(pkg, datagen):
     return out
 
 
+def smoother_large(pkg, datagen):
+    """Information-form smoother at the large configurations (BASELINE.json configs[2], configs[3]) on one GPU:
+    dense-radio N=65536 (T=48, m=128, N_K=3) complete, and a 24-step run of dense-mag N=8192 (the per-GPU share of
+    N=65536 at 8 GPUs), m=512, N_K=2 (a full T=3000 pass takes 3000 such steps per iteration)."""
+    import numpy as np
+    out = {"unit": "s"}
+    T = 48
+    Qr = datagen.radio_Q(T, "square_3D")
+    th = [0.25, 2.0, 0.01]                                                       # examples/slam-dense-radio/main.m:24
+    d = datagen.planar_heading(T, Qr, th, 1.0, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = pkg.dense_radio_prior(128, d["LL"], th)
+    t0 = time.perf_counter()
+    XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
+                                                    x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3))
+    out["dense_radio_N65536_T48_m128_NK3"] = round(time.perf_counter() - t0, 3)
+    out["dense_radio_finite"] = bool(np.all(np.isfinite(XNK)))
+    Q = q_mag()
+    for T, timed in ((4, False), (24, True)):                                    # the short run only warms the allocator up
+        d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=1)
+        mdl, x0, P0, R = pkg.dense_mag_prior(512, d["LL"], THETA_MAG)
+        t0 = time.perf_counter()
+        pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q,
+                                            R, 8192, 2, 0.01, rng=pkg.PhiloxRNG(3))
+        if timed:
+            out["dense_mag_N8192_T24_m512_NK2"] = round(time.perf_counter() - t0, 3)
+    out["note"] = ("dense-mag N=8192 is the per-GPU share of N=65536 at 8 GPUs; the time includes creating the 87 GB of "
+                   "particle banks; steady state is 6.7 ms (plain step) + 38.5 ms (step with ancestor sampling) per time step, "
+                   "profiles/r01f_smoother_N8192_m512_summary.txt")
+    return out
+
+
+def config2_filter(pkg, datagen, args):
+    """BASELINE.json configs[2], filter part, on this one GPU: N=65536, m=512 (nLin=515), fp64 -- a single covariance
+    bank of 139 GB rewritten in place (rbpf_options.inplace, automatic).  45 timed steps after 6 warm-up steps."""
+    Q = q_mag()
+    T, K, W = 3000, 45, 6
+    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)
+    model, x0_lin, P0, R = pkg.dense_mag_prior(512, data["LL"], THETA_MAG)
+    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, 65536, 0.01,
+                           rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=3, inplace=0) as sess:
+        sess.advance(W)
+        sess.sync()
+        sess.timing(enable=True)
+        t0 = time.perf_counter()
+        sess.advance(K)
+        sess.sync()
+        dt_s = time.perf_counter() - t0
+        tm = sess.timing(reset=True)
+    avg_ms = tm["ms"] / max(tm["launches"], 1)
+    ach = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    return {"workload": "slam-dense-mag N=65536 T=3000 m=512 (nLin=515) fp64 filter, 1 GPU, single bank in place",
+            "value": 65536 * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tm["bytes_per_launch"]},
+            "full_run": "profiles/r01e_filter_N65536_m512_T3000_bench.json (2980 timed steps: 2.05 M/s, 95 s)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,6 +162,7 @@ def main():
     ap.add_argument("--T", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the N=65536 single-GPU legs (configs[2] filter, large smoothers)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=3, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
@@ -217,6 +275,20 @@ def main():
                 line["smoother"] = smoother_wallclock(pkg, datagen)
             except Exception as exc:
                 line["smoother"] = {"error": str(exc)}
+            if not args.no_large:
+                try:
+                    line["smoother"]["large"] = smoother_large(pkg, datagen)
+                except Exception as exc:
+                    line["smoother"]["large"] = {"error": str(exc)}
+        if world == 1 and not args.no_large and not args.force_sharded and N_local == 8192 and args.m == 256:
+            try:
+                free_b, _ = torch.cuda.mem_get_info()
+                if free_b > 170e9:
+                    line["config2_filter"] = config2_filter(pkg, datagen, args)
+                else:
+                    line["config2_filter"] = {"skipped": f"only {free_b / 1e9:.0f} GB free"}
+            except Exception as exc:
+                line["config2_filter"] = {"error": str(exc)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)

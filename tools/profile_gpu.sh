@@ -3,7 +3,7 @@
 # Usage: tools/profile_gpu.sh <tag> [bench args...]
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 200 --warmup 20 --no-cpu-baseline --no-smoother}
+ARGS=${@:---steps 200 --warmup 20 --no-cpu-baseline --no-smoother --no-large}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_smoother -o pmc -- python3 $REPO/tools/smoother_bench.py mag 8192 12 512 2 info > $OUT/smoother.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_filter -o pmc -- python3 $REPO/bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-smoother > $OUT/filter.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_filter -o pmc -- python3 $REPO/bench.py --steps 60 --warmup 6 --no-cpu-baseline --no-smoother --no-large > $OUT/filter.log 2>&1
 cd $REPO
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, os, sys
