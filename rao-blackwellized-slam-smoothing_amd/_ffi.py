@@ -46,7 +46,7 @@ class rbpf_rng(C.Structure):
 
 class rbpf_options(C.Structure):
     _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
-                ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("reserved_", C.c_int32)]
+                ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32)]
 
 
 class rbpf_filter_out(C.Structure):

@@ -199,6 +199,11 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->lay = make_layout(prob->n_lin, prob->n_y);
   c->lay_low = make_layout_low_regs(prob->n_lin, prob->n_y);
   const bool sparse = model->kind == RBPF_MODEL_SPARSE_VISUAL_2D;
+  c->fp32 = c->opt.storage == 1;
+  if (c->opt.storage != 0 && c->opt.storage != 1) { set_error("options.storage must be 0 (fp64) or 1 (fp32)"); return RBPF_ERR_INVALID_ARG; }
+  if (c->fp32 && (smoother || ex || sparse || prob->n_y != 3)) {
+    set_error("fp32 storage of the covariance banks: unsharded dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
+  }
   if (sparse) {
     if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }
     if (ex) { set_error("the sparseFeatures branch is not sharded"); return RBPF_ERR_UNSUPPORTED; }
@@ -256,7 +261,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
       int s1 = dmalloc(&c->d_P0t, std::max<size_t>(L.szT, 1));
       int s2 = dmalloc(&c->d_P0b, std::max<size_t>(L.szB, 1));
       if (s1 != RBPF_OK || s2 != RBPF_OK) { hipFree(tmp); return s1 != RBPF_OK ? s1 : s2; }
-      e = launch_pack_P(L, tmp, 0, c->d_P0t, c->d_P0b, 1, c->stream);
+      e = launch_pack_P(L, tmp, 0, c->d_P0t, c->d_P0b, 1, c->stream, c->fp32 ? 1 : 0);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }
     hipFree(tmp);
@@ -289,15 +294,16 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     if (c->opt.inplace == 0 && can) {
       size_t fr = 0, tot = 0;
       HIPCHK(hipMemGetInfo(&fr, &tot));
-      const size_t two = 2 * c->bank_cap * (L.szT + L.szB) * sizeof(double);
+      const size_t two = 2 * c->bank_cap * (L.szT + L.szB) * (c->fp32 ? sizeof(float) : sizeof(double));
       c->inplace = (double)two > 0.85 * (double)fr;
     }
   }
   for (int b = 0; b < 2; ++b) {
     if (b == 1 && c->inplace) { c->Pt[1] = c->Pt[0]; c->Pb[1] = c->Pb[0]; }
     else {
-      RB_TRY(dmalloc(&c->Pt[b], c->bank_cap * L.szT));
-      RB_TRY(dmalloc(&c->Pb[b], c->bank_cap * L.szB));
+      // (counts in doubles; a float bank needs half of them)
+      RB_TRY(dmalloc(&c->Pt[b], c->fp32 ? (c->bank_cap * L.szT + 1) / 2 : c->bank_cap * L.szT));
+      RB_TRY(dmalloc(&c->Pb[b], c->fp32 ? (c->bank_cap * L.szB + 1) / 2 : c->bank_cap * L.szB));
     }
     RB_TRY(dmalloc(&c->F[b], c->bank_cap * 2 * d * L.ldx));
     RB_TRY(dmalloc(&c->xl[b], c->bank_cap * L.ldx));
@@ -496,6 +502,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   for (int q = 0; q < kMaxSets; ++q) { a.fset[q] = nullptr; a.fset_idx_old[q] = nullptr; a.fset_idx_new[q] = nullptr; }
   a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
   a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1;
+  a.fp32 = c->fp32 ? 1 : 0;
   a.n_sets = (t > 0) ? 1 : 0; a.write_base = 1;
   if (lazy) {
     // multi-step lazy update: sets produced at steps t-ell .. t-1 are pending; every C-th step rewrites the matrices
@@ -607,7 +614,8 @@ int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out) {
   const Layout& L = c->lay;
   const int d = c->mdl.d, N = c->N;
   if (c->lazy_depth < 2) {
-    HIPCHK(launch_unpack_P(L, d, c->Pt[c->cur], c->Pb[c->cur], c->t > 0 ? c->F[c->cur] : nullptr, d_index, count, d_out, c->stream));
+    HIPCHK(launch_unpack_P(L, d, c->Pt[c->cur], c->Pb[c->cur], c->t > 0 ? c->F[c->cur] : nullptr, d_index, count, d_out, c->stream,
+                           c->fp32 ? 1 : 0));
     return RBPF_OK;
   }
   const int C = c->lazy_depth, B = C + 1, t = c->t;          // state after step t-1
@@ -617,7 +625,8 @@ int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out) {
     const int bank = (t - ell + q) % B;
     fset[q] = c->Fb[bank]; fidx[q] = c->fidx[c->tcur] + (size_t)bank * N;
   }
-  HIPCHK(launch_unpack_P_sets(L, d, c->Pt[c->cur], c->Pb[c->cur], ell, fset, fidx, c->base[c->tcur], d_index, count, d_out, c->stream));
+  HIPCHK(launch_unpack_P_sets(L, d, c->Pt[c->cur], c->Pb[c->cur], ell, fset, fidx, c->base[c->tcur], d_index, count, d_out, c->stream,
+                              c->fp32 ? 1 : 0));
   return RBPF_OK;
 }
 
@@ -667,7 +676,8 @@ int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, 
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;
   size_t b = 2 * bank_bytes(L, p->n_y, p->N_P);
-  if (opt && opt->inplace > 0) b -= (size_t)p->N_P * (L.szT + L.szB) * sizeof(double);   // one covariance bank
+  if (opt && opt->storage == 1) b -= (size_t)p->N_P * (L.szT + L.szB) * sizeof(double);  // float banks: half of two double banks
+  if (opt && opt->inplace > 0) b -= (size_t)p->N_P * (L.szT + L.szB) * (opt->storage == 1 ? sizeof(float) : sizeof(double));   // one bank
   b += (size_t)(hist ? p->N_T : 2) * p->n_nonlin * p->N_P * sizeof(double);
   b += (size_t)(hist ? p->N_T : 1) * p->N_P * sizeof(int);
   b += (size_t)(trace ? 2 * p->N_T : 2) * p->N_P * sizeof(double) + (size_t)p->N_P * sizeof(double);
@@ -726,7 +736,7 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
   out->stream_kernel_ms = ms;
   out->stream_kernel_launches = (int64_t)c->events.size();
   const double n = c->mdl.n, nN = c->mdl.nN;
-  out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * 8.0;
+  out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * (c->fp32 ? 4.0 : 8.0);   // SURVEY 8d, s = 4 | 8
   if (reset) {
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     c->events.clear();

@@ -71,6 +71,7 @@ struct rbpf_ctx {
   int* fidx[2] = {nullptr, nullptr};   // [lazy_depth+1][N] entry tables, ping-pong
   int* base[2] = {nullptr, nullptr};   // [N] stored-matrix slot of every lineage, ping-pong
   int tcur = 0;
+  bool fp32 = false;        // the covariance banks hold float (rbpf_options.storage = 1)
   bool inplace = false;     // single covariance bank, rewritten in place at every flush (rbpf_options.inplace)
   int* d_ip = nullptr;      // [5][N] in-place flush plan: destination entry, phase, scratch
   // history

@@ -64,6 +64,7 @@ struct StepArgs {
   // launch only processes the slots whose phase_of[i] equals `phase` (phase < 0: all).  Phase 0 = children that move
   // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.
   const int* dst_slot; const int* phase_of; int phase;
+  int fp32;                      // 1: the covariance banks (Pt / Pb) hold float; strides stay in elements
   const int* slot_ids;           // logical (global) id of each local slot (null: slot_offset + i); when set,
                                  // `ai` is indexed by that logical id
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of
@@ -158,13 +159,14 @@ constexpr int kSingleWgResampleMaxN = 8192;   // above this the multi-workgroup 
 hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s);
 
 // pack / unpack between MATLAB column-major n x n images and the bank layout
+// fp32 != 0: the banks hold float (rbpf_options.storage = 1); pointers stay typed double* on the host side
 hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src_stride, double* Pt,
-                         double* Pb, int count, hipStream_t s);
+                         double* Pb, int count, hipStream_t s, int fp32 = 0);
 hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
-                           const int* index, int count, double* P_colmajor, hipStream_t s);
+                           const int* index, int count, double* P_colmajor, hipStream_t s, int fp32 = 0);
 hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, const double* Pb, int n_sets,
                                 const double* const* fset, const int* const* fidx, const int* base, const int* index,
-                                int count, double* P_colmajor, hipStream_t s);
+                                int count, double* P_colmajor, hipStream_t s, int fp32 = 0);
 hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
                                    hipStream_t s);
 hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,

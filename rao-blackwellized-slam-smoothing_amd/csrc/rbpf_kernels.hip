@@ -39,19 +39,56 @@ namespace rbpf {
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ dbl2 ld_stream(const double* p) {
+// Two consecutive rows of a stored covariance.  TS = double (the reference's precision) or float (fp32 STORAGE of the
+// covariance banks, rbpf_options.storage = 1: half the HBM traffic; all arithmetic stays fp64).
+typedef float flt2 __attribute__((ext_vector_type(2)));
+
+template <typename TS> __device__ __forceinline__ dbl2 ld_pair(const TS* p);
+template <> __device__ __forceinline__ dbl2 ld_pair<double>(const double* p) { return *reinterpret_cast<const dbl2*>(p); }
+template <> __device__ __forceinline__ dbl2 ld_pair<float>(const float* p) {
+  const flt2 v = *reinterpret_cast<const flt2*>(p);
+  dbl2 o; o.x = (double)v.x; o.y = (double)v.y;
+  return o;
+}
+template <typename TS> __device__ __forceinline__ void st_pair(TS* p, dbl2 v);
+template <> __device__ __forceinline__ void st_pair<double>(double* p, dbl2 v) { *reinterpret_cast<dbl2*>(p) = v; }
+template <> __device__ __forceinline__ void st_pair<float>(float* p, dbl2 v) {
+  flt2 o; o.x = (float)v.x; o.y = (float)v.y;
+  *reinterpret_cast<flt2*>(p) = o;
+}
+
+template <typename TS> __device__ __forceinline__ dbl2 ld_stream(const TS* p);
+template <> __device__ __forceinline__ dbl2 ld_stream<double>(const double* p) {
 #if RBPF_NT_LOAD
   return __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(p));
 #else
   return *reinterpret_cast<const dbl2*>(p);
 #endif
 }
+template <> __device__ __forceinline__ dbl2 ld_stream<float>(const float* p) {
+#if RBPF_NT_LOAD
+  const flt2 v = __builtin_nontemporal_load(reinterpret_cast<const flt2*>(p));
+#else
+  const flt2 v = *reinterpret_cast<const flt2*>(p);
+#endif
+  dbl2 o; o.x = (double)v.x; o.y = (double)v.y;
+  return o;
+}
 
-__device__ __forceinline__ void st_stream(double* p, dbl2 v) {
+template <typename TS> __device__ __forceinline__ void st_stream(TS* p, dbl2 v);
+template <> __device__ __forceinline__ void st_stream<double>(double* p, dbl2 v) {
 #if RBPF_NT_STORE
   __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(p));
 #else
   *reinterpret_cast<dbl2*>(p) = v;
+#endif
+}
+template <> __device__ __forceinline__ void st_stream<float>(float* p, dbl2 v) {
+  flt2 o; o.x = (float)v.x; o.y = (float)v.y;
+#if RBPF_NT_STORE
+  __builtin_nontemporal_store(o, reinterpret_cast<flt2*>(p));
+#else
+  *reinterpret_cast<flt2*>(p) = o;
 #endif
 }
 
@@ -181,8 +218,8 @@ __device__ inline void H_column(const ModelDev& M, int c, const double* tabS, co
 template <int NSA>
 struct SetPtrs { const double* p[NSA]; };
 
-template <int D, int E, int CPL, int UC, int NS, bool WR>
-__device__ __forceinline__ void stream_core(const double* __restrict__ src, double* __restrict__ dst,
+template <typename TS, int D, int E, int CPL, int UC, int NS, bool WR>
+__device__ __forceinline__ void stream_core(const TS* __restrict__ src, TS* __restrict__ dst,
                                             const double* __restrict__ HK, const SetPtrs<(NS > 0 ? NS : 1)> KSrows,
                                             int ldx, int n, int nb, int mc, int chunk0, int chunk_stride, int CS,
                                             int wc, int lane, double* __restrict__ out_acc /* [D+E][mc] */) {
@@ -208,8 +245,8 @@ __device__ __forceinline__ void stream_core(const double* __restrict__ src, doub
     }
   }
   const size_t colstep = (size_t)CS * mc;               // elements between two columns of this wave
-  const double* sp = src + (size_t)wc * mc;
-  double* dp = dst + (size_t)wc * mc;
+  const TS* sp = src + (size_t)wc * mc;
+  TS* dp = dst + (size_t)wc * mc;
   const double* hk = HK + (size_t)wc * REC;
   const int hkstep = CS * REC;
 
@@ -345,7 +382,7 @@ hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
 #ifndef RBPF_MINWAVES
 #define RBPF_MINWAVES 1     // min waves per SIMD requested from the register allocator (tuning)
 #endif
-template <int D, int E, int CPL, int NS, bool WR>
+template <typename TS, int D, int E, int CPL, int NS, bool WR>
 __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, REC = DE + ND, NSA = NS > 0 ? NS : 1;
@@ -386,8 +423,9 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   const int baseb = pre_i[3];
   const bool remoteP = a.rec != nullptr && baseb >= a.n_bank_local;        // stored matrix in a (persisting) record
   const double* recP = remoteP ? a.rec + (size_t)(baseb - a.n_bank_local) * a.rec_stride : nullptr;
-  const double* srcT = remoteP ? recP : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
-  const double* srcB = remoteP ? recP + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
+  // (records hold fp64 matrices: the sharded filter does not use fp32 storage)
+  const TS* srcT = remoteP ? reinterpret_cast<const TS*>(recP) : reinterpret_cast<const TS*>(a.Pt_old) + (size_t)baseb * a.Pt_old_stride;
+  const TS* srcB = remoteP ? reinterpret_cast<const TS*>(recP + a.rec_off_B) : reinterpret_cast<const TS*>(a.Pb_old) + (size_t)baseb * a.Pb_old_stride;
   const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
   // pending factor sets (KS rows then K columns, [2][D][ldx] each), oldest first
   SetPtrs<NSA> srcFs;
@@ -475,21 +513,21 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
     if (mc > 0 && wc < Ly.CS) {
-      const double* src = srcT;
-      double* dst = a.Pt_new + (size_t)dslot * Ly.szT;
+      const TS* src = srcT;
+      TS* dst = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
       if (CPL > 0)
-        stream_core<D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
+        stream_core<TS, D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
       const int rem = Ly.CH - CPL * Ly.RS;
       if (wr < rem)
-        stream_core<D, E, 1, RBPF_UC, NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
+        stream_core<TS, D, E, 1, RBPF_UC, NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
-      const double* src = srcB + (size_t)b * ldb;
-      double* dst = a.Pb_new + (size_t)dslot * Ly.szB + (size_t)b * ldb;
+      const TS* src = srcB + (size_t)b * ldb;
+      TS* dst = reinterpret_cast<TS*>(a.Pb_new) + (size_t)dslot * Ly.szB + (size_t)b * ldb;
       double ksb[ND > 0 ? ND : 1];
 #pragma unroll
       for (int sset = 0; sset < NS; ++sset)
@@ -499,7 +537,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 #pragma unroll
       for (int k = 0; k < DE; ++k) accb[k] = 0.0;
       for (int c = 2 * lane; c < ldb; c += 128) {
-        const dbl2 vv = *reinterpret_cast<const dbl2*>(src + c);
+        const dbl2 vv = ld_pair<TS>(src + c);
         double p[2] = {vv.x, vv.y};
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
             for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], HK[cc * REC + k], accb[k]);
           }
         }
-        if (WR) { dbl2 o; o.x = p[0]; o.y = p[1]; *reinterpret_cast<dbl2*>(dst + c) = o; }
+        if (WR) { dbl2 o; o.x = p[0]; o.y = p[1]; st_pair<TS>(dst + c, o); }
       }
 #pragma unroll
       for (int k = 0; k < DE; ++k) {
@@ -693,36 +731,36 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   RBPF_KSTAMP(6);
 }
 
-template <int D, int E, int CPL, int NS, bool WR>
+template <typename TS, int D, int E, int CPL, int NS, bool WR>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
   const size_t lds = step_lds_bytes(a.mdl, a.lay, E, NS);
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<D, E, CPL, NS, WR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((step_kernel<D, E, CPL, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }
 
-template <int D, int E, int NS, bool WR>
+template <typename TS, int D, int E, int NS, bool WR>
 static hipError_t launch_step_cpl(const StepArgs& a, hipStream_t s) {
   switch (a.lay.CPL) {
-    case 0: return launch_step_t<D, E, 0, NS, WR>(a, s);
-    case 1: return launch_step_t<D, E, 1, NS, WR>(a, s);
-    case 2: return launch_step_t<D, E, 2, NS, WR>(a, s);
-    case 3: return launch_step_t<D, E, 3, NS, WR>(a, s);
+    case 0: return launch_step_t<TS, D, E, 0, NS, WR>(a, s);
+    case 1: return launch_step_t<TS, D, E, 1, NS, WR>(a, s);
+    case 2: return launch_step_t<TS, D, E, 2, NS, WR>(a, s);
+    case 3: return launch_step_t<TS, D, E, 3, NS, WR>(a, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 // multi-step lazy variants (filter only, E = 0): up to kMaxSets pending sets, light (read-only) or flush
-template <int D>
+template <typename TS, int D>
 static hipError_t launch_step_lazy(const StepArgs& a, hipStream_t s) {
   if (a.lay.CPL < 1 || a.lay.CPL > 2) return hipErrorInvalidValue;
-#define RBPF_LZ(NS_, WR_) (a.lay.CPL == 1 ? launch_step_t<D, 0, 1, NS_, WR_>(a, s) : launch_step_t<D, 0, 2, NS_, WR_>(a, s))
+#define RBPF_LZ(NS_, WR_) (a.lay.CPL == 1 ? launch_step_t<TS, D, 0, 1, NS_, WR_>(a, s) : launch_step_t<TS, D, 0, 2, NS_, WR_>(a, s))
   if (a.write_base) {
     switch (a.n_sets) { case 2: return RBPF_LZ(2, true); case 3: return RBPF_LZ(3, true); case 4: return RBPF_LZ(4, true); default: break; }
   } else {
@@ -736,19 +774,25 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   const int D = a.mdl.d;
   if (a.n_sets < 0 || a.n_sets > kMaxSets) return hipErrorInvalidValue;
   const bool legacy = a.write_base && a.n_sets <= 1;       // one pending set, rewritten every step
+  if (a.fp32) {
+    // fp32 storage of the covariance banks: filter only (E = 0), dense-mag outputs (D = 3), no remote records
+    if (a.info || a.rec != nullptr || D != 3) return hipErrorInvalidValue;
+    if (!legacy) return launch_step_lazy<float, 3>(a, s);
+    return a.n_sets ? launch_step_cpl<float, 3, 0, 1, true>(a, s) : launch_step_cpl<float, 3, 0, 0, true>(a, s);
+  }
   if (!legacy) {
     if (a.info) return hipErrorInvalidValue;
-    if (D == 3) return launch_step_lazy<3>(a, s);
-    if (D == 1) return launch_step_lazy<1>(a, s);
+    if (D == 3) return launch_step_lazy<double, 3>(a, s);
+    if (D == 1) return launch_step_lazy<double, 1>(a, s);
     return hipErrorInvalidValue;
   }
   if (a.info) {
-    if (D == 3) return a.n_sets ? launch_step_cpl<3, 2, 1, true>(a, s) : launch_step_cpl<3, 2, 0, true>(a, s);
-    if (D == 1) return a.n_sets ? launch_step_cpl<1, 2, 1, true>(a, s) : launch_step_cpl<1, 2, 0, true>(a, s);
+    if (D == 3) return a.n_sets ? launch_step_cpl<double, 3, 2, 1, true>(a, s) : launch_step_cpl<double, 3, 2, 0, true>(a, s);
+    if (D == 1) return a.n_sets ? launch_step_cpl<double, 1, 2, 1, true>(a, s) : launch_step_cpl<double, 1, 2, 0, true>(a, s);
     return hipErrorInvalidValue;
   }
-  if (D == 3) return a.n_sets ? launch_step_cpl<3, 0, 1, true>(a, s) : launch_step_cpl<3, 0, 0, true>(a, s);
-  if (D == 1) return a.n_sets ? launch_step_cpl<1, 0, 1, true>(a, s) : launch_step_cpl<1, 0, 0, true>(a, s);
+  if (D == 3) return a.n_sets ? launch_step_cpl<double, 3, 0, 1, true>(a, s) : launch_step_cpl<double, 3, 0, 0, true>(a, s);
+  if (D == 1) return a.n_sets ? launch_step_cpl<double, 1, 0, 1, true>(a, s) : launch_step_cpl<double, 1, 0, 0, true>(a, s);
   return hipErrorInvalidValue;
 }
 
@@ -1229,27 +1273,30 @@ hipError_t launch_search(const SearchArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // pack / unpack / extraction kernels
 // ---------------------------------------------------------------------------------------------
-__global__ void pack_P_kernel(Layout L, const double* __restrict__ P, size_t src_stride, double* __restrict__ Pt,
-                              double* __restrict__ Pb) {
+template <typename TS>
+__global__ void pack_P_kernel(Layout L, const double* __restrict__ P, size_t src_stride, TS* __restrict__ Pt,
+                              TS* __restrict__ Pb) {
   const int p = blockIdx.x;
   const double* src = P + (size_t)p * src_stride;
-  double* t = Pt + (size_t)p * L.szT;
-  double* b = Pb + (size_t)p * L.szB;
+  TS* t = Pt + (size_t)p * L.szT;
+  TS* b = Pb + (size_t)p * L.szB;
   const size_t nn = (size_t)L.n * L.n;
   for (size_t q = threadIdx.x; q < nn; q += blockDim.x) {
     const int r = (int)(q % L.n), c = (int)(q / L.n);
     const double v = src[q];
-    if (r < L.nb) b[(size_t)r * L.ldb + c] = v;
-    else t[(size_t)c * L.mc + (r - L.nb)] = v;
+    if (r < L.nb) b[(size_t)r * L.ldb + c] = (TS)v;
+    else t[(size_t)c * L.mc + (r - L.nb)] = (TS)v;
   }
   // zero the pad column of the border block
   if (L.ldb > L.n)
-    for (int r = threadIdx.x; r < L.nb; r += blockDim.x) b[(size_t)r * L.ldb + L.n] = 0.0;
+    for (int r = threadIdx.x; r < L.nb; r += blockDim.x) b[(size_t)r * L.ldb + L.n] = (TS)0;
 }
 
 hipError_t launch_pack_P(const Layout& lay, const double* P_colmajor, size_t src_stride, double* Pt, double* Pb,
-                         int count, hipStream_t s) {
-  hipLaunchKernelGGL(pack_P_kernel, dim3(count), dim3(256), 0, s, lay, P_colmajor, src_stride, Pt, Pb);
+                         int count, hipStream_t s, int fp32) {
+  if (fp32) hipLaunchKernelGGL(pack_P_kernel<float>, dim3(count), dim3(256), 0, s, lay, P_colmajor, src_stride,
+                               reinterpret_cast<float*>(Pt), reinterpret_cast<float*>(Pb));
+  else hipLaunchKernelGGL(pack_P_kernel<double>, dim3(count), dim3(256), 0, s, lay, P_colmajor, src_stride, Pt, Pb);
   return hipGetLastError();
 }
 
@@ -1263,14 +1310,15 @@ struct UnpackSets {
 
 // grid (count, ceil(n / 16)): a workgroup expands 16 columns of one particle
 constexpr int kUnpackCols = 16;
-__global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const double* __restrict__ Pt,
-                                                       const double* __restrict__ Pb, UnpackSets us,
+template <typename TS>
+__global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const TS* __restrict__ Pt,
+                                                       const TS* __restrict__ Pb, UnpackSets us,
                                                        const int* __restrict__ index, double* __restrict__ P) {
   const int p = blockIdx.x;
   const int src = index ? index[p] : p;
   const int bsl = us.base ? us.base[src] : src;
-  const double* t = Pt + (size_t)bsl * L.szT;
-  const double* b = Pb + (size_t)bsl * L.szB;
+  const TS* t = Pt + (size_t)bsl * L.szT;
+  const TS* b = Pb + (size_t)bsl * L.szB;
   double* dst = P + (size_t)p * L.n * L.n;
   const int c0 = blockIdx.y * kUnpackCols, c1 = min(L.n, c0 + kUnpackCols);
   const double* F[kMaxSets];
@@ -1278,7 +1326,7 @@ __global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const do
     F[sset] = sset < us.n_sets ? us.fset[sset] + (size_t)(us.fidx[sset] ? us.fidx[sset][src] : src) * 2 * d * L.ldx : nullptr;
   for (int r = threadIdx.x; r < L.n; r += 256) {
     for (int c = c0; c < c1; ++c) {
-      double v = (r < L.nb) ? b[(size_t)r * L.ldb + c] : t[(size_t)c * L.mc + (r - L.nb)];
+      double v = (r < L.nb) ? (double)b[(size_t)r * L.ldb + c] : (double)t[(size_t)c * L.mc + (r - L.nb)];
       for (int sset = 0; sset < us.n_sets; ++sset)
         for (int k = 0; k < d; ++k) v = fma(-F[sset][(size_t)k * L.ldx + r], F[sset][(size_t)(d + k) * L.ldx + c], v);
       dst[(size_t)c * L.n + r] = v;
@@ -1286,24 +1334,31 @@ __global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const do
   }
 }
 
+static hipError_t launch_unpack_impl(const Layout& lay, int d, const double* Pt, const double* Pb, const UnpackSets& us,
+                                     const int* index, int count, double* P_colmajor, hipStream_t s, int fp32) {
+  const dim3 grid(count, (lay.n + kUnpackCols - 1) / kUnpackCols);
+  if (fp32) hipLaunchKernelGGL(unpack_P_kernel<float>, grid, dim3(256), 0, s, lay, d, reinterpret_cast<const float*>(Pt),
+                               reinterpret_cast<const float*>(Pb), us, index, P_colmajor);
+  else hipLaunchKernelGGL(unpack_P_kernel<double>, grid, dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
+  return hipGetLastError();
+}
+
 hipError_t launch_unpack_P(const Layout& lay, int d, const double* Pt, const double* Pb, const double* F,
-                           const int* index, int count, double* P_colmajor, hipStream_t s) {
+                           const int* index, int count, double* P_colmajor, hipStream_t s, int fp32) {
   UnpackSets us;
   us.n_sets = F ? 1 : 0; us.base = nullptr;
   for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = nullptr; us.fidx[q] = nullptr; }
   us.fset[0] = F;
-  hipLaunchKernelGGL(unpack_P_kernel, dim3(count, (lay.n + kUnpackCols - 1) / kUnpackCols), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
-  return hipGetLastError();
+  return launch_unpack_impl(lay, d, Pt, Pb, us, index, count, P_colmajor, s, fp32);
 }
 
 hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, const double* Pb, int n_sets,
                                 const double* const* fset, const int* const* fidx, const int* base, const int* index,
-                                int count, double* P_colmajor, hipStream_t s) {
+                                int count, double* P_colmajor, hipStream_t s, int fp32) {
   UnpackSets us;
   us.n_sets = n_sets; us.base = base;
   for (int q = 0; q < kMaxSets; ++q) { us.fset[q] = q < n_sets ? fset[q] : nullptr; us.fidx[q] = q < n_sets ? fidx[q] : nullptr; }
-  hipLaunchKernelGGL(unpack_P_kernel, dim3(count, (lay.n + kUnpackCols - 1) / kUnpackCols), dim3(256), 0, s, lay, d, Pt, Pb, us, index, P_colmajor);
-  return hipGetLastError();
+  return launch_unpack_impl(lay, d, Pt, Pb, us, index, count, P_colmajor, s, fp32);
 }
 
 // xl_mean = sum(xl.*w,2)  (particleFilter.m:226)

@@ -353,6 +353,15 @@ class _Problem:
         self.c = p
 
 
+def _storage_code(storage):
+    """rbpf_options.storage: "fp64" (default, the reference's precision) or "fp32" storage of the covariance banks."""
+    if storage in ("fp64", 0, None):
+        return 0
+    if storage in ("fp32", 1):
+        return 1
+    raise ValueError("storage must be 'fp64' or 'fp32'")
+
+
 def _check_sparse_flag(model, sparseFeatures):
     """sparseFeatures selects the measModel calling convention (particleFilter.m:123-129): it has to match the family."""
     if bool(sparseFeatures) != bool(getattr(model, "sparse", False)):
@@ -380,7 +389,7 @@ def _recognise(dynModel, measModel, dynResNorm=None):
 # ------------------------------------------------------------------------------------------------
 def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, *, rng=None, trace=False,
-                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0):
+                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64"):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended."""
@@ -390,7 +399,8 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, 1)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=0,
-                            lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace))
+                            lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
+                            storage=_storage_code(storage))
     mdesc = model.descriptor()
     nN, n, N, T = model.nNonLin, model.nLin, prob.N_P, prob.N_T
 
@@ -524,13 +534,14 @@ class FilterSession:
     """Thin RAII wrapper over rbpf_filter_create / advance / sync / timing / destroy."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng=None, keep_history=False,
-                 trace=False, lazy_depth=0, inplace=0):
+                 trace=False, lazy_depth=0, inplace=0, storage="fp64"):
         self.lib = load_library()
         self.model = model
         self.prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
         self.blk, self._rng = _rng_block(rng, self.prob.N_P, self.prob.N_T, model.nw, 1)
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=1 if trace else 0, fix_p_mean=0,
-                                     lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace))
+                                     lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
+                                     storage=_storage_code(storage))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         check(self.lib.rbpf_filter_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),

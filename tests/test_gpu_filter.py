@@ -92,3 +92,33 @@ def test_single_bank_inplace_flush_is_bit_identical(rbpf, kind, N_P, N_T, m, laz
         np.testing.assert_array_equal(a, b)
     for k in ("ai", "logw", "w", "xl", "P", "xn"):
         np.testing.assert_array_equal(out1[8][k], out0[8][k])
+
+
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (3, -1), (3, 1)])
+@pytest.mark.parametrize("N_P,N_T,m", [(24, 10, 125), (10, 8, 256)])
+def test_fp32_storage_of_the_covariance_banks(rbpf, N_P, N_T, m, lazy_depth, inplace):
+    """storage="fp32" (BASELINE.json configs[4]): the covariance banks hold float, all arithmetic stays fp64.  Every
+    stored element carries a 6e-8 relative rounding per rewrite, so the run agrees with the fp64 oracle to ~1e-5, not to
+    1e-9: tolerance 2e-5 on normalised weights / states / covariances over these few steps, and -- for these seeds --
+    the same resampling indices (a weight perturbation of 1e-6 can move a draw that lands that close to a bin edge)."""
+    c = cases.mag_case(N_P, N_T, m, seed=41)
+    ref = cases.oracle_filter(c)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                              c["N_P"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth,
+                              inplace=inplace, storage="fp32")
+    ex, tr = out[8], ref["trace"]
+    np.testing.assert_array_equal(ex["ai"][1:], tr["ai"][1:])
+    TOL = 2e-5
+    assert rel(ex["w"], tr["w"]) <= TOL
+    assert rel(out[1], ref["traj_mean"]) <= TOL and rel(out[2], ref["xl_max"]) <= TOL and rel(out[4], ref["P_max"]) <= TOL
+    assert rel(ex["xl"], tr["xl"]) <= TOL and rel(ex["P"], tr["P"]) <= TOL
+    assert rel(ex["P"], tr["P"]) > 1e-12                                        # it really is a different storage precision
+
+
+def test_fp32_storage_is_rejected_where_it_is_not_implemented(rbpf):
+    c = cases.radio_case(6, 5, 16, seed=1, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError):                                         # dense-radio (ny = 1): fp64 only
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 1.0,
+                            rng=cases.device_rng(rbpf, c), storage="fp32")
