@@ -57,6 +57,17 @@ template <> __device__ __forceinline__ void st_pair<float>(float* p, dbl2 v) {
   *reinterpret_cast<flt2*>(p) = o;
 }
 
+template <typename TS> struct Pair;                       // two stored rows as they sit in memory
+template <> struct Pair<double> { typedef dbl2 type; };
+template <> struct Pair<float> { typedef flt2 type; };
+template <typename TS> __device__ __forceinline__ typename Pair<TS>::type ld_stream_raw(const TS* p) {
+#if RBPF_NT_LOAD
+  return __builtin_nontemporal_load(reinterpret_cast<const typename Pair<TS>::type*>(p));
+#else
+  return *reinterpret_cast<const typename Pair<TS>::type*>(p);
+#endif
+}
+
 template <typename TS> __device__ __forceinline__ dbl2 ld_stream(const TS* p);
 template <> __device__ __forceinline__ dbl2 ld_stream<double>(const double* p) {
 #if RBPF_NT_LOAD
@@ -252,11 +263,11 @@ __device__ __forceinline__ void stream_core(const TS* __restrict__ src, TS* __re
 
   int c = wc;
   for (; c + (UC - 1) * CS < n; c += UC * CS) {
-    dbl2 v[UC][CPL];
+    typename Pair<TS>::type v[UC][CPL];                 // kept in the stored type until used: float keeps half the registers
 #pragma unroll
     for (int u = 0; u < UC; ++u)
 #pragma unroll
-      for (int q = 0; q < CPL; ++q) v[u][q] = ld_stream(sp + u * colstep + r0[q]);
+      for (int q = 0; q < CPL; ++q) v[u][q] = ld_stream_raw<TS>(sp + u * colstep + r0[q]);
 #pragma unroll
     for (int u = 0; u < UC; ++u) {
       double h[DE], kc[NDA];
@@ -266,7 +277,7 @@ __device__ __forceinline__ void stream_core(const TS* __restrict__ src, TS* __re
       for (int k = 0; k < ND; ++k) kc[k] = hk[u * hkstep + DE + k];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
-        double p0 = v[u][q].x, p1 = v[u][q].y;
+        double p0 = (double)v[u][q].x, p1 = (double)v[u][q].y;
 #pragma unroll
         for (int k = 0; k < ND; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
 #pragma unroll
@@ -515,14 +526,20 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     if (mc > 0 && wc < Ly.CS) {
       const TS* src = srcT;
       TS* dst = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
+      // a float load brings half the bytes: twice the columns in flight keep the same bytes outstanding
+#ifndef RBPF_UF32
+#define RBPF_UF32 2
+#endif
+      constexpr int kUF = (sizeof(TS) == 4 && CPL <= 1) ? RBPF_UF32 : 1;     // (two chunks per wave already keep 2x the loads in flight;
+                                                                              //  doubling again measured 0.39 vs 0.63 M/s at n = 1027)
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
       if (CPL > 0)
-        stream_core<TS, D, E, (CPL > 0 ? CPL : 1), (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
+        stream_core<TS, D, E, (CPL > 0 ? CPL : 1), kUF * (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, out_acc);
       const int rem = Ly.CH - CPL * Ly.RS;
       if (wr < rem)
-        stream_core<TS, D, E, 1, RBPF_UC, NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
+        stream_core<TS, D, E, 1, kUF * RBPF_UC, NS, WR>(src, dst, HK, srcFs, ldx, n, nb, mc, CPL * Ly.RS + wr, 1, Ly.CS, wc, lane, out_acc);
     }
     // border rows (row-major block B): lanes walk columns, wave-reduce per row
     for (int b = wave; b < nb; b += kWaves) {
