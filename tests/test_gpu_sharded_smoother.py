@@ -90,6 +90,18 @@ def test_two_ranks_equal_single_gpu_smoother(rbpf, kind, n_local, T, m, N_K):
     np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
 
 
+def test_two_ranks_above_8192_particles_equal_single_gpu(rbpf):
+    """N_global > 8192: the replicated normalisation runs the multi-workgroup pipeline on every rank."""
+    kind, n_local, T, m, N_K = "radio", 4200, 4, 8, 2
+    res = _run(2, "gloo", "host", kind, n_local, T, m, N_K)
+    _, ref = _single(rbpf, kind, 2 * n_local, T, m, N_K)
+    for rank, XNK, XLK, PK, aks, stats in res:
+        np.testing.assert_array_equal(np.asarray(aks), ref[3]["ak"])
+        np.testing.assert_array_equal(XNK, ref[0])
+        np.testing.assert_array_equal(XLK, ref[1])
+        np.testing.assert_array_equal(PK, ref[2])
+
+
 def test_world_size_one_rccl_smoother(rbpf):
     kind, n_local, T, m, N_K = "mag", 20, 6, 130, 2
     res = _run(1, "nccl", "device", kind, n_local, T, m, N_K)

@@ -52,3 +52,12 @@ def test_information_form_smoother_matches_oracle(rbpf, kind, N_P, N_T, m):
     c = mk(N_P, N_T, m, seed=9, N_K=3)
     ref, out = run_both(rbpf, c, info_form=True)
     check(ref, out, 3)
+
+
+def test_information_form_smoother_above_8192_particles(rbpf):
+    """N_P > 8192: weights and ancestor probabilities are normalised by the multi-workgroup pipeline (parallel prefix,
+    certified search, exact fallback) instead of the single-workgroup kernels -- same indices as the strict
+    left-to-right cumsum of tools/sample.m:30."""
+    c = cases.radio_case(8300, 3, 8, seed=13, N_K=2)
+    ref, out = run_both(rbpf, c, info_form=True)
+    check(ref, out, 2)
