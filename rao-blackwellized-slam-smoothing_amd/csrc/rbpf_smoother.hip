@@ -383,7 +383,9 @@ __device__ inline void sqrt_rsqrt(double x, double& g, double& rinv) {
 // W waves per workgroup (4, 8 or 16): the smallest that keeps <= 4 row tiles per wave.  A small matrix then leaves room
 // for several workgroups per CU, whose single-wave diagonal-tile sections and barriers overlap (a 16-wave workgroup owns
 // the whole register file: at n = 128 seven of its waves had no tile and every CU waited on one particle's serial chain).
-template <int W>
+// NTMAX: the most row tiles a wave can own for this matrix size, ceil(RT / W); variants above it are not compiled in
+// (their operand buffers would only raise the register pressure of the whole kernel).
+template <int W, int NTMAX>
 __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
   constexpr int kThreadsW = W * 64;
   extern __shared__ double csm[];
@@ -454,17 +456,19 @@ __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
       const int fsel = nt ? nt + 4 * a.mode : 0;  // wave-uniform
+#define RBPF_CF(NT_, MODE_) chol_block_front<(NT_ <= NTMAX ? NT_ : 1), MODE_>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc)
       switch (fsel) {
-        case 1: chol_block_front<1, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 2: chol_block_front<2, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 3: chol_block_front<3, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 4: chol_block_front<4, 0>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 5: chol_block_front<1, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 6: chol_block_front<2, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 7: chol_block_front<3, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
-        case 8: chol_block_front<4, 1>(a, p, Lt, RT, jt, rt, M, rhs_s, Hs, RH, jit, lane, acc); break;
+        case 1: RBPF_CF(1, 0); break;
+        case 2: if (NTMAX >= 2) RBPF_CF(2, 0); break;
+        case 3: if (NTMAX >= 3) RBPF_CF(3, 0); break;
+        case 4: if (NTMAX >= 4) RBPF_CF(4, 0); break;
+        case 5: RBPF_CF(1, 1); break;
+        case 6: if (NTMAX >= 2) RBPF_CF(2, 1); break;
+        case 7: if (NTMAX >= 3) RBPF_CF(3, 1); break;
+        case 8: if (NTMAX >= 4) RBPF_CF(4, 1); break;
         default: break;
       }
+#undef RBPF_CF
       CSTAMP(0);
       // diagonal tile: wave 0, slot 0
       if (wv == 0) {
@@ -578,16 +582,26 @@ __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
 }
 
 static size_t chol_lds_bytes(int M, int d) { return ((size_t)256 + 256 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double); }
-template <int W>
+template <int W, int NTMAX>
 static hipError_t launch_chol_w(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel<W, NTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL(chol_solve_kernel<W>, dim3(batch), dim3(W * 64), lds, st, ca);
+  hipLaunchKernelGGL((chol_solve_kernel<W, NTMAX>), dim3(batch), dim3(W * 64), lds, st, ca);
   return hipGetLastError();
+}
+
+template <int W>
+static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int ntmax, hipStream_t st) {
+  switch (ntmax) {
+    case 1: return launch_chol_w<W, 1>(ca, batch, lds, st);
+    case 2: return launch_chol_w<W, 2>(ca, batch, lds, st);
+    case 3: return launch_chol_w<W, 3>(ca, batch, lds, st);
+    default: return launch_chol_w<W, 4>(ca, batch, lds, st);
+  }
 }
 
 // batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0)
@@ -597,9 +611,10 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
-  if (W == 4) return launch_chol_w<4>(ca, batch, lds, st);
-  if (W == 8) return launch_chol_w<8>(ca, batch, lds, st);
-  return launch_chol_w<16>(ca, batch, lds, st);
+  const int ntmax = (RT + W - 1) / W;
+  if (W == 4) return launch_chol_nt<4>(ca, batch, lds, ntmax, st);
+  if (W == 8) return launch_chol_nt<8>(ca, batch, lds, ntmax, st);
+  return launch_chol_nt<16>(ca, batch, lds, ntmax, st);
 }
 
 static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 1 + 15) / 16); return mp * mp; }
