@@ -1087,3 +1087,75 @@ def generate_line_3D(N_T, Q, theta, dt, seed, m_sim=2000, nLL=2, traj="line_3D")
         x[i], _ = mdl.dynModel(x[i - 1], dx[i - 1], dte[i - 1], Qe[:, :, i - 1], zo[i - 1])
     dxn = np.hstack((dx[:, 0:2], np.diff(x[:, 2])[:, None]))               # :319
     return dict(dx=dxn, initState=initState, y=y.reshape(-1, 1), LL=LL, pos=pos)
+
+
+# --------------------------------------------------------------------------------------
+# examples/slam-dense-mag/ekf_dense.m -- the EKF comparison baseline
+# --------------------------------------------------------------------------------------
+def measModel_ekf(model, LL, x, q):
+    """run_dense3D_magfield.m:281-299: [yhat, dy] with the state x = [pos(3); orientation deviation(3); map(m+3)]."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    LL = np.asarray(LL, dtype=np.float64)
+    pos = x[0:3][None, :]
+    m = model.NN.shape[0]
+    dPhi = np.vstack((np.concatenate(([1.0, 0.0, 0.0], eigenfun_dx(model.NN, pos, 0, model.L)[0])),      # :282-287
+                      np.concatenate(([0.0, 1.0, 0.0], eigenfun_dx(model.NN, pos, 1, model.L)[0])),
+                      np.concatenate(([0.0, 0.0, 1.0], eigenfun_dx(model.NN, pos, 2, model.L)[0]))))
+    Rnb = quat2rmat(q)                                                                                  # :288
+    yhat = Rnb.T @ dPhi @ x[6:]                                                                         # :290
+    dy = np.zeros((3, dPhi.shape[1] + 6))
+    J = JacobianPhi3D(x[0:3], m, LL[0, 0], LL[1, 0], LL[0, 1], LL[1, 1], LL[0, 2], LL[1, 2], model.NN)  # :292-294
+    J3 = np.tensordot(J[:, :, :, 0], x[9:], axes=([2], [0]))                                            # reshape(9,m)*x(10:end)
+    dy[:, 0:3] = Rnb.T @ J3                                                                             # :296
+    dy[:, 3:6] = Rnb.T @ mcross(dPhi @ x[6:])                                                           # :297
+    dy[:, 6:] = Rnb.T @ dPhi                                                                            # :298
+    return yhat, dy
+
+
+def dynModel_ekf(x, q, dx):
+    """run_dense3D_magfield.m:310-316."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    dx = np.asarray(dx, dtype=np.float64).ravel()
+    xpred = x.copy()
+    xpred[0:3] = x[0:3] + dx[0:3]
+    qpred = qLeft(q) @ dx[3:7]
+    F = np.eye(x.size)
+    G = np.zeros((x.size, 6))
+    G[0:3, 0:3] = np.eye(3)
+    G[3:6, 3:6] = quat2rmat(qpred)
+    return xpred, qpred, F, G
+
+
+def ekf_dense(model, LL, odometry, y, x0, q0, P0, Q, R, dt):
+    """examples/slam-dense-mag/ekf_dense.m:41-102 -> (xf_traj [nStates x T], qnb_traj [4 x T], Pf_traj [n x n x T])."""
+    y = np.atleast_2d(np.asarray(y, dtype=np.float64))
+    odometry = np.atleast_2d(np.asarray(odometry, dtype=np.float64))
+    xp = np.asarray(x0, dtype=np.float64).ravel().copy()
+    Pp = np.asarray(P0, dtype=np.float64).copy()
+    q_nb = np.asarray(q0, dtype=np.float64).ravel().copy()
+    nStates, N_T = xp.size, y.shape[0]
+    Q, dt = _expand_Q_dt(Q, dt, N_T)
+    jitter = 1e-3                                                   # :58
+    xf_traj = np.full((nStates, N_T), np.nan)
+    Pf_traj = np.full((nStates, nStates, N_T), np.nan)
+    qnb_traj = np.full((4, N_T), np.nan)
+    xf, Pf = xp, Pp
+    for t in range(N_T):                                            # :67
+        if t != 0:
+            xp, q_nb, F, G = dynModel_ekf(xf, q_nb, odometry[t - 1, :])          # :71
+            Qt = dt[t - 1] * Q[:, :, t - 1]
+            Pp = F @ Pf @ F.T + G @ Qt @ G.T                        # :73
+        yhat, dy = measModel_ekf(model, LL, xp, q_nb)               # :78
+        e = y[t, :] - yhat
+        SS = dy @ Pp @ dy.T + R
+        cS = _chol_lower_with_jitter(SS, jitter)                    # :83-86
+        Mx = np.linalg.solve(cS, dy).T
+        Mx = np.linalg.solve(cS.T, Mx.T).T
+        K = Pp @ Mx                                                 # :87
+        xf = xp + K @ e                                             # :90
+        Pf = Pp - K @ SS @ K.T
+        Pf = 0.5 * (Pf + Pf.T)                                      # :92
+        q_nb = qLeft(expq(xf[3:6] / 2.0)) @ q_nb                    # :95
+        xf[3:6] = 0.0
+        xf_traj[:, t], Pf_traj[:, :, t], qnb_traj[:, t] = xf, Pf, q_nb
+    return xf_traj, qnb_traj, Pf_traj

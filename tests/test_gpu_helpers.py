@@ -128,3 +128,23 @@ def test_jacobianphi3d(rbpf, oracle):
     got = mdl.JacobianPhi3D(x, LL[0], LL[1])
     assert got.shape == want.shape
     assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+
+
+@pytest.mark.gpu
+def test_ekf_baseline_matches_oracle(rbpf):
+    """examples/slam-dense-mag/ekf_dense.m with measModel_ekf / dynModel_ekf (run_dense3D_magfield.m:281-299,310-316):
+    host recursion over the device helper kernels (rotated basis gradient, basis Hessian) against the oracle."""
+    import importlib
+    import rbpf_oracle as O
+    ekf = importlib.import_module(rbpf.__name__ + ".ekf")
+    c = cases.mag_case(4, 14, 40, seed=8)
+    mdl, x0l, P0l, R = cases.device_model(rbpf, c)
+    n = mdl.nLin
+    x0 = np.concatenate((c["x0_nonLin"][0:3], np.zeros(3), x0l))                # run_dense3D_magfield.m:248-250
+    P0 = np.zeros((6 + n, 6 + n))
+    P0[6:, 6:] = P0l
+    q0 = c["x0_nonLin"][3:7]
+    ref = O.ekf_dense(c["model"], c["LL"], c["odometry"], c["y"], x0, q0, P0, c["Q"], c["R"], c["dt"])
+    got = ekf.ekf_dense(mdl, c["LL"], c["odometry"], c["y"], x0, q0, P0, c["Q"], R, c["dt"])
+    for g, r in zip(got, ref):
+        assert np.max(np.abs(g - r)) <= 1e-9 * max(1.0, np.max(np.abs(r)))

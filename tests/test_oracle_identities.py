@@ -188,3 +188,24 @@ def test_smoother_reference_slot_consumes_one_uniform_q9():
     c2 = dict(c, rng=rng2)
     again = cases.oracle_smoother(c2, info_form=False)
     np.testing.assert_array_equal(base["XNK"], again["XNK"])
+
+
+def test_ekf_measurement_jacobian_matches_finite_differences(oracle):
+    """measModel_ekf (run_dense3D_magfield.m:281-299): the position block uses JacobianPhi3D with the domain's lower /
+    upper bounds, the prediction uses eigenfun_dx with half-widths -- central differences of yhat tie the two together;
+    the orientation block Rnb'*[dPhi*xl x] is the derivative of R(q (x) expq(eta/2))' g at eta = 0 up to the sign
+    convention of the error state, checked through the map block (exact, linear)."""
+    import cases
+    c = cases.mag_case(3, 4, 24, seed=4)
+    m, n = c["model"], c["model"].nLin
+    rs = np.random.RandomState(1)
+    x = np.concatenate((0.3 * rs.standard_normal(3), np.zeros(3), rs.standard_normal(n)))
+    q = oracle.expq(0.2 * rs.standard_normal(3))
+    yh, dy = oracle.measModel_ekf(m, c["LL"], x, q)
+    J = np.zeros((3, 3))
+    for j in range(3):
+        d = np.zeros_like(x)
+        d[j] = 1e-6
+        J[:, j] = (oracle.measModel_ekf(m, c["LL"], x + d, q)[0] - oracle.measModel_ekf(m, c["LL"], x - d, q)[0]) / 2e-6
+    np.testing.assert_allclose(dy[:, 0:3], J, rtol=1e-6, atol=1e-8 * np.abs(J).max())
+    np.testing.assert_allclose(dy[:, 6:] @ x[6:], yh, rtol=1e-12)              # linear in the map states
