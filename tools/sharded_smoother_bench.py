@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Wall-clock of the particle-sharded information-form smoother (one process per GPU; launch with torchrun for more than
+one rank).  At world size 1 it shows the host-side overhead of the sharded session against the unsharded smoother.
+Usage: [torchrun --nproc-per-node W --master-addr 127.0.0.1] sharded_smoother_bench.py mag|radio N_local T m N_K"""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rbpf = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+dg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
+mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
+import bench  # noqa: E402
+
+kind = sys.argv[1]
+N_local, T, m, N_K = (int(v) for v in sys.argv[2:6])
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29544")
+dist.init_process_group("nccl", rank=rank, world_size=world)
+if kind == "mag":
+    Q, dt = bench.q_mag(), 0.01
+    d = dg.bean_6D(T, Q, bench.THETA_MAG, dt, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], bench.THETA_MAG)
+else:
+    dt, th = 1.0, [0.25, 2.0, 0.01]
+    Q = dg.radio_Q(T, "square_3D")
+    d = dg.planar_heading(T, Q, th, dt, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = rbpf.dense_radio_prior(m, d["LL"], th)
+s = mg.ShardedSmootherSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, Q, R, N_local, N_K, dt, rng=rbpf.PhiloxRNG(3),
+                              rank=rank, world=world)
+torch.cuda.synchronize()
+dist.barrier()
+t0 = time.perf_counter()
+XNK, XLK, PK = s.run()
+torch.cuda.synchronize()
+dist.barrier()
+secs = time.perf_counter() - t0
+st = dict(s.stats)
+s.close()
+if rank == 0:
+    ph = st.pop("phase_s", {})
+    st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 3) for k, v in ph.items()}
+    print(json.dumps({"smoother": "info (sharded)", "model": "dense-" + kind, "world": world, "N_local": N_local,
+                      "N_global": N_local * world, "T": T, "m": m, "N_K": N_K, "seconds": round(secs, 3),
+                      "finite": bool(np.all(np.isfinite(XNK))), "sharding": st}), flush=True)
+dist.destroy_process_group()
