@@ -124,7 +124,7 @@ typedef struct {
                           * were written to dead slots) instead of ping-pong banks -- halves the memory, same    *
                           * results bit for bit.  0: automatic (when two banks do not fit the device), 1: on,    *
                           * -1: off                                                                              */
-  int32_t storage;       /* filter only: 0 = the covariance banks hold fp64 (the reference's precision); 1 = fp32     *
+  int32_t storage;       /* dense-mag filter (also sharded): 0 = the covariance banks hold fp64 (the reference's precision); 1 = fp32     *
                           * STORAGE of the banks (BASELINE.json configs[4]): half the HBM traffic and memory, all     *
                           * arithmetic and every other state stay fp64.  Results then agree with the fp64 run to     *
                           * ~1e-6 relative per step (not to 1e-9) and resampling indices may differ.                 */

@@ -201,8 +201,8 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   const bool sparse = model->kind == RBPF_MODEL_SPARSE_VISUAL_2D;
   c->fp32 = c->opt.storage == 1;
   if (c->opt.storage != 0 && c->opt.storage != 1) { set_error("options.storage must be 0 (fp64) or 1 (fp32)"); return RBPF_ERR_INVALID_ARG; }
-  if (c->fp32 && (smoother || ex || sparse || prob->n_y != 3)) {
-    set_error("fp32 storage of the covariance banks: unsharded dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
+  if (c->fp32 && (smoother || sparse || prob->n_y != 3)) {
+    set_error("fp32 storage of the covariance banks: dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
   }
   if (sparse) {
     if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }

@@ -183,11 +183,12 @@ hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, con
                                  double* J, hipStream_t s);
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride = 0);
+                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride = 0,
+                               int fp32 = 0);
 hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx, int count, const double* Pt,
                                        const double* Pb, int n_sets, const double* const* fset, const int* const* fidx,
                                        const int* base, int n_bank_local, const double* rec, size_t rec_stride,
-                                       const double* xl, double* out, hipStream_t s);
+                                       const double* xl, double* out, hipStream_t s, int fp32 = 0);
 hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
                               double* logw, double* xn_soa, hipStream_t s);
 hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);

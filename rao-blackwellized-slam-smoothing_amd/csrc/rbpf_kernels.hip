@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   const int baseb = pre_i[3];
   const bool remoteP = a.rec != nullptr && baseb >= a.n_bank_local;        // stored matrix in a (persisting) record
   const double* recP = remoteP ? a.rec + (size_t)(baseb - a.n_bank_local) * a.rec_stride : nullptr;
-  // (records hold fp64 matrices: the sharded filter does not use fp32 storage)
+  // (a record keeps the covariance blocks in the stored type; rec_off_B is in doubles)
   const TS* srcT = remoteP ? reinterpret_cast<const TS*>(recP) : reinterpret_cast<const TS*>(a.Pt_old) + (size_t)baseb * a.Pt_old_stride;
   const TS* srcB = remoteP ? reinterpret_cast<const TS*>(recP + a.rec_off_B) : reinterpret_cast<const TS*>(a.Pb_old) + (size_t)baseb * a.Pb_old_stride;
   const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
@@ -792,8 +792,8 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   if (a.n_sets < 0 || a.n_sets > kMaxSets) return hipErrorInvalidValue;
   const bool legacy = a.write_base && a.n_sets <= 1;       // one pending set, rewritten every step
   if (a.fp32) {
-    // fp32 storage of the covariance banks: filter only (E = 0), dense-mag outputs (D = 3), no remote records
-    if (a.info || a.rec != nullptr || D != 3) return hipErrorInvalidValue;
+    // fp32 storage of the covariance banks: filter only (E = 0), dense-mag outputs (D = 3)
+    if (a.info || D != 3) return hipErrorInvalidValue;
     if (!legacy) return launch_step_lazy<float, 3>(a, s);
     return a.n_sets ? launch_step_cpl<float, 3, 0, 1, true>(a, s) : launch_step_cpl<float, 3, 0, 0, true>(a, s);
   }
@@ -1580,21 +1580,25 @@ hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, h
   return hipGetLastError();
 }
 
-// copy the bank entries of `count` particles into particle-major records [Pt | Pb | F | xl]
-__global__ void pack_records_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
-                                    const double* __restrict__ Pb, const double* __restrict__ F,
+// copy the bank entries of `count` particles into particle-major records [Pt | Pb | F | xl].  With fp32 storage the two
+// covariance blocks keep their stored type inside the record (they take szT / 2 and szB / 2 doubles; both are even).
+template <typename TS>
+__global__ void pack_records_kernel(Layout L, int d, const int* __restrict__ idx, const TS* __restrict__ Pt,
+                                    const TS* __restrict__ Pb, const double* __restrict__ F,
                                     const double* __restrict__ xl, double* __restrict__ rec, size_t rec_stride) {
+  constexpr size_t PER = sizeof(double) / sizeof(TS);       // stored elements per double
   const int p = blockIdx.x;
   const int src = idx[p];
   const size_t szF = (size_t)2 * d * L.ldx;
-  const size_t recsz = rec_stride ? rec_stride : L.szT + L.szB + szF + L.ldx;
+  const size_t offB = L.szT / PER, offF = (L.szT + L.szB) / PER;
+  const size_t recsz = rec_stride ? rec_stride : offF + szF + L.ldx;
   double* r = rec + (size_t)p * recsz;
-  const dbl2* a = reinterpret_cast<const dbl2*>(Pt + (size_t)src * L.szT);
-  dbl2* b = reinterpret_cast<dbl2*>(r);
-  for (size_t q = threadIdx.x; q < L.szT / 2; q += blockDim.x) b[q] = a[q];
-  for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) r[L.szT + q] = Pb[(size_t)src * L.szB + q];
-  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[L.szT + L.szB + q] = F[(size_t)src * szF + q];
-  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[L.szT + L.szB + szF + q] = xl[(size_t)src * L.ldx + q];
+  const double* a = reinterpret_cast<const double*>(Pt + (size_t)src * L.szT);       // raw 8-byte words
+  const double* bsrc = reinterpret_cast<const double*>(Pb + (size_t)src * L.szB);
+  for (size_t q = threadIdx.x; q < offB; q += blockDim.x) r[q] = a[q];
+  for (size_t q = threadIdx.x; q < L.szB / PER; q += blockDim.x) r[offB + q] = bsrc[q];
+  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[offF + q] = F[(size_t)src * szF + q];
+  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[offF + szF + q] = xl[(size_t)src * L.ldx + q];
 }
 
 // Same records, but with the lineage's pending factor sets applied while packing (sharded filter with the
@@ -1607,55 +1611,65 @@ struct PackSets {
   const double* rec; size_t rec_stride;       // bases of previously imported lineages live in the record buffer
 };
 
-__global__ void pack_records_flushed_kernel(Layout L, int d, const int* __restrict__ idx, const double* __restrict__ Pt,
-                                            const double* __restrict__ Pb, PackSets ps, const double* __restrict__ xl,
+template <typename TS>
+__global__ void pack_records_flushed_kernel(Layout L, int d, const int* __restrict__ idx, const TS* __restrict__ Pt,
+                                            const TS* __restrict__ Pb, PackSets ps, const double* __restrict__ xl,
                                             double* __restrict__ out) {
+  constexpr size_t PER = sizeof(double) / sizeof(TS);
   const int p = blockIdx.x;
   const int src = idx[p];
   const size_t szF = (size_t)2 * d * L.ldx;
-  const size_t recsz = L.szT + L.szB + szF + L.ldx;
+  const size_t offB = L.szT / PER, offF = (L.szT + L.szB) / PER;
+  const size_t recsz = ps.rec_stride ? ps.rec_stride : offF + szF + L.ldx;
   double* r = out + (size_t)p * recsz;
+  TS* rt = reinterpret_cast<TS*>(r);
+  TS* rb = reinterpret_cast<TS*>(r + offB);
   const int bsl = ps.base ? ps.base[src] : src;
   const bool inrec = ps.rec != nullptr && bsl >= ps.n_bank_local;
-  const double* t = inrec ? ps.rec + (size_t)(bsl - ps.n_bank_local) * ps.rec_stride : Pt + (size_t)bsl * L.szT;
-  const double* b = inrec ? ps.rec + (size_t)(bsl - ps.n_bank_local) * ps.rec_stride + L.szT : Pb + (size_t)bsl * L.szB;
+  const double* recp = inrec ? ps.rec + (size_t)(bsl - ps.n_bank_local) * ps.rec_stride : nullptr;
+  const TS* t = inrec ? reinterpret_cast<const TS*>(recp) : Pt + (size_t)bsl * L.szT;
+  const TS* b = inrec ? reinterpret_cast<const TS*>(recp + offB) : Pb + (size_t)bsl * L.szB;
   const double* F[kMaxSets];
   for (int s = 0; s < ps.n_sets; ++s) F[s] = ps.fset[s] + (size_t)(ps.fidx[s] ? ps.fidx[s][src] : src) * szF;
   for (size_t q = threadIdx.x; q < L.szT; q += blockDim.x) {
     const int c = (int)(q / L.mc), rr = L.nb + (int)(q % L.mc);
-    double v = t[q];
+    double v = (double)t[q];
     for (int s = 0; s < ps.n_sets; ++s)
       for (int k = 0; k < d; ++k) v = fma(-F[s][(size_t)k * L.ldx + rr], F[s][(size_t)(d + k) * L.ldx + c], v);
-    r[q] = v;
+    rt[q] = (TS)v;
   }
   for (size_t q = threadIdx.x; q < L.szB; q += blockDim.x) {
     const int rr = (int)(q / L.ldb), c = (int)(q % L.ldb);
-    double v = b[q];
+    double v = (double)b[q];
     if (c < L.n)
       for (int s = 0; s < ps.n_sets; ++s)
         for (int k = 0; k < d; ++k) v = fma(-F[s][(size_t)k * L.ldx + rr], F[s][(size_t)(d + k) * L.ldx + c], v);
-    r[L.szT + q] = v;
+    rb[q] = (TS)v;
   }
-  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[L.szT + L.szB + q] = 0.0;
-  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[L.szT + L.szB + szF + q] = xl[(size_t)src * L.ldx + q];
+  for (size_t q = threadIdx.x; q < szF; q += blockDim.x) r[offF + q] = 0.0;
+  for (size_t q = threadIdx.x; q < (size_t)L.ldx; q += blockDim.x) r[offF + szF + q] = xl[(size_t)src * L.ldx + q];
 }
 
 hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx, int count, const double* Pt,
                                        const double* Pb, int n_sets, const double* const* fset, const int* const* fidx,
                                        const int* base, int n_bank_local, const double* rec, size_t rec_stride,
-                                       const double* xl, double* out, hipStream_t s) {
+                                       const double* xl, double* out, hipStream_t s, int fp32) {
   if (count <= 0) return hipSuccess;
   PackSets ps;
   ps.n_sets = n_sets; ps.n_bank_local = n_bank_local; ps.base = base; ps.rec = rec; ps.rec_stride = rec_stride;
   for (int q = 0; q < kMaxSets; ++q) { ps.fset[q] = q < n_sets ? fset[q] : nullptr; ps.fidx[q] = q < n_sets ? fidx[q] : nullptr; }
-  hipLaunchKernelGGL(pack_records_flushed_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, ps, xl, out);
+  if (fp32) hipLaunchKernelGGL(pack_records_flushed_kernel<float>, dim3(count), dim3(256), 0, s, lay, d, idx,
+                               reinterpret_cast<const float*>(Pt), reinterpret_cast<const float*>(Pb), ps, xl, out);
+  else hipLaunchKernelGGL(pack_records_flushed_kernel<double>, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, ps, xl, out);
   return hipGetLastError();
 }
 
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
-                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride) {
+                               const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride, int fp32) {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_records_kernel, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, rec, rec_stride);
+  if (fp32) hipLaunchKernelGGL(pack_records_kernel<float>, dim3(count), dim3(256), 0, s, lay, d, idx, reinterpret_cast<const float*>(Pt),
+                               reinterpret_cast<const float*>(Pb), F, xl, rec, rec_stride);
+  else hipLaunchKernelGGL(pack_records_kernel<double>, dim3(count), dim3(256), 0, s, lay, d, idx, Pt, Pb, F, xl, rec, rec_stride);
   return hipGetLastError();
 }
 

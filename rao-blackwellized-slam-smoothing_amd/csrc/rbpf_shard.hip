@@ -68,7 +68,10 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   s->rank = rank; s->world = world; s->Nloc = (int)Nloc; s->Nglob = (int)(Nloc * world);
   const Layout& L = c->lay;
   const int nN = c->mdl.nN, d = c->mdl.d;
-  s->recsz = L.szT + L.szB + (size_t)2 * d * L.ldx + L.ldx;
+  // covariance blocks in their stored type (float: half the doubles), then the fp64 factors and mean
+  const size_t per = c->fp32 ? 2 : 1;
+  s->recsz = (L.szT + L.szB) / per + (size_t)2 * d * L.ldx + L.ldx;
+  s->recsz += s->recsz & 1;
   s->recsz_base = s->recsz;
   s->smoother = smoother;
   if (smoother) {
@@ -218,10 +221,10 @@ int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
     const double* fset[kMaxSets]; const int* fidx[kMaxSets];
     for (int q = 0; q < ell; ++q) { const int bank = (t - ell + q) % B; fset[q] = c->Fb[bank]; fidx[q] = c->fidx[c->tcur] + (size_t)bank * N; }
     HIPCHK(launch_pack_records_flushed(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], ell, fset, fidx, c->base[c->tcur], N,
-                                       s->recv_rec, s->recsz, c->xl[c->xcur], s->send_rec, c->stream));
+                                       s->recv_rec, s->recsz, c->xl[c->xcur], s->send_rec, c->stream, c->fp32 ? 1 : 0));
   } else {
     HIPCHK(launch_pack_records(c->lay, c->mdl.d, idx, count, c->Pt[ob], c->Pb[ob], c->F[ob], c->xl[ob], s->send_rec,
-                               c->stream, s->recsz));
+                               c->stream, s->recsz, c->fp32 ? 1 : 0));
   }
   if (s->smoother) RB_TRY(shard_smoother_pack_info(c, idx, count));
   HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
@@ -300,12 +303,14 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
     a.Pt_old = c->Pt[ob]; a.Pb_old = c->Pb[ob]; a.Pt_old_stride = L.szT; a.Pb_old_stride = L.szB;
     a.n_bank_local = N;
     a.rec = s->recv_rec; a.rec_stride = s->recsz;
-    a.rec_off_B = L.szT; a.rec_off_F = L.szT + L.szB; a.rec_off_X = L.szT + L.szB + (size_t)2 * d * L.ldx;
+    const size_t per = c->fp32 ? 2 : 1;                      // stored elements per double in the covariance blocks
+    a.rec_off_B = L.szT / per; a.rec_off_F = (L.szT + L.szB) / per; a.rec_off_X = a.rec_off_F + (size_t)2 * d * L.ldx;
     a.rec_off_I = s->rec_off_I; a.rec_off_hld = s->rec_off_hld;
     // the host places the new generation in ancestor order, so physical order is already cache-friendly
   }
   a.xl_new = c->xl[xn]; a.F_new = lazy ? c->Fb[t % (c->lazy_depth + 1)] : c->F[nb];
   a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
+  a.fp32 = c->fp32 ? 1 : 0;
   a.rng_mode = c->rng_mode; a.k_iter = k_iter; a.seed = c->seed;
   a.Z = (c->d_Z && t > 0) ? c->d_Z + ((size_t)k_iter * std::max(c->T - 1, 0) + (size_t)(t - 1)) * s->Nglob * nw : nullptr;
   a.xref = xref_t; a.xref_gslot = s->Nglob - 1;

@@ -29,7 +29,7 @@ import numpy as np
 
 from . import _ffi
 from ._ffi import check, load_library
-from .host import PhiloxRNG, _Problem, _dp, _ip, _rng_block
+from .host import PhiloxRNG, _Problem, _dp, _ip, _rng_block, _storage_code
 
 
 # ------------------------------------------------------------------------------------------------
@@ -167,7 +167,7 @@ class ShardedFilterSession:
     transport="host"  : device -> host -> gloo -> device (lets two ranks share ONE GPU in tests)."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
-                 transport="device", planner="device", lazy_depth=0):
+                 transport="device", planner="device", lazy_depth=0, storage="fp64"):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -192,7 +192,8 @@ class ShardedFilterSession:
                                          self.prob.N_T, model.nw, self._n_iter())
         if lazy_depth >= 2 and planner != "device":
             raise ValueError("lazy_depth >= 2 needs planner='device'")
-        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0)
+        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
+                                     storage=_storage_code(storage))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         self._create()
