@@ -29,8 +29,15 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_kernel(int N, int worl
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int S = (N + kPlanThreads - 1) / kPlanThreads;
   const int j0 = min(tid * S, N), j1 = min(j0 + S, N);
+  constexpr int NBATCH = 8;                             // loads in flight per thread (a lone workgroup is latency-bound)
   int tot = 0;
-  for (int j = j0; j < j1; ++j) tot += counts[j];
+  for (int jb = j0; jb < j1; jb += NBATCH) {
+    int v[NBATCH];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) v[k] = counts[min(jb + k, N - 1)];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) tot += (jb + k < j1) ? v[k] : 0;
+  }
   int inc = tot;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -41,7 +48,14 @@ __global__ __launch_bounds__(kPlanThreads) void plan_scan_kernel(int N, int worl
   __syncthreads();
   int run = inc - tot;
   for (int w = 0; w < wave; ++w) run += swave[w];
-  for (int j = j0; j < j1; ++j) { offsets[j] = run; run += counts[j]; }
+  for (int jb = j0; jb < j1; jb += NBATCH) {
+    int v[NBATCH];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k) v[k] = counts[min(jb + k, N - 1)];
+#pragma unroll
+    for (int k = 0; k < NBATCH; ++k)
+      if (jb + k < j1) { offsets[jb + k] = run; run += v[k]; }
+  }
   if (tid == kPlanThreads - 1) offsets[N] = run;
   __syncthreads();
   if (tid == 0) {
