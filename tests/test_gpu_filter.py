@@ -122,3 +122,35 @@ def test_fp32_storage_is_rejected_where_it_is_not_implemented(rbpf):
     with pytest.raises(rbpf.RBPFError):                                         # dense-radio (ny = 1): fp64 only
         rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 1.0,
                             rng=cases.device_rng(rbpf, c), storage="fp32")
+
+
+@pytest.fixture(scope="module")
+def reduced_c2(rbpf, tmp_path_factory):
+    """BASELINE.md section 3 "reduced C2": slam-dense-mag N=1024, T=300, m=256, fp64, replayed random numbers, and the
+    plain-C restatement's outputs on it (all host cores; computed once for the tests below)."""
+    import importlib
+    import oracle_c
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T, m = 1024, 300, 256
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    rs = np.random.RandomState(77)
+    rng = rbpf.ReplayRNG(rs.random_sample((1, T - 1, N)), rs.standard_normal((1, T - 1, N, 6)))
+    import bench                                                             # usable_cores(): affinity mask / cgroup quota
+    lib = oracle_c.build(native_dir=str(tmp_path_factory.mktemp("oracle_native")))      # -O3 -march=native -fopenmp
+    ref, _ = oracle_c.particle_filter(rbpf, mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng,
+                                      n_threads=bench.usable_cores(), want_full=False, lib_path=lib)
+    return dict(d=d, mdl=mdl, x0=x0, P0=P0, R=R, rng=rng, N=N, ref=ref)
+
+
+@pytest.mark.parametrize("lazy_depth", [0, 3])
+def test_reduced_c2_against_the_c_restatement(rbpf, reduced_c2, lazy_depth):
+    """Too large for the numpy oracle, so the HIP filter is compared with the plain-C restatement (itself pinned to the
+    numpy oracle, tests/test_oracle_c.py) on the same replayed random numbers: 300 steps x 1024 draws of identical
+    resampling (any differing index would show up in every later trajectory summary) and states / maps to 1e-9."""
+    c = reduced_c2
+    d, mdl, ref = c["d"], c["mdl"], c["ref"]
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], c["x0"], c["P0"], cases.Q_MAG, c["R"],
+                              c["N"], 0.01, rng=c["rng"], want_xn_traj=False, lazy_depth=lazy_depth)
+    assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
+    assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
