@@ -144,3 +144,34 @@ def test_large_particle_count_uses_the_multi_workgroup_resample_pipeline(rbpf, k
     assert rel(ex["w"], ref["trace"]["w"]) <= RTOL
     assert rel(out[1], ref["traj_mean"]) <= RTOL
     assert rel(out[4], ref["P_max"]) <= RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lazy_depth", [0, 3])
+def test_device_kalman_recursion_equals_batch_gp_posterior(rbpf, oracle, lazy_depth):
+    """Known-answer test that does not go through the oracle's filter: with (numerically) no process noise every
+    particle follows the odometry exactly, so the T per-step Kalman updates of the step kernel (particleFilter.m:184-198)
+    along that fixed path must equal the batch reduced-rank GP posterior of tools/gp_scalar_potential_fast.m:190-192,
+        mean = L'\\(L\\(Phi'*y)),  cov = sigma2 * inv(Phi'*Phi + diag(sigma2./k)),  L = chol(Phi'*Phi + diag(sigma2./k)),
+    with Phi the stacked measurement Jacobians.  Benchmark basis size (m = 256, nLin = 259), 150 steps."""
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    T, m, N = 150, 256, 4
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=2, m_sim=400)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    Qtiny = 1e-24 * np.eye(6)
+    rng = rbpf.ReplayRNG(np.full((1, T - 1, N), 0.5), np.zeros((1, T - 1, N, 6)))
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, Qtiny, R, N, 0.01, rng=rng,
+                              extras=True, lazy_depth=lazy_depth)
+    xn_traj, ex = out[7], out[8]
+    path = xn_traj[:, 0, :]                                                     # every particle is on the same path
+    assert np.max(np.abs(xn_traj - path[:, None, :])) == 0.0
+    omdl = oracle.DenseMagModel(NN=mdl.NN.astype(np.int64), L=mdl.L)
+    Phi = omdl.measModel(path).reshape(-1, mdl.nLin)                            # [3T x nLin]
+    sigma2, k = R[0, 0], np.diag(P0)
+    Lc = np.linalg.cholesky(Phi.T @ Phi + np.diag(sigma2 / k))
+    mean = np.linalg.solve(Lc.T, np.linalg.solve(Lc, Phi.T @ d["y"].reshape(-1)))
+    cov = sigma2 * np.linalg.inv(Lc @ Lc.T)
+    for i in range(N):
+        np.testing.assert_allclose(ex["xl"][:, i], mean, rtol=1e-7, atol=1e-8 * np.max(np.abs(mean)))
+        np.testing.assert_allclose(ex["P"][:, :, i], cov, rtol=1e-6, atol=1e-9 * np.max(np.abs(cov)))
