@@ -262,6 +262,9 @@ int rbpf_shard_step(rbpf_ctx* ctx, const int32_t* anc_bank_host, const int32_t* 
  * the read-only steps of a lazy cycle).  Afterwards rbpf_shard_pack(ctx, NULL, n_send), rbpf_shard_step(ctx, NULL, NULL) and
  * rbpf_shard_normalise_search(ctx, NULL, ...) use the device plan.                                      */
 int rbpf_shard_plan(rbpf_ctx* ctx, int64_t* counts_host);
+/* rbpf_shard_normalise_search(ctx, NULL, draw) + rbpf_shard_plan(ctx, counts) in one call (what the production loop
+ * uses): the ancestors are not copied to the host and the stream is synchronised once.                        */
+int rbpf_shard_normalise_plan(rbpf_ctx* ctx, int64_t* counts_host);
 /* Test hook: this rank's view of the current device plan.                                             */
 int rbpf_shard_plan_read(rbpf_ctx* ctx, int32_t* slot_ids, int32_t* anc_bank, int32_t* send_idx,
                          int32_t n_send, int32_t* new_gid);

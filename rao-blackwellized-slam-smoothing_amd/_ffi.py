@@ -77,7 +77,7 @@ EXPORTS = [
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
-    "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read",
+    "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read", "rbpf_shard_normalise_plan",
     "rbpf_shard_smoother_create", "rbpf_shard_smoother_views_get", "rbpf_shard_smoother_begin",
     "rbpf_shard_smoother_normalise", "rbpf_shard_smoother_anc_weights", "rbpf_shard_smoother_anc_sample",
     "rbpf_shard_smoother_step", "rbpf_shard_smoother_end",

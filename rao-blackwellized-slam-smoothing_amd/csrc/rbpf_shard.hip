@@ -11,6 +11,7 @@
 #include "rbpf_shard_state.hpp"
 
 #include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <vector>
 
@@ -157,6 +158,9 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* 
 
 }  // extern "C"
 
+// ai_host == kDrawOnly: draw the ancestors but leave them on the device (device planner: nobody reads them on the host)
+static int32_t* const kDrawOnly = reinterpret_cast<int32_t*>(static_cast<intptr_t>(-1));
+
 int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host, int k_iter, int n_draw) {
   HIPCHK(hipSetDevice(c->device));
   ShardState* s = c->sh;
@@ -184,7 +188,7 @@ int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* a
     sa.approx = 1; sa.ambiguous = c->d_flags + 4; sa.w = s->w_glob; sa.wc_exact = s->wc_glob;
     if (N > kSingleWgResampleMaxN) HIPCHK(launch_resample_pipeline(nm, &sa, nullptr, nullptr, nullptr, c->d_rs, c->stream));
     else HIPCHK(launch_normalise_resample(nm, sa, nullptr, nullptr, c->stream));
-    HIPCHK(hipMemcpyAsync(ai_host, s->ai_glob, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (ai_host != kDrawOnly) HIPCHK(hipMemcpyAsync(ai_host, s->ai_glob, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   } else if (N > kSingleWgResampleMaxN) {
     HIPCHK(launch_resample_pipeline(nm, nullptr, nullptr, nullptr, nullptr, c->d_rs, c->stream));
   } else {
@@ -196,11 +200,20 @@ int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* a
       HIPCHK(hipMemcpyAsync(s->Ahist + (size_t)c->t * N, s->ai_glob, (size_t)n_draw * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
   }
   s->t_norm = t_done + 1;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  if (ai_host != kDrawOnly) HIPCHK(hipStreamSynchronize(c->stream));
   return RBPF_OK;
 }
 
 extern "C" {
+
+// rbpf_shard_normalise_search + rbpf_shard_plan in one call for the device planner: the ancestors stay on the device
+// and the stream is synchronised once (by the plan's count read-back).
+int rbpf_shard_normalise_plan(rbpf_ctx* c, int64_t* counts_host) {
+  if (!c || !c->sh || !counts_host) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  if (c->sh->smoother) { set_error("smoother context: use the rbpf_shard_smoother_* sequence"); return RBPF_ERR_STATE; }
+  RB_TRY(shard_normalise_impl(c, nullptr, kDrawOnly, 0, c->sh->Nglob));
+  return rbpf_shard_plan(c, counts_host);
+}
 
 int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
   if (!c || !c->sh || count < 0) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }

@@ -180,6 +180,7 @@ class ShardedFilterSession:
                            ("rbpf_shard_pack", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
                            ("rbpf_shard_step", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p]),
                            ("rbpf_shard_plan", [C.c_void_p, C.POINTER(C.c_int64)]),
+                           ("rbpf_shard_normalise_plan", [C.c_void_p, C.POINTER(C.c_int64)]),
                            ("rbpf_shard_plan_read", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p, _ffi.c_int32_p, C.c_int32,
                                                      _ffi.c_int32_p]),
                            ("rbpf_shard_trajectories", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p])):
@@ -290,12 +291,12 @@ class ShardedFilterSession:
                 t0 = time.perf_counter()
                 self._gather()
                 t1 = time.perf_counter()
-                self._normalise(True)
-                t2 = time.perf_counter()
                 if self.planner == "device":
+                    # normalise + draw + plan in one library call: ancestors stay on the device, one stream sync
                     cnt = np.zeros(2 * self.world + 2, dtype=np.int64)
-                    check(self.lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
-                    t3 = time.perf_counter()
+                    check(self.lib.rbpf_shard_normalise_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
+                    self.t_norm += 1
+                    t2 = t3 = time.perf_counter()
                     if self.world > 1:
                         self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]), int(cnt[2 * self.world + 1]))
                     t4 = time.perf_counter()
@@ -307,6 +308,8 @@ class ShardedFilterSession:
                     self.t += 1
                     self.stats["steps"] += 1
                     continue
+                self._normalise(True)
+                t2 = time.perf_counter()
                 plan = plan_generation(self.ai, self.cur_rank, self.cur_idx, self.world, self.N_local)
                 rp = rank_view(plan, self.ai, self.cur_rank, self.cur_idx, self.rank, self.world, self.N_local)
                 t3 = time.perf_counter()
