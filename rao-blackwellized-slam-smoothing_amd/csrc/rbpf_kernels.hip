@@ -393,7 +393,10 @@ hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
 #ifndef RBPF_MINWAVES
 #define RBPF_MINWAVES 1     // min waves per SIMD requested from the register allocator (tuning)
 #endif
-template <typename TS, int D, int E, int CPL, int NS, bool WR>
+// UFX: extra unroll of the covariance stream for float storage when a wave owns two row chunks of WHOLE columns
+// (RS = 4, CS = 1: n >= 1024); measured at n = 1027: 1: 0.62, 2: 0.39, 3: 0.68, 4: 0.76, 6: 0.67, 8: 0.70 M/s.  With
+// CS = 4 (n = 259) the same factor costs a third of the throughput, hence a launch-time choice.
+template <typename TS, int D, int E, int CPL, int NS, bool WR, int UFX = 1>
 __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, REC = DE + ND, NSA = NS > 0 ? NS : 1;
@@ -530,8 +533,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 #ifndef RBPF_UF32
 #define RBPF_UF32 2
 #endif
-      constexpr int kUF = (sizeof(TS) == 4 && CPL <= 1) ? RBPF_UF32 : 1;     // (two chunks per wave already keep 2x the loads in flight;
-                                                                              //  doubling again measured 0.39 vs 0.63 M/s at n = 1027)
+      constexpr int kUF = ((sizeof(TS) == 4 && CPL <= 1) ? RBPF_UF32 : 1) * UFX;
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
@@ -751,6 +753,24 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 template <typename TS, int D, int E, int CPL, int NS, bool WR>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
   const size_t lds = step_lds_bytes(a.mdl, a.lay, E, NS);
+  // launch-time unroll choices that depend on the wave decomposition (see step_kernel): float storage with whole
+  // columns per wave and two row chunks (n >= 1024) x4; double storage in the 2 x 2 decomposition (the flush kernel of
+  // the lazy update at n = 259) x2 (8.2 vs 7.7 M particle-steps/s at N = 8192)
+  constexpr int kWide = (sizeof(TS) == 4 && CPL == 2) ? 4 : ((sizeof(TS) == 8 && CPL == 1 && E == 0) ? 2 : 1);
+  if constexpr (kWide > 1) {
+    const bool wide = (sizeof(TS) == 4) ? (a.lay.CS == 1) : (a.lay.CS == 2 && a.lay.RS == 2);
+    if (wide) {
+      static bool attr_wide = false;
+      if (!attr_wide) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR, kWide>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_wide = true;
+      }
+      hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR, kWide>), dim3(a.N), dim3(kThreads), lds, s, a);
+      return hipGetLastError();
+    }
+  }
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR>),
