@@ -56,7 +56,12 @@ typedef enum {
    * pfslam.m:82 -> measurement.m:32-84 (1-D pinhole camera, point landmarks), dynResNorm = [] (psslam.m:119).
    * sparseFeatures = true: per-particle EKF linearisation, NaN in y = not observed (particleFilter.m:127-137,
    * 165-181).  nNonLin=3 (x,y,heading), ny = m_basis landmarks, nw=3, n_odo=3, nLin = 2*m_basis.              */
-  RBPF_MODEL_SPARSE_VISUAL_2D = 3
+  RBPF_MODEL_SPARSE_VISUAL_2D = 3,
+  /* Arbitrary dense model (any dynModel / measModel handles, sparseFeatures = false): the caller evaluates the handles
+   * itself -- dynModel per particle (particleFilter.m:108), measModel on the whole batch (:124) -- and hands states and
+   * Jacobians to rbpf_filter_step_external; everything else of the step (weights, normalisation, resampling, Kalman
+   * update, ancestry) runs on the device.  n_y must be 1 or 3.  The slow path behind unrecognised handles.         */
+  RBPF_MODEL_GENERIC_DENSE = 4
 } rbpf_model_kind;
 
 typedef struct {
@@ -208,6 +213,15 @@ int rbpf_sync(rbpf_ctx* ctx);
 int rbpf_filter_finish(rbpf_ctx* ctx, rbpf_filter_out* out);
 /* Current step index (number of steps processed).                                                 */
 int rbpf_filter_tell(const rbpf_ctx* ctx, int32_t* t);
+/* Generic model family (RBPF_MODEL_GENERIC_DENSE), one time step at a time:
+ *   t = 0:  rbpf_filter_step_external(ctx, xn0, measModel(xn0))
+ *   t > 0:  rbpf_filter_ancestors(ctx, ai, xn_prev); xn(:,i) = dynModel(xn_prev(:,ai(i)+1), ...); 
+ *           rbpf_filter_step_external(ctx, xn, measModel(xn))
+ * ai [N_P] 0-based ancestors of the step about to run (drawn by the previous step), xn_prev [n_nonlin x N_P] the
+ * states of the last step; xn_new [n_nonlin x N_P]; dy [N_P x n_y x n_lin] exactly as measModel returns it
+ * ([N_P x n_lin] memory for n_y = 1).                                                                       */
+int rbpf_filter_ancestors(rbpf_ctx* ctx, int32_t* ai, double* xn_prev);
+int rbpf_filter_step_external(rbpf_ctx* ctx, const double* xn_new, const double* dy);
 /* Enable (1) / disable (0) per-launch HIP-event timing of the stream kernel; read / reset it.     */
 int rbpf_timing_enable(rbpf_ctx* ctx, int32_t on);
 int rbpf_timing_read(rbpf_ctx* ctx, rbpf_timing* out, int32_t reset);

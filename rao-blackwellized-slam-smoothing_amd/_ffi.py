@@ -21,6 +21,7 @@ RBPF_ERR_STATE = 7
 RBPF_MODEL_DENSE_MAG_6D = 1
 RBPF_MODEL_DENSE_RADIO_2DH = 2
 RBPF_MODEL_SPARSE_VISUAL_2D = 3
+RBPF_MODEL_GENERIC_DENSE = 4
 RBPF_RNG_REPLAY = 0
 RBPF_RNG_PHILOX = 1
 
@@ -73,7 +74,7 @@ EXPORTS = [
     "rbpf_abi_version", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
     "rbpf_particle_filter", "rbpf_particle_smoother",
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
-    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
+    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
@@ -120,6 +121,8 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_sync.argtypes = [C.c_void_p]
     lib.rbpf_filter_finish.argtypes = [C.c_void_p, C.POINTER(rbpf_filter_out)]
     lib.rbpf_filter_tell.argtypes = [C.c_void_p, c_int32_p]
+    lib.rbpf_filter_ancestors.argtypes = [C.c_void_p, c_int32_p, c_double_p]
+    lib.rbpf_filter_step_external.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.rbpf_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.rbpf_timing_read.argtypes = [C.c_void_p, C.POINTER(rbpf_timing), C.c_int32]
     lib.rbpf_destroy.argtypes = [C.c_void_p]

@@ -60,6 +60,7 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
     double* Lb = &blk[(size_t)t * nw * nw];
     double* Lf = &full[(size_t)t * nw * nw];
     bool ok = true;
+    if (model->kind == RBPF_MODEL_GENERIC_DENSE) continue;                // dynModel runs on the host: Q is its business
     if (model->kind == RBPF_MODEL_DENSE_MAG_6D) {
       ok = chol_lower_host(A.data(), 3, nw, Lb, nw) && chol_lower_host(A.data() + 3 + 3 * nw, 3, nw, Lb + 3 + 3 * nw, nw);
     } else if (model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
@@ -78,7 +79,7 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
 
 int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
                    ModelDev& M, std::vector<int>& nn_axis_major) {
-  if (!model || (!model->NN && model->kind != RBPF_MODEL_SPARSE_VISUAL_2D)) { set_error("model / model->NN is NULL"); return RBPF_ERR_INVALID_ARG; }
+  if (!model || (!model->NN && model->kind != RBPF_MODEL_SPARSE_VISUAL_2D && model->kind != RBPF_MODEL_GENERIC_DENSE)) { set_error("model / model->NN is NULL"); return RBPF_ERR_INVALID_ARG; }
   std::memset(&M, 0, sizeof(M));
   M.kind = model->kind;
   M.m = model->m_basis;
@@ -95,6 +96,18 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
       set_error("dense-radio-2D+heading expects dim=2, nNonLin=3, ny=1, nw=1, n_odo=3, nLin=m");
       return RBPF_ERR_INVALID_ARG;
     }
+  } else if (model->kind == RBPF_MODEL_GENERIC_DENSE) {
+    if ((d != 1 && d != 3) || nN < 1 || nN > 8 || nw < 1 || nw > 8 || n < 1) {
+      set_error("generic dense family: n_y must be 1 or 3, n_nonlin and n_w <= 8"); return RBPF_ERR_UNSUPPORTED;
+    }
+    M.m = n; M.dim = 0; M.ktot = 0;
+    for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
+    for (int q = 0; q < d * d; ++q) M.Rinv[q] = std::nan("");
+    M.halfLogDetR = std::nan("");
+    M.jitter = jitter;
+    M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
+    nn_axis_major.clear();
+    return RBPF_OK;
   } else if (model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
     if (nN != 3 || nw != 3 || nodo != 3 || d != model->m_basis || n != 2 * model->m_basis || d < 1 || d > 32) {
       set_error("sparse-visual-2D expects nNonLin=3, nw=3, n_odo=3, ny = landmarks <= 32, nLin = 2*landmarks");
@@ -203,6 +216,11 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->opt.storage != 0 && c->opt.storage != 1) { set_error("options.storage must be 0 (fp64) or 1 (fp32)"); return RBPF_ERR_INVALID_ARG; }
   if (c->fp32 && (smoother || sparse || prob->n_y != 3)) {
     set_error("fp32 storage of the covariance banks: dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
+  }
+  if (model->kind == RBPF_MODEL_GENERIC_DENSE) {
+    if (smoother || ex) { set_error("generic (host-callback) models: unsharded particleFilter only"); return RBPF_ERR_UNSUPPORTED; }
+    RB_TRY(dmalloc(&c->d_xn_ext, (size_t)prob->n_nonlin * prob->N_P));
+    RB_TRY(dmalloc(&c->d_H_ext, (size_t)prob->N_P * prob->n_y * c->lay.ldx));
   }
   if (sparse) {
     if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }
@@ -376,7 +394,7 @@ void ctx_free(rbpf_ctx* c) {
   if (!c) return;
   if (c->stream) hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-  hipFree(c->d_R);
+  hipFree(c->d_R); hipFree(c->d_xn_ext); hipFree(c->d_H_ext);
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
@@ -503,6 +521,10 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
   a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1;
   a.fp32 = c->fp32 ? 1 : 0;
+  a.xn_ext = c->ext_xn; a.H_ext = c->ext_H;
+  if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE && (!a.xn_ext || !a.H_ext)) {
+    set_error("generic (host-callback) model: advance with rbpf_filter_step_external"); return RBPF_ERR_STATE;
+  }
   a.n_sets = (t > 0) ? 1 : 0; a.write_base = 1;
   if (lazy) {
     // multi-step lazy update: sets produced at steps t-ell .. t-1 are pending; every C-th step rewrites the matrices
@@ -696,6 +718,44 @@ int rbpf_filter_advance(rbpf_ctx* c, int32_t n_steps) {
   HIPCHK(hipSetDevice(c->device));
   c->fuse_resample = true;
   for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N, nullptr));
+  return RBPF_OK;
+}
+
+int rbpf_filter_ancestors(rbpf_ctx* c, int32_t* ai, double* xn_prev) {
+  if (!c || !ai || !xn_prev) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  const int t = c->t, N = c->N, nN = c->mdl.nN;
+  if (t < 1 || t >= c->T || c->ready_step != t) { set_error("no ancestors drawn for the next step (run a step first)"); return RBPF_ERR_STATE; }
+  const bool hist = c->opt.keep_history != 0;
+  HIPCHK(hipMemcpyAsync(ai, c->A + (hist ? (size_t)t * N : 0), (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> soa((size_t)nN * N);
+  HIPCHK(hipMemcpyAsync(soa.data(), c->X + (size_t)(hist ? t - 1 : ((t - 1) & 1)) * nN * N, soa.size() * sizeof(double),
+                        hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < N; ++i)
+    for (int q = 0; q < nN; ++q) xn_prev[q + (size_t)nN * i] = soa[(size_t)q * N + i];
+  return RBPF_OK;
+}
+
+int rbpf_filter_step_external(rbpf_ctx* c, const double* xn_new, const double* dy) {
+  if (!c || !xn_new || !dy) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  if (!c->d_xn_ext || !c->d_H_ext) { set_error("not a generic-model context"); return RBPF_ERR_STATE; }
+  HIPCHK(hipSetDevice(c->device));
+  const int N = c->N, nN = c->mdl.nN, d = c->mdl.d, n = c->mdl.n, ldx = c->lay.ldx;
+  std::vector<double> soa((size_t)nN * N), H((size_t)N * d * ldx, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int q = 0; q < nN; ++q) soa[(size_t)q * N + i] = xn_new[q + (size_t)nN * i];
+  for (int cc = 0; cc < n; ++cc)                     // dy(i, k, cc) at i + N*(k + d*cc)  ->  H[(i*d + k)*ldx + cc]
+    for (int k = 0; k < d; ++k)
+      for (int i = 0; i < N; ++i) H[((size_t)i * d + k) * ldx + cc] = dy[(size_t)i + (size_t)N * (k + (size_t)d * cc)];
+  HIPCHK(hipMemcpyAsync(c->d_xn_ext, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_H_ext, H.data(), H.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  c->ext_xn = c->d_xn_ext; c->ext_H = c->d_H_ext;
+  c->fuse_resample = true;
+  const int st = ctx_step(c, 0, nullptr, c->N, nullptr);
+  c->ext_xn = nullptr; c->ext_H = nullptr;
+  if (st != RBPF_OK) return st;
+  HIPCHK(hipStreamSynchronize(c->stream));          // the host vectors above go out of scope
   return RBPF_OK;
 }
 

@@ -71,6 +71,9 @@ struct rbpf_ctx {
   int* fidx[2] = {nullptr, nullptr};   // [lazy_depth+1][N] entry tables, ping-pong
   int* base[2] = {nullptr, nullptr};   // [N] stored-matrix slot of every lineage, ping-pong
   int tcur = 0;
+  // generic model family: host-evaluated states / Jacobians of the step about to run (consumed by ctx_step)
+  double *d_xn_ext = nullptr, *d_H_ext = nullptr;
+  const double *ext_xn = nullptr, *ext_H = nullptr;
   bool fp32 = false;        // the covariance banks hold float (rbpf_options.storage = 1)
   bool inplace = false;     // single covariance bank, rewritten in place at every flush (rbpf_options.inplace)
   int* d_ip = nullptr;      // [5][N] in-place flush plan: destination entry, phase, scratch

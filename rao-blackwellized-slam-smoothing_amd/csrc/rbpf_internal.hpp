@@ -65,6 +65,10 @@ struct StepArgs {
   // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.
   const int* dst_slot; const int* phase_of; int phase;
   int fp32;                      // 1: the covariance banks (Pt / Pb) hold float; strides stay in elements
+  // generic model family (arbitrary host callbacks): the propagated states and the measurement Jacobians of this step
+  // were evaluated on the host and uploaded
+  const double* xn_ext;          // SoA [nN][N] new non-linear states (null: dynModel runs on the device)
+  const double* H_ext;           // [N][d][ldx] measurement Jacobian H_i of every slot (null: measModel on the device)
   const int* slot_ids;           // logical (global) id of each local slot (null: slot_offset + i); when set,
                                  // `ai` is indexed by that logical id
   // remote ancestors (sharded filter): bank index >= n_bank_local refers to record (index - n_bank_local) of

@@ -332,7 +332,10 @@ __global__ void propagate_kernel(const StepArgs a) {
   double x[8], xp[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) x[c] = (c < nN) ? a.xn_old[(size_t)c * a.xn_old_stride + anc] : 0.0;
-  if (a.xref != nullptr && gslot == a.xref_gslot) {
+  if (a.xn_ext != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) xp[c] = (c < nN) ? a.xn_ext[(size_t)c * a.N + i] : 0.0;     // dynModel was evaluated on the host
+  } else if (a.xref != nullptr && gslot == a.xref_gslot) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) xp[c] = (c < nN) ? a.xref[c] : 0.0;                 // particleSmoother.m:242
   } else if (a.propagate) {
@@ -377,6 +380,7 @@ __global__ void propagate_kernel(const StepArgs a) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) pd[c] = xp[c];
   if (M.kind == 1) quat2rmat_dev(&xp[3], &pd[8]);
+  else { for (int c = 0; c < 9; ++c) pd[8 + c] = 0.0; }
 }
 
 hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
@@ -506,7 +510,12 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     }
     for (int c = tid; c < n; c += kThreads) {
       double h[D];
-      H_column<D>(M, c, tabS, tabC, &misc[8], h);
+      if (a.H_ext != nullptr) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) h[k] = a.H_ext[((size_t)i * D + k) * ldx + c];         // measModel was evaluated on the host
+      } else {
+        H_column<D>(M, c, tabS, tabC, &misc[8], h);
+      }
 #pragma unroll
       for (int k = 0; k < D; ++k) HK[c * REC + k] = h[k];
       if (E > 0) {

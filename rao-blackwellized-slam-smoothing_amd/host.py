@@ -215,6 +215,23 @@ class SparseVisualModel(_ModelFamily):
         raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "the sparse-visual closures are only evaluated inside the estimators")
 
 
+class GenericDenseModel:
+    """Descriptor behind arbitrary (unrecognised) dynModel / measModel callables with sparseFeatures = false: the host
+    evaluates the handles -- dynModel per particle (particleFilter.m:108), measModel on the whole batch (:124) -- and
+    the device does the rest of every step (RBPF_MODEL_GENERIC_DENSE).  The slow path: one host round trip per step."""
+    kind = _ffi.RBPF_MODEL_GENERIC_DENSE
+    sparse = False
+
+    def __init__(self, nNonLin, nLin, ny, nw, n_odo):
+        self.nNonLin, self.nLin, self.ny, self.nw, self.n_odo = int(nNonLin), int(nLin), int(ny), int(nw), int(n_odo)
+
+    def descriptor(self, use_dyn_res_norm=False):
+        d = _ffi.rbpf_model()
+        d.kind, d.m_basis, d.dim, d.use_dyn_res_norm = self.kind, self.nLin, 0, 0
+        d.NN = None
+        return d
+
+
 def dense_mag_prior(m, LL, theta):
     """GP prior of run_dense3D_magfield.m:83-107,122-131 -> (model, x0_lin, P0_lin, R)."""
     L, NN = domain_cartesian_dx(m, 3, LL)
@@ -393,6 +410,11 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended."""
+    if not isinstance(getattr(dynModel, "model", None), _ModelFamily) and callable(dynModel) and callable(measModel):
+        if sparseFeatures:
+            raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "sparseFeatures=true is implemented for the sparse-visual family only")
+        return _particle_filter_generic(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, makePlots,
+                                        rng, trace, want_xn_traj, extras, lazy_depth)
     model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
     _check_sparse_flag(model, sparseFeatures)
     lib = load_library()
@@ -453,6 +475,78 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
         ex = dict(logw=b["trace_logw"].T.copy(), w=b["trace_w"].T.copy(), ai=b["trace_ai"].T.copy(),
                   xn=b["final_xn"], xl=b["final_xl"], P=b["final_P"], iw_max=int(b["iw_max"][0]))
         return res + (ex,)
+    return res
+
+
+def _particle_filter_generic(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, makePlots, rng, trace,
+                             want_xn_traj, extras, lazy_depth):
+    """particleFilter for arbitrary callables (the reference's calling conventions, particleFilter.m:108,124):
+        xn_new [nN] = dynModel(xn_i [nN], odometry(t-1,:), dt(t-1), Q(:,:,t-1))      -- draws its own random numbers
+        dy [N x ny x nLin] (or [N x nLin] for ny = 1) = measModel(xn [nN x N])
+    Every step makes one host round trip: ancestors and states come down, the handles are evaluated here, states and
+    Jacobians go up (rbpf_filter_step_external); weights, normalisation, resampling, the Kalman update and the
+    ancestry bookkeeping stay on the device.  Resampling uniforms come from `rng` (the normals of a ReplayRNG are not
+    used: dynModel owns its randomness, as in the reference)."""
+    lib = load_library()
+    y2 = np.asarray(y, dtype=np.float64)
+    y2 = y2.reshape(-1, 1) if y2.ndim == 1 else y2
+    Qa = np.asarray(Q, dtype=np.float64)
+    Qa = Qa.reshape(1, 1) if Qa.ndim == 0 else Qa
+    x0l = np.asarray(x0_lin, dtype=np.float64)
+    odo = np.asarray(odometry, dtype=np.float64)
+    odo = odo.reshape(1, -1) if odo.ndim == 1 else odo
+    nN, n, d, nw = np.asarray(x0_nonLin).size, x0l.shape[0], y2.shape[1], Qa.shape[0]
+    model = GenericDenseModel(nN, n, d, nw, odo.shape[1])
+    prob = _Problem(model, odo, y2, x0_nonLin, x0_lin, P0_lin, Qa, R, N_P, dt)
+    N, T = prob.N_P, prob.N_T
+    Q3 = Qa[:, :, None] if Qa.ndim == 2 else Qa
+    dtv = np.atleast_1d(np.asarray(dt, dtype=np.float64)).ravel()
+    if rng is not None and isinstance(rng, ReplayRNG) and rng.Z is None:
+        rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (nw,)), rng.Ufin)
+    blk, _keep = _rng_block(rng, N, T, nw, 1)
+    opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=0, lazy_depth=int(lazy_depth),
+                            jitter=0.0)
+    mdesc = model.descriptor()
+    ctx = C.c_void_p()
+    check(lib.rbpf_filter_create(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(ctx)))
+    try:
+        xn = np.asfortranarray(np.repeat(np.asarray(x0_nonLin, dtype=np.float64).reshape(-1, 1), N, axis=1))   # :59
+        ai = np.zeros(N, dtype=np.int32)
+        xprev = np.empty((nN, N), order="F")
+        for t in range(T):
+            if t > 0:
+                check(lib.rbpf_filter_ancestors(ctx, _ip(ai), _dp(xprev)))
+                Qt = Q3[:, :, t - 1 if Q3.shape[2] > 1 else 0]
+                dtt = float(dtv[t - 1 if dtv.size > 1 else 0])
+                xn = np.empty((nN, N), order="F")
+                for i in range(N):                                                    # :104-109
+                    xn[:, i] = np.asarray(dynModel(xprev[:, ai[i]].copy(), odo[t - 1, :], dtt, Qt), dtype=np.float64).ravel()
+            dy = np.asarray(measModel(xn), dtype=np.float64)                           # :124
+            if dy.ndim == 2:
+                dy = dy.reshape(N, 1, n)
+            if dy.shape != (N, d, n):
+                raise ValueError(f"measModel returned shape {dy.shape}, expected {(N, d, n)}")
+            check(lib.rbpf_filter_step_external(ctx, _dp(np.asfortranarray(xn)), _dp(np.asfortranarray(dy))))
+        o = _ffi.rbpf_filter_out()
+        b = dict(traj_max=np.empty((nN, T), order="F"), traj_mean=np.empty((nN, T), order="F"), xl_max=np.empty(n),
+                 xl_mean=np.empty(n), P_max=np.empty((n, n), order="F"), P_mean=np.empty((n, n), order="F"),
+                 traj_sample_iwmax=np.empty((nN, T), order="F"), iw_max=np.zeros(1, dtype=np.int32))
+        if want_xn_traj or extras:
+            b["xn_traj"] = np.empty((nN, N, T), order="F")
+        if extras:
+            b.update(trace_logw=np.empty((N, T), order="F"), trace_w=np.empty((N, T), order="F"),
+                     trace_ai=np.zeros((N, T), dtype=np.int32, order="F"), final_xn=np.empty((nN, N), order="F"),
+                     final_xl=np.empty((n, N), order="F"), final_P=np.empty((n, n, N), order="F"))
+        for k, v in b.items():
+            setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
+        check(lib.rbpf_filter_finish(ctx, C.byref(o)))
+    finally:
+        lib.rbpf_destroy(ctx)
+    res = (b["traj_max"], b["traj_mean"], b["xl_max"], b["xl_mean"], b["P_max"], b["P_mean"], b["traj_sample_iwmax"],
+           b.get("xn_traj"))
+    if extras:
+        res = res + (dict(logw=b["trace_logw"].T.copy(), w=b["trace_w"].T.copy(), ai=b["trace_ai"].T.copy(),
+                          xn=b["final_xn"], xl=b["final_xl"], P=b["final_P"], iw_max=int(b["iw_max"][0])),)
     return res
 
 

@@ -154,3 +154,27 @@ def test_reduced_c2_against_the_c_restatement(rbpf, reduced_c2, lazy_depth):
                               c["N"], 0.01, rng=c["rng"], want_xn_traj=False, lazy_depth=lazy_depth)
     assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
     assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
+
+
+@pytest.mark.parametrize("kind,N_P,N_T,m,lazy_depth", [("mag", 10, 8, 130, 0), ("mag", 12, 9, 125, 3), ("radio", 9, 7, 128, 0)])
+def test_generic_host_callback_path_matches_oracle(rbpf, oracle, kind, N_P, N_T, m, lazy_depth):
+    """Arbitrary dynModel / measModel callables (here: plain Python closures over the oracle's model objects, unknown
+    to the library) run through the generic family: the host evaluates the handles every step, the device does weights,
+    normalisation, resampling and the Kalman update.  Same answers as the oracle's particleFilter."""
+    c = (cases.mag_case if kind == "mag" else cases.radio_case)(N_P, N_T, m, seed=19)
+    ref = cases.oracle_filter(c)
+    mdl, Z = c["model"], c["rng"].Z
+    calls = {"n": 0}
+
+    def dynModel(xn, dx, dt, Q):                                  # called for t = 1.., i = 0..N-1 in that order (:104-109)
+        t, i = divmod(calls["n"], N_P)
+        calls["n"] += 1
+        return mdl.dynModel(xn, dx, dt, Q, Z[0, t, i])[0]
+
+    def measModel(xn):
+        return mdl.measModel(xn)
+
+    out = rbpf.particleFilter(dynModel, measModel, c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"], c["Q"], c["R"],
+                              N_P, c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth)
+    assert calls["n"] == (N_T - 1) * N_P
+    check_filter(ref, out)
