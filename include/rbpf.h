@@ -119,7 +119,8 @@ typedef struct {
   int32_t keep_history;  /* 1: keep xn history + ancestor table (needed for traj_sample_iwmax,  *
                           *    xn_traj and every smoother); 0: ping-pong only                   */
   int32_t trace;         /* 1: record per-step logw / w / ancestor indices (tests)              */
-  int32_t fix_p_mean;    /* 0: reproduce quirk Q3 (particleFilter.m:228-230 overwrites P_mean)  */
+  int32_t fix_p_mean;    /* 0: reproduce quirk Q3 (particleFilter.m:228-230 overwrites P_mean);  *
+                          * 1: accumulate it over the particles (the evident intent)            */
   int32_t lazy_depth;    /* filter only: C >= 2 keeps up to C pending rank-n_y downdates on the fly and rewrites  *
                           * the stored covariances every C-th step only (C-1 read-only steps in between);      *
                           * 0/1: rewrite every step.  Results agree to rounding (same algebra).   max 4       */

@@ -563,7 +563,7 @@ def _normalise(logw):
 # src/particleFilter.m
 # --------------------------------------------------------------------------------------
 def particleFilter(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng: ReplayRNG,
-                   sparseFeatures=False, makePlots: Optional[Callable] = None, trace=False):
+                   sparseFeatures=False, makePlots: Optional[Callable] = None, trace=False, fix_p_mean=False):
     """src/particleFilter.m:1-234 (dense branch, and the sparseFeatures EKF branch :127-137,165-181 for models
     whose measModel(xn_i, xl_i) returns (yhat, dy)).
 
@@ -646,7 +646,8 @@ def particleFilter(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
     P_mean = np.zeros((xl_mean.size, xl_mean.size))
     for i in range(N_P):                                           # :228-230 -- quirk Q3: '=' not '+='
         dlt = xl_mean - xl[:, i]
-        P_mean = w[i] * (P[:, :, i] + np.outer(dlt, dlt))
+        term = w[i] * (P[:, :, i] + np.outer(dlt, dlt))
+        P_mean = P_mean + term if fix_p_mean else term          # fix_p_mean: the evident intent ("+="), not the reference
     traj_sample_iwmax = xn_traj[:, iw_max, :].copy()               # :233
     out = dict(traj_max=traj_max, traj_mean=traj_mean, xl_max=xl_max, xl_mean=xl_mean,
                P_max=P_max, P_mean=P_mean, traj_sample_iwmax=traj_sample_iwmax, xn_traj=xn_traj,

@@ -652,6 +652,58 @@ int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out) {
   return RBPF_OK;
 }
 
+// fix_p_mean = 1: P_mean = sum_i w(i) * (P(:,:,i) + (xl_mean - xl(:,i)) * (xl_mean - xl(:,i))'), i.e. particleFilter.m:228-230
+// with "+=" instead of the reference's "=" (quirk Q3).  One thread per matrix element, particles added in index order.
+__global__ void p_mean_accum_kernel(int n, int ldx, int i0, int count, const double* __restrict__ dP,
+                                    const double* __restrict__ xl, const double* __restrict__ xl_mean,
+                                    const double* __restrict__ w, double* __restrict__ acc) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)n * n) return;
+  const int r = (int)(q % n), cc = (int)(q / n);
+  double s = acc[q];
+  for (int j = 0; j < count; ++j) {
+    const int i = i0 + j;
+    const double dr = xl_mean[r] - xl[(size_t)i * ldx + r], dc = xl_mean[cc] - xl[(size_t)i * ldx + cc];
+    s += w[i] * (dP[(size_t)j * n * n + q] + dr * dc);
+  }
+  acc[q] = s;
+}
+
+__global__ void iota_kernel(int count, int first, int* out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < count) out[j] = first + j;
+}
+
+static int accumulate_p_mean(rbpf_ctx* c, const double* w_last, const std::vector<double>& xl_mean_h, double* P_mean_host) {
+  const int N = c->N, n = c->mdl.n, ldx = c->lay.ldx, cur = c->xcur;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)N, ((size_t)64 << 20) / ((size_t)n * n * sizeof(double))));
+  double *dP = nullptr, *dacc = nullptr, *dmean = nullptr; int* didx = nullptr;
+  int st = dmalloc(&dP, (size_t)chunk * n * n);
+  if (st == RBPF_OK) st = dmalloc(&dacc, (size_t)n * n);
+  if (st == RBPF_OK) st = dmalloc(&dmean, (size_t)n);
+  if (st == RBPF_OK) st = dmalloc(&didx, (size_t)chunk);
+  hipError_t e = hipSuccess;
+  if (st == RBPF_OK) {
+    e = hipMemsetAsync(dacc, 0, (size_t)n * n * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dmean, xl_mean_h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    for (int i0 = 0; i0 < N && e == hipSuccess && st == RBPF_OK; i0 += chunk) {
+      const int count = std::min(chunk, N - i0);
+      hipLaunchKernelGGL(iota_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, count, i0, didx);
+      st = ctx_unpack(c, didx, count, dP);
+      if (st != RBPF_OK) break;
+      hipLaunchKernelGGL(p_mean_accum_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, c->stream, n, ldx, i0,
+                         count, dP, c->xl[cur], dmean, w_last, dacc);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess && st == RBPF_OK) e = hipMemcpyAsync(P_mean_host, dacc, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && st == RBPF_OK) e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(dP); hipFree(dacc); hipFree(dmean); hipFree(didx);
+  if (st != RBPF_OK) return st;
+  HIPCHK(e);
+  return RBPF_OK;
+}
+
 int ctx_check_flags(rbpf_ctx* c) {
   int flags[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(flags, c->d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
@@ -863,8 +915,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
     if (e == hipSuccess && o->P_mean) {
       if (c->opt.fix_p_mean) {
         hipFree(dP); hipFree(didx);
-        set_error("fix_p_mean=1 (accumulated P_mean) is not implemented; the reference overwrites (quirk Q3)");
-        return RBPF_ERR_UNSUPPORTED;
+        return accumulate_p_mean(c, w_last, xl_mean, o->P_mean);   // consciously fixed quirk Q3 (option, not the default)
       }
       // quirk Q3 (particleFilter.m:228-230): P_mean = w(N)*(P(:,:,N) + (xl_mean-xl(:,N))*(...)')
       const int last = N - 1;

@@ -406,7 +406,7 @@ def _recognise(dynModel, measModel, dynResNorm=None):
 # ------------------------------------------------------------------------------------------------
 def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, *, rng=None, trace=False,
-                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64"):
+                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64", fix_p_mean=False):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended."""
@@ -420,7 +420,7 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     lib = load_library()
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, 1)
-    opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=0,
+    opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=1 if fix_p_mean else 0,
                             lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
                             storage=_storage_code(storage))
     mdesc = model.descriptor()

@@ -175,3 +175,20 @@ def test_device_kalman_recursion_equals_batch_gp_posterior(rbpf, oracle, lazy_de
     for i in range(N):
         np.testing.assert_allclose(ex["xl"][:, i], mean, rtol=1e-7, atol=1e-8 * np.max(np.abs(mean)))
         np.testing.assert_allclose(ex["P"][:, :, i], cov, rtol=1e-6, atol=1e-9 * np.max(np.abs(cov)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lazy_depth", [0, 3])
+def test_fix_p_mean_accumulates_over_particles(rbpf, oracle, lazy_depth):
+    """rbpf_options.fix_p_mean = 1 (off by default): P_mean = sum_i w(i)*(P_i + (xl_mean - xl_i)(xl_mean - xl_i)'), the
+    evident intent of particleFilter.m:228-230, instead of the reference's overwrite (quirk Q3, reproduced by default)."""
+    c = cases.mag_case(40, 9, 130, seed=21)
+    ref = oracle.particleFilter(c["model"], c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"], c["Q"], c["R"],
+                                c["N_P"], c["dt"], c["rng"], fix_p_mean=True)
+    q3 = cases.oracle_filter(c)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"],
+                              c["dt"], rng=cases.device_rng(rbpf, c), lazy_depth=lazy_depth, fix_p_mean=True)
+    scale = np.max(np.abs(ref["P_mean"]))
+    assert np.max(np.abs(out[5] - ref["P_mean"])) <= 1e-9 * scale
+    assert np.max(np.abs(ref["P_mean"] - q3["P_mean"])) > 1e-3 * scale          # and it is not the quirk's value
