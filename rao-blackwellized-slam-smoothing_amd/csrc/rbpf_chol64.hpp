@@ -1,0 +1,445 @@
+// Ancestor-weight factorisation, 64-column variant (included by rbpf_smoother.hip inside namespace rbpf, after the
+// 16-column kernel whose argument block, element loader and scalar helpers it shares).
+//
+//   particleSmoother.m:221-229                  cS = chol(S,'lower') (+ jitter retry), v = cS \ e, sum(log(diag(cS)))
+//   particleSmootherInformationForm.m:224-236   cIend = chol(Imat_i + ImatAddt), v = cIend \ (ivec_i + ivecAddt)
+//
+// Why a second kernel.  The 16-column left-looking kernel re-reads the finished factor once per 16 columns:
+// n^3/96 elements = 12 MB per particle at n = 515, 100 GB per launch of 8192 particles, which caps it at ~14 ms even at
+// the HBM rate, and every block column has a one-wave diagonal tile with fifteen waves waiting.  Here a block column is
+// 64 wide (4 sub-columns of 16), so the factor is re-read four times less, and the serial part runs beside the bulk:
+//
+//   * one workgroup = 8 wave64 (256 registers each) per particle;
+//   * wave 0 owns the 64 x 64 DIAGONAL BLOCK of the block column (row tiles 4J..4J+3): its panel product, the four
+//     16 x 16 tile factorisations, the solves and updates between them all stay in that wave's registers — no barrier;
+//   * waves 1..7 own the row tiles below (up to 4 each, 16 accumulators = one 16 x 64 strip per tile) and run their
+//     panel product  Z += L(diag rows, k) * L(own rows, k)'  meanwhile (A operand: fragments of the four diagonal-block
+//     rows, B operand: fragments of the own rows, four-deep register ring of 512 B operand loads);
+//   * ONE barrier; then waves 1..7 solve their strips against the diagonal block: X_c = V_c * inv(Ld_cc)', and
+//     V_c' -= X_c * Ld(c',c)' for c' > c, with -inv(Ld_cc) and Ld(c',c) read from LDS as ready-made MFMA operands;
+//   * a second barrier publishes the block column.
+//
+// Accumulators hold Z = -(A - W) so that neither the products nor the updates need a negated operand; the diagonal tile
+// negates its four registers once.  The diagonal tile is factorised *in the MFMA result layout* (lane l: row l & 15,
+// columns (l >> 4) + 4 q) with ds_bpermute broadcasts, and its inverse is swept in the same loop, so the tile never
+// goes through LDS and the inverse is directly an MFMA A operand.
+//
+// Factor storage: row-tile major, fragment order — the 64 values L(16 rt + r, 4 kg + kk) sit at
+// ((rt * KGS + kg) * 64 + kk * 16 + r), KGS = 4 RT, so a row tile streams through consecutive 512 B fragments.
+#pragma once
+
+// keeps the operand ring as written: without it the compiler gathers the ring's loads at the top of the loop body and
+// consumes them in the same iteration (no prefetch distance left)
+#define C64_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
+#ifdef RBPF_C64_STAMPS                           // tuning aid: per-phase clocks of waves 0 / 1 of workgroup 0
+#define C64_STAMP(k) do { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } while (0)
+#define C64_STAMP_ARGS , long long (&cst)[8], long long& clast
+#define C64_STAMP_PASS , cst, clast
+#else
+#define C64_STAMP(k) do { } while (0)
+#define C64_STAMP_ARGS
+#define C64_STAMP_PASS
+#endif
+
+constexpr int kC64Waves = 8;
+constexpr int kC64Threads = kC64Waves * 64;
+constexpr int kC64TilesPerPass = 4 * (kC64Waves - 1);
+
+__device__ inline double bperm_f64(double v, int src_lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ inline v4d mfma4(const double (&a)[4], const v4d& b, v4d acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+  return acc;
+}
+__device__ inline v4d mfma4(const v4d& a, const v4d& b, v4d acc) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+  return acc;
+}
+
+// 16 x 16 Cholesky of V (lower triangle used) and the negated inverse of its factor, both in the MFMA operand layout
+// "natural": lane l holds row r = l & 15, columns g + 4 q (g = l >> 4) in register q.  Columns >= nvalid are padding
+// (pivot := 1).  Returns true when a pivot was not positive.
+//
+// Blocked by 4 columns = one register: inside a panel the four columns sit in the four lane groups, a column step is
+// pivot -> sqrt / 1/sqrt (uniform) -> scale -> two ds_bpermute broadcasts -> one fma; the trailing columns take ONE
+// MFMA per panel (D = P P' with the panel register as both operands; by symmetry the result layout is the natural one).
+// The inverse X = inv(Ld) is swept alongside in the MFMA *result* layout (lane: column, register/group: row), where
+// the rank-4 update of the rows below a panel is again one MFMA (A = panel of Ld, B = the four finished rows of X);
+// a final product with -I transposes it into the natural layout, i.e. into a ready-made A operand.
+__device__ inline bool chol_diag_tile_frag(v4d& V, v4d& NI, int nvalid, int lane) {
+  const int r = lane & 15, g = lane >> 4;
+  bool bad = false;
+  double Lv[4], XT[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { Lv[q] = V[q]; XT[q] = (r == 4 * q + g) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = 4 * kb + kk;
+      double piv = readlane_f64(Lv[kb], kk * 16 + k);
+      if (k >= nvalid) piv = 1.0;
+      bad |= !(piv > 0.0);
+      double ljj, rinv;
+      sqrt_rsqrt(piv, ljj, rinv);
+      const double cv = (r == k) ? ljj : ((r > k) ? Lv[kb] * rinv : 0.0);
+      Lv[kb] = (g == kk) ? cv : Lv[kb];                                     // column k of Ld, row k of X are final
+      XT[kb] *= (g == kk) ? rinv : 1.0;                                     // (selects, not branches: this is a serial chain)
+      if (kk < 3) {
+        const double lrk = bperm_f64(Lv[kb], kk * 16 + r);                  // Ld(r, k)
+        const double lck = bperm_f64(Lv[kb], kk * 16 + 4 * kb + g);         // Ld(4 kb + g, k)
+        const double xk = bperm_f64(XT[kb], kk * 16 + r);                   // X(k, c), c = lane & 15
+        const double mck = (g > kk) ? lck : 0.0;
+        Lv[kb] = fma(-lrk, mck, Lv[kb]);
+        XT[kb] = fma(-mck, xk, XT[kb]);
+      }
+    }
+    if (kb < 3) {
+      const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+      const v4d D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lv[kb], Lv[kb], zero, 0, 0, 0);
+      const v4d D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lv[kb], XT[kb], zero, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q > kb) { Lv[q] -= D1[q]; XT[q] -= D2[q]; }
+    }
+  }
+  v4d ni = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    V[q] = Lv[q];
+    ni = __builtin_amdgcn_mfma_f64_16x16x4f64(XT[q], (r == 4 * q + g) ? -1.0 : 0.0, ni, 0, 0, 0);
+  }
+  NI = ni;
+  return bad;
+}
+
+__device__ inline int c64_pair(int cp, int c) { return cp * (cp - 1) / 2 + c; }   // (c' > c) -> 0..5
+
+__device__ inline int c64_tri(int i, int c) { return i * (i + 1) / 2 + c; }         // (i >= c) -> 0..9
+
+// Row tile I of the diagonal block (one of waves 4..7): elements and panel product of its I + 1 lower tiles, handed to
+// wave 0 through LDS (Zd: [10][4][64]).
+template <int I, int MODE>
+__device__ inline void c64_diag_product(const CholArgs& a, int p, const double* __restrict__ Lt, int KGS, int J, int M,
+                                        const double* rhs_s, const double* Hs, const double* RH, double jit, int lane,
+                                        double* Zd C64_STAMP_ARGS) {
+  v4d Z[I + 1];
+#pragma unroll
+  for (int c = 0; c <= I; ++c) {
+    v4d e;
+    chol_aug_elems<MODE>(a, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+    Z[c] = -e;
+  }
+  C64_STAMP(0);
+  if (J > 0) {
+    const double* pf[I + 1];
+#pragma unroll
+    for (int c = 0; c <= I; ++c) pf[c] = Lt + (size_t)(4 * J + c) * KGS * 64;   // wave-uniform bases, + lane per load
+    const int nkg = 16 * J;
+    double F[4][I + 1];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      C64_PIN();
+#pragma unroll
+      for (int c = 0; c <= I; ++c) F[b][c] = (pf[c] + (size_t)b * 64)[lane];
+      C64_PIN();
+    }
+    for (int kg = 0; kg < nkg; kg += 4) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int c = 0; c <= I; ++c) Z[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][I], Z[c], 0, 0, 0);
+        const size_t kn = (size_t)min(kg + 4 + b, nkg - 1) * 64;
+        C64_PIN();
+#pragma unroll
+        for (int c = 0; c <= I; ++c) F[b][c] = (pf[c] + kn)[lane];
+        C64_PIN();
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c <= I; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Zd[(c64_tri(I, c) * 4 + q) * 64 + lane] = Z[c][q];
+  C64_STAMP(1);
+}
+
+// Wave 0: factorisation of the diagonal block of block column J from the tiles waves 4..7 left in LDS.  nd = number of
+// its row tiles that exist (4 except at the very end).
+// (noinline: as a real call it gets registers of its own — inlined, the values the kernel keeps live across the block
+// column loop pushed parts of this serial chain into scratch, 15 K clocks per tile instead of 4 K)
+__device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
+                                      const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
+  v4d Z[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c <= i; ++c)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Z[i][c][q] = (i < nd) ? Zd[(c64_tri(i, c) * 4 + q) * 64 + lane] : 0.0;
+  C64_STAMP(1);
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < nd) {
+      v4d V = -Z[c][c], NI;
+      bad |= chol_diag_tile_frag(V, NI, M - (64 * J + 16 * c), lane);
+      C64_STAMP(2);
+      double* dst = Lt + ((size_t)(4 * J + c) * KGS + 16 * J + 4 * c) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dst[q * 64] = V[q]; NLs[(c * 4 + q) * 64 + lane] = NI[q]; }
+      v4d xs[4];
+#pragma unroll
+      for (int i = c + 1; i < 4; ++i) {
+        xs[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (i < nd) {
+          xs[i] = mfma4(NI, Z[i][c], xs[i]);                                // X' = inv(Ld) V'  (NI = -inv, Z = -V')
+          double* dx = Lt + ((size_t)(4 * J + i) * KGS + 16 * J + 4 * c) * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { dx[q * 64] = xs[i][q]; Lds[(c64_pair(i, c) * 4 + q) * 64 + lane] = xs[i][q]; }
+        }
+      }
+#pragma unroll
+      for (int i = c + 1; i < 4; ++i)
+#pragma unroll
+        for (int cp = c + 1; cp <= i; ++cp) Z[i][cp] = mfma4(xs[cp], xs[i], Z[i][cp]);   // Z(i,c') += Ld(c',c) X(i,c)'
+      C64_STAMP(4);
+    }
+  }
+  return bad;
+}
+
+// Waves 1..7: NT row tiles below the diagonal block (all four sub-columns exist: nd == 4 whenever such tiles exist).
+template <int NT, int MODE>
+__device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int J,
+                                     const int (&rt)[4], int M, const double* rhs_s, const double* Hs, const double* RH,
+                                     double jit, int lane, const double* NLs, const double* Lds, bool barrier C64_STAMP_ARGS) {
+  v4d Z[NT][4];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v4d e;
+      chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+      Z[s][c] = -e;
+    }
+  C64_STAMP(0);
+  if (J > 0) {
+    const double* pa = Lt + (size_t)(4 * J) * KGS * 64;                     // wave-uniform bases, + lane per load
+    const size_t ts = (size_t)KGS * 64;                                     // stride between row tiles
+    const double* pb[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) pb[s] = Lt + (size_t)rt[s] * ts;
+    const int nkg = 16 * J;
+    double A[4][4], B[4][NT];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      C64_PIN();                                                            // same issue order as in the loop: the wait
+#pragma unroll                                                              // counts at the loop head then match
+      for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + (size_t)b * 64)[lane];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) B[b][s] = (pb[s] + (size_t)b * 64)[lane];
+      C64_PIN();
+    }
+    for (int kg = 0; kg < nkg; kg += 4) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int s = 0; s < NT; ++s)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Z[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c], 0, 0, 0);
+        const size_t kn = (size_t)min(kg + 4 + b, nkg - 1) * 64;
+        C64_PIN();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + kn)[lane];
+#pragma unroll
+        for (int s = 0; s < NT; ++s) B[b][s] = (pb[s] + kn)[lane];
+        C64_PIN();
+      }
+    }
+  }
+  C64_STAMP(1);
+  if (barrier) __syncthreads();                                             // the diagonal block's LDS operands are ready
+  C64_STAMP(3);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double ni[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ni[q] = NLs[(c * 4 + q) * 64 + lane];
+    v4d x[NT];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) {
+      x[s] = mfma4(ni, Z[s][c], (v4d){0.0, 0.0, 0.0, 0.0});
+      double* dx = Lt + ((size_t)rt[s] * KGS + 16 * J + 4 * c) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dx[q * 64] = x[s][q];
+    }
+#pragma unroll
+    for (int cp = c + 1; cp < 4; ++cp) {
+      double lf[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) lf[q] = Lds[(c64_pair(cp, c) * 4 + q) * 64 + lane];
+#pragma unroll
+      for (int s = 0; s < NT; ++s) Z[s][cp] = mfma4(lf, x[s], Z[s][cp]);
+    }
+  }
+  C64_STAMP(4);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in) {
+  extern __shared__ double csm[];
+  CholArgs a = a_in;
+  const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
+  if (MODE == 1) {
+    const int src = a.imat_anc ? a.imat_anc[p] : p;
+    const bool remote = a.rec != nullptr && src >= a.n_bank_local;
+    a.Imat = remote ? a.rec + (size_t)(src - a.n_bank_local) * a.rec_stride + a.rec_off_Imat
+                    : a.Imat + (size_t)src * a.imat_stride;
+    a.imat_stride = 0;
+  }
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices and operand bases in SGPRs
+  const int RT = (M + 1 + 15) >> 4, KGS = 4 * RT;
+  double* Lt = a.Lbuf + (size_t)p * a.ldL;
+  double* NLs = csm;                              // [4][4][64]  -inv(Ld_cc) as MFMA A fragments
+  double* Lds = NLs + 1024;                       // [6][4][64]  Ld(c',c), c' > c, as MFMA A fragments
+  double* Zd = Lds + 1536;                        // [10][4][64] the diagonal block's tiles on their way to wave 0
+  double* red = Zd + 2560;                        // [32]
+  double* rhs_s = red + 32;                       // [M]
+  int* sfail = reinterpret_cast<int*>(rhs_s + M);   // [2]: block column J reports in slot J & 1 (sticky), so a fast wave 0 cannot
+                                                    // overtake the check of the previous block column
+  int* ready = sfail + 2;                         // diagonal-block tiles handed over so far (monotonic within an attempt)
+  const bool pend = (MODE == 1 && a.Hb != nullptr);
+  double* Hs = (pend || MODE == 0) ? rhs_s + M + 2 : nullptr;
+  double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
+  chol_prologue(a, p, tid, kC64Threads, M, rhs_s, Hs, RH, pend);
+  const int NJ = (RT + 3) >> 2;
+#ifdef RBPF_C64_STAMPS
+  long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = clock64();
+#endif
+  double jit = 0.0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (tid == 0) { sfail[0] = 0; sfail[1] = 0; *ready = 0; }
+    int handed = 0;
+    __syncthreads();
+    for (int J = 0; J < NJ; ++J) {
+      const int nd = min(4, RT - 4 * J);
+      const int first = 4 * J + nd, count = RT - first;
+      const int npass = max(1, (count + kC64TilesPerPass - 1) / kC64TilesPerPass);
+      handed += nd;
+      if (wv == 0) {
+        // wait for the nd tiles of the diagonal block (only this wave waits; bounded, so a lost hand-off cannot hang the GPU)
+        int spins = 0;
+        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
+          __builtin_amdgcn_s_sleep(4);
+          ++spins;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        C64_STAMP(0);
+        bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, Zd, NLs, Lds C64_STAMP_PASS);
+        bad |= (spins >= (1 << 24));
+        if (bad && lane == 0) sfail[J & 1] = 1;
+        __syncthreads();
+        C64_STAMP(3);
+      } else {
+        const int di = kC64Waves - 1 - wv;          // waves 7, 6, 5, 4 take row tiles 0, 1, 2, 3 of the diagonal block
+        if (di < nd) {
+#define RBPF_C64D(I_) c64_diag_product<I_, MODE>(a, p, Lt, KGS, J, M, rhs_s, Hs, RH, jit, lane, Zd C64_STAMP_PASS)
+          switch (di) {
+            case 0: RBPF_C64D(0); break;
+            case 1: RBPF_C64D(1); break;
+            case 2: RBPF_C64D(2); break;
+            default: RBPF_C64D(3); break;
+          }
+#undef RBPF_C64D
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        for (int pass = 0; pass < npass; ++pass) {
+          int rt[4], nt = 0;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int u = kC64TilesPerPass * pass + (wv - 1) + (kC64Waves - 1) * s;
+            rt[s] = first + min(u, count - 1);
+            nt += (u < count) ? 1 : 0;
+          }
+#define RBPF_C64(NT_) c64_tile_pass<NT_, MODE>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
+          switch (nt) {
+            case 1: RBPF_C64(1); break;
+            case 2: RBPF_C64(2); break;
+            case 3: RBPF_C64(3); break;
+            case 4: RBPF_C64(4); break;
+            default: if (pass == 0) __syncthreads(); break;
+          }
+#undef RBPF_C64
+        }
+      }
+      __syncthreads();                            // the block column is visible to the next panel products
+      C64_STAMP(5);
+      if (sfail[J & 1]) break;
+    }
+#ifdef RBPF_C64_STAMPS
+    if (p == 0 && lane == 0 && (wv <= 1 || wv == 7) && M >= 200)
+      printf("chol64 M=%d wave %d clocks: elems(w0:spin) %lld product %lld diagtile %lld waitA %lld solve/update %lld waitB %lld\n", M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5]);
+#endif
+    __syncthreads();
+    const int failed = sfail[0] | sfail[1];
+    __syncthreads();
+    if (!failed) {
+      double sl = 0.0, vv = 0.0;
+      for (int j = tid; j < M; j += kC64Threads) {
+        const size_t off = (size_t)(j >> 2) * 64 + (size_t)(j & 3) * 16;
+        const double dj = Lt[(size_t)(j >> 4) * KGS * 64 + off + (j & 15)];
+        const double vj = Lt[(size_t)(M >> 4) * KGS * 64 + off + (M & 15)];
+        sl += log(dj);
+        vv = fma(vj, vj, vv);
+      }
+      sl = wave_sum(sl); vv = wave_sum(vv);
+      if (lane == 0) { red[wv] = sl; red[16 + wv] = vv; }
+      __syncthreads();
+      if (tid == 0) {
+        sl = 0.0; vv = 0.0;
+        for (int w = 0; w < kC64Waves; ++w) { sl += red[w]; vv += red[16 + w]; }
+        double lw;
+        if (MODE == 0) lw = -sl - 0.5 * vv - 0.5 * (double)M * 1.8378770664093453;     // log(2*pi)
+        else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
+        a.pant_log[p] += lw;
+      }
+      return;
+    }
+    if (MODE == 1 || attempt == 1) {
+      if (tid == 0) { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
+      return;
+    }
+    jit = a.jitter;                                                         // particleSmoother.m:223
+  }
+}
+
+static size_t chol64_lds_bytes(int M, int d) {
+  return ((size_t)1024 + 1536 + 2560 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
+}
+
+template <int MODE>
+static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((chol_solve64_kernel<MODE>), dim3(batch), dim3(kC64Threads), lds, st, ca);
+  return hipGetLastError();
+}
+
+static hipError_t launch_chol64(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
+  const size_t lds = chol64_lds_bytes(ca.Msz, d_lds);
+  return ca.mode == 1 ? launch_chol64_mode<1>(ca, batch, lds, st) : launch_chol64_mode<0>(ca, batch, lds, st);
+}

@@ -380,6 +380,36 @@ __device__ inline void sqrt_rsqrt(double x, double& g, double& rinv) {
   rinv = h + h;
 }
 
+// Right-hand side (and, for the information form, the pending measurement term H, R^-1 H of this particle) into LDS.
+__device__ inline void chol_prologue(const CholArgs& a, int p, int tid, int nthreads, int M, double* rhs_s, double* Hs,
+                                     double* RH, bool pend) {
+  for (int i = tid; i < M; i += nthreads) {
+    double r;
+    if (a.mode == 0 && a.rhs) {
+      r = a.rhs[(size_t)p * M + i];                                         // particleSmoother.m:207-208 (sparse branch)
+    } else if (a.mode == 0) {
+      double s = 0.0;
+      const double* dr = a.dyf + (size_t)i * a.n;
+      const double* x = a.xl + (size_t)p * a.ldx;
+      for (int c = 0; c < a.n; ++c) s = fma(dr[c], x[c], s);
+      r = a.yf[i] - s;                                                      // particleSmoother.m:193
+    } else {
+      r = a.ivec[(size_t)p * a.ldx + i] + a.ivecAdd[i];                     // InformationForm.m:224
+    }
+    rhs_s[i] = r;
+    if (a.mode == 0) reinterpret_cast<int*>(Hs)[i] = ((i / a.d) << 3) | (i % a.d);
+    if (pend) {
+      const double* H = a.Hb + (size_t)p * a.d * a.ldx;
+      for (int aa = 0; aa < a.d; ++aa) {
+        double t = 0.0;
+        for (int bb = 0; bb < a.d; ++bb) t = fma(a.Rinv[aa + a.d * bb], H[(size_t)bb * a.ldx + i], t);
+        Hs[aa * M + i] = H[(size_t)aa * a.ldx + i];
+        RH[aa * M + i] = t;
+      }
+    }
+  }
+}
+
 // W waves per workgroup (4, 8 or 16): the smallest that keeps <= 4 row tiles per wave.  A small matrix then leaves room
 // for several workgroups per CU, whose single-wave diagonal-tile sections and barriers overlap (a 16-wave workgroup owns
 // the whole register file: at n = 128 seven of its waves had no tile and every CU waited on one particle's serial chain).
@@ -413,31 +443,7 @@ __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
 #ifdef RBPF_CHOL_STAMPS
   long long cst[6] = {0, 0, 0, 0, 0, 0}, clast = clock64();
 #endif
-  for (int i = tid; i < M; i += kThreadsW) {
-    double r;
-    if (a.mode == 0 && a.rhs) {
-      r = a.rhs[(size_t)p * M + i];                                         // particleSmoother.m:207-208 (sparse branch)
-    } else if (a.mode == 0) {
-      double s = 0.0;
-      const double* dr = a.dyf + (size_t)i * a.n;
-      const double* x = a.xl + (size_t)p * a.ldx;
-      for (int c = 0; c < a.n; ++c) s = fma(dr[c], x[c], s);
-      r = a.yf[i] - s;                                                      // particleSmoother.m:193
-    } else {
-      r = a.ivec[(size_t)p * a.ldx + i] + a.ivecAdd[i];                     // InformationForm.m:224
-    }
-    rhs_s[i] = r;
-    if (a.mode == 0) reinterpret_cast<int*>(Hs)[i] = ((i / a.d) << 3) | (i % a.d);
-    if (pend) {
-      const double* H = a.Hb + (size_t)p * a.d * a.ldx;
-      for (int aa = 0; aa < a.d; ++aa) {
-        double t = 0.0;
-        for (int bb = 0; bb < a.d; ++bb) t = fma(a.Rinv[aa + a.d * bb], H[(size_t)bb * a.ldx + i], t);
-        Hs[aa * M + i] = H[(size_t)aa * a.ldx + i];
-        RH[aa * M + i] = t;
-      }
-    }
-  }
+  chol_prologue(a, p, tid, kThreadsW, M, rhs_s, Hs, RH, pend);
   const int cr = lane & 15, cg = lane >> 4;       // my row within a tile / my column group within a block
   double jit = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
@@ -604,10 +610,16 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
   }
 }
 
-// batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0)
+#include "rbpf_chol64.hpp"
+
+// batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0).
+// Matrices of more than 16 row tiles take the 64-column kernel (rbpf_chol64.hpp), smaller ones the 16-column kernel
+// with several workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
 static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
   static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
+  const char* v64 = getenv("RBPF_CHOL64");
   const int RT = (ca.Msz + 1 + 15) >> 4;
+  if (v64 ? atoi(v64) != 0 : RT > 16) return launch_chol64(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
@@ -1275,5 +1287,67 @@ int rbpf_shard_smoother_end(rbpf_ctx* c, double* XNK_k, double* XLK_k, double* P
   }
   return RBPF_OK;
 }
+
+// The batched ancestor-weight factorisation on its own (tests and tools/chol_bench.py): for every matrix of the batch
+//   cS = chol(S,'lower') (retry with S + jitter I), v = cS \ e, logw = -sum(log(diag(cS))) - .5 v'v - M/2 log(2 pi)
+// (particleSmoother.m:221-229).  variant: 0 automatic, 16 / 64 force the 16- / 64-column kernel.  reps > 1 repeats
+// the launch and reports the mean kernel time in *ms (HIP events on the launch stream).
+int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e, double jitter, int32_t variant,
+                      int32_t reps, double* logw, int32_t* status, double* ms) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 || (variant != 0 && variant != 16 && variant != 64)) {
+    set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
+  }
+  double *dS = nullptr, *de = nullptr, *dL = nullptr, *dlw = nullptr; int* dst = nullptr;
+  auto cleanup = [&]() { hipFree(dS); hipFree(de); hipFree(dL); hipFree(dlw); hipFree(dst); };
+  int rc = dmalloc(&dS, (size_t)batch * M * M);
+  if (rc == RBPF_OK) rc = dmalloc(&de, (size_t)batch * M);
+  if (rc == RBPF_OK) rc = dmalloc(&dL, (size_t)batch * chol_factor_doubles(M));
+  if (rc == RBPF_OK) rc = dmalloc(&dlw, (size_t)batch);
+  if (rc == RBPF_OK) rc = dmalloc(&dst, 4);
+  if (rc != RBPF_OK) { cleanup(); return rc; }
+  hipError_t err = hipMemcpy(dS, S, (size_t)batch * M * M * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(de, e, (size_t)batch * M * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemset(dst, 0, 16);
+  CholArgs ca;
+  std::memset(&ca, 0, sizeof(ca));
+  ca.mode = 0; ca.Msz = M; ca.d = 1; ca.n = M; ca.ldx = M; ca.Lbuf = dL; ca.ldL = (long)chol_factor_doubles(M);
+  ca.S = dS; ca.R = nullptr; ca.rhs = de; ca.jitter = jitter; ca.pant_log = dlw; ca.status = dst;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  float total = 0.f;
+  for (int r = 0; r < reps && err == hipSuccess; ++r) {
+    err = hipMemsetAsync(dlw, 0, (size_t)batch * 8, nullptr);
+    if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
+    if (err == hipSuccess) {
+      if (variant == 64) err = launch_chol64(ca, batch, 0, nullptr);
+      else if (variant == 16) {
+        const int RT = (M + 1 + 15) >> 4, W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
+        const size_t lds = chol_lds_bytes(M, 0);
+        const int ntmax = (RT + W - 1) / W;
+        err = (W == 4) ? launch_chol_nt<4>(ca, batch, lds, ntmax, nullptr) : (W == 8) ? launch_chol_nt<8>(ca, batch, lds, ntmax, nullptr)
+                                                                                      : launch_chol_nt<16>(ca, batch, lds, ntmax, nullptr);
+      } else err = launch_chol(ca, batch, 0, nullptr);
+    }
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
+    total += t;
+  }
+  if (err == hipSuccess) err = hipMemcpy(logw, dlw, (size_t)batch * 8, hipMemcpyDeviceToHost);
+  int flags[4] = {0, 0, 0, 0};
+  if (err == hipSuccess) err = hipMemcpy(flags, dst, 16, hipMemcpyDeviceToHost);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  cleanup();
+  if (err != hipSuccess) return hip_fail(err, "rbpf_chol_weights", __FILE__, __LINE__);
+  if (status) *status = flags[0];
+  if (ms) *ms = (double)total / reps;
+  return RBPF_OK;
+}
+
 
 }  // extern "C"

@@ -621,6 +621,22 @@ def sample(w, u):
     return ind
 
 
+def chol_weights(S, e, jitter=0.0, variant=0, reps=1):
+    """particleSmoother.m:221-229 for a batch: S [B, M, M] (symmetric; the lower triangle is read), e [B, M] ->
+    (logw [B], status, mean kernel ms).  variant 0 / 16 / 64 selects the factorisation kernel."""
+    lib = load_library()
+    S = np.ascontiguousarray(np.asarray(S, dtype=np.float64))
+    e = np.ascontiguousarray(np.asarray(e, dtype=np.float64))
+    B, M = e.shape
+    assert S.shape == (B, M, M)
+    St = np.ascontiguousarray(np.transpose(S, (0, 2, 1)))                  # column-major per matrix
+    logw = np.empty(B, dtype=np.float64)
+    status = np.zeros(1, dtype=np.int32)
+    ms = np.zeros(1, dtype=np.float64)
+    check(lib.rbpf_chol_weights(M, B, _dp(St), _dp(e), float(jitter), int(variant), int(reps), _dp(logw), _ip(status), _dp(ms)))
+    return logw, int(status[0]), float(ms[0])
+
+
 # ------------------------------------------------------------------------------------------------
 # resident-state driver used by bench.py (inputs already in HBM when the timed region starts)
 # ------------------------------------------------------------------------------------------------

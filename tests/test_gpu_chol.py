@@ -1,0 +1,120 @@
+"""GPU parity of the batched ancestor-weight factorisation (particleSmoother.m:221-229,
+particleSmootherInformationForm.m:224-236) on its own: both kernels (16-column, 64-column) against numpy's Cholesky,
+the jitter retry, the failure flag, and the smoothers with the 64-column kernel forced at small sizes."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+LOG2PI = 1.8378770664093453
+
+
+def spd_batch(B, M, seed, scale_spread=0.0):
+    rs = np.random.RandomState(seed)
+    A = rs.standard_normal((B, M, M + 8))
+    S = A @ np.transpose(A, (0, 2, 1)) / (M + 8) + 0.5 * np.eye(M)
+    if scale_spread:                                     # badly scaled diagonal, like diag(1./diag(P0)) of the information form
+        s = 10.0 ** rs.uniform(-scale_spread, scale_spread, (B, M))
+        S = S * s[:, :, None] * s[:, None, :]
+    e = rs.standard_normal((B, M))
+    return S, e
+
+
+def numpy_logw(S, e, jitter=None):
+    out = np.empty(S.shape[0])
+    for b in range(S.shape[0]):
+        try:
+            L = np.linalg.cholesky(S[b])
+        except np.linalg.LinAlgError:
+            if jitter is None:
+                out[b] = np.nan
+                continue
+            try:
+                L = np.linalg.cholesky(S[b] + jitter * np.eye(S.shape[1]))     # particleSmoother.m:223
+            except np.linalg.LinAlgError:
+                out[b] = np.nan
+                continue
+        import scipy.linalg as sl
+        v = sl.solve_triangular(L, e[b], lower=True)
+        out[b] = -np.sum(np.log(np.diag(L))) - 0.5 * v @ v - 0.5 * S.shape[1] * LOG2PI
+    return out
+
+
+@pytest.mark.parametrize("variant", [16, 64])
+@pytest.mark.parametrize("M", [5, 16, 63, 64, 65, 130, 259, 515, 516, 576, 640])
+def test_batched_factorisation_matches_numpy(rbpf, M, variant):
+    B = 9 if M > 300 else 21
+    S, e = spd_batch(B, M, seed=M)
+    got, status, _ = rbpf.chol_weights(S, e, jitter=1e-2, variant=variant)
+    want = numpy_logw(S, e)
+    assert status == 0
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("variant", [16, 64])
+def test_factorisation_of_badly_scaled_matrices(rbpf, variant):
+    """Row/column scales spread over 8 decades (the information form starts from diag(1./diag(P0)))."""
+    S, e = spd_batch(7, 259, seed=5, scale_spread=4.0)
+    got, status, _ = rbpf.chol_weights(S, e, variant=variant)
+    want = numpy_logw(S, e)
+    assert status == 0
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-8)
+
+
+@pytest.mark.parametrize("variant", [16, 64])
+@pytest.mark.parametrize("M", [40, 300])
+def test_jitter_retry_and_failure_flag(rbpf, M, variant):
+    """particleSmoother.m:221-224: a failed chol is retried once with S + jitter*I; a second failure is an error."""
+    S, e = spd_batch(6, M, seed=3)
+    w, V = np.linalg.eigh(S[1])
+    w[0] = -1e-3                                                    # slightly indefinite: passes with jitter 1e-2
+    S[1] = (V * w) @ V.T
+    w, V = np.linalg.eigh(S[4])
+    w[0] = -5.0                                                     # fails twice
+    S[4] = (V * w) @ V.T
+    got, status, _ = rbpf.chol_weights(S, e, jitter=1e-2, variant=variant)
+    want = numpy_logw(S, e, jitter=1e-2)
+    assert status & 2
+    assert np.isnan(got[4]) and np.isnan(want[4])
+    ok = [0, 1, 2, 3, 5]
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-9, atol=1e-8)
+
+
+def test_largest_supported_size(rbpf):
+    S, e = spd_batch(3, 1023, seed=11)
+    for variant in (16, 64):
+        got, status, _ = rbpf.chol_weights(S, e, variant=variant)
+        assert status == 0
+        np.testing.assert_allclose(got, numpy_logw(S, e), rtol=1e-11, atol=1e-9)
+
+
+@pytest.fixture
+def force_chol64():
+    old = os.environ.get("RBPF_CHOL64")
+    os.environ["RBPF_CHOL64"] = "1"
+    yield
+    if old is None:
+        del os.environ["RBPF_CHOL64"]
+    else:
+        os.environ["RBPF_CHOL64"] = old
+
+
+@pytest.mark.parametrize("info_form", [False, True])
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 6, 5, 130), ("radio", 9, 7, 128)])
+def test_smoothers_with_the_64_column_kernel_forced(rbpf, force_chol64, kind, N_P, N_T, m, info_form):
+    import test_gpu_smoother as ts
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=21, N_K=3)
+    ref, out = ts.run_both(rbpf, c, info_form=info_form)
+    ts.check(ref, out, 3)
+
+
+def test_information_form_smoother_at_the_benchmark_basis_size(rbpf):
+    """m = 256 (nLin = 259, 17 row tiles): the size class that takes the 64-column kernel by default."""
+    import test_gpu_smoother as ts
+    c = cases.mag_case(6, 5, 256, seed=23, N_K=2)
+    ref, out = ts.run_both(rbpf, c, info_form=True)
+    ts.check(ref, out, 2)

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the batched ancestor-weight factorisation kernels on their own (rbpf_chol_weights):
+   python tools/chol_bench.py [--M 515] [--batch 2048] [--reps 5]
+Prints one JSON line per kernel variant: mean launch ms (HIP events), algorithmic TFLOP/s (M^3/3 per matrix) and the
+fraction of the 78.6 TFLOP/s fp64 matrix peak."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--M", type=int, default=515)
+    ap.add_argument("--batch", type=int, default=2048)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--variants", default="16,64")
+    args = ap.parse_args()
+    pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+    rs = np.random.RandomState(0)
+    M, B = args.M, args.batch
+    A = rs.standard_normal((B, M, 24))
+    S = A @ np.transpose(A, (0, 2, 1)) / 24 + np.eye(M)
+    e = rs.standard_normal((B, M))
+    ref = None
+    for v in [int(x) for x in args.variants.split(",")]:
+        pkg.chol_weights(S[:64], e[:64], variant=v)                           # warm-up (module load, attributes)
+        logw, status, ms = pkg.chol_weights(S, e, variant=v, reps=args.reps)
+        flops = B * M ** 3 / 3.0
+        line = {"kernel": f"chol {v}-column", "M": M, "batch": B, "reps": args.reps, "ms": round(ms, 3),
+                "tflops": round(flops / (ms * 1e-3) / 1e12, 2), "frac_of_fp64_matrix_peak": round(flops / (ms * 1e-3) / 78.6e12, 3),
+                "status": status}
+        if ref is None:
+            ref = logw
+        else:
+            line["max_abs_diff_vs_first"] = float(np.max(np.abs(logw - ref)))
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()
