@@ -423,6 +423,7 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
   }
 }
 
+constexpr size_t kC64MaxLds = 160 * 1024;         // the whole LDS of a CU (one workgroup per CU anyway)
 static size_t chol64_lds_bytes(int M, int d) {
   return ((size_t)1024 + 1536 + 2560 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
 }
@@ -431,7 +432,7 @@ template <int MODE>
 static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC64MaxLds);
     if (e != hipSuccess) return e;
     attr = true;
   }

@@ -619,7 +619,7 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
   static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
   const char* v64 = getenv("RBPF_CHOL64");
   const int RT = (ca.Msz + 1 + 15) >> 4;
-  if (v64 ? atoi(v64) != 0 : RT > 16) return launch_chol64(ca, batch, d_lds, st);
+  if ((v64 ? atoi(v64) != 0 : RT > 16) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
