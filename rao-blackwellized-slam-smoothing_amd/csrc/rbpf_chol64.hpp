@@ -27,11 +27,15 @@
 // Factor storage: row-tile major, fragment order — the 64 values L(16 rt + r, 4 kg + kk) sit at
 // ((rt * KGS + kg) * 64 + kk * 16 + r), KGS = 4 RT, so a row tile streams through consecutive 512 B fragments.
 #pragma once
+#include <type_traits>
 
 // keeps the operand ring as written: without it the compiler gathers the ring's loads at the top of the loop body and
 // consumes them in the same iteration (no prefetch distance left)
 #define C64_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
+#ifndef RBPF_C64_LATE
+#define RBPF_C64_LATE 0
+#endif
 #ifdef RBPF_C64_STAMPS                           // tuning aid: per-phase clocks of waves 0 / 1 of workgroup 0
 #define C64_STAMP(k) do { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } while (0)
 #define C64_STAMP_ARGS , long long (&cst)[8], long long& clast
@@ -119,6 +123,55 @@ __device__ inline bool chol_diag_tile_frag(v4d& V, v4d& NI, int nvalid, int lane
   }
   NI = ni;
   return bad;
+}
+
+// (Negated) matrix elements of an INTERIOR strip — row tile rt_s strictly below the diagonal block, not the last row
+// tile, block column entirely left of column M — i.e. no index clamp, no triangle mask, no jitter, no right-hand-side
+// row (and, covariance form, at least 17 rows below the diagonal: no kron(I, R) entry).  Same operations in the same
+// order as chol_aug_elems; what goes is its per-element address and predicate arithmetic (the general loader is
+// VALU-bound: ~1.2 K clocks per four elements, 45 % of the information-form kernel at n = 515): one per-lane offset
+// r + ld g, everything else wave-uniform, so every load / store is scalar base + that one register.
+template <int MODE, bool ACC>
+__device__ inline void c64_strip_fast(const CholArgs& a, int p, int rt_s, int J, int M, const double* Hs, const double* RH,
+                                      int lane, v4d (&Zs)[4]) {
+  const int r = lane & 15, g = lane >> 4;
+  const int ld = (MODE == 0) ? M : a.n;
+  const unsigned lo = (unsigned)(r + ld * g);
+  const size_t t0 = (size_t)16 * rt_s + (size_t)ld * (64 * J);               // wave-uniform
+  const double* src = ((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
+  const double* add = (MODE == 1) ? a.ImatAdd + t0 : nullptr;
+  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)blockIdx.x * a.n * a.n + t0 : nullptr;
+  const double* hrow = Hs ? Hs + 16 * rt_s + r : nullptr;                    // Hs[aa * M + i]
+  const double* rcol = RH ? RH + 64 * J + g : nullptr;                       // RH[aa * M + j]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double ad[4], v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[q] = (src + (size_t)ld * (16 * c + 4 * q))[lo];
+      ad[q] = (MODE == 1) ? (add + (size_t)ld * (16 * c + 4 * q))[lo] : 0.0;
+    }
+    if (MODE == 1) {
+      if (Hs) {                                                              // + dyi'/R*dyi of the last update (:334)
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int aa = 0; aa < a.d; ++aa) {
+          const double h = hrow[aa * M];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sacc[q] = fma(h, rcol[aa * M + 16 * c + 4 * q], sacc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += sacc[q];
+      }
+      if (dst) {                                                             // Imat(:,:,i) of the new generation
+#pragma unroll
+        for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(v[q], &(dst + (size_t)ld * (16 * c + 4 * q))[lo]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += ad[q];                             // :225
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Zs[c][q] = ACC ? Zs[c][q] - v[q] : -v[q];
+  }
 }
 
 __device__ inline int c64_pair(int cp, int c) { return cp * (cp - 1) / 2 + c; }   // (c' > c) -> 0..5
@@ -218,19 +271,40 @@ __device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt
 }
 
 // Waves 1..7: NT row tiles below the diagonal block (all four sub-columns exist: nd == 4 whenever such tiles exist).
-template <int NT, int MODE>
+// LATE (experiment, RBPF_C64_LATE = 1, off): the panel product runs first, from zero, and the matrix elements are
+// subtracted afterwards, on waves 4..7 only, so that on every SIMD one wave streams elements while the other multiplies.
+// Measured slower (information form, n = 515: 21.8 instead of 18.7 ms per launch): the element phase is bound by the
+// CU's memory rate (~10 B/clk), not by a SIMD, and then competes with the factor re-reads of the products.
+template <int NT, int MODE, bool LATE>
 __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int J,
                                      const int (&rt)[4], int M, const double* rhs_s, const double* Hs, const double* RH,
                                      double jit, int lane, const double* NLs, const double* Lds, bool barrier C64_STAMP_ARGS) {
   v4d Z[NT][4];
+  const int RTl = (M + 1 + 15) >> 4;
+  auto elems = [&](auto acc) {
+    constexpr bool ACC = decltype(acc)::value;
 #pragma unroll
-  for (int s = 0; s < NT; ++s)
+    for (int s = 0; s < NT; ++s) {
+      if (rt[s] >= 4 * J + 5 && rt[s] < RTl - 1 && 64 * J + 64 <= M) {      // interior strip (wave-uniform)
+        c64_strip_fast<MODE, ACC>(a, p, rt[s], J, M, Hs, RH, lane, Z[s]);
+      } else {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      v4d e;
-      chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
-      Z[s][c] = -e;
+        for (int c = 0; c < 4; ++c) {
+          v4d e;
+          chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+          Z[s][c] = ACC ? Z[s][c] - e : -e;
+        }
+      }
     }
+  };
+  if (LATE && J > 0) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Z[s][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+  } else {
+    elems(std::false_type{});
+  }
   C64_STAMP(0);
   if (J > 0) {
     const double* pa = Lt + (size_t)(4 * J) * KGS * 64;                     // wave-uniform bases, + lane per load
@@ -266,6 +340,7 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
       }
     }
   }
+  if (LATE && J > 0) elems(std::true_type{});
   C64_STAMP(1);
   if (barrier) __syncthreads();                                             // the diagonal block's LDS operands are ready
   C64_STAMP(3);
@@ -371,12 +446,22 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
             rt[s] = first + min(u, count - 1);
             nt += (u < count) ? 1 : 0;
           }
-#define RBPF_C64(NT_) c64_tile_pass<NT_, MODE>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
+#define RBPF_C64(NT_, LATE_) c64_tile_pass<NT_, MODE, LATE_>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
+#if RBPF_C64_LATE
+          switch (nt == 0 ? 0 : nt + (wv >= 4 ? 4 : 0)) {   // 0: no tile in this pass (only the barrier)
+#else
           switch (nt) {
-            case 1: RBPF_C64(1); break;
-            case 2: RBPF_C64(2); break;
-            case 3: RBPF_C64(3); break;
-            case 4: RBPF_C64(4); break;
+#endif
+            case 1: RBPF_C64(1, false); break;
+            case 2: RBPF_C64(2, false); break;
+            case 3: RBPF_C64(3, false); break;
+            case 4: RBPF_C64(4, false); break;
+#if RBPF_C64_LATE
+            case 5: RBPF_C64(1, true); break;
+            case 6: RBPF_C64(2, true); break;
+            case 7: RBPF_C64(3, true); break;
+            case 8: RBPF_C64(4, true); break;
+#endif
             default: if (pass == 0) __syncthreads(); break;
           }
 #undef RBPF_C64
