@@ -121,8 +121,8 @@ def smoother_large(pkg, datagen):
         if timed:
             out["dense_mag_N8192_T24_m512_NK2"] = round(time.perf_counter() - t0, 3)
     out["note"] = ("dense-mag N=8192 is the per-GPU share of N=65536 at 8 GPUs; the time includes creating the 87 GB of "
-                   "particle banks; steady state is 6.7 ms (plain step) + 38.5 ms (step with ancestor sampling) per time step, "
-                   "profiles/r01f_smoother_N8192_m512_summary.txt")
+                   "particle banks; steady state is 6.5 ms (plain step) + 26 ms (step with ancestor sampling) per time step, "
+                   "profiles/r01u_smoother_mag_N8192_m512_chol64_summary.txt")
     return out
 
 
