@@ -118,3 +118,15 @@ def test_information_form_smoother_at_the_benchmark_basis_size(rbpf):
     c = cases.mag_case(6, 5, 256, seed=23, N_K=2)
     ref, out = ts.run_both(rbpf, c, info_form=True)
     ts.check(ref, out, 2)
+
+
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 4, 100, 16), ("radio", 5, 300, 24)])
+def test_covariance_form_smoother_with_long_horizons(rbpf, kind, N_P, N_T, m):
+    """particleSmoother.m:159-241 with d*(T-t) up to 297 / 299 stacked future measurements: the covariance form's
+    S = dy*P*dy' + kron(I, R) goes through the 64-column kernel (more than 16 row tiles) for the early time steps and
+    through the 16-column kernel for the late ones."""
+    import test_gpu_smoother as ts
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=31, N_K=2)
+    ref, out = ts.run_both(rbpf, c, info_form=False)
+    ts.check(ref, out, 2)
