@@ -410,6 +410,8 @@ __device__ inline void chol_prologue(const CholArgs& a, int p, int tid, int nthr
   }
 }
 
+__device__ inline bool chol_diag_tile_frag(v4d& V, v4d& NI, int nvalid, int lane);   // rbpf_chol64.hpp
+
 // W waves per workgroup (4, 8 or 16): the smallest that keeps <= 4 row tiles per wave.  A small matrix then leaves room
 // for several workgroups per CU, whose single-wave diagonal-tile sections and barriers overlap (a 16-wave workgroup owns
 // the whole register file: at n = 128 seven of its waves had no tile and every CU waited on one particle's serial chain).
@@ -476,56 +478,17 @@ __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
       }
 #undef RBPF_CF
       CSTAMP(0);
-      // diagonal tile: wave 0, slot 0
+      // diagonal tile: wave 0, slot 0 — factorised in the accumulator's own layout (rbpf_chol64.hpp), 4.5 K clocks
+      // instead of the 15 K of the former lane-per-row routine through LDS
       if (wv == 0) {
+        v4d V = acc[0], NI;
+        const bool bad = chol_diag_tile_frag(V, NI, M - j0, lane);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Dg[(cg + 4 * q) * 16 + cr] = acc[0][q];
-        __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
-        double row[16], inv[16];
-        const int r = lane & 15;                  // lanes >= 16 mirror lanes 0..15 (results unused)
-#pragma unroll
-        for (int c = 0; c < 16; ++c) row[c] = Dg[c * 16 + r];
-        bool bad = false;
-        double dinv_r = 1.0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double piv = readlane_f64(row[c], c);
-          if (j0 + c >= M) piv = 1.0;             // augmented / padding columns: nothing below them matters
-          bad |= !(piv > 0.0);
-          double ljj, rinv;
-          sqrt_rsqrt(piv, ljj, rinv);
-          row[c] = (r == c) ? ljj : ((r > c) ? row[c] * rinv : 0.0);
-          if (r == c) dinv_r = rinv;
-#pragma unroll
-          for (int cc = c + 1; cc < 16; ++cc) {
-            const double lcc = readlane_f64(row[c], cc);                     // Ld(cc, c)
-            if (cc <= r) row[cc] = fma(-row[c], lcc, row[cc]);
-          }
+        for (int q = 0; q < 4; ++q) {
+          LinvT[64 * q + lane] = -NI[q];                                     // inv(Ld)(lane & 15, 4 q + (lane >> 4))
+          Lt[((size_t)(4 * jt + q) * RT + jt) * 64 + lane] = V[q];
         }
-        // inv(Ld): row r of the inverse, rows finished in order (forward substitution, :0 <= cc <= r)
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) inv[cc] = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          // row k is final once rows < k were folded in: inv(k, cc) = (delta - sum) / Ld(k,k)
-#pragma unroll
-          for (int cc = 0; cc <= k; ++cc) {
-            double fin = ((cc == k) ? 1.0 : 0.0) - inv[cc];
-            fin *= dinv_r;
-            if (r == k) inv[cc] = fin;
-            const double b = readlane_f64(inv[cc], k);                       // inv(k, cc)
-            if (r > k) inv[cc] = fma(row[k], b, inv[cc]);                    // running sum_k Ld(r,k) inv(k,cc)
-          }
-        }
-        if (lane < 16) {
-#pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            LinvT[c * 16 + r] = (c <= r) ? inv[c] : 0.0;
-            Lt[((size_t)(4 * jt + (c >> 2)) * RT + jt) * 64 + (c & 3) * 16 + r] = row[c];
-          }
-          if (bad && lane == 0) sfail = 1;
-        }
+        if (bad && lane == 0) sfail = 1;
       }
       __syncthreads();
       CSTAMP(2);
@@ -613,13 +576,13 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 #include "rbpf_chol64.hpp"
 
 // batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0).
-// Matrices of more than 16 row tiles take the 64-column kernel (rbpf_chol64.hpp), smaller ones the 16-column kernel
-// with several workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
+// Matrices of more than 18 row tiles (n >= 288; measured crossover, profiles/r01v_chol_bench.jsonl) take the 64-column
+// kernel (rbpf_chol64.hpp), smaller ones the 16-column kernel with several workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
 static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
   static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
   const char* v64 = getenv("RBPF_CHOL64");
   const int RT = (ca.Msz + 1 + 15) >> 4;
-  if ((v64 ? atoi(v64) != 0 : RT > 16) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
+  if ((v64 ? atoi(v64) != 0 : RT > 18) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);

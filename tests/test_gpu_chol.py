@@ -112,10 +112,12 @@ def test_smoothers_with_the_64_column_kernel_forced(rbpf, force_chol64, kind, N_
     ts.check(ref, out, 3)
 
 
-def test_information_form_smoother_at_the_benchmark_basis_size(rbpf):
-    """m = 256 (nLin = 259, 17 row tiles): the size class that takes the 64-column kernel by default."""
+@pytest.mark.parametrize("m", [256, 300])
+def test_information_form_smoother_at_the_benchmark_basis_sizes(rbpf, m):
+    """m = 256 (nLin = 259, 17 row tiles: 16-column kernel, two workgroups per CU) and m = 300 (nLin = 303, 19 row tiles:
+    the smallest size class that takes the 64-column kernel by default)."""
     import test_gpu_smoother as ts
-    c = cases.mag_case(6, 5, 256, seed=23, N_K=2)
+    c = cases.mag_case(6, 5, m, seed=23, N_K=2)
     ref, out = ts.run_both(rbpf, c, info_form=True)
     ts.check(ref, out, 2)
 
