@@ -133,6 +133,25 @@ __device__ inline bool chol_diag_tile_frag(v4d& V, v4d& NI, int nvalid, int lane
   return bad;
 }
 
+__device__ inline const CholArgs* c64_kernarg() {   // the kernel's only parameter, at offset 0 of its argument segment
+  return (const CholArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+}
+
+// The general element loader (chol_aug_elems: clamps, triangle mask, jitter, right-hand-side row) as a real call.  It
+// is only needed for the few edge strips of a block column; inlined sixteen times per pass its hoisted index arithmetic
+// was kept in scratch (91 spill stores per block column and thread = 1.1 MB of extra HBM writes per matrix at n = 515).
+// The argument block reaches it by pointer to the kernel-argument segment (by value it would travel through the stack of
+// every lane); imat_src is the resolved stored matrix of this particle (ancestor's bank entry or received record).
+template <int MODE>
+__device__ __attribute__((noinline)) v4d c64_elems_general(const CholArgs* ka, const double* imat_src, int p, int i, int jb, int M,
+                                                           const double* rhs_s, const double* Hs, const double* RH, double jit) {
+  CholArgs a = *ka;
+  if (MODE == 1) { a.Imat = imat_src; a.imat_stride = 0; }
+  v4d e;
+  chol_aug_elems<MODE>(a, p, i, jb, M, rhs_s, Hs, RH, jit, e);
+  return e;
+}
+
 // (Negated) matrix elements of an INTERIOR strip — row tile rt_s strictly below the diagonal block, not the last row
 // tile, block column entirely left of column M — i.e. no index clamp, no triangle mask, no jitter, no right-hand-side
 // row (and, covariance form, at least 17 rows below the diagonal: no kron(I, R) entry).  Same operations in the same
@@ -194,11 +213,8 @@ __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* 
                                         double* Zd C64_STAMP_ARGS) {
   v4d Z[I + 1];
 #pragma unroll
-  for (int c = 0; c <= I; ++c) {
-    v4d e;
-    chol_aug_elems<MODE>(a, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
-    Z[c] = -e;
-  }
+  for (int c = 0; c <= I; ++c)
+    Z[c] = -c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
   C64_STAMP(0);
   if (J > 0) {
     const double* pf[I + 1];
@@ -298,8 +314,7 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          v4d e;
-          chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+          const v4d e = c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
           Z[s][c] = ACC ? Z[s][c] - e : -e;
         }
       }
