@@ -125,8 +125,8 @@ def smoother_large(pkg, datagen):
     # one more time step = one plain step (iteration 1) + one step with ancestor sampling (iteration 2)
     out["dense_mag_N8192_m512_ms_per_time_step_NK2"] = round((secs[72] - secs[24]) / 48.0 * 1e3, 2)
     out["note"] = ("dense-mag N=8192 is the per-GPU share of N=65536 at 8 GPUs; the run times include creating the 87 GB of "
-                   "particle banks, ms_per_time_step is the difference of the two runs / 48; kernel times: 6.5 ms (plain step) + 26 ms (step with ancestor sampling) per time step, "
-                   "profiles/r01u_smoother_mag_N8192_m512_chol64_summary.txt")
+                   "particle banks, ms_per_time_step is the difference of the two runs / 48; kernel times: 6.5 ms (plain step) + 23 ms (step with ancestor sampling) per time step, "
+                   "profiles/r01x_smoother_mag_N8192_m512_chol64_summary.txt")
     return out
 
 
@@ -147,8 +147,8 @@ def smoother_kernel_roofline(pkg):
     return {"kernel": "chol_solve64_kernel", "workload": f"{B} matrices, n={M}, fp64", "bound": "mfma", "achieved": ach, "peak": 78.6,
             "unit": "TFLOP/s", "frac": ach / 78.6, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flops, "traffic": None,
             "finite": bool(np.all(np.isfinite(logw))) and status == 0,
-            "in_smoother": "19.4 ms per launch of 8192 (24 % of the peak) with the Imat gather folded in, "
-                           "profiles/r01u_smoother_mag_N8192_m512_chol64_summary.txt"}
+            "in_smoother": "16.6 ms per launch of 8192 (28.6 % of the peak; 77.6 GB of HBM traffic = 4.7 TB/s) with the Imat gather "
+                           "folded in, profiles/r01x_smoother_mag_N8192_m512_chol64_summary.txt, profiles/r01x_chol64_counters_summary.txt"}
 
 
 def config2_filter(pkg, datagen, args):

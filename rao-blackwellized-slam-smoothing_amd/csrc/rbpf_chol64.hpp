@@ -28,9 +28,9 @@
 // ONE MFMA per panel for the trailing columns, the inverse swept alongside (also one MFMA per panel), so the tile never
 // goes through LDS and the inverse is directly an MFMA A operand (4.5 K clocks per tile instead of 15 K).
 //
-// Measured (MI355X, n = 515): 3.68 ms per 2048 matrices standalone (25 TFLOP/s = 32 % of the fp64 matrix peak; the
-// 16-column kernel: 5.68 ms), 19.4 ms per launch of 8192 inside the information-form smoother (29.5 ms), where 45 % of
-// the time is the element phase (stored matrix + ImatAddt in, Imat(:,:,ai) out) at the ~10 B/clk a CU streams from HBM.
+// Measured (MI355X, n = 515): 3.50 ms per 2048 matrices standalone (26.6 TFLOP/s = 34 % of the fp64 matrix peak; the
+// 16-column kernel: 5.1-5.7 ms), 16.6 ms per launch of 8192 inside the information-form smoother (29.5 ms), where it moves
+// 77.6 GB (stored matrix + ImatAddt + factor re-reads in, factor + Imat(:,:,ai) out) = 4.7 TB/s: HBM-bound.
 //
 // Factor storage: row-tile major, fragment order — the 64 values L(16 rt + r, 4 kg + kk) sit at
 // ((rt * KGS + kg) * 64 + kk * 16 + r), KGS = 4 RT, so a row tile streams through consecutive 512 B fragments.
