@@ -54,9 +54,10 @@
 #define C64_STAMP_PASS
 #endif
 
-constexpr int kC64Waves = 8;
-constexpr int kC64Threads = kC64Waves * 64;
-constexpr int kC64TilesPerPass = 4 * (kC64Waves - 1);
+// Two shapes: W = 8 waves of 256 registers, up to 4 row tiles per worker wave, one workgroup per CU (large matrices);
+// W = 4 waves, up to 2 row tiles per worker wave, two workgroups per CU (12..27 row tiles: the serial diagonal blocks
+// of two particles overlap).  Three or four workgroups per CU would need a call-free kernel below 170 registers; inlined,
+// the diagonal block and the general element loader spill (389 registers), and a callee does not honour the kernel's bound.
 
 __device__ inline double bperm_f64(double v, int src_lane) {
   const long long b = __double_as_longlong(v);
@@ -207,14 +208,21 @@ __device__ inline int c64_tri(int i, int c) { return i * (i + 1) / 2 + c; }     
 
 // Row tile I of the diagonal block (one of waves 4..7): elements and panel product of its I + 1 lower tiles, handed to
 // wave 0 through LDS (Zd: [10][4][64]).
-template <int I, int MODE>
+template <int I, int MODE, bool CALLS>
 __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* __restrict__ Lt, int KGS, int J, int M,
                                         const double* rhs_s, const double* Hs, const double* RH, double jit, int lane,
                                         double* Zd C64_STAMP_ARGS) {
   v4d Z[I + 1];
 #pragma unroll
-  for (int c = 0; c <= I; ++c)
-    Z[c] = -c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+  for (int c = 0; c <= I; ++c) {
+    if (CALLS) {
+      Z[c] = -c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+    } else {
+      v4d e;
+      chol_aug_elems<MODE>(a, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+      Z[c] = -e;
+    }
+  }
   C64_STAMP(0);
   if (J > 0) {
     const double* pf[I + 1];
@@ -253,8 +261,8 @@ __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* 
 // its row tiles that exist (4 except at the very end).
 // (noinline: as a real call it gets registers of its own — inlined, the values the kernel keeps live across the block
 // column loop pushed parts of this serial chain into scratch, 15 K clocks per tile instead of 4 K)
-__device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
-                                      const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
+__device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
+                                           const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
   v4d Z[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -294,12 +302,17 @@ __device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt
   return bad;
 }
 
+__device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
+                                                         const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
+  return c64_diag_block_body(Lt, KGS, J, nd, M, lane, Zd, NLs, Lds C64_STAMP_PASS);
+}
+
 // Waves 1..7: NT row tiles below the diagonal block (all four sub-columns exist: nd == 4 whenever such tiles exist).
 // LATE (experiment, RBPF_C64_LATE = 1, off): the panel product runs first, from zero, and the matrix elements are
 // subtracted afterwards, on waves 4..7 only, so that on every SIMD one wave streams elements while the other multiplies.
 // Measured slower (information form, n = 515: 21.8 instead of 18.7 ms per launch): the element phase is bound by the
 // CU's memory rate (~10 B/clk), not by a SIMD, and then competes with the factor re-reads of the products.
-template <int NT, int MODE, bool LATE>
+template <int NT, int MODE, bool LATE, bool CALLS>
 __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int J,
                                      const int (&rt)[4], int M, const double* rhs_s, const double* Hs, const double* RH,
                                      double jit, int lane, const double* NLs, const double* Lds, bool barrier C64_STAMP_ARGS) {
@@ -314,7 +327,9 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const v4d e = c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+          v4d e;
+          if (CALLS) e = c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+          else chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
           Z[s][c] = ACC ? Z[s][c] - e : -e;
         }
       }
@@ -392,8 +407,9 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
   C64_STAMP(4);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in) {
+template <int MODE, int W>
+__global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(CholArgs a_in) {
+  constexpr int kThreads = W * 64, kNTMax = (W == 8) ? 4 : 2, kTilesPerPass = kNTMax * (W - 1);
   extern __shared__ double csm[];
   CholArgs a = a_in;
   const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
@@ -409,8 +425,10 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
   double* Lt = a.Lbuf + (size_t)p * a.ldL;
   double* NLs = csm;                              // [4][4][64]  -inv(Ld_cc) as MFMA A fragments
   double* Lds = NLs + 1024;                       // [6][4][64]  Ld(c',c), c' > c, as MFMA A fragments
-  double* Zd = Lds + 1536;                        // [10][4][64] the diagonal block's tiles on their way to wave 0
-  double* red = Zd + 2560;                        // [32]
+  double* Zd = csm;                               // [10][4][64] the diagonal block's tiles on their way to wave 0 — the same
+                                                  // 20 KB: wave 0 has them in registers before it writes NLs / Lds, and the
+                                                  // next block column's tiles are written after the barrier that ends the solves
+  double* red = csm + 2560;                       // [32]
   double* rhs_s = red + 32;                       // [M]
   int* sfail = reinterpret_cast<int*>(rhs_s + M);   // [2]: block column J reports in slot J & 1 (sticky), so a fast wave 0 cannot
                                                     // overtake the check of the previous block column
@@ -418,7 +436,7 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
   const bool pend = (MODE == 1 && a.Hb != nullptr);
   double* Hs = (pend || MODE == 0) ? rhs_s + M + 2 : nullptr;
   double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
-  chol_prologue(a, p, tid, kC64Threads, M, rhs_s, Hs, RH, pend);
+  chol_prologue(a, p, tid, kThreads, M, rhs_s, Hs, RH, pend);
   const int NJ = (RT + 3) >> 2;
 #ifdef RBPF_C64_STAMPS
   long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = clock64();
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
     for (int J = 0; J < NJ; ++J) {
       const int nd = min(4, RT - 4 * J);
       const int first = 4 * J + nd, count = RT - first;
-      const int npass = max(1, (count + kC64TilesPerPass - 1) / kC64TilesPerPass);
+      const int npass = max(1, (count + kTilesPerPass - 1) / kTilesPerPass);
       handed += nd;
       if (wv == 0) {
         // wait for the nd tiles of the diagonal block (only this wave waits; bounded, so a lost hand-off cannot hang the GPU)
@@ -448,9 +466,9 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
         __syncthreads();
         C64_STAMP(3);
       } else {
-        const int di = kC64Waves - 1 - wv;          // waves 7, 6, 5, 4 take row tiles 0, 1, 2, 3 of the diagonal block
-        if (di < nd) {
-#define RBPF_C64D(I_) c64_diag_product<I_, MODE>(a, p, Lt, KGS, J, M, rhs_s, Hs, RH, jit, lane, Zd C64_STAMP_PASS)
+        // row tile i of the diagonal block is formed by wave W - 1 - i % (W - 1): waves 7, 6, 5, 4 (W = 8) or 3, 2, 1, 3 (W = 4)
+        for (int di = W - 1 - wv; di < nd; di += W - 1) {
+#define RBPF_C64D(I_) c64_diag_product<I_, MODE, true>(a, p, Lt, KGS, J, M, rhs_s, Hs, RH, jit, lane, Zd C64_STAMP_PASS)
           switch (di) {
             case 0: RBPF_C64D(0); break;
             case 1: RBPF_C64D(1); break;
@@ -465,11 +483,11 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
           int rt[4], nt = 0;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const int u = kC64TilesPerPass * pass + (wv - 1) + (kC64Waves - 1) * s;
+            const int u = kTilesPerPass * pass + (wv - 1) + (W - 1) * s;
             rt[s] = first + min(u, count - 1);
-            nt += (u < count) ? 1 : 0;
+            nt += (s < kNTMax && u < count) ? 1 : 0;
           }
-#define RBPF_C64(NT_, LATE_) c64_tile_pass<NT_, MODE, LATE_>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
+#define RBPF_C64(NT_, LATE_) c64_tile_pass<NT_, MODE, LATE_, true>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
 #if RBPF_C64_LATE
           switch (nt == 0 ? 0 : nt + (wv >= 4 ? 4 : 0)) {   // 0: no tile in this pass (only the barrier)
 #else
@@ -477,8 +495,8 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
 #endif
             case 1: RBPF_C64(1, false); break;
             case 2: RBPF_C64(2, false); break;
-            case 3: RBPF_C64(3, false); break;
-            case 4: RBPF_C64(4, false); break;
+            case 3: if (kNTMax >= 3) RBPF_C64(3, false); break;
+            case 4: if (kNTMax >= 4) RBPF_C64(4, false); break;
 #if RBPF_C64_LATE
             case 5: RBPF_C64(1, true); break;
             case 6: RBPF_C64(2, true); break;
@@ -503,7 +521,7 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
     __syncthreads();
     if (!failed) {
       double sl = 0.0, vv = 0.0;
-      for (int j = tid; j < M; j += kC64Threads) {
+      for (int j = tid; j < M; j += kThreads) {
         const size_t off = (size_t)(j >> 2) * 64 + (size_t)(j & 3) * 16;
         const double dj = Lt[(size_t)(j >> 4) * KGS * 64 + off + (j & 15)];
         const double vj = Lt[(size_t)(M >> 4) * KGS * 64 + off + (M & 15)];
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
       __syncthreads();
       if (tid == 0) {
         sl = 0.0; vv = 0.0;
-        for (int w = 0; w < kC64Waves; ++w) { sl += red[w]; vv += red[16 + w]; }
+        for (int w = 0; w < W; ++w) { sl += red[w]; vv += red[16 + w]; }
         double lw;
         if (MODE == 0) lw = -sl - 0.5 * vv - 0.5 * (double)M * 1.8378770664093453;     // log(2*pi)
         else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
@@ -531,24 +549,31 @@ __global__ __launch_bounds__(kC64Threads) void chol_solve64_kernel(CholArgs a_in
   }
 }
 
-constexpr size_t kC64MaxLds = 160 * 1024;         // the whole LDS of a CU (one workgroup per CU anyway)
+constexpr size_t kC64MaxLds = 160 * 1024;         // the whole LDS of a CU
 static size_t chol64_lds_bytes(int M, int d) {
-  return ((size_t)1024 + 1536 + 2560 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
+  return ((size_t)2560 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
 }
 
-template <int MODE>
+template <int MODE, int W>
 static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC64MaxLds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC64MaxLds);
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((chol_solve64_kernel<MODE>), dim3(batch), dim3(kC64Threads), lds, st, ca);
+  hipLaunchKernelGGL((chol_solve64_kernel<MODE, W>), dim3(batch), dim3(W * 64), lds, st, ca);
   return hipGetLastError();
 }
 
-static hipError_t launch_chol64(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
+// waves: 8 or 4 (0: by size)
+static hipError_t launch_chol64(const CholArgs& ca, int batch, int d_lds, hipStream_t st, int waves = 0) {
   const size_t lds = chol64_lds_bytes(ca.Msz, d_lds);
-  return ca.mode == 1 ? launch_chol64_mode<1>(ca, batch, lds, st) : launch_chol64_mode<0>(ca, batch, lds, st);
+  const int RT = (ca.Msz + 1 + 15) >> 4;
+  if (waves == 0) {
+    const char* we = getenv("RBPF_CHOL64_WAVES");                           // tuning: force 4 / 8
+    waves = (we && (atoi(we) == 4 || atoi(we) == 8)) ? atoi(we) : (RT > 27) ? 8 : 4;
+  }
+  if (waves == 8) return ca.mode == 1 ? launch_chol64_mode<1, 8>(ca, batch, lds, st) : launch_chol64_mode<0, 8>(ca, batch, lds, st);
+  return ca.mode == 1 ? launch_chol64_mode<1, 4>(ca, batch, lds, st) : launch_chol64_mode<0, 4>(ca, batch, lds, st);
 }

@@ -576,13 +576,14 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 #include "rbpf_chol64.hpp"
 
 // batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0).
-// Matrices of more than 18 row tiles (n >= 288; measured crossover, profiles/r01v_chol_bench.jsonl) take the 64-column
-// kernel (rbpf_chol64.hpp), smaller ones the 16-column kernel with several workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
+// Matrices of more than 11 row tiles (n >= 176) take the 64-column kernel (rbpf_chol64.hpp; 4 waves and two workgroups per
+// CU up to 27 row tiles, 8 waves above; measured crossovers, profiles/r01y_chol_bench.jsonl), smaller ones the 16-column
+// kernel with four workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
 static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
   static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
   const char* v64 = getenv("RBPF_CHOL64");
   const int RT = (ca.Msz + 1 + 15) >> 4;
-  if ((v64 ? atoi(v64) != 0 : RT > 18) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
+  if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
@@ -1259,7 +1260,7 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
                       int32_t reps, double* logw, int32_t* status, double* ms) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
-  if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 || (variant != 0 && variant != 16 && variant != 64)) {
+  if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 || (variant != 0 && variant != 16 && variant != 64 && variant != 648 && variant != 644)) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
   }
   double *dS = nullptr, *de = nullptr, *dL = nullptr, *dlw = nullptr; int* dst = nullptr;
@@ -1285,7 +1286,7 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
     err = hipMemsetAsync(dlw, 0, (size_t)batch * 8, nullptr);
     if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
     if (err == hipSuccess) {
-      if (variant == 64) err = launch_chol64(ca, batch, 0, nullptr);
+      if (variant == 64 || variant == 648 || variant == 644) err = launch_chol64(ca, batch, 0, nullptr, variant == 648 ? 8 : variant == 644 ? 4 : 0);
       else if (variant == 16) {
         const int RT = (M + 1 + 15) >> 4, W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
         const size_t lds = chol_lds_bytes(M, 0);

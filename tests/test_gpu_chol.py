@@ -43,7 +43,7 @@ def numpy_logw(S, e, jitter=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [16, 64])
+@pytest.mark.parametrize("variant", [16, 648, 644])
 @pytest.mark.parametrize("M", [5, 16, 63, 64, 65, 130, 259, 515, 516, 576, 640])
 def test_batched_factorisation_matches_numpy(rbpf, M, variant):
     B = 9 if M > 300 else 21
@@ -85,7 +85,7 @@ def test_jitter_retry_and_failure_flag(rbpf, M, variant):
 
 def test_largest_supported_size(rbpf):
     S, e = spd_batch(3, 1023, seed=11)
-    for variant in (16, 64):
+    for variant in (16, 648, 644):
         got, status, _ = rbpf.chol_weights(S, e, variant=variant)
         assert status == 0
         np.testing.assert_allclose(got, numpy_logw(S, e), rtol=1e-11, atol=1e-9)
@@ -114,8 +114,8 @@ def test_smoothers_with_the_64_column_kernel_forced(rbpf, force_chol64, kind, N_
 
 @pytest.mark.parametrize("m", [256, 300])
 def test_information_form_smoother_at_the_benchmark_basis_sizes(rbpf, m):
-    """m = 256 (nLin = 259, 17 row tiles: 16-column kernel, two workgroups per CU) and m = 300 (nLin = 303, 19 row tiles:
-    the smallest size class that takes the 64-column kernel by default)."""
+    """m = 256 (nLin = 259, 17 row tiles) and m = 300 (nLin = 303, 19 row tiles): the size class of the 4-wave shape of the
+    64-column kernel (two workgroups per CU)."""
     import test_gpu_smoother as ts
     c = cases.mag_case(6, 5, m, seed=23, N_K=2)
     ref, out = ts.run_both(rbpf, c, info_form=True)
