@@ -349,9 +349,12 @@ int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
                         const double* lower, const double* upper, double* J);
 /* particleSmoother.m:221-229 for a batch of matrices: cS = chol(S,'lower') (one retry with S + jitter*I),
  * v = cS \ e, logw[b] = -sum(log(diag(cS))) - v'v/2 - M/2*log(2*pi).  S [batch][M x M] column-major (lower
- * triangle read), e [batch][M].  variant 0: automatic kernel choice, 16 / 64: force the 16- / 64-column
- * factorisation kernel.  reps >= 1 repeats the launch; *ms (may be NULL) = mean kernel time (HIP events).
- * *status (may be NULL): bit 1 set when a factorisation failed twice (its logw is NaN).           */
+ * triangle read), e [batch][M].  variant 0: automatic kernel choice; 16: the 16-column kernel; 64 / 648 / 644: the
+ * 64-column kernel (waves by size / 8 / 4); 1: the register-resident kernel (64 <= M <= 143, information form only).
+ * variant + 1000: the information-form loaders and expression of particleSmootherInformationForm.m:224-236 with
+ * ImatAddt = ivecAddt = 0, i.e. logw[b] = -sum(log(diag(cI))) + v'v/2 and no retry.  reps >= 1 repeats the launch;
+ * *ms (may be NULL) = mean kernel time (HIP events).  *status (may be NULL): bit 1 set when a factorisation failed
+ * (its logw is NaN).                                                                               */
 int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e, double jitter,
                       int32_t variant, int32_t reps, double* logw, int32_t* status, double* ms);
 

@@ -574,16 +574,19 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 }
 
 #include "rbpf_chol64.hpp"
+#include "rbpf_chol_small.hpp"
 
 // batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0).
 // Matrices of more than 11 row tiles (n >= 176) take the 64-column kernel (rbpf_chol64.hpp; 4 waves and two workgroups per
-// CU up to 27 row tiles, 8 waves above; measured crossovers, profiles/r01y_chol_bench.jsonl), smaller ones the 16-column
-// kernel with four workgroups per CU.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
+// CU up to 27 row tiles, 8 waves above; measured crossovers, profiles/r01y_chol_bench.jsonl), information-form matrices of
+// 5..9 row tiles (dense-radio n = 128) the register-resident kernel (rbpf_chol_small.hpp), the rest the 16-column kernel.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
 static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
   static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
   const char* v64 = getenv("RBPF_CHOL64");
   const int RT = (ca.Msz + 1 + 15) >> 4;
   if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
+  const char* vsm = getenv("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
+  if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
   if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
@@ -1260,11 +1263,16 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
                       int32_t reps, double* logw, int32_t* status, double* ms) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
-  if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 || (variant != 0 && variant != 16 && variant != 64 && variant != 648 && variant != 644)) {
+  const bool info = variant >= 1000;                 // information-form expression and loaders (see rbpf.h)
+  if (info) variant -= 1000;
+  if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 ||
+      (variant != 0 && variant != 1 && variant != 16 && variant != 64 && variant != 648 && variant != 644) ||
+      (variant == 1 && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
   }
   double *dS = nullptr, *de = nullptr, *dL = nullptr, *dlw = nullptr; int* dst = nullptr;
-  auto cleanup = [&]() { hipFree(dS); hipFree(de); hipFree(dL); hipFree(dlw); hipFree(dst); };
+  double* dzero_p = nullptr;
+  auto cleanup = [&]() { hipFree(dS); hipFree(de); hipFree(dL); hipFree(dlw); hipFree(dst); hipFree(dzero_p); };
   int rc = dmalloc(&dS, (size_t)batch * M * M);
   if (rc == RBPF_OK) rc = dmalloc(&de, (size_t)batch * M);
   if (rc == RBPF_OK) rc = dmalloc(&dL, (size_t)batch * chol_factor_doubles(M));
@@ -1276,8 +1284,18 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   if (err == hipSuccess) err = hipMemset(dst, 0, 16);
   CholArgs ca;
   std::memset(&ca, 0, sizeof(ca));
-  ca.mode = 0; ca.Msz = M; ca.d = 1; ca.n = M; ca.ldx = M; ca.Lbuf = dL; ca.ldL = (long)chol_factor_doubles(M);
-  ca.S = dS; ca.R = nullptr; ca.rhs = de; ca.jitter = jitter; ca.pant_log = dlw; ca.status = dst;
+  ca.Msz = M; ca.d = 1; ca.n = M; ca.ldx = M; ca.Lbuf = dL; ca.ldL = (long)chol_factor_doubles(M);
+  ca.jitter = jitter; ca.pant_log = dlw; ca.status = dst;
+  double* dzero = nullptr;                           // information form: ImatAddt = 0, ivecAddt = 0, qf = hld = 0
+  if (!info) {
+    ca.mode = 0; ca.S = dS; ca.R = nullptr; ca.rhs = de;
+  } else {
+    if (err == hipSuccess) err = hipMalloc(&dzero, ((size_t)M * M + M + batch) * 8);
+    if (err == hipSuccess) err = hipMemset(dzero, 0, ((size_t)M * M + M + batch) * 8);
+    ca.mode = 1; ca.Imat = dS; ca.imat_stride = (long)M * M; ca.ivec = de; ca.ImatAdd = dzero; ca.ivecAdd = dzero + (size_t)M * M;
+    ca.qf = dzero + (size_t)M * M + M; ca.hld = ca.qf;
+    dzero_p = dzero;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (err == hipSuccess) err = hipEventCreate(&e0);
   if (err == hipSuccess) err = hipEventCreate(&e1);
@@ -1286,7 +1304,8 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
     err = hipMemsetAsync(dlw, 0, (size_t)batch * 8, nullptr);
     if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
     if (err == hipSuccess) {
-      if (variant == 64 || variant == 648 || variant == 644) err = launch_chol64(ca, batch, 0, nullptr, variant == 648 ? 8 : variant == 644 ? 4 : 0);
+      if (variant == 1) err = launch_chol_small(ca, batch, 1, nullptr);
+      else if (variant == 64 || variant == 648 || variant == 644) err = launch_chol64(ca, batch, 0, nullptr, variant == 648 ? 8 : variant == 644 ? 4 : 0);
       else if (variant == 16) {
         const int RT = (M + 1 + 15) >> 4, W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
         const size_t lds = chol_lds_bytes(M, 0);

@@ -621,9 +621,12 @@ def sample(w, u):
     return ind
 
 
-def chol_weights(S, e, jitter=0.0, variant=0, reps=1):
+def chol_weights(S, e, jitter=0.0, variant=0, reps=1, info_form=False):
     """particleSmoother.m:221-229 for a batch: S [B, M, M] (symmetric; the lower triangle is read), e [B, M] ->
-    (logw [B], status, mean kernel ms).  variant 0 / 16 / 64 selects the factorisation kernel (648 / 644: the 64-column kernel with 8 / 4 waves)."""
+    (logw [B], status, mean kernel ms).  variant 0 / 16 / 64 selects the factorisation kernel (648 / 644: the 64-column kernel
+    with 8 / 4 waves; 1: the register-resident kernel, information form and 64 <= M <= 143 only).  info_form: the
+    information-form loaders and expression of particleSmootherInformationForm.m:224-236 with ImatAddt = ivecAddt = 0:
+    logw = -sum(log(diag(cI))) + v'v/2, no retry."""
     lib = load_library()
     S = np.ascontiguousarray(np.asarray(S, dtype=np.float64))
     e = np.ascontiguousarray(np.asarray(e, dtype=np.float64))
@@ -633,7 +636,8 @@ def chol_weights(S, e, jitter=0.0, variant=0, reps=1):
     logw = np.empty(B, dtype=np.float64)
     status = np.zeros(1, dtype=np.int32)
     ms = np.zeros(1, dtype=np.float64)
-    check(lib.rbpf_chol_weights(M, B, _dp(St), _dp(e), float(jitter), int(variant), int(reps), _dp(logw), _ip(status), _dp(ms)))
+    check(lib.rbpf_chol_weights(M, B, _dp(St), _dp(e), float(jitter), int(variant) + (1000 if info_form else 0), int(reps),
+                                _dp(logw), _ip(status), _dp(ms)))
     return logw, int(status[0]), float(ms[0])
 
 

@@ -132,3 +132,35 @@ def test_covariance_form_smoother_with_long_horizons(rbpf, kind, N_P, N_T, m):
     c = mk(N_P, N_T, m, seed=31, N_K=2)
     ref, out = ts.run_both(rbpf, c, info_form=False)
     ts.check(ref, out, 2)
+
+
+def numpy_logw_info(S, e):
+    import scipy.linalg as sl
+    out = np.empty(S.shape[0])
+    for b in range(S.shape[0]):
+        L = np.linalg.cholesky(S[b])
+        v = sl.solve_triangular(L, e[b], lower=True)
+        out[b] = -np.sum(np.log(np.diag(L))) + 0.5 * v @ v                   # particleSmootherInformationForm.m:234-236
+    return out
+
+
+@pytest.mark.parametrize("variant", [1, 16, 644])
+@pytest.mark.parametrize("M", [64, 65, 79, 80, 100, 127, 128, 129, 143])
+def test_information_form_factorisation_of_small_matrices(rbpf, M, variant):
+    """5..9 row tiles: the register-resident kernel (variant 1) against numpy and the two other kernels."""
+    S, e = spd_batch(33, M, seed=100 + M, scale_spread=1.0)
+    got, status, _ = rbpf.chol_weights(S, e, variant=variant, info_form=True)
+    assert status == 0
+    np.testing.assert_allclose(got, numpy_logw_info(S, e), rtol=1e-11, atol=1e-9)
+
+
+def test_information_form_failure_is_flagged(rbpf):
+    """particleSmootherInformationForm.m:224-236 has no usable retry (quirk Q4): a failed factorisation is an error."""
+    S, e = spd_batch(5, 128, seed=9)
+    w, V = np.linalg.eigh(S[2])
+    w[0] = -1.0
+    S[2] = (V * w) @ V.T
+    got, status, _ = rbpf.chol_weights(S, e, variant=1, info_form=True)
+    assert status & 2 and np.isnan(got[2])
+    ok = [0, 1, 3, 4]
+    np.testing.assert_allclose(got[ok], numpy_logw_info(S[ok], e[ok]), rtol=1e-11, atol=1e-9)

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--variants", default="16,64")
+    ap.add_argument("--info", action="store_true", help="information-form loaders / expression (needed for variant 1)")
     args = ap.parse_args()
     pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
     rs = np.random.RandomState(0)
@@ -29,10 +30,10 @@ def main():
     e = rs.standard_normal((B, M))
     ref = None
     for v in [int(x) for x in args.variants.split(",")]:
-        pkg.chol_weights(S[:64], e[:64], variant=v)                           # warm-up (module load, attributes)
-        logw, status, ms = pkg.chol_weights(S, e, variant=v, reps=args.reps)
+        pkg.chol_weights(S[:64], e[:64], variant=v, info_form=args.info)      # warm-up (module load, attributes)
+        logw, status, ms = pkg.chol_weights(S, e, variant=v, reps=args.reps, info_form=args.info)
         flops = B * M ** 3 / 3.0
-        line = {"kernel": {16: "chol 16-column", 64: "chol 64-column", 648: "chol 64-column, 8 waves", 644: "chol 64-column, 4 waves"}.get(v, str(v)), "M": M, "batch": B, "reps": args.reps, "ms": round(ms, 3),
+        line = {"kernel": {1: "chol register-resident", 16: "chol 16-column", 64: "chol 64-column", 648: "chol 64-column, 8 waves", 644: "chol 64-column, 4 waves"}.get(v, str(v)), "M": M, "batch": B, "reps": args.reps, "ms": round(ms, 3),
                 "tflops": round(flops / (ms * 1e-3) / 1e12, 2), "frac_of_fp64_matrix_peak": round(flops / (ms * 1e-3) / 78.6e12, 3),
                 "status": status}
         if ref is None:
