@@ -73,7 +73,10 @@ def _single(rbpf, kind, N, T, m, N_K):
     return c, out
 
 
-@pytest.mark.parametrize("kind,n_local,T,m,N_K", [("mag", 12, 8, 130, 3), ("mag", 40, 7, 16, 3), ("radio", 24, 10, 128, 3)])
+# m = 130 / 128: the register-resident factorisation kernel; m = 16: the 16-column kernel; m = 200 (nLin = 203, 13 row
+# tiles): the 64-column kernel, whose element loaders then read received records
+@pytest.mark.parametrize("kind,n_local,T,m,N_K", [("mag", 12, 8, 130, 3), ("mag", 40, 7, 16, 3), ("radio", 24, 10, 128, 3),
+                                                  ("mag", 10, 6, 200, 2)])
 def test_two_ranks_equal_single_gpu_smoother(rbpf, kind, n_local, T, m, N_K):
     res = _run(2, "gloo", "host", kind, n_local, T, m, N_K)
     c, ref = _single(rbpf, kind, 2 * n_local, T, m, N_K)
