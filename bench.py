@@ -106,24 +106,28 @@ def smoother_large(pkg, datagen):
     th = [0.25, 2.0, 0.01]                                                       # examples/slam-dense-radio/main.m:24
     d = datagen.planar_heading(T, Qr, th, 1.0, seed=1, nLL=4, traj="square_3D")
     mdl, x0, P0, R = pkg.dense_radio_prior(128, d["LL"], th)
-    t0 = time.perf_counter()
-    XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
-                                                    x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3))
-    out["dense_radio_N65536_T48_m128_NK3"] = round(time.perf_counter() - t0, 3)
+    runs = []
+    for _ in range(2):                                                           # the first run also pays for the first touch of 30 GB
+        t0 = time.perf_counter()
+        XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
+                                                        x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3))
+        runs.append(round(time.perf_counter() - t0, 3))
+    out["dense_radio_N65536_T48_m128_NK3"] = min(runs)
+    out["dense_radio_N65536_T48_m128_NK3_runs"] = runs
     out["dense_radio_finite"] = bool(np.all(np.isfinite(XNK)))
     Q = q_mag()
     secs = {}
-    for T in (4, 24, 72):                                                        # the T=4 run only warms the allocator up
-        d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=1)
-        mdl, x0, P0, R = pkg.dense_mag_prior(512, d["LL"], THETA_MAG)
+    for T in (4, 24, 24, 72, 72):                                                # the T=4 run only warms the allocator up; best of two:
+        d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=1)                       # creating / first-touching the 87 GB of banks
+        mdl, x0, P0, R = pkg.dense_mag_prior(512, d["LL"], THETA_MAG)            # takes anything between 0 and 6 s
         t0 = time.perf_counter()
         pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q,
                                             R, 8192, 2, 0.01, rng=pkg.PhiloxRNG(3))
-        secs[T] = time.perf_counter() - t0
+        secs[T] = min(secs.get(T, 1e30), time.perf_counter() - t0)
     out["dense_mag_N8192_T24_m512_NK2"] = round(secs[24], 3)
     out["dense_mag_N8192_T72_m512_NK2"] = round(secs[72], 3)
     out["note"] = ("dense-mag N=8192 is the per-GPU share of N=65536 at 8 GPUs; the run times include creating the 87 GB of "
-                   "particle banks and the T-long histories (wall clock, not steady state); kernel times from rocprofv3: 6.5 ms (plain step) + 23 ms (step with ancestor sampling) per time step, "
+                   "particle banks and the T-long histories (wall clock, best of two); kernel times from rocprofv3: 6.5 ms (plain step) + 23 ms (step with ancestor sampling) per time step, "
                    "profiles/r01x_smoother_mag_N8192_m512_chol64_summary.txt")
     return out
 
