@@ -164,3 +164,22 @@ def test_information_form_failure_is_flagged(rbpf):
     assert status & 2 and np.isnan(got[2])
     ok = [0, 1, 3, 4]
     np.testing.assert_allclose(got[ok], numpy_logw_info(S[ok], e[ok]), rtol=1e-11, atol=1e-9)
+
+
+def test_every_kernel_over_a_sweep_of_sizes(rbpf):
+    """All residues of M modulo 16 and 64 around the tile / block-column / dispatch boundaries, every kernel that accepts
+    the size, both forms (the information form without retry)."""
+    sizes = sorted(set(list(range(1, 20)) + list(range(60, 70)) + list(range(124, 150)) + [175, 176, 177, 191, 192, 193,
+                   207, 208, 255, 256, 257, 271, 272, 287, 288, 289, 319, 320, 321, 383, 384, 385, 431, 432, 433, 447, 448, 449]))
+    for M in sizes:
+        S, e = spd_batch(3, M, seed=1000 + M)
+        want0, want1 = numpy_logw(S, e), numpy_logw_info(S, e)
+        rt = (M + 16) // 16
+        for variant in (0, 16, 644, 648):
+            got, status, _ = rbpf.chol_weights(S, e, jitter=1e-2, variant=variant)
+            assert status == 0, (M, variant)
+            np.testing.assert_allclose(got, want0, rtol=1e-11, atol=1e-9, err_msg=f"M={M} variant={variant}")
+        for variant in (0, 16, 644) + ((1,) if 5 <= rt <= 9 else ()):
+            got, status, _ = rbpf.chol_weights(S, e, variant=variant, info_form=True)
+            assert status == 0, (M, variant)
+            np.testing.assert_allclose(got, want1, rtol=1e-11, atol=1e-9, err_msg=f"M={M} variant={variant} info")
