@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 3
+#define RBPF_ABI_VERSION 4
 
 typedef enum {
   RBPF_OK = 0,
@@ -41,7 +41,8 @@ typedef enum {
   RBPF_ERR_OUT_OF_MEMORY = 5,
   RBPF_ERR_CHOL_FAILED = 6,     /* second Cholesky failure: MATLAB would throw                      *
                                  * (particleFilter.m:147, particleSmootherInformationForm.m:228-231) */
-  RBPF_ERR_STATE = 7            /* call sequence error (e.g. advance past N_T)                      */
+  RBPF_ERR_STATE = 7,           /* call sequence error (e.g. advance past N_T)                      */
+  RBPF_ERR_CALLBACK = 8         /* a host callback (model handle / on_step hook) returned non-zero   */
 } rbpf_status;
 
 /* Model families = the closures defined in the reference's example runners. */
@@ -64,6 +65,23 @@ typedef enum {
   RBPF_MODEL_GENERIC_DENSE = 4
 } rbpf_model_kind;
 
+/* Host callbacks of the generic family = the reference's handle contracts, batched over columns so that a binding
+ * makes one call per step (the MEX gateway: one mexCallMATLAB each).  All matrices column-major.
+ * A non-zero return aborts the run with RBPF_ERR_CALLBACK.
+ *   dyn_model    xn_new(:,j) = dynModel(xn_anc(:,j), odometry(t,:), dt(t), Q(:,:,t)) for j = 0..n_cols-1, in this order
+ *                (the handle draws its own random numbers: particleFilter.m:108, particleSmoother.m:134-136); t is the
+ *                0-based row of odometry (= MATLAB's t-1)
+ *   meas_model   dy = measModel(xn [n_nonlin x n_cols]) -> [n_cols x n_y x n_lin] ([n_cols x n_lin] memory for
+ *                n_y = 1), particleFilter.m:124, particleSmoother.m:120
+ *   dyn_res_norm e_dyn(:,j) = dynResNorm(xnk_t, xn(:,j), odometry(t,:), dt(t), Q(:,:,t))' [n_w x n_cols]
+ *                (particleSmoother.m:178-180); NULL = isempty(dynResNorm): the additive default (:175-177) on the device */
+typedef struct {
+  int (*dyn_model)(void* user, int32_t t, int32_t n_cols, const double* xn_anc, double* xn_new);
+  int (*meas_model)(void* user, int32_t n_cols, const double* xn, double* dy);
+  int (*dyn_res_norm)(void* user, int32_t t, int32_t n_cols, const double* xnk_t, const double* xn, double* e_dyn);
+  void* user;
+} rbpf_callbacks;
+
 typedef struct {
   int32_t kind;          /* rbpf_model_kind                                                     */
   int32_t m_basis;       /* number of basis functions m (tools/domain_cartesian_dx.m:43)        */
@@ -74,6 +92,9 @@ typedef struct {
                           * RBPF_MODEL_SPARSE_VISUAL_2D                                                       */
   double L[3];           /* domain half-widths (domain_cartesian_dx.m:27-29)                    */
   double cam[3];         /* RBPF_MODEL_SPARSE_VISUAL_2D: f, fp, fw (load_data.m:58-60)          */
+  const rbpf_callbacks* callbacks; /* RBPF_MODEL_GENERIC_DENSE: the handles (one-shot entry points and            *
+                                    * rbpf_filter_advance call them every step); NULL: the caller drives the       *
+                                    * filter itself with rbpf_filter_ancestors / rbpf_filter_step_external          */
 } rbpf_model;
 
 typedef struct {
@@ -115,6 +136,21 @@ typedef struct {
   uint64_t seed;         /* RBPF_RNG_PHILOX: key of the counter-based device generator          */
 } rbpf_rng;
 
+typedef struct rbpf_ctx rbpf_ctx;      /* opaque filter / smoother context (device-resident state) */
+
+/* Per-step hook = the reference's makePlots call sites: after every time step of the filter
+ * (src/particleFilter.m:215-217: makePlots(xn,xl_max,P_max,traj_max,yhattraj,xn_traj,traj_mean,xl,P)) and after every
+ * iteration of the smoothers (src/particleSmoother.m:360-362: makePlots(xnk,xlk,k,XNK,XLK,PK)).  Filter: `ctx` is
+ * valid inside the callback for rbpf_filter_finish(ctx, &partial), which returns any of the outputs / final_* banks
+ * as of step t.  Smoothers: iteration k's pages of the caller's XNK / XLK / PK buffers are complete when it runs.
+ * A non-zero return aborts with RBPF_ERR_CALLBACK.                                                                */
+typedef struct {
+  rbpf_ctx* ctx;         /* filter only (NULL for the smoothers)                                */
+  int32_t t;             /* filter: 0-based time step just finished; smoother: 0-based iteration */
+  int32_t is_smoother;
+} rbpf_view;
+typedef int (*rbpf_on_step_fn)(const rbpf_view* view, void* user);
+
 typedef struct {
   int32_t keep_history;  /* 1: keep xn history + ancestor table (needed for traj_sample_iwmax,  *
                           *    xn_traj and every smoother); 0: ping-pong only                   */
@@ -134,6 +170,11 @@ typedef struct {
                           * STORAGE of the banks (BASELINE.json configs[4]): half the HBM traffic and memory, all     *
                           * arithmetic and every other state stay fp64.  Results then agree with the fp64 run to     *
                           * ~1e-6 relative per step (not to 1e-9) and resampling indices may differ.                 */
+  int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
+                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 as  *
+                          * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
+  rbpf_on_step_fn on_step; /* NULL: no hook                                                       */
+  void* on_step_user;
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */
@@ -168,8 +209,6 @@ typedef struct {
   double* trace_paNt;        /* [N_P x N_T x N_K] ancestor probabilities AI(:,t) (:240)         */
   int32_t* trace_ak;         /* [N_K] 0-based                                                   */
 } rbpf_smoother_out;
-
-typedef struct rbpf_ctx rbpf_ctx;      /* opaque filter / smoother context (device-resident state) */
 
 /* Timing of the dominant kernel (the fused resample-gather + weight + Kalman-update stream kernel),
  * measured with HIP events on the context's own stream.                                           */
@@ -357,6 +396,18 @@ int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
  * (its logw is NaN).                                                                               */
 int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e, double jitter,
                       int32_t variant, int32_t reps, double* logw, int32_t* status, double* ms);
+/* Quaternion helpers of tools/ on the device, batched over n columns, for the parity tests:
+ *   op 0  expq, scalar branch   tools/expq.m:22-31  (flip when q0 < 0)          in [3 x n]      -> out [4 x n]
+ *   op 1  expq, batched branch  tools/expq.m:33-37  (flip when q0 <= 0)         in [3 x n]      -> out [4 x n]
+ *   op 2  logq, scalar branch   tools/logq.m:25-30  (flip when q0 < 0)          in [4 x n]      -> out [3 x n]
+ *   op 3  logq, batched branch  tools/logq.m:32-35  (flip when q0 <= 0)         in [4 x n]      -> out [3 x n]
+ *   op 4  qLeft                 tools/qLeft.m:30-40                              in [4 x n]      -> out [4 x 4 x n]
+ *   op 5  qRight                tools/qRight.m:29-39                             in [4 x n]      -> out [4 x 4 x n]
+ *   op 6  qInv                  tools/qInv.m:27-31                               in [4 x n]      -> out [4 x n]
+ *   op 7  quat2rmat             tools/quat2rmat.m:27-40                          in [4 x n]      -> out [3 x 3 x n]
+ *   op 8  mcross                tools/mcross.m:33-42                             in [3 x n]      -> out [3 x 3 x n]
+ * q0 > 1 by rounding is clamped before acos (quirk Q7).                                                             */
+int rbpf_quat_helpers(int32_t op, int32_t n, const double* in, double* out);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,41 @@ def mcross(v):
                      [-v[1], v[0], 0.0]])
 
 
+def mcross_batched(v):
+    """tools/mcross.m:38-42 (N x 3 branch): reshape([0 v3 -v2 -v3 0 v1 v2 -v1 0]', 3, 3, N) -- the matrix is filled
+    column by column via the unvec operation.  Returned here as [N,3,3]."""
+    v = np.asarray(v, dtype=np.float64)
+    N = v.shape[0]
+    z = np.zeros(N)
+    rows = np.column_stack((z, v[:, 2], -v[:, 1], -v[:, 2], z, v[:, 0], v[:, 1], -v[:, 0], z))   # N x 9
+    M = rows.T.reshape((3, 3, N), order="F")                                                      # reshape(rows', 3, 3, N)
+    return np.transpose(M, (2, 0, 1))
+
+
+def qLeft_batched(q):
+    """tools/qLeft.m:36-40 (N x 4 branch): [q0, -qv'; qv, q0*I + mcross(qv)] per page.  Returned as [N,4,4]."""
+    q = np.asarray(q, dtype=np.float64)
+    N = q.shape[0]
+    out = np.empty((N, 4, 4))
+    out[:, 0, 0] = q[:, 0]
+    out[:, 0, 1:] = -q[:, 1:4]
+    out[:, 1:, 0] = q[:, 1:4]
+    out[:, 1:, 1:] = q[:, 0][:, None, None] * np.eye(3)[None] + mcross_batched(q[:, 1:4])
+    return out
+
+
+def qRight_batched(q):
+    """tools/qRight.m:35-39 (N x 4 branch): [q0, -qv'; qv, multiprod(q0, I) - mcross(qv)] per page.  [N,4,4]."""
+    q = np.asarray(q, dtype=np.float64)
+    N = q.shape[0]
+    out = np.empty((N, 4, 4))
+    out[:, 0, 0] = q[:, 0]
+    out[:, 0, 1:] = -q[:, 1:4]
+    out[:, 1:, 0] = q[:, 1:4]
+    out[:, 1:, 1:] = q[:, 0][:, None, None] * np.eye(3)[None] - mcross_batched(q[:, 1:4])
+    return out
+
+
 def expq(phi):
     """tools/expq.m:22-31 (vector branch, any(size(phi)==1)): sign flip on eq(1) < 0."""
     phi = np.asarray(phi, dtype=np.float64).ravel()

@@ -9,10 +9,11 @@ HIP C-ABI library.  The directory name contains hyphens, so import it with
 from ._build import build, LIBPATH                                    # noqa: F401
 from ._ffi import (RBPFError, load_library, EXPORTS,                  # noqa: F401
                    RBPF_OK, RBPF_ERR_INVALID_ARG, RBPF_ERR_UNSUPPORTED, RBPF_ERR_HIP, RBPF_ERR_NO_DEVICE,
-                   RBPF_ERR_OUT_OF_MEMORY, RBPF_ERR_CHOL_FAILED, RBPF_ERR_STATE)
+                   RBPF_ERR_OUT_OF_MEMORY, RBPF_ERR_CHOL_FAILED, RBPF_ERR_STATE, RBPF_ERR_CALLBACK)
 from .host import (particleFilter, particleSmoother, particleSmootherInformationForm,   # noqa: F401
                    DenseMagModel, DenseRadioModel, SparseVisualModel, dense_mag_prior, dense_radio_prior,
-                   domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample, chol_weights)
+                   domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample, chol_weights, quat_helper,
+                   GenericDenseModel, particle_filter_external)
 
 
 def device_count() -> int:

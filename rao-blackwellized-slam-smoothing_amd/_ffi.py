@@ -17,6 +17,7 @@ RBPF_ERR_NO_DEVICE = 4
 RBPF_ERR_OUT_OF_MEMORY = 5
 RBPF_ERR_CHOL_FAILED = 6
 RBPF_ERR_STATE = 7
+RBPF_ERR_CALLBACK = 8
 
 RBPF_MODEL_DENSE_MAG_6D = 1
 RBPF_MODEL_DENSE_RADIO_2DH = 2
@@ -26,9 +27,21 @@ RBPF_RNG_REPLAY = 0
 RBPF_RNG_PHILOX = 1
 
 
+# host callbacks of the generic family (include/rbpf.h rbpf_callbacks)
+DYN_MODEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p)
+MEAS_MODEL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, c_double_p, c_double_p)
+DYN_RES_NORM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p)
+
+
+class rbpf_callbacks(C.Structure):
+    _fields_ = [("dyn_model", DYN_MODEL_FN), ("meas_model", MEAS_MODEL_FN), ("dyn_res_norm", DYN_RES_NORM_FN),
+                ("user", C.c_void_p)]
+
+
 class rbpf_model(C.Structure):
     _fields_ = [("kind", C.c_int32), ("m_basis", C.c_int32), ("dim", C.c_int32), ("use_dyn_res_norm", C.c_int32),
-                ("NN", c_int32_p), ("L", C.c_double * 3), ("cam", C.c_double * 3)]
+                ("NN", c_int32_p), ("L", C.c_double * 3), ("cam", C.c_double * 3),
+                ("callbacks", C.POINTER(rbpf_callbacks))]
 
 
 class rbpf_problem(C.Structure):
@@ -45,9 +58,17 @@ class rbpf_rng(C.Structure):
                 ("Ufin", c_double_p), ("seed", C.c_uint64)]
 
 
+class rbpf_view(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("t", C.c_int32), ("is_smoother", C.c_int32)]
+
+
+ON_STEP_FN = C.CFUNCTYPE(C.c_int, C.POINTER(rbpf_view), C.c_void_p)
+
+
 class rbpf_options(C.Structure):
     _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
-                ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32)]
+                ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
+                ("chol_variant", C.c_int32), ("on_step", ON_STEP_FN), ("on_step_user", C.c_void_p)]
 
 
 class rbpf_filter_out(C.Structure):
@@ -76,7 +97,7 @@ EXPORTS = [
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
     "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
-    "rbpf_jacobian_phi3d", "rbpf_chol_weights",
+    "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_quat_helpers",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
     "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read", "rbpf_shard_normalise_plan",
     "rbpf_shard_smoother_create", "rbpf_shard_smoother_views_get", "rbpf_shard_smoother_begin",
@@ -138,6 +159,9 @@ def load_library(build_if_missing: bool = True):
                                         c_double_p]
     lib.rbpf_chol_weights.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, C.c_int32,
                                       c_double_p, c_int32_p, c_double_p]
+    lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
+    if lib.rbpf_abi_version() != 4:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 4 (rebuild)")
     _lib = lib
     return lib
 

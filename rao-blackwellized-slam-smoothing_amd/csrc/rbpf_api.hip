@@ -46,7 +46,8 @@ static bool chol_lower_host(const double* A, int n, int lda, double* Lc, int ldl
 // chol(dt*Q) factors per step.  For dense-mag dynModel uses the two diagonal 3x3 blocks separately
 // (run_dense3D_magfield.m:304-305) while dynResNorm uses the full 6x6 factor (:203).
 static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, std::vector<double>& blk,
-                              std::vector<double>& full, int& pages) {
+                              std::vector<double>& full, int& pages, bool* full_ok = nullptr) {
+  if (full_ok) *full_ok = true;
   const int nw = p->n_w;
   const bool varying = (p->q_pages > 1) || (p->dt_len > 1);
   pages = varying ? std::max(p->N_T - 1, 1) : 1;
@@ -60,7 +61,12 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
     double* Lb = &blk[(size_t)t * nw * nw];
     double* Lf = &full[(size_t)t * nw * nw];
     bool ok = true;
-    if (model->kind == RBPF_MODEL_GENERIC_DENSE) continue;                // dynModel runs on the host: Q is its business
+    if (model->kind == RBPF_MODEL_GENERIC_DENSE) {
+      // dynModel runs on the host: Q is its business.  Only the additive default of an empty dynResNorm
+      // (particleSmoother.m:175-177) needs chol(dt*Q,'lower'); a failure is reported when a smoother asks for it.
+      if (!chol_lower_host(A.data(), nw, nw, Lf, nw) && full_ok) *full_ok = false;
+      continue;
+    }
     if (model->kind == RBPF_MODEL_DENSE_MAG_6D) {
       ok = chol_lower_host(A.data(), 3, nw, Lb, nw) && chol_lower_host(A.data() + 3 + 3 * nw, 3, nw, Lb + 3 + 3 * nw, nw);
     } else if (model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
@@ -75,6 +81,23 @@ static int build_chol_factors(const rbpf_model* model, const rbpf_problem* p, st
     }
   }
   return RBPF_OK;
+}
+
+// inv(R) and 0.5*log(det(R)) for the information-form recursions (particleSmootherInformationForm.m:292,298,304), d <= 3.
+// Only the information-form smoother needs them; the filter accepts any R whose innovation covariance passes chol
+// (with the jitter retry), so a failure here only leaves NaNs behind.
+static void invert_R_small(const double* R, int d, double* Rinv, double& halfLogDetR) {
+  double Lr[9] = {0};
+  const bool pd = R && d <= 3 && chol_lower_host(R, d, d, Lr, d);
+  halfLogDetR = pd ? 0.0 : std::nan("");
+  for (int q = 0; q < d * d && q < 9; ++q) Rinv[q] = std::nan("");
+  for (int j = 0; pd && j < d; ++j) halfLogDetR += std::log(Lr[j + d * j]);
+  for (int col = 0; pd && col < d; ++col) {
+    double y[3], x[3];
+    for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + d * k] * y[k]; y[i] = v / Lr[i + d * i]; }
+    for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + d * i] * x[k]; x[i] = v / Lr[i + d * i]; }
+    for (int i = 0; i < d; ++i) Rinv[i + d * col] = x[i];
+  }
 }
 
 int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int nodo, const double* R, double jitter,
@@ -102,8 +125,7 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
     }
     M.m = n; M.dim = 0; M.ktot = 0;
     for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
-    for (int q = 0; q < d * d; ++q) M.Rinv[q] = std::nan("");
-    M.halfLogDetR = std::nan("");
+    invert_R_small(R, d, M.Rinv, M.halfLogDetR);
     M.jitter = jitter;
     M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
     nn_axis_major.clear();
@@ -140,22 +162,8 @@ int fill_model_dev(const rbpf_model* model, int nN, int n, int d, int nw, int no
     if (!(M.L[a] > 0)) { set_error("domain half-widths L must be positive"); return RBPF_ERR_INVALID_ARG; }
   }
   for (int q = 0; q < d * d; ++q) M.R[q] = R ? R[q] : 0.0;
-  if (R) {   // inv(R) and 0.5*log(det(R)) for the information-form recursions (:292,298,304)
-    double Lr[64] = {0};
-    if (d > 8) { set_error("n_y <= 8 supported"); return RBPF_ERR_UNSUPPORTED; }
-    // Only the information-form smoother needs inv(R) / log det R; the filter accepts any R whose
-    // innovation covariance passes chol (with the jitter retry), so a failure here is not an error yet.
-    const bool pd = chol_lower_host(R, d, d, Lr, d);
-    M.halfLogDetR = pd ? 0.0 : std::nan("");
-    for (int q = 0; q < d * d; ++q) M.Rinv[q] = std::nan("");
-    for (int j = 0; pd && j < d; ++j) M.halfLogDetR += std::log(Lr[j + d * j]);
-    for (int col = 0; pd && col < d; ++col) {
-      double y[8], x[8];
-      for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + d * k] * y[k]; y[i] = v / Lr[i + d * i]; }
-      for (int i = d - 1; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + d * i] * x[k]; x[i] = v / Lr[i + d * i]; }
-      for (int i = 0; i < d; ++i) M.Rinv[i + d * col] = x[i];
-    }
-  }
+  if (d > 3) { set_error("n_y <= 3 supported by the dense families"); return RBPF_ERR_UNSUPPORTED; }
+  if (R) invert_R_small(R, d, M.Rinv, M.halfLogDetR);
   M.jitter = jitter;
   M.logconst = -0.5 * d * std::log(2.0 * 3.14159265358979323846);
   return RBPF_OK;
@@ -172,6 +180,8 @@ static int validate_problem(const rbpf_problem* p) {
   if (p->q_pages != 1 && p->q_pages < p->N_T - 1) { set_error("Q must have 1 or >= N_T-1 pages"); return RBPF_ERR_INVALID_ARG; }
   if (p->dt_len != 1 && p->dt_len < p->N_T - 1) { set_error("dt must have 1 or >= N_T-1 entries"); return RBPF_ERR_INVALID_ARG; }
   if (p->n_nonlin > 8 || p->n_w > 8) { set_error("n_nonlin, n_w <= 8 supported"); return RBPF_ERR_UNSUPPORTED; }
+  // the multi-workgroup resample pipeline stages one block total per 1024 particles in a 1024-entry LDS array
+  if (p->N_P > kMaxParticles) { set_error("N_P above 1048576 is not supported (resample pipeline: 1024 blocks of 1024)"); return RBPF_ERR_UNSUPPORTED; }
   return RBPF_OK;
 }
 
@@ -217,10 +227,23 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->fp32 && (smoother || sparse || prob->n_y != 3)) {
     set_error("fp32 storage of the covariance banks: dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
   }
+  {
+    const int cv = c->opt.chol_variant;
+    if (cv != 0 && cv != 1 && cv != 16 && cv != 64 && cv != 648 && cv != 644) { set_error("options.chol_variant must be 0, 1, 16, 64, 648 or 644"); return RBPF_ERR_INVALID_ARG; }
+  }
   if (model->kind == RBPF_MODEL_GENERIC_DENSE) {
-    if (smoother || ex) { set_error("generic (host-callback) models: unsharded particleFilter only"); return RBPF_ERR_UNSUPPORTED; }
+    if (ex) { set_error("generic (host-callback) models are not sharded"); return RBPF_ERR_UNSUPPORTED; }
+    if (model->callbacks) {
+      c->cb = *model->callbacks; c->has_cb = true;
+      if (!c->cb.dyn_model || !c->cb.meas_model) { set_error("generic model: callbacks need dyn_model and meas_model"); return RBPF_ERR_INVALID_ARG; }
+    } else if (smoother) { set_error("generic (host-callback) smoothers need rbpf_model.callbacks"); return RBPF_ERR_INVALID_ARG; }
     RB_TRY(dmalloc(&c->d_xn_ext, (size_t)prob->n_nonlin * prob->N_P));
     RB_TRY(dmalloc(&c->d_H_ext, (size_t)prob->N_P * prob->n_y * c->lay.ldx));
+    c->h_odo.assign((size_t)std::max(prob->N_T - 1, 1) * prob->n_odo, 0.0);
+    for (int t = 0; t < prob->N_T - 1; ++t) for (int k = 0; k < prob->n_odo; ++k) c->h_odo[(size_t)t * prob->n_odo + k] = prob->odometry[t + (size_t)prob->odo_ld * k];
+    c->h_Q.assign(prob->Q, prob->Q + (size_t)prob->n_w * prob->n_w * prob->q_pages);
+    c->h_dt.assign(prob->dt, prob->dt + prob->dt_len);
+    c->q_pages = prob->q_pages; c->dt_len = prob->dt_len;
   }
   if (sparse) {
     if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }
@@ -253,7 +276,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     HIPCHK(hipMemcpy(c->d_y, yt.data(), yt.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(c->d_odo, od.data(), od.size() * sizeof(double), hipMemcpyHostToDevice));
     std::vector<double> blk, full;
-    RB_TRY(build_chol_factors(model, prob, blk, full, c->chol_pages));
+    RB_TRY(build_chol_factors(model, prob, blk, full, c->chol_pages, &c->cholQfull_ok));
     RB_TRY(dmalloc(&c->d_cholQ, blk.size()));
     RB_TRY(dmalloc(&c->d_cholQfull, full.size()));
     HIPCHK(hipMemcpy(c->d_cholQ, blk.data(), blk.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -387,6 +410,11 @@ int ctx_reset(rbpf_ctx* c) {
   c->xcur = 0;
   c->tcur = 0;
   c->ready_step = -1;
+  c->drawn_step = -1;
+  if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) {              // particleFilter.m:59: xn = repmat(x0_nonLin, 1, N_P)
+    c->h_xn.resize((size_t)c->mdl.nN * c->N);
+    for (int i = 0; i < c->N; ++i) for (int q = 0; q < c->mdl.nN; ++q) c->h_xn[q + (size_t)c->mdl.nN * i] = c->h_x0n[q];
+  }
   return RBPF_OK;
 }
 
@@ -410,6 +438,78 @@ void ctx_free(rbpf_ctx* c) {
   delete c;
 }
 
+// Ancestors of the ordinary slots [0, n_draw) of the step about to run (particleFilter.m:106, particleSmoother.m:134):
+// the weights of step t-1 were scanned in parallel, so draws within the rounding bound of a bin edge are flagged and
+// resolved with the strict left-to-right cumsum (tools/sample.m:30) only then.
+static int ctx_draw_ancestors(rbpf_ctx* c, int k_iter, int n_draw) {
+  const int t = c->t, N = c->N;
+  const bool hist = c->opt.keep_history != 0;
+  int* A_t = c->A + (hist ? (size_t)t * N : 0);
+  const size_t rng_page = (size_t)k_iter * N * std::max(c->T - 1, 0);
+  SearchArgs s;
+  s.N = N; s.n_draw = n_draw; s.t = t; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
+  s.U = c->d_U ? c->d_U + rng_page + (size_t)(t - 1) * N : nullptr;
+  s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
+  s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + (c->opt.trace ? (size_t)(t - 1) * N : 0); s.wc_exact = c->wc;
+  HIPCHK(launch_search(s, c->stream));
+  HIPCHK(launch_resample_fixup(s, c->stream));
+  return RBPF_OK;
+}
+
+// ---- generic family driven through rbpf_model.callbacks ---------------------------------------------------------
+// The reference's handle contracts (particleFilter.m:104-109,124; particleSmoother.m:132-137,149-152): dynModel once per
+// ordinary slot in slot order on the ancestor's state, measModel once on the whole batch.  The host keeps the states of
+// the last step (it produced them), so only the ancestor indices come down and states + Jacobians go up.
+int generic_draw_propagate(rbpf_ctx* c, int k_iter, int n_draw) {
+  const int t = c->t, N = c->N, nN = c->mdl.nN;
+  if (!c->has_cb) { set_error("generic model without callbacks"); return RBPF_ERR_STATE; }
+  c->h_xn_new.assign((size_t)nN * N, 0.0);
+  if (t == 0) { c->h_xn_new = c->h_xn; return RBPF_OK; }
+  const bool hist = c->opt.keep_history != 0;
+  int* A_t = c->A + (hist ? (size_t)t * N : 0);
+  if (c->ready_step != t && c->drawn_step != t && n_draw > 0) { RB_TRY(ctx_draw_ancestors(c, k_iter, n_draw)); c->drawn_step = t; }
+  c->h_ai.resize(N);
+  HIPCHK(hipMemcpyAsync(c->h_ai.data(), A_t, (size_t)N * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  std::vector<double> anc((size_t)nN * std::max(n_draw, 1));
+  for (int i = 0; i < n_draw; ++i) {
+    const int a = std::min(std::max(c->h_ai[i], 0), N - 1);
+    for (int q = 0; q < nN; ++q) anc[q + (size_t)nN * i] = c->h_xn[q + (size_t)nN * a];
+  }
+  if (n_draw > 0 && c->cb.dyn_model(c->cb.user, t - 1, n_draw, anc.data(), c->h_xn_new.data()) != 0) {
+    set_error("the dynModel callback failed"); return RBPF_ERR_CALLBACK;
+  }
+  return RBPF_OK;
+}
+
+// xref_host != null: slot N-1 is the conditioned reference trajectory (particleSmoother.m:242).
+int generic_finish_inputs(rbpf_ctx* c, const double* xref_host) {
+  const int N = c->N, nN = c->mdl.nN, d = c->mdl.d, n = c->mdl.n, ldx = c->lay.ldx;
+  if (xref_host) for (int q = 0; q < nN; ++q) c->h_xn_new[q + (size_t)nN * (N - 1)] = xref_host[q];
+  c->h_dy.assign((size_t)N * d * n, 0.0);
+  if (c->cb.meas_model(c->cb.user, N, c->h_xn_new.data(), c->h_dy.data()) != 0) { set_error("the measModel callback failed"); return RBPF_ERR_CALLBACK; }
+  std::vector<double> soa((size_t)nN * N), H((size_t)N * d * ldx, 0.0);
+  for (int i = 0; i < N; ++i)
+    for (int q = 0; q < nN; ++q) soa[(size_t)q * N + i] = c->h_xn_new[q + (size_t)nN * i];
+  for (int cc = 0; cc < n; ++cc)                     // dy(i, k, cc) at i + N*(k + d*cc)  ->  H[(i*d + k)*ldx + cc]
+    for (int k = 0; k < d; ++k)
+      for (int i = 0; i < N; ++i) H[((size_t)i * d + k) * ldx + cc] = c->h_dy[(size_t)i + (size_t)N * (k + (size_t)d * cc)];
+  HIPCHK(hipMemcpyAsync(c->d_xn_ext, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemcpyAsync(c->d_H_ext, H.data(), H.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));          // the host vectors above go out of scope
+  c->ext_xn = c->d_xn_ext; c->ext_H = c->d_H_ext;
+  c->h_xn = c->h_xn_new;
+  return RBPF_OK;
+}
+
+int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother) {
+  if (!c->opt.on_step) return RBPF_OK;
+  rbpf_view v;
+  v.ctx = is_smoother ? nullptr : c; v.t = t; v.is_smoother = is_smoother ? 1 : 0;
+  if (c->opt.on_step(&v, c->opt.on_step_user) != 0) { set_error("the on_step hook returned non-zero"); return RBPF_ERR_CALLBACK; }
+  return RBPF_OK;
+}
+
 // One time step of particleFilter.m:100-218 / particleSmoother.m:124-341 (iteration k_iter).
 // xref != nullptr: slot N-1 is the conditioned reference trajectory (its ancestor index has
 // already been written to A_t[N-1] by the ancestor-sampling kernels).
@@ -425,17 +525,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   const size_t rng_page = (size_t)k_iter * N * std::max(c->T - 1, 0);
 
   const bool pre_drawn = (c->ready_step == t);       // ancestors + order came from the fused kernel of step t-1
-  if (t > 0 && n_draw > 0 && !pre_drawn) {
-    SearchArgs s;
-    s.N = N; s.n_draw = n_draw; s.t = t; s.wc = c->wc; s.rng_mode = c->rng_mode; s.k_iter = k_iter;
-    s.U = c->d_U ? c->d_U + rng_page + (size_t)(t - 1) * N : nullptr;
-    s.seed = c->seed; s.ai = A_t; s.overflow = c->d_flags + 1; s.slot0 = 0; s.u_is_scalar = 0;
-    // the weights of step t-1 were scanned in parallel: flag draws within the rounding bound of a bin edge
-    // and resolve them with the strict left-to-right cumsum (tools/sample.m:30) only then
-    s.approx = 1; s.ambiguous = c->d_flags + 4; s.w = c->w + (c->opt.trace ? (size_t)(t - 1) * N : 0); s.wc_exact = c->wc;
-    HIPCHK(launch_search(s, c->stream));
-    HIPCHK(launch_resample_fixup(s, c->stream));
-  }
+  if (t > 0 && n_draw > 0 && !pre_drawn && c->drawn_step != t) RB_TRY(ctx_draw_ancestors(c, k_iter, n_draw));
   if (c->mdl.kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
     // sparseFeatures branch: one small kernel does gather, dynModel, EKF weight and update (rbpf_sparse.hip);
     // the update is applied at once, so the pending-factor banks stay zero
@@ -481,8 +571,8 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.slot_ids = nullptr; a.n_bank_local = 0; a.rec = nullptr; a.rec_stride = 0; a.rec_off_B = a.rec_off_F = a.rec_off_X = 0;
   a.rec_off_I = a.rec_off_hld = 0;
   {
-    static const int no_order = getenv("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only
-    static const int dbg_order = getenv("RBPF_DEBUG_ORDER") ? 1 : 0;
+    static const int no_order = tuning_env("RBPF_NO_ORDER") ? 1 : 0;      // tuning / debugging only
+    static const int dbg_order = tuning_env("RBPF_DEBUG_ORDER") ? 1 : 0;
     if (no_order) a.order = nullptr;
 #ifdef RBPF_STAMPS
     if (t >= 100 && t <= 103) {
@@ -769,7 +859,16 @@ int rbpf_filter_advance(rbpf_ctx* c, int32_t n_steps) {
   if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
   c->fuse_resample = true;
-  for (int s = 0; s < n_steps; ++s) RB_TRY(ctx_step(c, 0, nullptr, c->N, nullptr));
+  for (int s = 0; s < n_steps; ++s) {
+    if (c->has_cb) {                                   // generic family: evaluate the handles of this step on the host
+      RB_TRY(generic_draw_propagate(c, 0, c->N));
+      RB_TRY(generic_finish_inputs(c, nullptr));
+    }
+    const int st = ctx_step(c, 0, nullptr, c->N, nullptr);
+    if (c->has_cb) { c->ext_xn = nullptr; c->ext_H = nullptr; }
+    RB_TRY(st);
+    RB_TRY(ctx_call_on_step(c, c->t - 1, false));      // particleFilter.m:215-217
+  }
   return RBPF_OK;
 }
 
@@ -808,7 +907,7 @@ int rbpf_filter_step_external(rbpf_ctx* c, const double* xn_new, const double* d
   c->ext_xn = nullptr; c->ext_H = nullptr;
   if (st != RBPF_OK) return st;
   HIPCHK(hipStreamSynchronize(c->stream));          // the host vectors above go out of scope
-  return RBPF_OK;
+  return ctx_call_on_step(c, c->t - 1, false);
 }
 
 int rbpf_filter_reset(rbpf_ctx* c) {
@@ -1158,6 +1257,19 @@ int rbpf_sample(int32_t N, const double* w, int32_t n_draws, const double* u, in
   HIPCHK(launch_search(s, 0));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(ind, di.p, (size_t)n_draws * 4, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_quat_helpers(int32_t op, int32_t n, const double* in, double* out) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (op < 0 || op > 8 || n < 1 || !in || !out) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  static const int nin_of[9] = {3, 3, 4, 4, 4, 4, 4, 4, 3}, nout_of[9] = {4, 4, 3, 3, 16, 16, 4, 9, 9};
+  DevBuf di, dout;
+  RB_TRY(di.alloc((size_t)n * nin_of[op] * 8)); RB_TRY(dout.alloc((size_t)n * nout_of[op] * 8));
+  HIPCHK(hipMemcpy(di.p, in, (size_t)n * nin_of[op] * 8, hipMemcpyHostToDevice));
+  HIPCHK(launch_quat_helpers(op, n, di.as<double>(), dout.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, dout.p, (size_t)n * nout_of[op] * 8, hipMemcpyDeviceToHost));
   return RBPF_OK;
 }
 

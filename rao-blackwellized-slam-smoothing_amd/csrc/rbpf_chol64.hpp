@@ -571,7 +571,7 @@ static hipError_t launch_chol64(const CholArgs& ca, int batch, int d_lds, hipStr
   const size_t lds = chol64_lds_bytes(ca.Msz, d_lds);
   const int RT = (ca.Msz + 1 + 15) >> 4;
   if (waves == 0) {
-    const char* we = getenv("RBPF_CHOL64_WAVES");                           // tuning: force 4 / 8
+    const char* we = tuning_env("RBPF_CHOL64_WAVES");                           // tuning: force 4 / 8
     waves = (we && (atoi(we) == 4 || atoi(we) == 8)) ? atoi(we) : (RT > 27) ? 8 : 4;
   }
   if (waves == 8) return ca.mode == 1 ? launch_chol64_mode<1, 8>(ca, batch, lds, st) : launch_chol64_mode<0, 8>(ca, batch, lds, st);

@@ -218,7 +218,7 @@ static size_t chol_small_lds_bytes(int M, int d) {
 
 static hipError_t launch_chol_small(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
   size_t lds = chol_small_lds_bytes(ca.Msz, d_lds);
-  if (const char* pad = getenv("RBPF_CS_LDS_PAD")) lds += (size_t)atoi(pad) * 1024;   // tuning: fewer workgroups per CU
+  if (const char* pad = tuning_env("RBPF_CS_LDS_PAD")) lds += (size_t)atoi(pad) * 1024;   // tuning: fewer workgroups per CU
   // information form only: inlined fifteen times per wave, the covariance form's kron(I, R) / jitter variant of the loader
   // does not fit the registers (449 spilled), and its matrices are small problems anyway (they keep the 16-column kernel)
   if (ca.mode != 1) return hipErrorInvalidValue;

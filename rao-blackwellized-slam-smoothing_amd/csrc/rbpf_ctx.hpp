@@ -74,6 +74,15 @@ struct rbpf_ctx {
   // generic model family: host-evaluated states / Jacobians of the step about to run (consumed by ctx_step)
   double *d_xn_ext = nullptr, *d_H_ext = nullptr;
   const double *ext_xn = nullptr, *ext_H = nullptr;
+  rbpf_callbacks cb = {nullptr, nullptr, nullptr, nullptr};   // the model's handles (copied at create; all null: caller-driven)
+  bool has_cb = false;
+  std::vector<double> h_xn;      // generic family: states of the last step [nN x N] column-major (host evaluates dynModel)
+  std::vector<double> h_xn_new, h_dy;   // scratch of the callbacks
+  std::vector<int> h_ai;
+  std::vector<double> h_odo, h_Q, h_dt;  // host copies for the callbacks' per-step arguments
+  int q_pages = 1, dt_len = 1;
+  bool cholQfull_ok = true;      // chol(dt*Q,'lower') of the full matrix exists (default additive dynResNorm needs it)
+  int drawn_step = -1;           // step whose ordinary ancestors were already drawn by generic_draw_propagate
   bool fp32 = false;        // the covariance banks hold float (rbpf_options.storage = 1)
   bool inplace = false;     // single covariance bank, rewritten in place at every flush (rbpf_options.inplace)
   int* d_ip = nullptr;      // [5][N] in-place flush plan: destination entry, phase, scratch
@@ -113,6 +122,11 @@ int ctx_reset(rbpf_ctx* c);
 void ctx_free(rbpf_ctx* c);
 int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const InfoStep* info);
 int ctx_check_flags(rbpf_ctx* c);
+// generic family with callbacks (rbpf_model.callbacks): ordinary ancestors of the step about to run + dynModel on the
+// host for slots [0, n_draw); then (generic_finish_inputs) the reference slot, measModel and the upload
+int generic_draw_propagate(rbpf_ctx* c, int k_iter, int n_draw);
+int generic_finish_inputs(rbpf_ctx* c, const double* xref_host);
+int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother);
 int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
 void shard_free(rbpf_ctx* c);

@@ -93,6 +93,60 @@ __device__ inline void logq_dev(const double qin[4], double lq[3]) {
   lq[2] = na * q[3] / den;
 }
 
+// tools/expq.m:33-37 (batched branch, one row): same value, but the sign flip also fires for q0 == 0 (quirk Q7)
+__device__ inline void expq_batched_dev(const double phi[3], double eq[4]) {
+  const double mag = sqrt(phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2]);
+  const double den = mag + (mag == 0.0 ? 1.0 : 0.0);
+  double s, c;
+  sincos(mag, &s, &c);
+  eq[0] = c;
+  eq[1] = phi[0] / den * s;
+  eq[2] = phi[1] / den * s;
+  eq[3] = phi[2] / den * s;
+  if (eq[0] <= 0.0) { eq[0] = -eq[0]; eq[1] = -eq[1]; eq[2] = -eq[2]; eq[3] = -eq[3]; }
+}
+
+// tools/logq.m:32-35 (batched branch, one row): flip when q0 <= 0; na .* q(2:4) ./ (sin(na) + (na == 0))
+__device__ inline void logq_batched_dev(const double qin[4], double lq[3]) {
+  double q[4] = {qin[0], qin[1], qin[2], qin[3]};
+  if (q[0] <= 0.0) { q[0] = -q[0]; q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  const double na = acos(fmin(q[0], 1.0));
+  const double den = sin(na) + (na == 0.0 ? 1.0 : 0.0);
+  lq[0] = na * q[1] / den;
+  lq[1] = na * q[2] / den;
+  lq[2] = na * q[3] / den;
+}
+
+// tools/mcross.m:33-42: [0 -v3 v2; v3 0 -v1; -v2 v1 0], column-major 3 x 3
+__device__ inline void mcross_dev(const double v[3], double M[9]) {
+  M[0] = 0.0;   M[3] = -v[2]; M[6] = v[1];
+  M[1] = v[2];  M[4] = 0.0;   M[7] = -v[0];
+  M[2] = -v[1]; M[5] = v[0];  M[8] = 0.0;
+}
+
+// tools/qLeft.m:30-40: [q0 -qv'; qv q0*I + [qv x]], column-major 4 x 4
+__device__ inline void qleft_mat_dev(const double q[4], double M[16]) {
+  double X[9];
+  mcross_dev(&q[1], X);
+  M[0] = q[0];
+  for (int r = 0; r < 3; ++r) { M[1 + r] = q[1 + r]; M[4 * (1 + r)] = -q[1 + r]; }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) M[(1 + r) + 4 * (1 + c)] = q[0] * (r == c ? 1.0 : 0.0) + X[r + 3 * c];
+}
+
+// tools/qRight.m:29-39: [q0 -qv'; qv q0*I - [qv x]], column-major 4 x 4
+__device__ inline void qright_mat_dev(const double q[4], double M[16]) {
+  double X[9];
+  mcross_dev(&q[1], X);
+  M[0] = q[0];
+  for (int r = 0; r < 3; ++r) { M[1 + r] = q[1 + r]; M[4 * (1 + r)] = -q[1 + r]; }
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) M[(1 + r) + 4 * (1 + c)] = q[0] * (r == c ? 1.0 : 0.0) - X[r + 3 * c];
+}
+
+// tools/qInv.m:27-31
+__device__ inline void qinv_dev(const double q[4], double r[4]) { r[0] = q[0]; r[1] = -q[1]; r[2] = -q[2]; r[3] = -q[3]; }
+
 // tools/quat2rmat.m:27-33 ; Rm[row*3+col]
 __device__ inline void quat2rmat_dev(const double q[4], double Rm[9]) {
   const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];

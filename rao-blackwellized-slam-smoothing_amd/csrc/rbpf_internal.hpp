@@ -3,8 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 namespace rbpf {
+
+// Tuning overrides read from the environment exist only in diagnostic builds (-DRBPF_TUNING, tools/tune_variants.py);
+// the product library never consults the environment.
+#ifdef RBPF_TUNING
+inline const char* tuning_env(const char* key) { return getenv(key); }
+#else
+inline const char* tuning_env(const char*) { return nullptr; }
+#endif
 
 constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
 constexpr int kWaves = kThreads / 64;
@@ -158,6 +167,7 @@ hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int
 size_t resample_scratch_doubles(int N);
 hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, int* order, int* counts, const int* remap,
                                     double* scratch, hipStream_t s);
+constexpr int kMaxParticles = 1024 * 1024;     // largest global particle count (rs_offsets_kernel: <= 1024 blocks of 1024)
 constexpr int kSingleWgResampleMaxN = 8192;   // above this the multi-workgroup pipeline is used
 // exact re-draw of every slot with the strict left-to-right cumsum if any draw was flagged ambiguous
 hipError_t launch_resample_fixup(const SearchArgs& a, hipStream_t s);
@@ -185,6 +195,7 @@ hipError_t launch_dyn_res_norm(const ModelDev& m, int np, const double* xnk_t, c
                                const double* odo, const double* cholQfull, double* e_dyn, hipStream_t s);
 hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, const double* lo, const double* up,
                                  double* J, hipStream_t s);
+hipError_t launch_quat_helpers(int op, int n, const double* in, double* out, hipStream_t s);
 hipError_t launch_transpose_soa(int N, int nN, const double* soa, double* aos, hipStream_t s);
 hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int count, const double* Pt, const double* Pb,
                                const double* F, const double* xl, double* rec, hipStream_t s, size_t rec_stride = 0,

@@ -151,9 +151,9 @@ Layout make_layout(int n, int d) {
   else if (L.CH == 3) { L.RS = 1; L.CS = kWaves; }
   else if (L.CH == 2) { L.RS = 1; L.CS = kWaves; }   // whole 2 KB columns per wave: measured 8% faster than 2x2
   else { L.RS = 1; L.CS = kWaves; }
-  if (const char* e = getenv("RBPF_RS")) {          // tuning override: RS x CS must be <= 4
+  if (const char* e = tuning_env("RBPF_RS")) {          // tuning override: RS x CS must be <= 4
     const int rs = atoi(e);
-    const char* e2 = getenv("RBPF_CS");
+    const char* e2 = tuning_env("RBPF_CS");
     const int cs = e2 ? atoi(e2) : kWaves / (rs > 0 ? rs : 1);
     if (rs >= 1 && cs >= 1 && rs * cs <= kWaves && L.CH > 0) { L.RS = rs; L.CS = cs; }
   }
@@ -1594,6 +1594,39 @@ hipError_t launch_jacobian_phi3d(const ModelDev& m, int np, const double* x, con
                                  double* J, hipStream_t s) {
   const size_t tot = (size_t)m.m * np;
   hipLaunchKernelGGL(jacobian_phi3d_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, m, np, x, lo, up, J);
+  return hipGetLastError();
+}
+
+// tools/ quaternion helpers, one thread per column (rbpf_quat_helpers)
+__global__ void quat_helpers_kernel(int op, int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int nin = (op <= 1 || op == 8) ? 3 : 4;
+  double v[4] = {0.0, 0.0, 0.0, 0.0}, r[16];
+  for (int c = 0; c < nin; ++c) v[c] = in[(size_t)i * nin + c];
+  int nout = 0;
+  switch (op) {
+    case 0: expq_dev(v, r); nout = 4; break;
+    case 1: expq_batched_dev(v, r); nout = 4; break;
+    case 2: logq_dev(v, r); nout = 3; break;
+    case 3: logq_batched_dev(v, r); nout = 3; break;
+    case 4: qleft_mat_dev(v, r); nout = 16; break;
+    case 5: qright_mat_dev(v, r); nout = 16; break;
+    case 6: qinv_dev(v, r); nout = 4; break;
+    case 7: {
+      double Rm[9];
+      quat2rmat_dev(v, Rm);                                   // Rm[row*3+col] -> column-major
+      for (int rr = 0; rr < 3; ++rr) for (int cc = 0; cc < 3; ++cc) r[rr + 3 * cc] = Rm[rr * 3 + cc];
+      nout = 9; break;
+    }
+    case 8: mcross_dev(v, r); nout = 9; break;
+    default: break;
+  }
+  for (int c = 0; c < nout; ++c) out[(size_t)i * nout + c] = r[c];
+}
+
+hipError_t launch_quat_helpers(int op, int n, const double* in, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(quat_helpers_kernel, dim3((n + 127) / 128), dim3(128), 0, s, op, n, in, out);
   return hipGetLastError();
 }
 

@@ -54,6 +54,10 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   if (!prob || !out || world < 1 || rank < 0 || rank >= world) { set_error("bad shard arguments"); return RBPF_ERR_INVALID_ARG; }
   if (prob->x0_lin_cols != 1) { set_error("sharded filter: x0_lin must be nLin x 1"); return RBPF_ERR_UNSUPPORTED; }
   const size_t Nloc = (size_t)prob->N_P;
+  if (world > kMaxWorld) { set_error("world size above 64 is not supported"); return RBPF_ERR_UNSUPPORTED; }
+  if (prob->N_P < 1 || Nloc * (size_t)world > (size_t)kMaxParticles) {
+    set_error("world * N_local above 1048576 particles is not supported (resample pipeline: 1024 blocks of 1024)"); return RBPF_ERR_UNSUPPORTED;
+  }
   CreateExtras ex;
   ex.bank_extra = 0;
   ex.rng_slots = Nloc * world;
@@ -112,7 +116,6 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   A(dmalloc(&s->pack_idx, s->send_cap));
   A(dmalloc(&s->send_rec, s->send_cap * s->recsz));
   A(dmalloc(&s->recv_rec, s->recv_cap * s->recsz));
-  if (world > kMaxWorld) { ctx_free(c); set_error("world size above 64 is not supported"); return RBPF_ERR_UNSUPPORTED; }
   {
     const size_t Ng = (size_t)s->Nglob;
     A(dmalloc(&s->pb.key, Ng)); A(dmalloc(&s->pb.counts, Ng + 1)); A(dmalloc(&s->pb.offsets, Ng + 1));

@@ -102,6 +102,16 @@ __global__ void anc_dyn_kernel(ModelDev M, int N, const double* __restrict__ xn_
   out[i] = log(w[i]) + (-0.5 * ss);
 }
 
+// Generic family: eDyn was evaluated by the dynResNorm handle on the host (particleSmoother.m:178-182): e_dyn [nw x N].
+__global__ void anc_dyn_ext_kernel(int N, int nw, const double* __restrict__ e_dyn, const double* __restrict__ w,
+                                   double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double ss = 0.0;
+  for (int q = 0; q < nw; ++q) { const double e = e_dyn[(size_t)i * nw + q]; ss += e * e; }
+  out[i] = log(w[i]) + (-0.5 * ss);
+}
+
 // Generic strided fp64 GEMM on the matrix cores, batched over blockIdx.z:  C = A * B.
 // Element (i,k) of A at A[i*rsA + k*csA] etc.  64 x 64 output tile per workgroup, 4 waves of 32 x 32
 // (2 x 2 v_mfma_f64_16x16x4 tiles); 16-deep slices of A and B go through LDS k-major so that an MFMA operand
@@ -217,6 +227,7 @@ struct CholArgs {
   int n_bank_local; const double* rec; size_t rec_stride, rec_off_Imat;
   double* pant_log;                 // += logwMeas
   int* status;
+  int variant;                      // host side only: rbpf_options.chol_variant (0: kernel by matrix size)
 };
 
 // Blocked left-looking Cholesky on the fp64 matrix cores, one workgroup (16 waves) per particle.
@@ -580,20 +591,43 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 // Matrices of more than 11 row tiles (n >= 176) take the 64-column kernel (rbpf_chol64.hpp; 4 waves and two workgroups per
 // CU up to 27 row tiles, 8 waves above; measured crossovers, profiles/r01y_chol_bench.jsonl), information-form matrices of
 // 5..9 row tiles (dense-radio n = 128) the register-resident kernel (rbpf_chol_small.hpp), the rest the 16-column kernel.  RBPF_CHOL64 = 0 / 1 forces one of them (tuning and tests).
-static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
-  static const int w_env = getenv("RBPF_CHOL_WAVES") ? atoi(getenv("RBPF_CHOL_WAVES")) : 0;      // tuning: force 4 / 8 / 16
-  const char* v64 = getenv("RBPF_CHOL64");
+static hipError_t launch_chol16(const CholArgs& ca, int batch, int d_lds, hipStream_t st, int w_force = 0) {
   const int RT = (ca.Msz + 1 + 15) >> 4;
-  if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
-  const char* vsm = getenv("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
-  if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
   int W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
-  if ((w_env == 4 || w_env == 8 || w_env == 16) && (RT + w_env - 1) / w_env <= 4) W = w_env;
+  if ((w_force == 4 || w_force == 8 || w_force == 16) && (RT + w_force - 1) / w_force <= 4) W = w_force;
   const size_t lds = chol_lds_bytes(ca.Msz, d_lds);
   const int ntmax = (RT + W - 1) / W;
   if (W == 4) return launch_chol_nt<4>(ca, batch, lds, ntmax, st);
   if (W == 8) return launch_chol_nt<8>(ca, batch, lds, ntmax, st);
   return launch_chol_nt<16>(ca, batch, lds, ntmax, st);
+}
+
+// rbpf_options.chol_variant / the `variant` of rbpf_chol_weights: is the kernel usable for this matrix?
+static bool chol_variant_ok(const CholArgs& ca, int d_lds, int variant) {
+  const int RT = (ca.Msz + 1 + 15) >> 4;
+  switch (variant) {
+    case 0: case 16: return true;
+    case 64: case 648: case 644: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
+    case 1: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
+    default: return false;
+  }
+}
+
+static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
+  const int RT = (ca.Msz + 1 + 15) >> 4;
+  if (ca.variant != 0) {                                                      // explicit choice (option / test entry point)
+    if (!chol_variant_ok(ca, d_lds, ca.variant)) return hipErrorInvalidValue;
+    if (ca.variant == 1) return launch_chol_small(ca, batch, d_lds, st);
+    if (ca.variant == 16) return launch_chol16(ca, batch, d_lds, st);
+    return launch_chol64(ca, batch, d_lds, st, ca.variant == 648 ? 8 : ca.variant == 644 ? 4 : 0);
+  }
+  // diagnostic builds (-DRBPF_TUNING) can override the choice from the environment
+  static const int w_env = tuning_env("RBPF_CHOL_WAVES") ? atoi(tuning_env("RBPF_CHOL_WAVES")) : 0;      // force 4 / 8 / 16
+  const char* v64 = tuning_env("RBPF_CHOL64");
+  if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
+  const char* vsm = tuning_env("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
+  if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
+  return launch_chol16(ca, batch, d_lds, st, w_env);
 }
 
 static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 1 + 15) / 16); return mp * mp; }
@@ -751,10 +785,18 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   hipStream_t st = c->stream;
   SmootherState* s = new SmootherState();
   c->sm = s;
-  if (!c->mdl.use_dyn_res_norm && nw != nN) {
+  const bool generic = c->mdl.kind == RBPF_MODEL_GENERIC_DENSE;
+  const bool drn_cb = generic && c->cb.dyn_res_norm != nullptr;      // the handle; otherwise isempty(dynResNorm)
+  if (generic) c->mdl.use_dyn_res_norm = 0;                          // device side: only the additive default exists
+  if (!c->mdl.use_dyn_res_norm && !drn_cb && nw != nN) {
     set_error("isempty(dynResNorm): the additive default (particleSmoother.m:176) needs size(Q,1) == nNonLin");
     return RBPF_ERR_INVALID_ARG;
   }
+  if (generic && !drn_cb && !c->cholQfull_ok) { set_error("isempty(dynResNorm): chol(dt*Q,'lower') failed (particleSmoother.m:177)"); return RBPF_ERR_CHOL_FAILED; }
+  double* d_edyn = nullptr;
+  struct EdynGuard { double** p; ~EdynGuard() { hipFree(*p); } } edyn_guard{&d_edyn};
+  if (drn_cb) RB_TRY(dmalloc(&d_edyn, (size_t)N * nw));
+  std::vector<double> h_edyn;
   const size_t Mmax = (size_t)d * T;
   s->Mmax = Mmax;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
@@ -849,6 +891,14 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     }
     if (k > 0 && !sparse) {
       // dy_xnk = measModel(xnk)  (:120)
+      if (generic) {
+        std::vector<double> dyT((size_t)T * d * n), Href((size_t)T * d * n);
+        if (c->cb.meas_model(c->cb.user, T, xnk_h.data(), dyT.data()) != 0) { set_error("the measModel callback failed"); return RBPF_ERR_CALLBACK; }
+        for (int cc = 0; cc < n; ++cc)                   // dy(tt, a, cc) at tt + T*(a + d*cc) -> [T][d][n]
+          for (int a = 0; a < d; ++a)
+            for (int tt = 0; tt < T; ++tt) Href[((size_t)tt * d + a) * n + cc] = dyT[(size_t)tt + (size_t)T * (a + (size_t)d * cc)];
+        HIPCHK(hipMemcpy(s->d_dyref, Href.data(), Href.size() * 8, hipMemcpyHostToDevice));
+      } else
       HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, st, 1));
       if (info_form) {                                                       // :132-146
         HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, st));
@@ -861,20 +911,34 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     for (int t = 0; t < T; ++t) {
       const double* xref = (k > 0) ? s->d_xnk + (size_t)t * nN : nullptr;
       int n_draw = N;
+      if (k > 0 && t > 0) n_draw = N - 1;
+      // generic family: ordinary ancestors + dynModel on the host first, in the reference's call order (:132-137)
+      if (generic) RB_TRY(generic_draw_propagate(c, k, n_draw));
       if (k > 0 && t > 0) {
-        n_draw = N - 1;
         // ---- ancestor weights of the reference trajectory (Steps 9-10 of Alg. 2) ----
         const double* X_prev = c->X + (size_t)(t - 1) * nN * N;
         const size_t tr_prev = c->opt.trace ? (size_t)(t - 1) * N : 0;
         const double* w_prev = c->w + tr_prev;
         const double* Lq = c->d_cholQfull + (size_t)((c->chol_pages > 1) ? t - 1 : 0) * nw * nw;
+        if (drn_cb) {
+          h_edyn.assign((size_t)N * nw, 0.0);
+          if (c->cb.dyn_res_norm(c->cb.user, t - 1, N, xnk_h.data() + (size_t)t * nN, c->h_xn.data(), h_edyn.data()) != 0) {
+            set_error("the dynResNorm callback failed"); return RBPF_ERR_CALLBACK;
+          }
+          HIPCHK(hipMemcpyAsync(d_edyn, h_edyn.data(), h_edyn.size() * 8, hipMemcpyHostToDevice, st));
+          hipLaunchKernelGGL(anc_dyn_ext_kernel, dim3((N + 63) / 64), dim3(64), 0, st, N, nw, d_edyn, w_prev, s->d_pant_log);
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipStreamSynchronize(st));
+        } else {
         hipLaunchKernelGGL(anc_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, c->mdl, N, X_prev, xref,
                            c->d_odo + (size_t)(t - 1) * c->mdl.nodo, Lq, w_prev, s->d_pant_log);
         HIPCHK(hipGetLastError());
+        }
         const int cur = c->cur;
         CholArgs ca;
         std::memset(&ca, 0, sizeof(ca));
         ca.d = d; ca.n = n; ca.ldx = L.ldx; ca.pant_log = s->d_pant_log; ca.status = c->d_flags;
+        ca.variant = c->opt.chol_variant;
         bool skip_chol = false;
         if (sparse) {
           const int M = pair_off[T] - pair_off[t];
@@ -910,8 +974,10 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         RB_TRY(normalise_draw_one(c, N, t, k, s->d_pant_log, s->d_pant + (c->opt.trace ? ((size_t)k * T + t) * N : 0), s->d_wc2, N - 1,
                                   c->d_U ? c->d_U + ((size_t)k * (T - 1) + (t - 1)) * N : nullptr, c->A + (size_t)t * N, st));
       }
-      if (info_form) RB_TRY(info_step(c, k, t, xref, n_draw, d_Rinv));
-      else RB_TRY(ctx_step(c, k, xref, n_draw, nullptr));
+      if (generic) RB_TRY(generic_finish_inputs(c, k > 0 ? xnk_h.data() + (size_t)t * nN : nullptr));
+      const int st_step = info_form ? info_step(c, k, t, xref, n_draw, d_Rinv) : ctx_step(c, k, xref, n_draw, nullptr);
+      if (generic) { c->ext_xn = nullptr; c->ext_H = nullptr; }
+      RB_TRY(st_step);
     }
     // ---- ak = sample(w); xnk = xn_traj(:,ak,:) (:346-354) ----
     {
@@ -933,7 +999,8 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       HIPCHK(hipMemcpyAsync(&ak, s->d_ak, 4, hipMemcpyDeviceToHost, st));
       RB_TRY(ctx_check_flags(c));
       const int cur = c->cur;
-      if (out->XNK) HIPCHK(hipMemcpy(out->XNK + (size_t)k * nN * T, s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(xnk_h.data(), s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
+      if (out->XNK) std::memcpy(out->XNK + (size_t)k * nN * T, xnk_h.data(), (size_t)nN * T * 8);
       if (out->XLK) HIPCHK(hipMemcpy(out->XLK + (size_t)k * n, c->xl[cur] + (size_t)ak * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
       if (out->PK) {
         double* dP = nullptr;
@@ -952,6 +1019,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         if (out->trace_paNt && k > 0)
           HIPCHK(hipMemcpy(out->trace_paNt + (size_t)k * N * T, s->d_pant + (size_t)k * T * N, (size_t)N * T * 8, hipMemcpyDeviceToHost));
       }
+      RB_TRY(ctx_call_on_step(c, k, true));              // particleSmoother.m:360-362
     }
   }
   return RBPF_OK;
@@ -1158,6 +1226,7 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   CholArgs ca;
   std::memset(&ca, 0, sizeof(ca));
   ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
+  ca.variant = c->opt.chol_variant;
   RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv, sh->pb.anc_bank));     // plan of the step that made this generation
   ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
   HIPCHK(launch_chol(ca, N, d, st));
@@ -1304,15 +1373,8 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
     err = hipMemsetAsync(dlw, 0, (size_t)batch * 8, nullptr);
     if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
     if (err == hipSuccess) {
-      if (variant == 1) err = launch_chol_small(ca, batch, 1, nullptr);
-      else if (variant == 64 || variant == 648 || variant == 644) err = launch_chol64(ca, batch, 0, nullptr, variant == 648 ? 8 : variant == 644 ? 4 : 0);
-      else if (variant == 16) {
-        const int RT = (M + 1 + 15) >> 4, W = (RT <= 16) ? 4 : (RT <= 32) ? 8 : 16;
-        const size_t lds = chol_lds_bytes(M, 0);
-        const int ntmax = (RT + W - 1) / W;
-        err = (W == 4) ? launch_chol_nt<4>(ca, batch, lds, ntmax, nullptr) : (W == 8) ? launch_chol_nt<8>(ca, batch, lds, ntmax, nullptr)
-                                                                                      : launch_chol_nt<16>(ca, batch, lds, ntmax, nullptr);
-      } else err = launch_chol(ca, batch, 0, nullptr);
+      ca.variant = variant;
+      err = launch_chol(ca, batch, variant == 1 ? 1 : 0, nullptr);
     }
     if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
     if (err == hipSuccess) err = hipEventSynchronize(e1);

@@ -216,19 +216,89 @@ class SparseVisualModel(_ModelFamily):
 
 
 class GenericDenseModel:
-    """Descriptor behind arbitrary (unrecognised) dynModel / measModel callables with sparseFeatures = false: the host
-    evaluates the handles -- dynModel per particle (particleFilter.m:108), measModel on the whole batch (:124) -- and
-    the device does the rest of every step (RBPF_MODEL_GENERIC_DENSE).  The slow path: one host round trip per step."""
+    """Descriptor behind arbitrary (unrecognised) dynModel / measModel / dynResNorm callables with sparseFeatures = false.
+    The handles cross the C ABI as `rbpf_callbacks` (include/rbpf.h): the library calls back once per step with the
+    ancestors' states of all ordinary slots (dynModel, evaluated here column by column in slot order exactly as
+    particleFilter.m:104-109 / particleSmoother.m:132-137 do) and once with the whole batch (measModel, :124); the
+    smoothers additionally call dynResNorm for all particles (particleSmoother.m:178-180) and measModel along the
+    reference trajectory (:120).  Everything else of every step stays on the device (RBPF_MODEL_GENERIC_DENSE).  The slow
+    path: one host round trip per step."""
     kind = _ffi.RBPF_MODEL_GENERIC_DENSE
     sparse = False
 
-    def __init__(self, nNonLin, nLin, ny, nw, n_odo):
+    def __init__(self, nNonLin, nLin, ny, nw, n_odo, dynModel=None, measModel=None, dynResNorm=None, odometry=None, Q=None,
+                 dt=None):
         self.nNonLin, self.nLin, self.ny, self.nw, self.n_odo = int(nNonLin), int(nLin), int(ny), int(nw), int(n_odo)
+        self._dyn, self._meas, self._drn = dynModel, measModel, dynResNorm
+        self._odo, self._Q, self._dt = odometry, Q, dt
+        self.error = None                                   # first exception raised inside a callback
+        self._cb = None
+
+    def _Qt(self, t):
+        return self._Q[:, :, t if self._Q.shape[2] > 1 else 0]
+
+    def _dtt(self, t):
+        return float(self._dt[t if self._dt.size > 1 else 0])
+
+    def _make_callbacks(self):
+        nN, n, d, nw = self.nNonLin, self.nLin, self.ny, self.nw
+
+        def dyn(_user, t, n_cols, xn_anc, xn_new):
+            try:
+                A = np.ctypeslib.as_array(xn_anc, shape=(n_cols * nN,)).reshape(n_cols, nN)
+                out = np.ctypeslib.as_array(xn_new, shape=(n_cols * nN,)).reshape(n_cols, nN)
+                Qt, dtt, odo = self._Qt(t), self._dtt(t), self._odo[t, :]
+                for i in range(n_cols):                                                   # particleFilter.m:104-109
+                    out[i, :] = np.asarray(self._dyn(A[i].copy(), odo, dtt, Qt), dtype=np.float64).ravel()
+                return 0
+            except Exception as exc:                                                      # noqa: BLE001
+                self.error = self.error or exc
+                return 1
+
+        def meas(_user, n_cols, xn, dy):
+            try:
+                X = np.ctypeslib.as_array(xn, shape=(n_cols * nN,)).reshape(n_cols, nN).T   # [nN x n_cols]
+                v = np.asarray(self._meas(np.asfortranarray(X)), dtype=np.float64)            # particleFilter.m:124
+                if v.ndim == 2:
+                    v = v.reshape(n_cols, 1, n)
+                if v.shape != (n_cols, d, n):
+                    raise ValueError(f"measModel returned shape {v.shape}, expected {(n_cols, d, n)}")
+                np.ctypeslib.as_array(dy, shape=(n_cols * d * n,))[:] = np.asfortranarray(v).ravel(order="F")
+                return 0
+            except Exception as exc:                                                      # noqa: BLE001
+                self.error = self.error or exc
+                return 1
+
+        def drn(_user, t, n_cols, xnk_t, xn, e_dyn):
+            try:
+                xk = np.ctypeslib.as_array(xnk_t, shape=(nN,)).copy()
+                X = np.ctypeslib.as_array(xn, shape=(n_cols * nN,)).reshape(n_cols, nN)
+                out = np.ctypeslib.as_array(e_dyn, shape=(n_cols * nw,)).reshape(n_cols, nw)
+                Qt, dtt, odo = self._Qt(t), self._dtt(t), self._odo[t, :]
+                for i in range(n_cols):                                                   # particleSmoother.m:178-180
+                    e = np.asarray(self._drn(xk, X[i].copy(), odo, dtt, Qt), dtype=np.float64).ravel()
+                    if e.size != nw:
+                        raise ValueError(f"dynResNorm returned {e.size} values, expected size(Q,1) = {nw}")
+                    out[i, :] = e
+                return 0
+            except Exception as exc:                                                      # noqa: BLE001
+                self.error = self.error or exc
+                return 1
+
+        cb = _ffi.rbpf_callbacks()
+        self._fns = (_ffi.DYN_MODEL_FN(dyn), _ffi.MEAS_MODEL_FN(meas),
+                     _ffi.DYN_RES_NORM_FN(drn) if self._drn is not None else _ffi.DYN_RES_NORM_FN())
+        cb.dyn_model, cb.meas_model, cb.dyn_res_norm = self._fns
+        cb.user = None
+        return cb
 
     def descriptor(self, use_dyn_res_norm=False):
         d = _ffi.rbpf_model()
         d.kind, d.m_basis, d.dim, d.use_dyn_res_norm = self.kind, self.nLin, 0, 0
         d.NN = None
+        if self._dyn is not None:
+            self._cb = self._make_callbacks()               # kept alive by the model object
+            d.callbacks = C.pointer(self._cb)
         return d
 
 
@@ -386,19 +456,48 @@ def _check_sparse_flag(model, sparseFeatures):
                         "sparseFeatures=%s does not match the measurement model of %s" % (bool(sparseFeatures), type(model).__name__))
 
 
+def _is_empty_handle(h):
+    return h is None or (isinstance(h, (list, tuple)) and len(h) == 0)
+
+
 def _recognise(dynModel, measModel, dynResNorm=None):
-    """Map handles to a model family (the MATLAB wrappers do the same on func2str)."""
+    """Map handles to a model family (the MATLAB wrappers do the same on functions(h)).  Returns (model, use_dynResNorm);
+    model is None when the handles belong to no known family -- the generic (host-callback) family then takes them."""
     mdl = getattr(dynModel, "model", None)
     if not isinstance(mdl, _ModelFamily) or getattr(measModel, "model", None) is not mdl:
-        raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED,
-                        "dynModel/measModel are not handles of one recognised model family; arbitrary "
-                        "callables cannot run inside the HIP kernels (generic host-callback path: not built)")
+        if isinstance(mdl, _ModelFamily) or isinstance(getattr(measModel, "model", None), _ModelFamily):
+            raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "dynModel and measModel are handles of different model families")
+        if not (callable(dynModel) and callable(measModel)):
+            raise RBPFError(_ffi.RBPF_ERR_INVALID_ARG, "dynModel / measModel must be callable")
+        return None, not _is_empty_handle(dynResNorm)
     use_drn = True
-    if dynResNorm is None or (isinstance(dynResNorm, (list, tuple)) and len(dynResNorm) == 0):
+    if _is_empty_handle(dynResNorm):
         use_drn = False                                       # isempty(dynResNorm), particleSmoother.m:175
     elif getattr(dynResNorm, "model", None) is not mdl:
         raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "dynResNorm is not the model family's handle")
     return mdl, use_drn
+
+
+def _generic_model(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, Q, dt):
+    """GenericDenseModel for arbitrary callables, sized from the problem arrays."""
+    y2 = np.asarray(y, dtype=np.float64)
+    y2 = y2.reshape(-1, 1) if y2.ndim == 1 else y2
+    Qa = np.asarray(Q, dtype=np.float64)
+    Qa = Qa.reshape(1, 1) if Qa.ndim == 0 else Qa
+    Q3 = Qa[:, :, None] if Qa.ndim == 2 else Qa
+    x0l = np.asarray(x0_lin, dtype=np.float64)
+    odo = np.asarray(odometry, dtype=np.float64)
+    odo = odo.reshape(1, -1) if odo.ndim == 1 else odo
+    dtv = np.atleast_1d(np.asarray(dt, dtype=np.float64)).ravel()
+    return GenericDenseModel(np.asarray(x0_nonLin).size, x0l.shape[0], y2.shape[1], Q3.shape[0], odo.shape[1], dynModel, measModel,
+                             None if _is_empty_handle(dynResNorm) else dynResNorm, odo, Q3, dtv)
+
+
+def _raise_callback_error(model, exc):
+    """A Python exception inside a handle surfaces as RBPF_ERR_CALLBACK from the library: re-raise the original."""
+    if isinstance(exc, RBPFError) and exc.status == _ffi.RBPF_ERR_CALLBACK and getattr(model, "error", None) is not None:
+        raise model.error from exc
+    raise exc
 
 
 # ------------------------------------------------------------------------------------------------
@@ -409,22 +508,33 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
                    want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64", fix_p_mean=False):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
-    extras=True a 9th element (dict of traces / final particle banks) is appended."""
-    if not isinstance(getattr(dynModel, "model", None), _ModelFamily) and callable(dynModel) and callable(measModel):
+    extras=True a 9th element (dict of traces / final particle banks) is appended.
+
+    Handles of a recognised family (DenseMagModel / DenseRadioModel / SparseVisualModel) run entirely in the HIP kernels.
+    Any other pair of callables takes the generic family: the reference's calling conventions (particleFilter.m:108,124)
+        xn_new [nN] = dynModel(xn_i [nN], odometry(t-1,:), dt(t-1), Q(:,:,t-1))      -- draws its own random numbers
+        dy [N x ny x nLin] (or [N x nLin] for ny = 1) = measModel(xn [nN x N])
+    evaluated on the host through `rbpf_callbacks`; resampling uniforms still come from `rng` (the normals of a ReplayRNG
+    are not used: dynModel owns its randomness, as in the reference).
+    makePlots is called after every step with the reference's nine arguments (particleFilter.m:215-217) through the
+    library's on_step hook."""
+    model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
+    generic = model is None
+    if generic:
         if sparseFeatures:
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "sparseFeatures=true is implemented for the sparse-visual family only")
-        return _particle_filter_generic(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, makePlots,
-                                        rng, trace, want_xn_traj, extras, lazy_depth)
-    model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
+        model = _generic_model(dynModel, measModel, None, odometry, y, x0_nonLin, x0_lin, Q, dt)
     _check_sparse_flag(model, sparseFeatures)
     lib = load_library()
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
-    blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, 1)
+    nN, n, N, T = model.nNonLin, model.nLin, prob.N_P, prob.N_T
+    if generic and isinstance(rng, ReplayRNG) and (rng.Z is None or rng.Z.size == 0):
+        rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
+    blk, _keep = _rng_block(rng, N, T, model.nw, 1)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=1 if fix_p_mean else 0,
                             lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
                             storage=_storage_code(storage))
     mdesc = model.descriptor()
-    nN, n, N, T = model.nNonLin, model.nLin, prob.N_P, prob.N_T
 
     def alloc_out(Tdone, full):
         o = _ffi.rbpf_filter_out()
@@ -448,22 +558,37 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
             setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
         return o, bufs
 
-    ctx = C.c_void_p()
-    check(lib.rbpf_filter_create(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(ctx)))
-    try:
-        if makePlots is None:
-            check(lib.rbpf_filter_advance(ctx, T))
-        else:
-            # slow path: the plot hook wants the particle cloud after every step (particleFilter.m:215-217)
-            for t in range(T):
-                check(lib.rbpf_filter_advance(ctx, 1))
+    hook_error = []
+    hook = None
+    if makePlots is not None:
+        def on_step(view_p, _user):
+            # the plot hook wants the particle cloud after every step (particleFilter.m:215-217)
+            try:
+                v = view_p.contents
+                t = int(v.t)
                 o, b = alloc_out(t + 1, full=False)
-                check(lib.rbpf_filter_finish(ctx, C.byref(o)))
+                check(lib.rbpf_filter_finish(C.c_void_p(v.ctx), C.byref(o)))
                 yhattraj = np.full((prob.ny, T), np.nan)
                 xn_traj = np.zeros((nN, N, T))
                 xn_traj[:, :, :t + 1] = b["xn_traj"]
                 makePlots(b["final_xn"], b["xl_max"], b["P_max"], b["traj_max"], yhattraj, xn_traj, b["traj_mean"],
                           b["final_xl"], b["final_P"])
+                return 0
+            except Exception as exc:                                                      # noqa: BLE001
+                hook_error.append(exc)
+                return 1
+        hook = _ffi.ON_STEP_FN(on_step)
+        opt.on_step = hook
+
+    ctx = C.c_void_p()
+    check(lib.rbpf_filter_create(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(ctx)))
+    try:
+        try:
+            check(lib.rbpf_filter_advance(ctx, T))
+        except RBPFError as exc:
+            if exc.status == _ffi.RBPF_ERR_CALLBACK and hook_error:
+                raise hook_error[0] from exc
+            _raise_callback_error(model, exc)
         o, b = alloc_out(T, full=True)
         check(lib.rbpf_filter_finish(ctx, C.byref(o)))
     finally:
@@ -478,34 +603,18 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     return res
 
 
-def _particle_filter_generic(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, makePlots, rng, trace,
-                             want_xn_traj, extras, lazy_depth):
-    """particleFilter for arbitrary callables (the reference's calling conventions, particleFilter.m:108,124):
-        xn_new [nN] = dynModel(xn_i [nN], odometry(t-1,:), dt(t-1), Q(:,:,t-1))      -- draws its own random numbers
-        dy [N x ny x nLin] (or [N x nLin] for ny = 1) = measModel(xn [nN x N])
-    Every step makes one host round trip: ancestors and states come down, the handles are evaluated here, states and
-    Jacobians go up (rbpf_filter_step_external); weights, normalisation, resampling, the Kalman update and the
-    ancestry bookkeeping stay on the device.  Resampling uniforms come from `rng` (the normals of a ReplayRNG are not
-    used: dynModel owns its randomness, as in the reference)."""
+def particle_filter_external(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng=None):
+    """The caller-driven form of the generic family (what a binding without callback support would do): one host round trip
+    per step through rbpf_filter_ancestors / rbpf_filter_step_external.  Same results as particleFilter with the same
+    callables; returns (traj_max, traj_mean, xl_max, P_max)."""
     lib = load_library()
-    y2 = np.asarray(y, dtype=np.float64)
-    y2 = y2.reshape(-1, 1) if y2.ndim == 1 else y2
-    Qa = np.asarray(Q, dtype=np.float64)
-    Qa = Qa.reshape(1, 1) if Qa.ndim == 0 else Qa
-    x0l = np.asarray(x0_lin, dtype=np.float64)
-    odo = np.asarray(odometry, dtype=np.float64)
-    odo = odo.reshape(1, -1) if odo.ndim == 1 else odo
-    nN, n, d, nw = np.asarray(x0_nonLin).size, x0l.shape[0], y2.shape[1], Qa.shape[0]
-    model = GenericDenseModel(nN, n, d, nw, odo.shape[1])
-    prob = _Problem(model, odo, y2, x0_nonLin, x0_lin, P0_lin, Qa, R, N_P, dt)
-    N, T = prob.N_P, prob.N_T
-    Q3 = Qa[:, :, None] if Qa.ndim == 2 else Qa
-    dtv = np.atleast_1d(np.asarray(dt, dtype=np.float64)).ravel()
-    if rng is not None and isinstance(rng, ReplayRNG) and rng.Z is None:
-        rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (nw,)), rng.Ufin)
-    blk, _keep = _rng_block(rng, N, T, nw, 1)
-    opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=0, lazy_depth=int(lazy_depth),
-                            jitter=0.0)
+    model = _generic_model(None, None, None, odometry, y, x0_nonLin, x0_lin, Q, dt)
+    prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
+    nN, n, N, T, d = model.nNonLin, model.nLin, prob.N_P, prob.N_T, model.ny
+    if isinstance(rng, ReplayRNG) and (rng.Z is None or rng.Z.size == 0):
+        rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
+    blk, _keep = _rng_block(rng, N, T, model.nw, 1)
+    opt = _ffi.rbpf_options(keep_history=1, trace=0, fix_p_mean=0, lazy_depth=0, jitter=0.0)
     mdesc = model.descriptor()
     ctx = C.c_void_p()
     check(lib.rbpf_filter_create(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(ctx)))
@@ -516,38 +625,23 @@ def _particle_filter_generic(dynModel, measModel, odometry, y, x0_nonLin, x0_lin
         for t in range(T):
             if t > 0:
                 check(lib.rbpf_filter_ancestors(ctx, _ip(ai), _dp(xprev)))
-                Qt = Q3[:, :, t - 1 if Q3.shape[2] > 1 else 0]
-                dtt = float(dtv[t - 1 if dtv.size > 1 else 0])
                 xn = np.empty((nN, N), order="F")
                 for i in range(N):                                                    # :104-109
-                    xn[:, i] = np.asarray(dynModel(xprev[:, ai[i]].copy(), odo[t - 1, :], dtt, Qt), dtype=np.float64).ravel()
+                    xn[:, i] = np.asarray(dynModel(xprev[:, ai[i]].copy(), model._odo[t - 1, :], model._dtt(t - 1), model._Qt(t - 1)),
+                                          dtype=np.float64).ravel()
             dy = np.asarray(measModel(xn), dtype=np.float64)                           # :124
             if dy.ndim == 2:
                 dy = dy.reshape(N, 1, n)
-            if dy.shape != (N, d, n):
-                raise ValueError(f"measModel returned shape {dy.shape}, expected {(N, d, n)}")
             check(lib.rbpf_filter_step_external(ctx, _dp(np.asfortranarray(xn)), _dp(np.asfortranarray(dy))))
         o = _ffi.rbpf_filter_out()
         b = dict(traj_max=np.empty((nN, T), order="F"), traj_mean=np.empty((nN, T), order="F"), xl_max=np.empty(n),
-                 xl_mean=np.empty(n), P_max=np.empty((n, n), order="F"), P_mean=np.empty((n, n), order="F"),
-                 traj_sample_iwmax=np.empty((nN, T), order="F"), iw_max=np.zeros(1, dtype=np.int32))
-        if want_xn_traj or extras:
-            b["xn_traj"] = np.empty((nN, N, T), order="F")
-        if extras:
-            b.update(trace_logw=np.empty((N, T), order="F"), trace_w=np.empty((N, T), order="F"),
-                     trace_ai=np.zeros((N, T), dtype=np.int32, order="F"), final_xn=np.empty((nN, N), order="F"),
-                     final_xl=np.empty((n, N), order="F"), final_P=np.empty((n, n, N), order="F"))
+                 P_max=np.empty((n, n), order="F"))
         for k, v in b.items():
-            setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
+            setattr(o, k, _dp(v))
         check(lib.rbpf_filter_finish(ctx, C.byref(o)))
     finally:
         lib.rbpf_destroy(ctx)
-    res = (b["traj_max"], b["traj_mean"], b["xl_max"], b["xl_mean"], b["P_max"], b["P_mean"], b["traj_sample_iwmax"],
-           b.get("xn_traj"))
-    if extras:
-        res = res + (dict(logw=b["trace_logw"].T.copy(), w=b["trace_w"].T.copy(), ai=b["trace_ai"].T.copy(),
-                          xn=b["final_xn"], xl=b["final_xl"], P=b["final_P"], iw_max=int(b["iw_max"][0])),)
-    return res
+    return b["traj_max"], b["traj_mean"], b["xl_max"], b["P_max"]
 
 
 def model_dyn_res_norm(dynModel):
@@ -556,38 +650,56 @@ def model_dyn_res_norm(dynModel):
 
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-              sparseFeatures, makePlots, rng, extras):
+              sparseFeatures, makePlots, rng, extras, chol_variant=0):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "This code has only been implemented for dense features")
     model, use_drn = _recognise(dynModel, measModel, dynResNorm)
+    if model is None:
+        # arbitrary handles (particleSmoother.m:134-136,175-180,264 accept any): the generic family through callbacks
+        if sparseFeatures:
+            raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "sparseFeatures=true is implemented for the sparse-visual family only")
+        model = _generic_model(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, Q, dt)
     _check_sparse_flag(model, sparseFeatures)
     lib = load_library()
     prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
     N_K = int(N_K)
-    blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
-    opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=0, jitter=0.0)
-    mdesc = model.descriptor(use_dyn_res_norm=use_drn)
     nN, n, N, T = model.nNonLin, model.nLin, prob.N_P, prob.N_T
+    if isinstance(model, GenericDenseModel) and isinstance(rng, ReplayRNG) and (rng.Z is None or rng.Z.size == 0):
+        rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
+    blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
+    opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=0, jitter=0.0,
+                            chol_variant=int(chol_variant))
+    mdesc = model.descriptor(use_dyn_res_norm=use_drn)
     o = _ffi.rbpf_smoother_out()
-    b = dict(XNK=np.empty((nN, T, N_K), order="F"), XLK=np.empty((n, N_K), order="F"),
-             PK=np.empty((n, n, N_K), order="F"))
+    b = dict(XNK=np.full((nN, T, N_K), np.nan, order="F"), XLK=np.full((n, N_K), np.nan, order="F"),
+             PK=np.full((n, n, N_K), np.nan, order="F"))
     if extras:
         b.update(trace_logw=np.empty((N, T, N_K), order="F"), trace_w=np.empty((N, T, N_K), order="F"),
                  trace_ai=np.zeros((N, T, N_K), dtype=np.int32, order="F"),
                  trace_paNt=np.full((N, T, N_K), np.nan, order="F"), trace_ak=np.zeros(N_K, dtype=np.int32))
     for k, v in b.items():
         setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
-    check(lib.rbpf_particle_smoother(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), N_K,
-                                     1 if info_form else 0, C.byref(o)))
+    hook_error = []
     if makePlots is not None:
-        for k in range(N_K):                                   # particleSmoother.m:360-362 (after the fact)
-            XNKp, XLKp, PKp = b["XNK"].copy(), b["XLK"].copy(), b["PK"].copy()
-            XNKp[:, :, k + 1:] = np.nan
-            XLKp[:, k + 1:] = np.nan
-            PKp[:, :, k + 1:] = np.nan
-            makePlots(b["XNK"][:, :, k], b["XLK"][:, k], k, XNKp, XLKp, PKp)
+        def on_iter(view_p, _user):                            # particleSmoother.m:360-362, after every iteration
+            try:
+                k = int(view_p.contents.t)
+                makePlots(b["XNK"][:, :, k], b["XLK"][:, k], k, b["XNK"], b["XLK"], b["PK"])
+                return 0
+            except Exception as exc:                                                      # noqa: BLE001
+                hook_error.append(exc)
+                return 1
+        hook = _ffi.ON_STEP_FN(on_iter)
+        opt.on_step = hook
+    try:
+        check(lib.rbpf_particle_smoother(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), N_K,
+                                         1 if info_form else 0, C.byref(o)))
+    except RBPFError as exc:
+        if exc.status == _ffi.RBPF_ERR_CALLBACK and hook_error:
+            raise hook_error[0] from exc
+        _raise_callback_error(model, exc)
     res = (b["XNK"], b["XLK"], b["PK"])
     if extras:
         ex = dict(logw=np.transpose(b["trace_logw"], (2, 1, 0)).copy(), w=np.transpose(b["trace_w"], (2, 1, 0)).copy(),
@@ -598,17 +710,18 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
 
 
 def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-                     sparseFeatures=False, makePlots=None, *, rng=None, extras=False):
+                     sparseFeatures=False, makePlots=None, *, rng=None, extras=False, chol_variant=0):
     """Mirror of src/particleSmoother.m:1-2 (covariance-form ancestor weights) -> (XNK, XLK, PK)."""
     return _smoother(False, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant)
 
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
-                                    N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False):
+                                    N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
+                                    chol_variant=0):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant)
 
 
 def sample(w, u):
@@ -619,6 +732,23 @@ def sample(w, u):
     ind = np.empty(u.size, dtype=np.int32)
     check(lib.rbpf_sample(w.size, _dp(w), u.size, _dp(u), _ip(ind)))
     return ind
+
+
+_QUAT_OPS = dict(expq=(0, 3, (4,)), expq_batched=(1, 3, (4,)), logq=(2, 4, (3,)), logq_batched=(3, 4, (3,)),
+                 qLeft=(4, 4, (4, 4)), qRight=(5, 4, (4, 4)), qInv=(6, 4, (4,)), quat2rmat=(7, 4, (3, 3)), mcross=(8, 3, (3, 3)))
+
+
+def quat_helper(name, x):
+    """tools/{expq,logq,qLeft,qRight,qInv,quat2rmat,mcross}.m on the device for a batch: x [n x 3] or [n x 4] (rows, as the
+    reference's batched branches take them) -> [n x 4] / [n x 3] / [n x 4 x 4] / [n x 3 x 3].  `expq` / `logq` are the scalar
+    branches (sign flip on q0 < 0), `*_batched` the batched ones (flip on q0 <= 0, quirk Q7)."""
+    op, nin, oshape = _QUAT_OPS[name]
+    lib = load_library()
+    x = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, nin))
+    n = x.shape[0]
+    out = np.empty((n,) + oshape[::-1], dtype=np.float64)          # column-major per item
+    check(lib.rbpf_quat_helpers(op, n, _dp(x), _dp(out)))
+    return np.transpose(out, (0, 2, 1)).copy() if len(oshape) == 2 else out
 
 
 def chol_weights(S, e, jitter=0.0, variant=0, reps=1, info_form=False):

@@ -91,25 +91,25 @@ def test_largest_supported_size(rbpf):
         np.testing.assert_allclose(got, numpy_logw(S, e), rtol=1e-11, atol=1e-9)
 
 
-@pytest.fixture
-def force_chol64():
-    old = os.environ.get("RBPF_CHOL64")
-    os.environ["RBPF_CHOL64"] = "1"
-    yield
-    if old is None:
-        del os.environ["RBPF_CHOL64"]
-    else:
-        os.environ["RBPF_CHOL64"] = old
-
-
 @pytest.mark.parametrize("info_form", [False, True])
 @pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 6, 5, 130), ("radio", 9, 7, 128)])
-def test_smoothers_with_the_64_column_kernel_forced(rbpf, force_chol64, kind, N_P, N_T, m, info_form):
+def test_smoothers_with_the_64_column_kernel_forced(rbpf, kind, N_P, N_T, m, info_form):
+    """rbpf_options.chol_variant = 64 sends every ancestor-weight factorisation of the run through the 64-column kernel."""
     import test_gpu_smoother as ts
     mk = cases.mag_case if kind == "mag" else cases.radio_case
     c = mk(N_P, N_T, m, seed=21, N_K=3)
-    ref, out = ts.run_both(rbpf, c, info_form=info_form)
+    ref, out = ts.run_both(rbpf, c, info_form=info_form, chol_variant=64)
     ts.check(ref, out, 3)
+
+
+def test_smoother_with_the_16_column_kernel_forced(rbpf):
+    """chol_variant = 16 at a size the automatic choice gives to the register-resident kernel (n = 128)."""
+    import test_gpu_smoother as ts
+    c = cases.radio_case(9, 7, 128, seed=22, N_K=2)
+    ref, out = ts.run_both(rbpf, c, info_form=True, chol_variant=16)
+    ts.check(ref, out, 2)
+    with pytest.raises(rbpf.RBPFError):
+        ts.run_both(rbpf, c, info_form=True, chol_variant=7)
 
 
 @pytest.mark.parametrize("m", [256, 300])

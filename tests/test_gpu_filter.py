@@ -178,3 +178,69 @@ def test_generic_host_callback_path_matches_oracle(rbpf, oracle, kind, N_P, N_T,
                               N_P, c["dt"], rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth)
     assert calls["n"] == (N_T - 1) * N_P
     check_filter(ref, out)
+
+
+def test_filter_makePlots_hook_sees_every_step(rbpf):
+    """particleFilter.m:215-217: makePlots(xn, xl_max, P_max, traj_max, yhattraj, xn_traj, traj_mean, xl, P) after every time
+    step, driven by the library's on_step hook; the final call's arguments equal the filter's outputs."""
+    c = cases.mag_case(9, 7, 20, seed=41)
+    ref = cases.oracle_filter(c)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    calls = []
+
+    def makePlots(xn, xl_max, P_max, traj_max, yhattraj, xn_traj, traj_mean, xl, P):
+        calls.append(dict(xn=xn.copy(), xl_max=xl_max.copy(), P_max=P_max.copy(), traj_max=traj_max.copy(), xl=xl.copy(), P=P.copy(),
+                          shapes=(yhattraj.shape, xn_traj.shape)))
+
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                              False, makePlots, rng=cases.device_rng(rbpf, c), extras=True)
+    check_filter(ref, out)
+    assert len(calls) == 7
+    assert calls[0]["shapes"] == ((3, 7), (7, 9, 7))
+    last = calls[-1]
+    assert rel(last["xl_max"], ref["xl_max"]) <= RTOL and rel(last["P_max"], ref["P_max"]) <= RTOL
+    assert rel(last["xn"], ref["trace"]["xn"]) <= RTOL and rel(last["P"], ref["trace"]["P"]) <= RTOL
+    for t, cl in enumerate(calls):                       # traj_max is NaN beyond the step just finished (particleFilter.m:92)
+        assert np.all(np.isfinite(cl["traj_max"][:, :t + 1])) and np.all(np.isnan(cl["traj_max"][:, t + 1:]))
+        assert rel(cl["traj_max"][:, :t + 1], ref["traj_max"][:, :t + 1]) <= RTOL
+
+    def bad(*a):
+        raise ZeroDivisionError("plot failed")
+    with pytest.raises(ZeroDivisionError):
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                            False, bad, rng=cases.device_rng(rbpf, c))
+
+
+def test_caller_driven_generic_api_equals_the_callback_form(rbpf):
+    """rbpf_filter_ancestors / rbpf_filter_step_external (a binding that cannot hand callbacks over) against
+    rbpf_callbacks inside rbpf_filter_advance: same numbers."""
+    c = cases.radio_case(9, 7, 24, seed=19)
+    mdl, Z = c["model"], c["rng"].Z
+
+    def make():
+        calls = {"n": 0}
+
+        def dynModel(xn, dx, dt, Q):
+            t, i = divmod(calls["n"], 9)
+            calls["n"] += 1
+            return mdl.dynModel(xn, dx, dt, Q, Z[0, t, i])[0]
+        return dynModel
+    meas = lambda xn: mdl.measModel(xn)                                   # noqa: E731
+    a = rbpf.particleFilter(make(), meas, c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"], c["Q"], c["R"], 9, c["dt"],
+                            rng=cases.device_rng(rbpf, c))
+    b = rbpf.particle_filter_external(make(), meas, c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"], c["Q"], c["R"], 9,
+                                      c["dt"], rng=cases.device_rng(rbpf, c))
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[4], b[3])
+
+
+def test_exception_inside_a_model_handle_surfaces(rbpf):
+    c = cases.radio_case(6, 4, 16, seed=2)
+
+    def dyn(xn, dx, dt, Q):
+        raise FloatingPointError("handle failed")
+    with pytest.raises(FloatingPointError):
+        rbpf.particleFilter(dyn, lambda xn: c["model"].measModel(xn), c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"],
+                            c["Q"], c["R"], 6, c["dt"], rng=cases.device_rng(rbpf, c))

@@ -148,3 +148,53 @@ def test_ekf_baseline_matches_oracle(rbpf):
     got = ekf.ekf_dense(mdl, c["LL"], c["odometry"], c["y"], x0, q0, P0, c["Q"], R, c["dt"])
     for g, r in zip(got, ref):
         assert np.max(np.abs(g - r)) <= 1e-9 * max(1.0, np.max(np.abs(r)))
+
+
+@pytest.mark.gpu
+def test_quaternion_helpers_match_oracle(rbpf, oracle):
+    """expq / logq (scalar and batched branches, quirk Q7), qLeft, qRight, qInv, quat2rmat, mcross on the
+    device against the restatement of tools/*.m, bit for bit where the arithmetic is exact, 1e-15 otherwise."""
+    rs = np.random.RandomState(4)
+    n = 257
+    phi = rs.standard_normal((n, 3)) * rs.choice([1e-9, 0.3, 2.0, 4.0], (n, 1))
+    phi[0] = 0.0                                                      # mag_phi == 0 guard (expq.m:24)
+    phi[1] = [np.pi / 2, 0.0, 0.0]                                    # cos = 6e-17 > 0: no flip
+    phi[2] = [0.0, 3 * np.pi / 2, 0.0]                                # cos < 0 by rounding: flip in both branches
+    q = rs.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    q[0] = [1.0, 0.0, 0.0, 0.0]                                       # na == 0 guard (logq.m:30)
+    q[1] = [0.0, 0.6, 0.0, 0.8]                                       # q0 == 0: scalar branch keeps, batched flips
+    q[2] = [1.0 + 2e-16, 1e-9, 0.0, 0.0]                              # q0 > 1 by rounding: clamped (quirk Q7)
+    q[3] = [-0.5, 0.5, -0.5, 0.5]
+    got = rbpf.quat_helper("expq", phi)
+    want = np.stack([oracle.expq(p) for p in phi])
+    assert np.max(np.abs(got - want)) <= 4e-16
+    gb = rbpf.quat_helper("expq_batched", phi)
+    assert np.max(np.abs(gb - oracle.expq_batched(phi))) <= 4e-16
+    pz = np.array([[np.pi / 2 * (1 + 1e-16), 0.0, 0.0]])             # a q0 that is exactly +0 or tiny: both stay valid rotations
+    assert np.allclose(np.abs(rbpf.quat_helper("expq", pz)), np.abs(rbpf.quat_helper("expq_batched", pz)), atol=1e-15)
+    gl = rbpf.quat_helper("logq", q)
+    wl = np.stack([oracle.logq(x) for x in q])
+    assert np.max(np.abs(gl - wl)) <= 1e-15 * max(1.0, np.max(np.abs(wl)))
+    glb = rbpf.quat_helper("logq_batched", q)
+    wlb = oracle.logq_batched(q)
+    assert np.max(np.abs(glb - wlb)) <= 1e-15 * max(1.0, np.max(np.abs(wlb)))
+    assert np.array_equal(glb[1], -gl[1]) and np.any(gl[1] != 0)      # the q0 == 0 row: opposite signs (quirk Q7)
+    np.testing.assert_array_equal(rbpf.quat_helper("qLeft", q), np.stack([oracle.qLeft(x) for x in q]))
+    np.testing.assert_array_equal(rbpf.quat_helper("qRight", q), np.stack([oracle.qRight(x) for x in q]))
+    np.testing.assert_array_equal(rbpf.quat_helper("qLeft", q), oracle.qLeft_batched(q))
+    np.testing.assert_array_equal(rbpf.quat_helper("qRight", q), oracle.qRight_batched(q))
+    np.testing.assert_array_equal(rbpf.quat_helper("qInv", q), oracle.qInv(q))
+    np.testing.assert_array_equal(rbpf.quat_helper("mcross", phi), oracle.mcross_batched(phi))
+    np.testing.assert_array_equal(rbpf.quat_helper("mcross", phi), np.stack([oracle.mcross(p) for p in phi]))
+    gr = rbpf.quat_helper("quat2rmat", q)
+    wr = oracle.quat2rmat_batched(q)
+    assert np.max(np.abs(gr - wr)) <= 4e-16
+    # identities the reference's algebra rests on (SURVEY 8c anchors), on the device outputs themselves
+    a, b = q[5:40], q[40:75]
+    QL, QR = rbpf.quat_helper("qLeft", a), rbpf.quat_helper("qRight", b)
+    assert np.max(np.abs(np.einsum("nij,nj->ni", QL, b) - np.einsum("nij,nj->ni", QR, a))) <= 4e-16   # qLeft(a)*b == qRight(b)*a
+    small = phi[np.linalg.norm(phi, axis=1) < np.pi / 2]
+    back = rbpf.quat_helper("logq", rbpf.quat_helper("expq", small))
+    assert np.max(np.abs(back - small)) <= 1e-12                      # logq(expq(phi)) = phi for |phi| < pi/2
+    assert np.max(np.abs(np.einsum("nij,nkj->nik", gr, gr) - np.eye(3))) <= 1e-14                     # orthonormal

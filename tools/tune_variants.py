@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Runs bench.py once per (library variant, layout override) and prints one compact line each.
-Tuning aid for the GPU box:  python3 tools/tune_variants.py [--steps K]"""
+Tuning aid for the GPU box:  python3 tools/tune_variants.py [--steps K] [-- extra bench.py flags]
+The RBPF_RS / RBPF_CS layout overrides are only read by libraries built with -DRBPF_TUNING
+(`_build.build(defines={"RBPF_TUNING": 1}, out=".../lib/librbpf_hip_tuning.so")`); the product library ignores the
+environment."""
 import json
 import os
 import subprocess
@@ -27,7 +30,7 @@ for name, lib, env_extra in variants:
     if lib:
         env["RBPF_LIB_PATH"] = lib
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps, "--warmup", "20",
-                        "--no-cpu-baseline --no-smoother"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                        "--no-cpu-baseline", "--no-smoother", "--no-large", "--no-traffic"] + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(f"{name:24s} FAILED: {r.stderr[-300:]}")
