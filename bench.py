@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
-"""Headline benchmark: forward Rao-Blackwellized particle filter throughput on synthetic
-slam-dense-mag trajectories (BASELINE.json configs[1]: N=8192, T=3000, m=256, fp64, filter only).
+"""Headline benchmark: forward Rao-Blackwellized particle filter throughput on synthetic slam-dense-mag trajectories at
+the configuration BASELINE.json's metric is quoted on -- configs[2]: N = 65 536 particles, T = 3000, m = 512 basis
+functions (nLin = 515), fp64 -- plus the smoother wall-clock of the same configuration.
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one time step of particleFilter (src/particleFilter.m:100-218) over all particles:
-resample-gather, dynModel, measModel, importance weights, normalisation and the Kalman map update.
-`value` = particle-steps/s over the K timed steps with all inputs resident in HBM.  One JSON line is
-printed by rank 0.  See DESIGN.md "Measurement".
+A "step" is one time step of particleFilter (src/particleFilter.m:100-218) over all particles: resample-gather,
+dynModel, measModel, importance weights, normalisation and the Kalman map update.  `value` = particle-steps/s over the K
+timed steps with all inputs resident in HBM.  The total particle count is fixed ("scaling": "strong"): --gpus N shards
+the 65 536 particles over N ranks (multigpu.ShardedFilterSession).  One JSON line is printed by rank 0.
+
+roofline: `achieved` = bytes the run's schedule has to move per launch of the step kernel (rbpf_timing
+.scheduled_bytes_per_launch: the stored covariance is read every step and rewritten every lazy_depth-th step) / mean launch
+time from HIP events on the library's stream; `frac` = achieved / 8 TB/s (<= 1 by construction).  The ratio against
+SURVEY 8(d)'s full read + write per step is reported separately as `algorithmic_GBps` / `algorithmic_ratio` (it exceeds
+the HBM peak when the lazy update elides writes, so it is not a roofline fraction).  `traffic` is measured in THIS run:
+two child runs of the same workload under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, FETCH x2 on
+gfx950 per MI355X_MICROARCH.md), null when rocprofv3 is unavailable.  See DESIGN.md "Measurement".
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import importlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-Q_MAG_DIAG = None
+THETA_MAG = [650.0, 1.2, 200.0, 10.0]                       # examples/slam-dense-mag/main.m:23
+HBM_PEAK_GBPS = 8000.0                                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
 def q_mag():
@@ -29,9 +44,6 @@ def q_mag():
     # examples/slam-dense-mag/main.m:22
     return np.diag(np.concatenate((10 ** 2 * np.array([0.05 ** 2, 0.05 ** 2, 0.01 ** 2]),
                                    (np.array([0.01, 0.01, 0.3]) * np.pi / 180) ** 2)))
-
-
-THETA_MAG = [650.0, 1.2, 200.0, 10.0]                       # examples/slam-dense-mag/main.m:23
 
 
 def usable_cores():
@@ -78,7 +90,120 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
                       f"(gcc {flags}, OpenMP over particles), {secs:.1f} s"}
 
 
-def smoother_wallclock(pkg, datagen):
+# ------------------------------------------------------------------------------------------------------------------
+# the filter leg (headline and the extra configurations)
+# ------------------------------------------------------------------------------------------------------------------
+def roofline_of(tm):
+    avg_ms = tm["ms"] / max(tm["launches"], 1)
+    sched = tm["scheduled_bytes_per_launch"]
+    ach = sched / (avg_ms * 1e-3) / 1e9
+    alg = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "kernel": "step_kernel", "avg_launch_ms": avg_ms, "launches": tm["launches"],
+            "scheduled_bytes_per_launch": sched,
+            "algorithmic_bytes_per_launch": tm["bytes_per_launch"], "algorithmic_GBps": alg,
+            "algorithmic_ratio": alg / HBM_PEAK_GBPS,
+            "note": "achieved/frac: bytes the schedule has to move (covariance read every step, rewritten every lazy_depth-th) / "
+                    "HIP-event launch time; algorithmic_*: SURVEY 8d's one read + one write per step over the same time (not a "
+                    "roofline fraction: the lazy update elides writes)"}
+
+
+def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage):
+    """One single-GPU filter run: W warm-up steps, K timed steps."""
+    import numpy as np
+    Q = q_mag()
+    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=seed)
+    model, x0_lin, P0, R = pkg.dense_mag_prior(m, data["LL"], THETA_MAG)
+    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N, 0.01,
+                           rng=pkg.PhiloxRNG(seed), keep_history=False, lazy_depth=lazy_depth, inplace=inplace,
+                           storage=storage) as sess:
+        sess.advance(W)
+        sess.sync()
+        sess.timing(enable=True)
+        t0 = time.perf_counter()
+        sess.advance(K)
+        sess.sync()
+        dt_s = time.perf_counter() - t0
+        tm = sess.timing(reset=True)
+        chk = sess.finish(want=("traj_mean",))
+    if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
+        raise RuntimeError("non-finite filter output")
+    return {"value": N * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
+            "roofline": roofline_of(tm)}, data, model, x0_lin, P0, R
+
+
+def workload_string(N_total, T, m, n, storage, lazy_depth, world, single_bank):
+    prec = "fp64" if storage == "fp64" else "fp64 arithmetic / fp32 covariance storage"
+    bank = "single covariance bank rewritten in place" if single_bank else "ping-pong covariance banks"
+    return (f"slam-dense-mag N={N_total} T={T} m={m} (nLin={n}) {prec}, forward filter, {world} GPU, lazy_depth {lazy_depth}, "
+            f"{bank}")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# HBM traffic of the step kernel, measured in this run (child processes under rocprofv3 --pmc, one counter per pass)
+# ------------------------------------------------------------------------------------------------------------------
+def under_profiler():
+    return any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
+        "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def measure_traffic(args, lazy_depth):
+    """Mean HBM bytes per launch of the step kernel: 2 * FETCH_SIZE + WRITE_SIZE (KiB counters; FETCH_SIZE reports half of
+    wide coalesced reads on gfx950).  Steps 1.. of a (1 + 4 * lazy_depth)-step child run, i.e. four whole lazy cycles;
+    the two launches of an in-place flush count as one step."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if under_profiler():
+        return None, "bench.py itself runs under a profiler: nested counter passes skipped"
+    cyc = max(lazy_depth, 1)
+    steps = 1 + 4 * cyc
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="rbpf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--traffic-child", "--steps", str(steps), "--warmup", "0",
+                   "--particles", str(args.particles), "--m", str(args.m), "--T", str(args.T), "--seed", str(args.seed),
+                   "--lazy-depth", str(args.lazy_depth), "--inplace", str(args.inplace), "--storage", args.storage]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stdout[-300:]}"
+            rows = [x for x in csv.DictReader(open(files[0])) if "step_kernel" in x.get("Kernel_Name", "") and x.get("Counter_Name") == ctr]
+            rows.sort(key=lambda x: int(x.get("Dispatch_Id", 0)))
+            if len(rows) < steps:
+                return None, f"{ctr}: {len(rows)} step-kernel dispatches, expected >= {steps}"
+            vals = [float(x["Counter_Value"]) for x in rows[1:]]           # drop t = 0 (reads the broadcast prior)
+            out[ctr] = sum(vals) * 1024.0 / (steps - 1)
+    except Exception as exc:                                               # report, never hide
+        return None, f"traffic measurement failed: {exc}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "FETCH_SIZE_bytes_x2": 2.0 * out["FETCH_SIZE"],
+            "WRITE_SIZE_bytes": out["WRITE_SIZE"], "steps_averaged": steps - 1}, "ok"
+
+
+def traffic_child(args):
+    """Child of measure_traffic: the same filter workload, nothing else (runs under rocprofv3 --pmc)."""
+    pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+    datagen = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
+    Q = q_mag()
+    data = datagen.bean_6D(args.T, Q, THETA_MAG, 0.01, seed=args.seed)
+    model, x0_lin, P0, R = pkg.dense_mag_prior(args.m, data["LL"], THETA_MAG)
+    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, args.particles, 0.01,
+                           rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=args.lazy_depth, inplace=args.inplace,
+                           storage=args.storage) as sess:
+        sess.advance(args.steps)
+        sess.sync()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# smoother legs
+# ------------------------------------------------------------------------------------------------------------------
+def smoother_reference_size(pkg, datagen):
     """Wall-clock of the two conditional particle smoothers at the reference's own dense-mag size
     (N_P=100, T=192, m=512: run_dense3D_magfield.m:85,134; generateData_dense.m:184-187), N_K=3, device Philox."""
     import numpy as np
@@ -95,12 +220,31 @@ def smoother_wallclock(pkg, datagen):
     return out
 
 
-def smoother_large(pkg, datagen):
-    """Information-form smoother at the large configurations (BASELINE.json configs[2], configs[3]) on one GPU:
-    dense-radio N=65536 (T=48, m=128, N_K=3) complete, and 24- and 72-step runs of dense-mag N=8192 (the per-GPU share of
-    N=65536 at 8 GPUs), m=512, N_K=2 (a full T=3000 pass takes 3000 such steps per iteration)."""
+def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed):
+    """The metric's smoother: particleSmootherInformationForm on slam-dense-mag m=512, T=3000, complete, for the per-GPU share
+    of N=65 536 at 8 GPUs (N_share = 8192 particles; the information-form state of all 65 536 -- 2 x 139 GB of Imat next to
+    the covariances -- does not fit one GPU).  Wall clock of the whole call, N_K iterations."""
     import numpy as np
-    out = {"unit": "s"}
+    Q = q_mag()
+    d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=seed)
+    mdl, x0, P0, R = pkg.dense_mag_prior(m, d["LL"], THETA_MAG)
+    marks = []
+    t0 = time.perf_counter()
+    XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0,
+                                                    Q, R, N_share, N_K, 0.01, False, lambda *a: marks.append(time.perf_counter()),
+                                                    rng=pkg.PhiloxRNG(3))
+    secs = time.perf_counter() - t0
+    its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
+    return {"workload": f"slam-dense-mag N_P={N_share} (1/8 of N=65536) T={T} m={m} N_K={N_K} fp64, information form, complete run",
+            "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
+            "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
+            "finite": bool(np.all(np.isfinite(XNK))),
+            "pos_rmse_m_last_iteration": round(float(np.sqrt(np.mean((XNK[0:3, :, -1] - d["pos"]) ** 2))), 4)}
+
+
+def smoother_radio_large(pkg, datagen):
+    """BASELINE.json configs[3] on one GPU: dense-radio N=65536 (T=48, m=128, N_K=3) through particleSmootherInformationForm."""
+    import numpy as np
     T = 48
     Qr = datagen.radio_Q(T, "square_3D")
     th = [0.25, 2.0, 0.01]                                                       # examples/slam-dense-radio/main.m:24
@@ -112,24 +256,8 @@ def smoother_large(pkg, datagen):
         XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
                                                         x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3))
         runs.append(round(time.perf_counter() - t0, 3))
-    out["dense_radio_N65536_T48_m128_NK3"] = min(runs)
-    out["dense_radio_N65536_T48_m128_NK3_runs"] = runs
-    out["dense_radio_finite"] = bool(np.all(np.isfinite(XNK)))
-    Q = q_mag()
-    secs = {}
-    for T in (4, 24, 24, 72, 72):                                                # the T=4 run only warms the allocator up; best of two:
-        d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=1)                       # creating / first-touching the 87 GB of banks
-        mdl, x0, P0, R = pkg.dense_mag_prior(512, d["LL"], THETA_MAG)            # takes anything between 0 and 6 s
-        t0 = time.perf_counter()
-        pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q,
-                                            R, 8192, 2, 0.01, rng=pkg.PhiloxRNG(3))
-        secs[T] = min(secs.get(T, 1e30), time.perf_counter() - t0)
-    out["dense_mag_N8192_T24_m512_NK2"] = round(secs[24], 3)
-    out["dense_mag_N8192_T72_m512_NK2"] = round(secs[72], 3)
-    out["note"] = ("dense-mag N=8192 is the per-GPU share of N=65536 at 8 GPUs; the run times include creating the 87 GB of "
-                   "particle banks and the T-long histories (wall clock, best of two); kernel times from rocprofv3: 6.5 ms (plain step) + 23 ms (step with ancestor sampling) per time step, "
-                   "profiles/r01x_smoother_mag_N8192_m512_chol64_summary.txt")
-    return out
+    return {"workload": "slam-dense-radio N_P=65536 T=48 m=128 N_K=3 fp64, information form (BASELINE.json configs[3] on one GPU)",
+            "seconds": min(runs), "runs": runs, "unit": "s", "finite": bool(np.all(np.isfinite(XNK)))}
 
 
 def smoother_kernel_roofline(pkg):
@@ -148,81 +276,41 @@ def smoother_kernel_roofline(pkg):
     ach = flops / (ms * 1e-3) / 1e12
     return {"kernel": "chol_solve64_kernel", "workload": f"{B} matrices, n={M}, fp64", "bound": "mfma", "achieved": ach, "peak": 78.6,
             "unit": "TFLOP/s", "frac": ach / 78.6, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flops, "traffic": None,
-            "finite": bool(np.all(np.isfinite(logw))) and status == 0,
-            "in_smoother": "16.6 ms per launch of 8192 (28.6 % of the peak; 77.6 GB of HBM traffic = 4.7 TB/s) with the Imat gather "
-                           "folded in, profiles/r01x_smoother_mag_N8192_m512_chol64_summary.txt, profiles/r01x_chol64_counters_summary.txt"}
+            "finite": bool(np.all(np.isfinite(logw))) and status == 0}
 
 
-def config2_filter(pkg, datagen, args):
-    """BASELINE.json configs[2], filter part, on this one GPU: N=65536, m=512 (nLin=515), fp64 -- a single covariance
-    bank of 139 GB rewritten in place (rbpf_options.inplace, automatic).  45 timed steps after 6 warm-up steps."""
-    Q = q_mag()
-    T, K, W = 3000, 45, 6
-    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)
-    model, x0_lin, P0, R = pkg.dense_mag_prior(512, data["LL"], THETA_MAG)
-    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, 65536, 0.01,
-                           rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=3, inplace=0) as sess:
-        sess.advance(W)
-        sess.sync()
-        sess.timing(enable=True)
-        t0 = time.perf_counter()
-        sess.advance(K)
-        sess.sync()
-        dt_s = time.perf_counter() - t0
-        tm = sess.timing(reset=True)
-    avg_ms = tm["ms"] / max(tm["launches"], 1)
-    ach = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-    return {"workload": "slam-dense-mag N=65536 T=3000 m=512 (nLin=515) fp64 filter, 1 GPU, single bank in place",
-            "value": 65536 * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tm["bytes_per_launch"]},
-            "full_run": "profiles/r01e_filter_N65536_m512_T3000_bench.json (2980 timed steps: 2.05 M/s, 95 s)"}
-
-
-def config4_share_filter(pkg, datagen, args):
-    """Per-GPU share of BASELINE.json configs[4] (N=262144, m=1024, fp32, 8 GPUs): N=32768 particles, nLin=1027, covariance
-    banks STORED in fp32 (arithmetic fp64), one 138 GB bank rewritten in place, lazy_depth 2.  30 timed steps."""
-    Q = q_mag()
-    T, K, W = 3000, 30, 4
-    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)
-    model, x0_lin, P0, R = pkg.dense_mag_prior(1024, data["LL"], THETA_MAG)
-    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, 32768, 0.01,
-                           rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=2, inplace=0, storage="fp32") as sess:
-        sess.advance(W)
-        sess.sync()
-        sess.timing(enable=True)
-        t0 = time.perf_counter()
-        sess.advance(K)
-        sess.sync()
-        dt_s = time.perf_counter() - t0
-        tm = sess.timing(reset=True)
-    avg_ms = tm["ms"] / max(tm["launches"], 1)
-    ach = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-    return {"workload": "slam-dense-mag N=32768 (1/8 of N=262144) T=3000 m=1024 (nLin=1027), fp32 covariance storage / fp64 arithmetic, "
-                        "filter, 1 GPU, single bank in place, lazy_depth 2",
-            "value": 32768 * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": tm["bytes_per_launch"]},
-            "parity": "fp32 storage agrees with the fp64 oracle to 2e-5 over short runs (tests/test_gpu_filter.py), not to 1e-9"}
+def guarded(f, *a):
+    try:
+        return f(*a)
+    except Exception as exc:                                   # report, never hide
+        return {"error": f"{type(exc).__name__}: {exc}"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--particles", type=int, default=8192, help="particles per GPU")
-    ap.add_argument("--m", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--particles", type=int, default=65536, help="particles: the total (strong scaling) or per GPU (--scaling weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--m", type=int, default=512)
     ap.add_argument("--T", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-smoother", action="store_true")
-    ap.add_argument("--no-large", action="store_true", help="skip the N=65536 single-GPU legs (configs[2] filter, large smoothers)")
+    ap.add_argument("--no-smoother", action="store_true", help="skip every smoother leg")
+    ap.add_argument("--no-smoother-full", action="store_true", help="skip the complete T=3000 smoother run of the per-GPU share (about a minute)")
+    ap.add_argument("--no-large", action="store_true", help="skip the extra filter configurations (configs[1], configs[4] share) and the N=65536 radio smoother")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=3, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
     ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     args = ap.parse_args()
+
+    if args.traffic_child:
+        traffic_child(args)
+        return
 
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
@@ -235,7 +323,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the RBPF path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or args.force_sharded:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
@@ -246,10 +335,13 @@ def main():
     K, W, T = args.steps, args.warmup, args.T
     if K + W > T:
         raise SystemExit(f"--steps + --warmup must be <= T={T}")
+    if args.scaling == "strong":
+        if args.particles % world:
+            raise SystemExit("--particles must be a multiple of --gpus")
+        N_local, N_total = args.particles // world, args.particles
+    else:
+        N_local, N_total = args.particles, args.particles * world
     Q = q_mag()
-    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)           # data seed 1
-    model, x0_lin, P0, R = pkg.dense_mag_prior(args.m, data["LL"], THETA_MAG)
-    N_local = args.particles
 
     def barrier():
         torch.cuda.synchronize()
@@ -257,105 +349,89 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world > 1 or args.force_sharded:
+    shard_stats = None
+    if sharded:
+        data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=args.seed)           # data seed 1
+        model, x0_lin, P0, R = pkg.dense_mag_prior(args.m, data["LL"], THETA_MAG)
         mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
         sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
                                        N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world,
                                        lazy_depth=args.lazy_depth, storage=args.storage)
-    else:
-        sess = pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N_local, 0.01,
-                                 rng=pkg.PhiloxRNG(args.seed), keep_history=False, lazy_depth=args.lazy_depth,
-                                 inplace=args.inplace, storage=args.storage)     # filter seed 1
-    sess.advance(W)
-    sess.sync()
-    sess.timing(enable=True)
-    barrier()
-    t0 = time.perf_counter()
-    sess.advance(K)
-    sess.sync()
-    barrier()
-    dt_s = time.perf_counter() - t0
-    tm = sess.timing(reset=True)
-    sess.timing(enable=False)
-    if dist is not None:
+        sess.advance(W)
+        sess.sync()
+        sess.timing(enable=True)
+        barrier()
+        t0 = time.perf_counter()
+        sess.advance(K)
+        sess.sync()
+        barrier()
+        dt_s = time.perf_counter() - t0
+        tm = sess.timing(reset=True)
+        sess.timing(enable=False)
         tt = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_s = float(tt.item())
-    chk = sess.finish(want=("traj_mean",))
-    if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
-        raise SystemExit("non-finite filter output")
-    shard_stats = getattr(sess, "stats", None)
-    sess.close()
+        chk = sess.finish(want=("traj_mean",))
+        if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
+            raise SystemExit("non-finite filter output")
+        shard_stats = getattr(sess, "stats", None)
+        sess.close()
+        head = {"value": N_total * K / dt_s, "ms_per_step": dt_s / K * 1e3, "roofline": roofline_of(tm)}
+        single_bank = False
+    else:
+        barrier()
+        head, data, model, x0_lin, P0, R = filter_leg(pkg, datagen, N_local, args.m, T, K, W, args.seed, args.lazy_depth,
+                                                     args.inplace, args.storage)
+        _free_b, tot_b = torch.cuda.mem_get_info()
+        n_ = model.nLin
+        single_bank = args.inplace > 0 or (args.inplace == 0 and args.lazy_depth >= 2 and
+                                           2.0 * N_local * n_ * n_ * (8 if args.storage == "fp64" else 4) > 0.85 * tot_b)
 
     if rank == 0:
         n = model.nLin
-        N_total = N_local * world
-        value = N_total * K / dt_s
-        avg_ms = tm["ms"] / max(tm["launches"], 1)
-        achieved = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tr_file = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tr_file):
-            try:
-                rec = json.load(open(tr_file))
-                if rec.get("N_P") == N_local and rec.get("m") == args.m and rec.get("lazy_depth", 0) == args.lazy_depth:
-                    traffic = rec.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         line = {
-            "metric": "particle-steps/s (filter)", "value": value, "unit": "particle-steps/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64" if args.storage == "fp64" else "f64 arithmetic, f32 covariance storage", "data": "synthetic",
-            "config": {"workload": f"slam-dense-mag N={N_total} T={T} m={args.m} (nLin={n}) fp64 filter only "
-                                   f"(BASELINE.json configs[1] x {world} GPU)",
-                       "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
-                       "lazy_depth": args.lazy_depth, "inplace": args.inplace, "storage": args.storage,
-                       "filter_seed": args.seed},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "step_kernel", "avg_launch_ms": avg_ms, "launches": tm["launches"],
-                         "algorithmic_bytes_per_launch": tm["bytes_per_launch"],
-                         "note": ("algorithmic bytes = the reference's one read + one write of every covariance per step "
-                                  "(SURVEY 8d); with lazy_depth C the stored covariances are rewritten every C-th step only, so "
-                                  "the measured HBM traffic is below the algorithmic figure and frac can exceed 1"
-                                  if args.lazy_depth >= 2 else "")},
+            "metric": "particle-steps/s (filter) + smoother wall-clock, N=65k T=3k", "value": head["value"], "unit": "particle-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f64" if args.storage == "fp64" else "f64 arithmetic, f32 covariance storage", "data": "synthetic",
+            "config": {"workload": workload_string(N_total, T, args.m, n, args.storage, args.lazy_depth, world, single_bank),
+                       "baseline_config": "BASELINE.json configs[2] (filter part)" if (N_total, T, args.m, args.storage) == (65536, 3000, 512, "fp64") else "custom",
+                       "particles_total": N_total, "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
+                       "lazy_depth": args.lazy_depth, "inplace": args.inplace, "storage": args.storage, "filter_seed": args.seed},
+            "roofline": head["roofline"],
         }
         if shard_stats:
             st = dict(shard_stats)
             ph = st.pop("phase_s", {})
             st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 4) for k, v in ph.items()}
             line["config"]["sharding"] = st
-        if world == 1 and not args.no_smoother and not args.force_sharded:
-            try:
-                line["smoother"] = smoother_wallclock(pkg, datagen)
-            except Exception as exc:
-                line["smoother"] = {"error": str(exc)}
-            try:
-                line["smoother"]["kernel_roofline"] = smoother_kernel_roofline(pkg)
-            except Exception as exc:
-                line["smoother"]["kernel_roofline"] = {"error": str(exc)}
+        solo = world == 1 and not args.force_sharded
+        if solo and not args.no_traffic:
+            tr, why = measure_traffic(args, args.lazy_depth)
+            if tr:
+                line["roofline"]["traffic"] = tr["bytes_per_launch"]
+                line["roofline"]["traffic_detail"] = tr
+                line["roofline"]["traffic_over_scheduled"] = tr["bytes_per_launch"] / line["roofline"]["scheduled_bytes_per_launch"]
+            else:
+                line["roofline"]["traffic_note"] = why
+        if solo and not args.no_smoother:
+            sm = {"reference_size": guarded(smoother_reference_size, pkg, datagen),
+                  "kernel_roofline": guarded(smoother_kernel_roofline, pkg)}
+            if not args.no_smoother_full:
+                sm["share_full"] = guarded(smoother_share_full, pkg, datagen, 8192, 3000, 512, 2, args.seed)
+                if "seconds" in sm["share_full"]:
+                    line["smoother_wall_clock_s"] = sm["share_full"]["seconds"]
+                    line["smoother_wall_clock_workload"] = sm["share_full"]["workload"]
             if not args.no_large:
-                try:
-                    line["smoother"]["large"] = smoother_large(pkg, datagen)
-                except Exception as exc:
-                    line["smoother"]["large"] = {"error": str(exc)}
-        if world == 1 and not args.no_large and not args.force_sharded and N_local == 8192 and args.m == 256:
-            try:
-                free_b, _ = torch.cuda.mem_get_info()
-                if free_b > 170e9:
-                    line["config2_filter"] = config2_filter(pkg, datagen, args)
-                else:
-                    line["config2_filter"] = {"skipped": f"only {free_b / 1e9:.0f} GB free"}
-            except Exception as exc:
-                line["config2_filter"] = {"error": str(exc)}
-            try:
-                free_b, _ = torch.cuda.mem_get_info()
-                if free_b > 170e9:
-                    line["config4_share_filter"] = config4_share_filter(pkg, datagen, args)
-                else:
-                    line["config4_share_filter"] = {"skipped": f"only {free_b / 1e9:.0f} GB free"}
-            except Exception as exc:
-                line["config4_share_filter"] = {"error": str(exc)}
+                sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
+            line["smoother"] = sm
+        if solo and not args.no_large:
+            def extra(N, m, Kx, Wx, lazy, storage):
+                r, *_ = filter_leg(pkg, datagen, N, m, 3000, Kx, Wx, args.seed, lazy, 0, storage)
+                r["workload"] = workload_string(N, 3000, m, m + 3, storage, lazy, 1, 2.0 * N * (m + 3) ** 2 * (8 if storage == "fp64" else 4) > 0.85 * 288e9)
+                return r
+            line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")            # BASELINE.json configs[1]
+            line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)

@@ -216,6 +216,11 @@ typedef struct {
   double stream_kernel_ms;   /* sum of launch durations since the last reset                     */
   int64_t stream_kernel_launches;
   double algorithmic_bytes_per_launch; /* N_P * (2 n^2 + 2 n + 2 nNonLin) * 8         */
+  double scheduled_bytes_per_launch;   /* mean over the timed launches of the bytes this run's schedule has to move:      *
+                                        * per particle one read of the stored covariance, one write of it only when the  *
+                                        * launch rewrites it (every lazy_depth-th step), the pending rank-n_y factor sets *
+                                        * it applies (2 n n_y each) and writes (one), the mean and the non-linear state   *
+                                        * in and out.  <= algorithmic; the roofline fraction is quoted on this figure     */
 } rbpf_timing;
 
 /* ---- library ---------------------------------------------------------------------------------- */

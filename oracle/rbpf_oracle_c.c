@@ -1,7 +1,8 @@
 /*
  * ORACLE -- TEST / BASELINE INFRASTRUCTURE ONLY.  NOT PART OF THE PRODUCT PATH.
  *
- * Plain-C restatement of src/particleFilter.m (dense branch) for the two dense model families,
+ * Plain-C restatement of src/particleFilter.m (dense branch), src/particleSmoother.m and
+ * src/particleSmootherInformationForm.m (dense branches) for the two dense model families,
  * used (a) as a second, independent oracle next to oracle/rbpf_oracle.py and (b) as the
  * "CPU restatement, not MATLAB" baseline that bench.py times on the GPU box's host cores
  * (cpu_baseline.kind = "port").  It keeps the reference's algorithmic structure -- including the
@@ -412,6 +413,473 @@ int rbpf_oracle_particle_filter(const rbpf_model* model, const rbpf_problem* p, 
 done:
   free(w); free(logw); free(xn); free(xn_); free(xl); free(xl2); free(P); free(P2); free(H); free(ai);
   free(hist); free(hist2); free(wc_all); free(scratch);
+  return status;
+}
+
+/* ================================================================================================================
+ * The two conditional particle smoothers (CPF-AS), dense branch: src/particleSmoother.m:88-366 (covariance-form ancestor
+ * weights) and src/particleSmootherInformationForm.m:98-362 (information-form ancestor weights).  Written from the .m
+ * files, not from oracle/rbpf_oracle.py: explicit *_pred arrays, eager history permutation, a fresh cumsum inside every
+ * sample() call, the stacked future Jacobian dy(t:T) materialised per step.  Randomness is replayed:
+ *   U [N_P x (N_T-1) x N_K]      rand of sample() for slot i at step t (k > 1: slot N_P's single rand of :241 / :248)
+ *   Z [n_w x N_P x (N_T-1) x N_K] randn of dynModel
+ *   Ufin [N_K]                   rand of ak = sample(w) (:346)
+ * ================================================================================================================ */
+static void logq(const double* qin, double* lq) {                 /* tools/logq.m:25-31, q0 > 1 clamped (quirk Q7) */
+  double q[4] = {qin[0], qin[1], qin[2], qin[3]};
+  if (q[0] < 0.0) for (int k = 0; k < 4; ++k) q[k] = -q[k];
+  const double na = acos(q[0] > 1.0 ? 1.0 : q[0]);
+  const double den = sin(na) + (na == 0.0 ? 1.0 : 0.0);
+  for (int k = 0; k < 3; ++k) lq[k] = na * q[1 + k] / den;
+}
+
+/* eDyn [1 x nw] = r' / chol(dt*Q,'lower')  (right division by the LOWER factor: x*L = r', solved from the last column) */
+static int dyn_res_norm(const omodel* M, int use_handle, const double* xnk, const double* xni, const double* odo, double dt,
+                        const double* Q, double* eDyn) {
+  const int nw = M->nw;
+  double r[8], A[64], L[64];
+  if (use_handle && M->kind == RBPF_MODEL_DENSE_MAG_6D) {         /* run_dense3D_magfield.m:202-203 */
+    for (int c = 0; c < 3; ++c) r[c] = xnk[c] - xni[c] - odo[c];
+    const double dqi[4] = {odo[3], -odo[4], -odo[5], -odo[6]};    /* qInv(dx(4:7)) */
+    const double xqi[4] = {xni[3], -xni[4], -xni[5], -xni[6]};    /* qInv(xni(iQuat)) */
+    double t1[4], t2[4];
+    qleft_mul(dqi, xqi, t1);                                      /* qLeft(qInv(dx)) * qInv(xni) */
+    qleft_mul(t1, &xnk[3], t2);                                   /* qLeft(...) * xnk(iQuat) */
+    logq(t2, &r[3]);
+  } else if (use_handle) {                                        /* run_dense2D_withHeading.m:77 */
+    r[0] = xnk[2] - xni[2] - odo[2];
+  } else {                                                        /* particleSmoother.m:176-177 */
+    for (int c = 0; c < nw; ++c) r[c] = xnk[c] - xni[c] - odo[c];
+  }
+  for (int q = 0; q < nw * nw; ++q) A[q] = dt * Q[q];
+  if (chol_lower(A, nw, L)) return 1;
+  for (int q = nw - 1; q >= 0; --q) {
+    double s = r[q];
+    for (int k = q + 1; k < nw; ++k) s -= L[k + nw * q] * eDyn[k];
+    eDyn[q] = s / L[q + nw * q];
+  }
+  return 0;
+}
+
+/* in-place lower Cholesky of the n x n column-major matrix A (only the lower triangle is read); 0 ok */
+static int chol_inplace(double* A, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = A[j + (size_t)n * j];
+    for (int k = 0; k < j; ++k) s -= A[j + (size_t)n * k] * A[j + (size_t)n * k];
+    if (!(s > 0.0)) return j + 1;
+    const double ljj = sqrt(s);
+    A[j + (size_t)n * j] = ljj;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i + (size_t)n * j];
+      for (int k = 0; k < j; ++k) v -= A[i + (size_t)n * k] * A[j + (size_t)n * k];
+      A[i + (size_t)n * j] = v / ljj;
+    }
+  }
+  return 0;
+}
+
+/* One Kalman / weight step of particle i shared by both smoothers (particleSmoother.m:266-294,305-340).
+ * Returns logw; updates xl, P in place when `update`. */
+static int smoother_meas(int n, int d, const double* Hi, double* Pi, double* xli, const double* yt, const double* R,
+                         double jitter, double* work /* 3*d*n */, double* logw_out, int update, double* SS_out, double* cS_out) {
+  double e[8], SS[64], cS[64], v[8];
+  double* HP = work; double* Mm = work + (size_t)d * n; double* K = Mm + (size_t)d * n;
+  if (innovation(n, d, Hi, Pi, xli, yt, R, jitter, HP, e, SS, cS)) return 1;
+  if (logw_out) {
+    double sl = 0.0, vv = 0.0;
+    for (int a = 0; a < d; ++a) {
+      double s = e[a];
+      for (int k = 0; k < a; ++k) s -= cS[a + d * k] * v[k];
+      v[a] = s / cS[a + d * a];
+      sl += log(cS[a + d * a]); vv += v[a] * v[a];
+    }
+    *logw_out = -sl - 0.5 * vv - 0.5 * d * log(2 * M_PI);
+  }
+  if (SS_out) memcpy(SS_out, SS, sizeof(double) * d * d);
+  if (cS_out) memcpy(cS_out, cS, sizeof(double) * d * d);
+  if (!update) return 0;
+  for (int r = 0; r < n; ++r) {                                   /* (dyi'/cS')/cS */
+    double u[8], kk[8];
+    for (int a = 0; a < d; ++a) { double s = Hi[a + (size_t)d * r]; for (int k = 0; k < a; ++k) s -= cS[a + d * k] * u[k]; u[a] = s / cS[a + d * a]; }
+    for (int a = d - 1; a >= 0; --a) { double s = u[a]; for (int k = a + 1; k < d; ++k) s -= cS[k + d * a] * kk[k]; kk[a] = s / cS[a + d * a]; }
+    for (int a = 0; a < d; ++a) Mm[r + (size_t)n * a] = kk[a];
+  }
+  for (int a = 0; a < d; ++a) for (int r = 0; r < n; ++r) K[r + (size_t)n * a] = 0.0;
+  for (int a = 0; a < d; ++a)
+    for (int c = 0; c < n; ++c) {
+      const double mv = Mm[c + (size_t)n * a];
+      const double* Pc = Pi + (size_t)n * c;
+      for (int r = 0; r < n; ++r) K[r + (size_t)n * a] += Pc[r] * mv;
+    }
+  for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += K[r + (size_t)n * a] * e[a]; xli[r] += s; }
+  double* KS = HP;                                                /* K*SS (HP is free now) */
+  for (int b = 0; b < d; ++b)
+    for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += K[r + (size_t)n * a] * SS[a + d * b]; KS[r + (size_t)n * b] = s; }
+  for (int c = 0; c < n; ++c) {
+    double* Pc = Pi + (size_t)n * c;
+    for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += KS[r + (size_t)n * a] * K[c + (size_t)n * a]; Pc[r] -= s; }
+  }
+  return 0;
+}
+
+int rbpf_oracle_particle_smoother(const rbpf_model* model, const rbpf_problem* p, const rbpf_rng* rng, const rbpf_options* opt,
+                                  int N_K, int info_form, rbpf_smoother_out* out, int n_threads, double* loop_seconds) {
+  if (!model || !p || !rng || !out || rng->mode != RBPF_RNG_REPLAY || !rng->Ufin || N_K < 1 || rng->n_iter < N_K) return RBPF_ERR_INVALID_ARG;
+  omodel M;
+  M.kind = model->kind; M.m = model->m_basis; M.dim = model->dim; M.NN = model->NN;
+  M.nN = p->n_nonlin; M.n = p->n_lin; M.d = p->n_y; M.nw = p->n_w; M.nodo = p->n_odo;
+  for (int a = 0; a < 3; ++a) M.L[a] = model->L[a];
+  const int N = p->N_P, T = p->N_T, nN = M.nN, n = M.n, d = M.d, nw = M.nw;
+  if (d > 3 || nN > 8 || nw > 8) return RBPF_ERR_UNSUPPORTED;
+  if (!model->use_dyn_res_norm && nw != nN) return RBPF_ERR_INVALID_ARG;
+  if (info_form && p->x0_lin_cols != 1) return RBPF_ERR_INVALID_ARG;                    /* quirk Q5 */
+  const double jitter = (opt && opt->jitter > 0) ? opt->jitter : 1e-2;                  /* particleSmoother.m:70 */
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+  const int nthr = omp_get_max_threads();
+#else
+  (void)n_threads;
+  const int nthr = 1;
+#endif
+  const size_t nn2 = (size_t)n * n;
+  const int Mmax = d * T;
+  int status = RBPF_OK;
+  double* w = malloc(sizeof(double) * N), *logw = malloc(sizeof(double) * N), *paNtLog = malloc(sizeof(double) * N), *paNt = malloc(sizeof(double) * N);
+  double* xn = malloc(sizeof(double) * nN * N), *xn_pred = malloc(sizeof(double) * nN * N);
+  double* xl = malloc(sizeof(double) * (size_t)n * N), *xl_pred = malloc(sizeof(double) * (size_t)n * N);
+  double* P = malloc(sizeof(double) * nn2 * N), *P_pred = malloc(sizeof(double) * nn2 * N);
+  double* ivec = info_form ? malloc(sizeof(double) * (size_t)n * N) : NULL, *ivec_pred = info_form ? malloc(sizeof(double) * (size_t)n * N) : NULL;
+  double* Imat = info_form ? malloc(sizeof(double) * nn2 * N) : NULL, *Imat_pred = info_form ? malloc(sizeof(double) * nn2 * N) : NULL;
+  double* hld = malloc(sizeof(double) * N), *hld2 = malloc(sizeof(double) * N);
+  double* H = malloc(sizeof(double) * (size_t)d * n * N);
+  double* xn_traj = calloc((size_t)nN * N * T, sizeof(double)), *trj2 = malloc(sizeof(double) * (size_t)nN * N);
+  double* xnk = calloc((size_t)nN * T, sizeof(double));
+  double* dy_xnk = malloc(sizeof(double) * (size_t)d * n * T);                           /* H along the reference trajectory: [T][d x n] */
+  double* ImatAddt = info_form ? calloc(nn2, sizeof(double)) : NULL, *ivecAddt = info_form ? calloc(n, sizeof(double)) : NULL;
+  int* ai = calloc(N, sizeof(int));
+  double* wc_all = malloc(sizeof(double) * (size_t)N * nthr);
+  /* per-thread scratch: 3*d*n for the Kalman step; covariance form: G [Mmax x n], S [Mmax x Mmax], e [Mmax]; info form: A [n x n], v [n], Pi [n] */
+  const size_t per = (size_t)3 * d * n + (info_form ? nn2 + 2 * (size_t)n : (size_t)Mmax * n + (size_t)Mmax * Mmax + Mmax);
+  double* scratch = malloc(sizeof(double) * per * nthr);
+  double Rinv[9], halfLogDetR = 0.0;
+  {
+    double Lr[9], yv[3], xv[3];
+    if (chol_lower(p->R, d, Lr)) { status = RBPF_ERR_CHOL_FAILED; goto done; }
+    for (int j = 0; j < d; ++j) halfLogDetR += log(Lr[j + d * j]);
+    for (int col = 0; col < d; ++col) {
+      for (int i = 0; i < d; ++i) { double v = (i == col); for (int k = 0; k < i; ++k) v -= Lr[i + d * k] * yv[k]; yv[i] = v / Lr[i + d * i]; }
+      for (int i = d - 1; i >= 0; --i) { double v = yv[i]; for (int k = i + 1; k < d; ++k) v -= Lr[k + d * i] * xv[k]; xv[i] = v / Lr[i + d * i]; }
+      for (int i = 0; i < d; ++i) Rinv[i + d * col] = xv[i];
+    }
+  }
+  if (!w || !logw || !paNtLog || !paNt || !xn || !xn_pred || !xl || !xl_pred || !P || !P_pred || !hld || !hld2 || !H || !xn_traj || !trj2 ||
+      !xnk || !dy_xnk || !ai || !wc_all || !scratch || (info_form && (!ivec || !ivec_pred || !Imat || !Imat_pred || !ImatAddt || !ivecAddt))) {
+    status = RBPF_ERR_OUT_OF_MEMORY; goto done;
+  }
+  const double t_start = now_s();
+  for (int k = 0; k < N_K; ++k) {
+    const double* Uk = rng->U + (size_t)k * N * (T - 1);
+    const double* Zk = rng->Z + (size_t)k * N * (T - 1) * nw;
+    /* initialisation :92-118 */
+    double hld0 = 0.0;
+    for (int r = 0; r < n; ++r) hld0 += log(sqrt(p->P0_lin[r + (size_t)n * r]));
+    for (int i = 0; i < N; ++i) {
+      w[i] = 1.0 / N; logw[i] = log(w[i]);
+      for (int c = 0; c < nN; ++c) xn[c + (size_t)nN * i] = p->x0_nonlin[c];
+      memcpy(xl + (size_t)n * i, p->x0_lin + (size_t)n * (p->x0_lin_cols > 1 ? i : 0), sizeof(double) * n);
+      memcpy(P + nn2 * i, p->P0_lin, sizeof(double) * nn2);
+      if (info_form) {                                                                  /* :110-115, quirk Q5 */
+        memset(Imat + nn2 * i, 0, sizeof(double) * nn2);
+        for (int r = 0; r < n; ++r) {
+          const double pd = p->P0_lin[r + (size_t)n * r];
+          Imat[nn2 * i + r + (size_t)n * r] = 1.0 / pd;
+          ivec[(size_t)n * i + r] = (1.0 / pd) * p->x0_lin[r];
+        }
+        hld[i] = hld0;
+      }
+    }
+    if (k > 0) {
+      for (int c = 0; c < nN; ++c) xn[c + (size_t)nN * (N - 1)] = xnk[c];               /* :103-107 */
+      for (int t = 0; t < T; ++t) memcpy(xn_traj + (size_t)nN * N * t + (size_t)nN * (N - 1), xnk + (size_t)nN * t, sizeof(double) * nN);   /* :112-114 */
+      for (int t = 0; t < T; ++t) meas_model(&M, xnk + (size_t)nN * t, dy_xnk + (size_t)d * n * t);   /* :119-121 */
+      if (info_form) {                                                                  /* :132-146, jj = 1..T in order */
+        memset(ImatAddt, 0, sizeof(double) * nn2); memset(ivecAddt, 0, sizeof(double) * n);
+        for (int jj = 0; jj < T; ++jj) {
+          const double* Hj = dy_xnk + (size_t)d * n * jj;
+          double Riy[3];
+          for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * p->y[jj + (size_t)T * b]; Riy[a] = s; }
+          for (int c = 0; c < n; ++c) {
+            double RiH[3];
+            for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * Hj[b + (size_t)d * c]; RiH[a] = s; }
+            for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hj[a + (size_t)d * r] * RiH[a]; ImatAddt[r + (size_t)n * c] += s; }
+          }
+          for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hj[a + (size_t)d * r] * Riy[a]; ivecAddt[r] += s; }
+        }
+      }
+    }
+    memcpy(xn_traj, xn, sizeof(double) * nN * N);                                       /* :117 */
+    for (int t = 0; t < T; ++t) {
+      double yt[3];
+      for (int a = 0; a < d; ++a) yt[a] = p->y[t + (size_t)T * a];
+      if (t != 0) {
+        const double dtt = p->dt[p->dt_len > 1 ? t - 1 : 0];
+        const double* Qt = p->Q + (size_t)(p->q_pages > 1 ? t - 1 : 0) * nw * nw;
+        double odo[8];
+        for (int q = 0; q < M.nodo; ++q) odo[q] = p->odometry[(t - 1) + (size_t)p->odo_ld * q];
+        const double* U = Uk + (size_t)(t - 1) * N;
+        const double* Z = Zk + (size_t)(t - 1) * N * nw;
+        const int n_ord = (k == 0) ? N : N - 1;                                          /* :132-137, :149-152 */
+        int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+        for (int i = 0; i < n_ord; ++i) {
+          int tid = 0;
+#ifdef _OPENMP
+          tid = omp_get_thread_num();
+#endif
+          int a = sample_ref(w, N, U[i], wc_all + (size_t)N * tid);
+          if (a >= N) a = N - 1;
+          ai[i] = a;
+          bad |= dyn_model(&M, xn + (size_t)nN * a, odo, dtt, Qt, Z + (size_t)nw * i, xn_pred + (size_t)nN * i);
+        }
+        if (bad) { status = RBPF_ERR_CHOL_FAILED; goto done; }
+        if (k > 0) {                                                                     /* :156-245 */
+          if (info_form) {                                                               /* the (t-1) term leaves the sums :194-201 */
+            const double* Hj = dy_xnk + (size_t)d * n * (t - 1);
+            double Riy[3];
+            for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * p->y[(t - 1) + (size_t)T * b]; Riy[a] = s; }
+            for (int c = 0; c < n; ++c) {
+              double RiH[3];
+              for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * Hj[b + (size_t)d * c]; RiH[a] = s; }
+              for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hj[a + (size_t)d * r] * RiH[a]; ImatAddt[r + (size_t)n * c] -= s; }
+            }
+            for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hj[a + (size_t)d * r] * Riy[a]; ivecAddt[r] -= s; }
+          }
+          const double* xnkt = xnk + (size_t)nN * t;
+          const int Mt = d * (T - t);                                                    /* ny*(N_T-t+1) in 1-based t */
+          bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+          for (int i = 0; i < N; ++i) {
+            int tid = 0;
+#ifdef _OPENMP
+            tid = omp_get_thread_num();
+#endif
+            double* wk = scratch + per * tid + (size_t)3 * d * n;
+            double eDyn[8], logwDyn = 0.0, logwMeas;
+            if (dyn_res_norm(&M, model->use_dyn_res_norm, xnkt, xn + (size_t)nN * i, odo, dtt, Qt, eDyn)) { bad |= 1; continue; }
+            for (int q = 0; q < nw; ++q) logwDyn += eDyn[q] * eDyn[q];
+            logwDyn *= -0.5;                                                             /* :182 */
+            const double* Pi = P + nn2 * i;
+            const double* xli = xl + (size_t)n * i;
+            if (!info_form) {                                                            /* :191-229 */
+              double* G = wk; double* S = G + (size_t)Mt * n; double* e = S + (size_t)Mt * Mt;
+              /* dy = rows (tt, a) = H_{xnk(:,tt)}(a,:), tt = t..T-1 : G = dy * P_i */
+              for (int q = 0; q < Mt; ++q) {
+                const double* Hrow = dy_xnk + (size_t)d * n * (t + q / d) + (q % d);     /* element (a, c) at Hrow[d*c] */
+                for (int c = 0; c < n; ++c) {
+                  const double* Pc = Pi + (size_t)n * c;
+                  double s = 0.0;
+                  for (int r = 0; r < n; ++r) s += Hrow[(size_t)d * r] * Pc[r];
+                  G[q + (size_t)Mt * c] = s;
+                }
+                double sx = 0.0;
+                for (int c = 0; c < n; ++c) sx += Hrow[(size_t)d * c] * xli[c];
+                e[q] = p->y[(t + q / d) + (size_t)T * (q % d)] - sx;                      /* :192-193 */
+              }
+              for (int q2 = 0; q2 < Mt; ++q2) {
+                const double* Hrow2 = dy_xnk + (size_t)d * n * (t + q2 / d) + (q2 % d);
+                for (int q = q2; q < Mt; ++q) {
+                  double s = 0.0;
+                  for (int c = 0; c < n; ++c) s += G[q + (size_t)Mt * c] * Hrow2[(size_t)d * c];
+                  if (q / d == q2 / d) s += p->R[(q % d) + d * (q2 % d)];                 /* kron(eye, R) */
+                  S[q + (size_t)Mt * q2] = s;
+                }
+              }
+              /* keep a copy of the lower triangle for the jitter retry: factor in place, on failure rebuild */
+              int fl = chol_inplace(S, Mt);
+              if (fl) {                                                                  /* :221-224: chol(SS + jitter*I) */
+                for (int q2 = 0; q2 < Mt; ++q2) {
+                  const double* Hrow2 = dy_xnk + (size_t)d * n * (t + q2 / d) + (q2 % d);
+                  for (int q = q2; q < Mt; ++q) {
+                    double s = 0.0;
+                    for (int c = 0; c < n; ++c) s += G[q + (size_t)Mt * c] * Hrow2[(size_t)d * c];
+                    if (q / d == q2 / d) s += p->R[(q % d) + d * (q2 % d)];
+                    if (q == q2) s += jitter;
+                    S[q + (size_t)Mt * q2] = s;
+                  }
+                }
+                if (chol_inplace(S, Mt)) { bad |= 1; continue; }
+              }
+              double sl = 0.0, vv = 0.0;
+              for (int q = 0; q < Mt; ++q) {                                             /* v = cS \ e */
+                double s = e[q];
+                for (int c = 0; c < q; ++c) s -= S[q + (size_t)Mt * c] * e[c];
+                e[q] = s / S[q + (size_t)Mt * q];
+                sl += log(S[q + (size_t)Mt * q]); vv += e[q] * e[q];
+              }
+              logwMeas = -sl - 0.5 * vv - (double)Mt / 2.0 * log(2 * M_PI);              /* :229 */
+            } else {                                                                     /* InformationForm.m:224-236 */
+              double* A = wk; double* v = A + nn2; double* Pv = v + n;
+              const double* Ii = Imat + nn2 * i; const double* iv = ivec + (size_t)n * i;
+              for (size_t q = 0; q < nn2; ++q) A[q] = Ii[q] + ImatAddt[q];
+              for (int r = 0; r < n; ++r) v[r] = iv[r] + ivecAddt[r];
+              if (chol_inplace(A, n)) { bad |= 1; continue; }                            /* quirk Q4: the reference's retry is unusable */
+              double sl = 0.0, vv = 0.0;
+              for (int q = 0; q < n; ++q) {
+                double s = v[q];
+                for (int c = 0; c < q; ++c) s -= A[q + (size_t)n * c] * v[c];
+                v[q] = s / A[q + (size_t)n * q];
+                sl += log(A[q + (size_t)n * q]); vv += v[q] * v[q];
+              }
+              double qf = 0.0;                                                           /* ivec' * P * ivec */
+              for (int r = 0; r < n; ++r) Pv[r] = 0.0;
+              for (int c = 0; c < n; ++c) { const double* Pc = Pi + (size_t)n * c; const double x = iv[c]; for (int r = 0; r < n; ++r) Pv[r] += Pc[r] * x; }
+              for (int r = 0; r < n; ++r) qf += iv[r] * Pv[r];
+              logwMeas = -0.5 * qf - hld[i] - sl + 0.5 * vv;
+            }
+            paNtLog[i] = log(w[i]) + logwDyn + logwMeas;                                 /* :232 */
+          }
+          if (bad) { status = RBPF_ERR_CHOL_FAILED; goto done; }
+          double c = -INFINITY, s = 0.0;                                                 /* :236-238 */
+          for (int i = 0; i < N; ++i) if (paNtLog[i] > c) c = paNtLog[i];
+          for (int i = 0; i < N; ++i) s += exp(paNtLog[i] - c);
+          const double lse = c + log(s);
+          for (int i = 0; i < N; ++i) paNt[i] = exp(paNtLog[i] - lse);
+          if (out->trace_paNt) memcpy(out->trace_paNt + ((size_t)k * T + t) * N, paNt, sizeof(double) * N);
+          int a = sample_ref(paNt, N, U[N - 1], wc_all);                                 /* :241 */
+          if (a >= N) a = N - 1;
+          ai[N - 1] = a;
+          memcpy(xn_pred + (size_t)nN * (N - 1), xnkt, sizeof(double) * nN);             /* :242 */
+        }
+        /* gather of the linear states :140-141, :243-244 (and ivec / Imat / halfLogDetP for the information form) */
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < N; ++i) {
+          memcpy(xl_pred + (size_t)n * i, xl + (size_t)n * ai[i], sizeof(double) * n);
+          memcpy(P_pred + nn2 * i, P + nn2 * ai[i], sizeof(double) * nn2);
+          if (info_form) {
+            memcpy(ivec_pred + (size_t)n * i, ivec + (size_t)n * ai[i], sizeof(double) * n);
+            memcpy(Imat_pred + nn2 * i, Imat + nn2 * ai[i], sizeof(double) * nn2);
+            hld2[i] = hld[ai[i]];
+          }
+        }
+        { double* tp; tp = xn; xn = xn_pred; xn_pred = tp; tp = xl; xl = xl_pred; xl_pred = tp; tp = P; P = P_pred; P_pred = tp; }
+        if (info_form) { double* tp; tp = ivec; ivec = ivec_pred; ivec_pred = tp; tp = Imat; Imat = Imat_pred; Imat_pred = tp; tp = hld; hld = hld2; hld2 = tp; }
+        memcpy(xn_traj + (size_t)nN * N * t, xn, sizeof(double) * nN * N);               /* :256-257 */
+        for (int s2 = 0; s2 < t; ++s2) {
+          double* hs = xn_traj + (size_t)nN * N * s2;
+          for (int i = 0; i < N; ++i) memcpy(trj2 + (size_t)nN * i, hs + (size_t)nN * ai[i], sizeof(double) * nN);
+          memcpy(hs, trj2, sizeof(double) * nN * N);
+        }
+      }
+      /* importance weights (step 12) and update (step 13) */
+#pragma omp parallel for schedule(static)
+      for (int i = 0; i < N; ++i) meas_model(&M, xn + (size_t)nN * i, H + (size_t)d * n * i);
+      int bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+      for (int i = 0; i < N; ++i) {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double* work = scratch + per * tid;
+        const double* Hi = H + (size_t)d * n * i;
+        double* Pi = P + nn2 * i; double* xli = xl + (size_t)n * i;
+        if (!info_form) {
+          bad |= smoother_meas(n, d, Hi, Pi, xli, yt, p->R, jitter, work, &logw[i], 0, NULL, NULL);
+        } else {                                                                        /* InformationForm.m:279-305 */
+          double SS[9], cS[9], lw_dummy;
+          double* iv = ivec + (size_t)n * i;
+          double* Pv = work + (size_t)3 * d * n + nn2;                                   /* [n] */
+          double* ivp = Pv + n;                                                          /* ivecPlus [n] */
+          double qa = 0.0, qb = 0.0;
+          for (int r = 0; r < n; ++r) Pv[r] = 0.0;
+          for (int c = 0; c < n; ++c) { const double* Pc = Pi + (size_t)n * c; const double x = iv[c]; for (int r = 0; r < n; ++r) Pv[r] += Pc[r] * x; }
+          for (int r = 0; r < n; ++r) qa += iv[r] * Pv[r];                               /* ivec' P ivec with the PRIOR P */
+          if (smoother_meas(n, d, Hi, Pi, xli, yt, p->R, jitter, work, &lw_dummy, 0, SS, cS)) { bad |= 1; continue; }
+          double Riy[3];
+          for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * yt[b]; Riy[a] = s; }
+          for (int r = 0; r < n; ++r) { double s = iv[r]; for (int a = 0; a < d; ++a) s += Hi[a + (size_t)d * r] * Riy[a]; ivp[r] = s; }   /* :292 */
+          /* K = P*((dyi'/cS')/cS) (:293); Pplus = P - K*SS*K' (:294), formed explicitly as the reference does */
+          double* K = work + (size_t)2 * d * n;                                          /* n x d */
+          double* Mm = work + (size_t)d * n;
+          double* KS = work;                                                             /* n x d */
+          double* Pplus = work + (size_t)3 * d * n;                                      /* n x n */
+          for (int r = 0; r < n; ++r) {
+            double u[3] = {0.0, 0.0, 0.0}, kk[3] = {0.0, 0.0, 0.0};
+            for (int a = 0; a < d; ++a) { double s = Hi[a + (size_t)d * r]; for (int q = 0; q < a; ++q) s -= cS[a + d * q] * u[q]; u[a] = s / cS[a + d * a]; }
+            for (int a = d - 1; a >= 0; --a) { double s = u[a]; for (int q = a + 1; q < d; ++q) s -= cS[q + d * a] * kk[q]; kk[a] = s / cS[a + d * a]; }
+            for (int a = 0; a < d; ++a) Mm[r + (size_t)n * a] = kk[a];
+          }
+          for (int a = 0; a < d; ++a) for (int r = 0; r < n; ++r) K[r + (size_t)n * a] = 0.0;
+          for (int a = 0; a < d; ++a)
+            for (int c = 0; c < n; ++c) { const double mv = Mm[c + (size_t)n * a]; const double* Pc = Pi + (size_t)n * c; for (int r = 0; r < n; ++r) K[r + (size_t)n * a] += Pc[r] * mv; }
+          for (int b = 0; b < d; ++b)
+            for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += K[r + (size_t)n * a] * SS[a + d * b]; KS[r + (size_t)n * b] = s; }
+          for (int c = 0; c < n; ++c) {
+            const double* Pc = Pi + (size_t)n * c; double* Qc = Pplus + (size_t)n * c;
+            for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += KS[r + (size_t)n * a] * K[c + (size_t)n * a]; Qc[r] = Pc[r] - s; }
+          }
+          for (int r = 0; r < n; ++r) Pv[r] = 0.0;
+          for (int c = 0; c < n; ++c) { const double* Qc = Pplus + (size_t)n * c; const double x = ivp[c]; for (int r = 0; r < n; ++r) Pv[r] += Qc[r] * x; }
+          for (int r = 0; r < n; ++r) qb += ivp[r] * Pv[r];                              /* ivecPlus' * Pplus * ivecPlus (:303) */
+          double sl = 0.0;
+          for (int a = 0; a < d; ++a) sl += log(cS[a + d * a]);
+          const double hldp = -sl + halfLogDetR + hld[i];                                /* :298 */
+          double yRy = 0.0;
+          for (int a = 0; a < d; ++a) yRy += yt[a] * Riy[a];
+          logw[i] = -0.5 * qa - hld[i] + hldp + 0.5 * qb - 0.5 * yRy - (0.5 * d * log(2 * M_PI) + halfLogDetR);   /* :301-304 */
+          hld2[i] = hldp;
+        }
+      }
+      if (bad) { status = RBPF_ERR_CHOL_FAILED; goto done; }
+      if (info_form) { double* tp = hld; hld = hld2; hld2 = tp; }                         /* :308 */
+      {
+        double c = -INFINITY, s = 0.0;
+        for (int i = 0; i < N; ++i) if (logw[i] > c) c = logw[i];
+        for (int i = 0; i < N; ++i) s += exp(logw[i] - c);
+        const double lse = c + log(s);
+        for (int i = 0; i < N; ++i) w[i] = exp(logw[i] - lse);
+      }
+      if (out->trace_logw) memcpy(out->trace_logw + ((size_t)k * T + t) * N, logw, sizeof(double) * N);
+      if (out->trace_w) memcpy(out->trace_w + ((size_t)k * T + t) * N, w, sizeof(double) * N);
+      if (out->trace_ai) for (int i = 0; i < N; ++i) out->trace_ai[((size_t)k * T + t) * N + i] = ai[i];
+      bad = 0;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+      for (int i = 0; i < N; ++i) {
+        int tid = 0;
+#ifdef _OPENMP
+        tid = omp_get_thread_num();
+#endif
+        double* work = scratch + per * tid;
+        const double* Hi = H + (size_t)d * n * i;
+        bad |= smoother_meas(n, d, Hi, P + nn2 * i, xl + (size_t)n * i, yt, p->R, jitter, work, NULL, 1, NULL, NULL);
+        if (info_form) {                                                                /* :333-334 */
+          double* iv = ivec + (size_t)n * i; double* Ii = Imat + nn2 * i;
+          double Riy[3];
+          for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * yt[b]; Riy[a] = s; }
+          for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hi[a + (size_t)d * r] * Riy[a]; iv[r] += s; }
+          for (int c = 0; c < n; ++c) {
+            double RiH[3];
+            for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s += Rinv[a + d * b] * Hi[b + (size_t)d * c]; RiH[a] = s; }
+            for (int r = 0; r < n; ++r) { double s = 0.0; for (int a = 0; a < d; ++a) s += Hi[a + (size_t)d * r] * RiH[a]; Ii[r + (size_t)n * c] += s; }
+          }
+        }
+      }
+      if (bad) { status = RBPF_ERR_CHOL_FAILED; goto done; }
+    }
+    /* ak = sample(w); xnk = xn_traj(:,ak,:) :346-354 */
+    int ak = sample_ref(w, N, rng->Ufin[k], wc_all);
+    if (ak >= N) ak = N - 1;
+    for (int t = 0; t < T; ++t) memcpy(xnk + (size_t)nN * t, xn_traj + (size_t)nN * N * t + (size_t)nN * ak, sizeof(double) * nN);
+    if (out->XNK) memcpy(out->XNK + (size_t)k * nN * T, xnk, sizeof(double) * nN * T);
+    if (out->XLK) memcpy(out->XLK + (size_t)k * n, xl + (size_t)n * ak, sizeof(double) * n);
+    if (out->PK) memcpy(out->PK + (size_t)k * nn2, P + nn2 * ak, sizeof(double) * nn2);
+    if (out->trace_ak) out->trace_ak[k] = ak;
+  }
+  if (loop_seconds) *loop_seconds = now_s() - t_start;
+done:
+  free(w); free(logw); free(paNtLog); free(paNt); free(xn); free(xn_pred); free(xl); free(xl_pred); free(P); free(P_pred);
+  free(ivec); free(ivec_pred); free(Imat); free(Imat_pred); free(hld); free(hld2); free(H); free(xn_traj); free(trj2); free(xnk);
+  free(dy_xnk); free(ImatAddt); free(ivecAddt); free(ai); free(wc_all); free(scratch);
   return status;
 }
 

@@ -87,7 +87,7 @@ class rbpf_smoother_out(C.Structure):
 
 class rbpf_timing(C.Structure):
     _fields_ = [("stream_kernel_ms", C.c_double), ("stream_kernel_launches", C.c_int64),
-                ("algorithmic_bytes_per_launch", C.c_double)]
+                ("algorithmic_bytes_per_launch", C.c_double), ("scheduled_bytes_per_launch", C.c_double)]
 
 
 # every symbol include/rbpf.h declares (tests/test_abi.py checks the library exports all of them)

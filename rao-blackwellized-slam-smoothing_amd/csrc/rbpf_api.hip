@@ -502,6 +502,16 @@ int generic_finish_inputs(rbpf_ctx* c, const double* xref_host) {
   return RBPF_OK;
 }
 
+// Bytes a timed launch of the step kernel has to move (rbpf_timing.scheduled_bytes_per_launch): the stored covariance in
+// (and out when it is rewritten), the pending factor sets it applies and the one it produces, the means and the states in
+// and out (+ ivec in / out and H out for the information form).
+void ctx_account_launch(rbpf_ctx* c, const StepArgs& a) {
+  const double sP = c->fp32 ? 4.0 : 8.0, nn = (double)c->mdl.n, d = (double)c->mdl.d, nN = (double)c->mdl.nN;
+  const double per = nn * nn * sP * ((a.t > 0 ? 1.0 : 0.0) + (a.write_base ? 1.0 : 0.0))
+                   + 8.0 * (2.0 * nn * d * (a.n_sets + 1) + 2.0 * nn + 2.0 * nN + (a.info ? 2.0 * nn + d * nn : 0.0));
+  c->sched_bytes += per * (double)a.N;
+}
+
 int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother) {
   if (!c->opt.on_step) return RBPF_OK;
   rbpf_view v;
@@ -686,7 +696,10 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   } else {
     HIPCHK(launch_step(a, c->stream));
   }
-  if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); }
+  if (c->timing_on) {
+    HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1);
+    ctx_account_launch(c, a);
+  }
 
   NormArgs nm;
   nm.N = N; nm.nN = nN; nm.t = t; nm.logw = c->logw + tr; nm.w = c->w + tr; nm.wc = c->wc; nm.xn = X_new;
@@ -948,9 +961,11 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
   out->stream_kernel_launches = (int64_t)c->events.size();
   const double n = c->mdl.n, nN = c->mdl.nN;
   out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * (c->fp32 ? 4.0 : 8.0);   // SURVEY 8d, s = 4 | 8
+  out->scheduled_bytes_per_launch = c->events.empty() ? 0.0 : c->sched_bytes / (double)c->events.size();
   if (reset) {
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     c->events.clear();
+    c->sched_bytes = 0.0;
   }
   return RBPF_OK;
 }

@@ -98,6 +98,7 @@ struct rbpf_ctx {
   int overflow_draws = 0;
   bool timing_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double sched_bytes = 0.0;  // bytes the timed launches had to move (rbpf_timing.scheduled_bytes_per_launch)
   rbpf::SmootherState* sm = nullptr;
   rbpf::ShardState* sh = nullptr;
   double* d_rs = nullptr;    // scratch of the multi-workgroup resample pipeline
@@ -127,6 +128,7 @@ int ctx_check_flags(rbpf_ctx* c);
 int generic_draw_propagate(rbpf_ctx* c, int k_iter, int n_draw);
 int generic_finish_inputs(rbpf_ctx* c, const double* xref_host);
 int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother);
+void ctx_account_launch(rbpf_ctx* c, const StepArgs& a);
 int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
 void shard_free(rbpf_ctx* c);

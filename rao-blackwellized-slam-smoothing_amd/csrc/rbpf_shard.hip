@@ -347,7 +347,7 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
   HIPCHK(launch_step(a, c->stream));
-  if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); }
+  if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); ctx_account_launch(c, a); }
   HIPCHK(hipStreamSynchronize(c->stream));     // fwd_local feeds the next collective
   if (dev_plan) {                                           // commit the placement of the new generation
     s->cur_gid = s->pb.new_gid;

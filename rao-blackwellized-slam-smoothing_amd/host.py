@@ -812,18 +812,22 @@ class FilterSession:
         tm = _ffi.rbpf_timing()
         check(self.lib.rbpf_timing_read(self.ctx, C.byref(tm), 1 if reset else 0))
         return dict(ms=tm.stream_kernel_ms, launches=tm.stream_kernel_launches,
-                    bytes_per_launch=tm.algorithmic_bytes_per_launch)
+                    bytes_per_launch=tm.algorithmic_bytes_per_launch,
+                    scheduled_bytes_per_launch=tm.scheduled_bytes_per_launch)
 
     def finish(self, want=("traj_max", "traj_mean", "xl_max", "P_max")):
+        """Any subset of the reference's outputs (particleFilter.m:220-233) and of the extras of rbpf_filter_out, as of the
+        last finished step.  trace_* need trace=True, traj_sample_iwmax / xn_traj / trace_ai need keep_history=True."""
         m = self.model
-        nN, n, N, T = m.nNonLin, m.nLin, self.prob.N_P, self.prob.N_T
+        nN, n, N, T, Td = m.nNonLin, m.nLin, self.prob.N_P, self.prob.N_T, self.tell()
         shapes = dict(traj_max=(nN, T), traj_mean=(nN, T), xl_max=(n,), xl_mean=(n,), P_max=(n, n), P_mean=(n, n),
+                      traj_sample_iwmax=(nN, Td), xn_traj=(nN, N, Td), trace_logw=(N, Td), trace_w=(N, Td), trace_ai=(N, Td),
                       final_xn=(nN, N), final_xl=(n, N), final_P=(n, n, N))
         o = _ffi.rbpf_filter_out()
         b = {}
         for k in want:
-            b[k] = np.empty(shapes[k], order="F")
-            setattr(o, k, _dp(b[k]))
+            b[k] = np.empty(shapes[k], dtype=np.int32 if k == "trace_ai" else np.float64, order="F")
+            setattr(o, k, _ip(b[k]) if k == "trace_ai" else _dp(b[k]))
         b["iw_max"] = np.zeros(1, dtype=np.int32)
         o.iw_max = _ip(b["iw_max"])
         check(self.lib.rbpf_filter_finish(self.ctx, C.byref(o)))

@@ -339,7 +339,8 @@ class ShardedFilterSession:
         tm = _ffi.rbpf_timing()
         check(self.lib.rbpf_timing_read(self.ctx, C.byref(tm), 1 if reset else 0))
         return dict(ms=tm.stream_kernel_ms, launches=tm.stream_kernel_launches,
-                    bytes_per_launch=tm.algorithmic_bytes_per_launch)
+                    bytes_per_launch=tm.algorithmic_bytes_per_launch,
+                    scheduled_bytes_per_launch=tm.scheduled_bytes_per_launch)
 
     def finish(self, want=("traj_max", "traj_mean")):
         """Normalises the last finished step and returns the global trajectory summaries."""
