@@ -1,33 +1,34 @@
 function [traj_max,traj_mean,xl_max,xl_mean,P_max,P_mean,traj_sample_iwmax,xn_traj] = ...
     particleFilter(dynModel,measModel,odometry,y,x0_nonLin,x0_lin,P0_lin,Q,R,N_P,dt,sparseFeatures,makePlots)
-% PARTICLEFILTER - drop-in for the reference src/particleFilter.m backed by the MI355X HIP library.
-% Same signature and outputs.  dynModel / measModel must be handles made by rbpf_model (a HIP kernel cannot call
-% a MATLAB closure).  Seed-exact mode: the random numbers are drawn HERE with MATLAB's own rand / randn in the
-% reference's interleaved order (particleFilter.m:106-108: per slot one rand, then the randn's of dynModel), so
-% rng(s,'twister') reproduces the reference run.  UNTESTED here: no MATLAB in the build image.
-  if nargin < 12 || isempty(sparseFeatures), sparseFeatures = false; end
-  if nargin < 13, makePlots = []; end %#ok<NASGU>
-  desc = rbpf_descriptor(dynModel, measModel);
-  if logical(sparseFeatures) ~= (desc.kind == 3)
-    error('rbpf:usage', 'sparseFeatures must be true for (and only for) the sparse-visual family');
-  end
+% PARTICLEFILTER - drop-in for the reference src/particleFilter.m backed by the MI355X HIP library: same signature, same
+% outputs, and the reference's example runners call it UNCHANGED (put this directory on the path before the reference's
+% src/).  The handles the examples pass are recognised (rbpf_recognise: proposal from functions(h), verified by
+% evaluation) and run as HIP kernels; any other handles run through the generic family (called back from the library every
+% step).  makePlots is called after every time step with the reference's nine arguments (particleFilter.m:215-217).
+%
+% Random numbers.  Recognised families: drawn HERE with MATLAB's own rand / randn in the reference's interleaved order
+% (particleFilter.m:106-108: per slot one rand, then the randn's of dynModel), so rng(s,'twister') reproduces the reference
+% run.  Generic family: the resampling rand's of a step are drawn before that step's dynModel calls (the handle draws its
+% own randn's), i.e. the same distribution but not the reference's exact interleaving.
+% UNTESTED under MATLAB here: no MATLAB in the build image (the MEX gateway is executed against a mex.h test double).
+  if nargin < 12 || isempty(sparseFeatures), sparseFeatures = false; end     % quirk Q1 of the reference's nargin tests
+  if nargin < 13, makePlots = []; end
+  desc = rbpf_recognise(dynModel, measModel, [], logical(sparseFeatures));
+  if desc.kind == 3, desc.nLand = size(y, 2); end
   N_T = size(y,1); nw = size(Q,1);
-  U = zeros(N_P, max(N_T-1,0)); Z = zeros(nw, N_P, max(N_T-1,0));
-  for t = 1:N_T-1
-    for i = 1:N_P
-      U(i,t) = rand; Z(:,i,t) = randn(nw,1);
+  U = zeros(N_P, max(N_T-1,0));
+  if desc.kind == 4
+    U(:) = rand(size(U));
+    rngblk = struct('mode','replay','U',U);
+  else
+    Z = zeros(nw, N_P, max(N_T-1,0));
+    for t = 1:N_T-1
+      for i = 1:N_P
+        U(i,t) = rand; Z(:,i,t) = randn(nw,1);
+      end
     end
+    rngblk = struct('mode','replay','U',U,'Z',Z);
   end
-  rngblk = struct('mode','replay','U',U,'Z',Z);
   [traj_max,traj_mean,xl_max,xl_mean,P_max,P_mean,traj_sample_iwmax,xn_traj] = ...
-      rbpf_mex('filter', desc, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rngblk);
-end
-
-function desc = rbpf_descriptor(dynModel, measModel)
-  f = functions(dynModel); g = functions(measModel);
-  if ~isfield(f,'workspace') || isempty(f.workspace) || ~isfield(f.workspace{1},'rbpf_desc') || ...
-     ~isfield(g,'workspace') || ~isfield(g.workspace{1},'rbpf_desc')
-    error('rbpf:unsupported', 'dynModel/measModel must come from rbpf_model (see INTEGRATION.md)');
-  end
-  desc = f.workspace{1}.rbpf_desc;
+      rbpf_mex('filter', desc, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rngblk, makePlots);
 end

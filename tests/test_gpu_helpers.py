@@ -168,17 +168,17 @@ def test_quaternion_helpers_match_oracle(rbpf, oracle):
     q[3] = [-0.5, 0.5, -0.5, 0.5]
     got = rbpf.quat_helper("expq", phi)
     want = np.stack([oracle.expq(p) for p in phi])
-    assert np.max(np.abs(got - want)) <= 4e-16
+    assert np.max(np.abs(got - want)) <= 2e-15                        # a few ulp: the device's sincos vs libm's
     gb = rbpf.quat_helper("expq_batched", phi)
-    assert np.max(np.abs(gb - oracle.expq_batched(phi))) <= 4e-16
+    assert np.max(np.abs(gb - oracle.expq_batched(phi))) <= 2e-15
     pz = np.array([[np.pi / 2 * (1 + 1e-16), 0.0, 0.0]])             # a q0 that is exactly +0 or tiny: both stay valid rotations
     assert np.allclose(np.abs(rbpf.quat_helper("expq", pz)), np.abs(rbpf.quat_helper("expq_batched", pz)), atol=1e-15)
     gl = rbpf.quat_helper("logq", q)
     wl = np.stack([oracle.logq(x) for x in q])
-    assert np.max(np.abs(gl - wl)) <= 1e-15 * max(1.0, np.max(np.abs(wl)))
+    assert np.max(np.abs(gl - wl)) <= 4e-15 * max(1.0, np.max(np.abs(wl)))
     glb = rbpf.quat_helper("logq_batched", q)
     wlb = oracle.logq_batched(q)
-    assert np.max(np.abs(glb - wlb)) <= 1e-15 * max(1.0, np.max(np.abs(wlb)))
+    assert np.max(np.abs(glb - wlb)) <= 4e-15 * max(1.0, np.max(np.abs(wlb)))
     assert np.array_equal(glb[1], -gl[1]) and np.any(gl[1] != 0)      # the q0 == 0 row: opposite signs (quirk Q7)
     np.testing.assert_array_equal(rbpf.quat_helper("qLeft", q), np.stack([oracle.qLeft(x) for x in q]))
     np.testing.assert_array_equal(rbpf.quat_helper("qRight", q), np.stack([oracle.qRight(x) for x in q]))
@@ -189,12 +189,17 @@ def test_quaternion_helpers_match_oracle(rbpf, oracle):
     np.testing.assert_array_equal(rbpf.quat_helper("mcross", phi), np.stack([oracle.mcross(p) for p in phi]))
     gr = rbpf.quat_helper("quat2rmat", q)
     wr = oracle.quat2rmat_batched(q)
-    assert np.max(np.abs(gr - wr)) <= 4e-16
+    assert np.max(np.abs(gr - wr)) <= 1e-15                           # fused multiply-adds on the device
     # identities the reference's algebra rests on (SURVEY 8c anchors), on the device outputs themselves
     a, b = q[5:40], q[40:75]
     QL, QR = rbpf.quat_helper("qLeft", a), rbpf.quat_helper("qRight", b)
-    assert np.max(np.abs(np.einsum("nij,nj->ni", QL, b) - np.einsum("nij,nj->ni", QR, a))) <= 4e-16   # qLeft(a)*b == qRight(b)*a
-    small = phi[np.linalg.norm(phi, axis=1) < np.pi / 2]
+    assert np.max(np.abs(np.einsum("nij,nj->ni", QL, b) - np.einsum("nij,nj->ni", QR, a))) <= 1e-15   # qLeft(a)*b == qRight(b)*a
+    nrm = np.linalg.norm(phi, axis=1)
+    small = phi[nrm < np.pi / 2]
     back = rbpf.quat_helper("logq", rbpf.quat_helper("expq", small))
-    assert np.max(np.abs(back - small)) <= 1e-12                      # logq(expq(phi)) = phi for |phi| < pi/2
+    # logq(expq(phi)) = phi for |phi| < pi/2 -- to sqrt(eps) only: tools/logq.m:29 takes acos(q0), which cannot resolve
+    # angles below ~1.5e-8 (q0 rounds to 1); the reference's arithmetic, reproduced as is
+    assert np.max(np.abs(back - small)) <= 3e-8
+    mid = phi[(nrm > 0.05) & (nrm < np.pi / 2)]
+    assert np.max(np.abs(rbpf.quat_helper("logq", rbpf.quat_helper("expq", mid)) - mid)) <= 1e-13
     assert np.max(np.abs(np.einsum("nij,nkj->nik", gr, gr) - np.eye(3))) <= 1e-14                     # orthonormal
