@@ -173,6 +173,10 @@ typedef struct {
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
                           * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 as  *
                           * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
+  int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
+                          * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
+                          * 0: min(N_local, max(1024, N_local / 4)).  A step that needs more fails on EVERY rank with         *
+                          * RBPF_ERR_OUT_OF_MEMORY before any collective is issued (the plan is replicated).                 */
   rbpf_on_step_fn on_step; /* NULL: no hook                                                       */
   void* on_step_user;
 } rbpf_options;
@@ -329,6 +333,23 @@ int rbpf_shard_plan_read(rbpf_ctx* ctx, int32_t* slot_ids, int32_t* anc_bank, in
                          int32_t n_send, int32_t* new_gid);
 /* traj_max / traj_mean [n_nonlin x N_T] of the steps normalised so far (identical on every rank).     */
 int rbpf_shard_trajectories(rbpf_ctx* ctx, double* traj_max, double* traj_mean);
+/* The HIP stream a context enqueues on (hipStream_t).  A caller that issues its collectives on this stream
+ * (torch.cuda.ExternalStream) needs no host synchronisation between the library calls and the collectives.      */
+int rbpf_stream_get(rbpf_ctx* ctx, void** hip_stream);
+/* on = 1: rbpf_shard_pack / rbpf_shard_step / rbpf_shard_smoother_step return without synchronising the stream (the caller's
+ * collectives are ordered behind them on the same stream); on = 0 (default): they synchronise (host / gloo transports).    */
+int rbpf_shard_set_async(rbpf_ctx* ctx, int32_t on);
+/* Final extraction of the sharded filter (particleFilter.m:220-233), after the last step was gathered and normalised.
+ * phase 0: iw_max (logical index, identical on every rank); xl_max [n], P_max [n x n] written by the rank that holds that
+ *          particle and zero-filled elsewhere; xl_mean [n] = this rank's share of sum_i w_i xl_i; traj_sample_iwmax
+ *          [n_nonlin x N_T] (needs keep_history; identical on every rank).  The caller sum-reduces xl_max, P_max, xl_mean.
+ * phase 1: xl_mean is INPUT (the reduced mean); P_mean [n x n] = quirk Q3's last-particle term w_N (P_N + (xl_mean - xl_N)
+ *          (xl_mean - xl_N)') written by the rank that holds logical slot N - 1, zero elsewhere (the caller sum-reduces it).
+ * NULL outputs are skipped.                                                                                          */
+int rbpf_shard_finish(rbpf_ctx* ctx, int32_t phase, double* xl_max, double* P_max, double* xl_mean, double* P_mean,
+                      double* traj_sample_iwmax, int32_t* iw_max);
+/* Test hook: replace the ancestors drawn for the next step (ai [N_global], logical ids) before rbpf_shard_plan.        */
+int rbpf_shard_set_ancestors(rbpf_ctx* ctx, const int32_t* ai);
 
 /* ---- particle-sharded information-form smoother ---------------------------------
  * particleSmootherInformationForm.m with the N = world * N_P particles of every CPF-AS iteration sharded like the

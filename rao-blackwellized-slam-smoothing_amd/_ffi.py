@@ -68,7 +68,8 @@ ON_STEP_FN = C.CFUNCTYPE(C.c_int, C.POINTER(rbpf_view), C.c_void_p)
 class rbpf_options(C.Structure):
     _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
                 ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
-                ("chol_variant", C.c_int32), ("on_step", ON_STEP_FN), ("on_step_user", C.c_void_p)]
+                ("chol_variant", C.c_int32), ("exchange_capacity", C.c_int32), ("on_step", ON_STEP_FN),
+                ("on_step_user", C.c_void_p)]
 
 
 class rbpf_filter_out(C.Structure):
@@ -100,6 +101,7 @@ EXPORTS = [
     "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_quat_helpers",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
     "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read", "rbpf_shard_normalise_plan",
+    "rbpf_stream_get", "rbpf_shard_set_async", "rbpf_shard_finish", "rbpf_shard_set_ancestors",
     "rbpf_shard_smoother_create", "rbpf_shard_smoother_views_get", "rbpf_shard_smoother_begin",
     "rbpf_shard_smoother_normalise", "rbpf_shard_smoother_anc_weights", "rbpf_shard_smoother_anc_sample",
     "rbpf_shard_smoother_step", "rbpf_shard_smoother_end",

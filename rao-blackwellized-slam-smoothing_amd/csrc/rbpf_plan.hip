@@ -166,6 +166,10 @@ __global__ __launch_bounds__(kPlanThreads) void plan_pairs_kernel(int world, int
     // what I receive from rank r: destination range (me) intersected with source range (r)
     const int rlo = max(ps->imp_start[me], ps->mv_off[r]), rhi = min(ps->imp_start[me + 1], ps->mv_off[r + 1]);
     counts_out[world + r] = cnt(rlo, rhi);
+    // totals of EVERY rank (the plan is replicated, so every rank can check every rank's buffers before the exchange):
+    // records rank r receives / sends in this step
+    counts_out[2 * world + 1 + r] = cnt(ps->imp_start[r], ps->imp_start[r + 1]);
+    counts_out[3 * world + 1 + r] = cnt(ps->mv_off[r], ps->mv_off[r + 1]);
   }
   if (tid == 0) counts_out[2 * world] = M;
 }

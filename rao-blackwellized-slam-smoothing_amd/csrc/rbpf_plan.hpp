@@ -18,7 +18,7 @@ struct PlanBuffers {
   int *key, *counts, *offsets, *fill, *tmp, *order, *new_gid, *mv_child, *mv_src, *mv_q, *pref;
   int *slot_ids, *anc_bank, *send_idx;   // this rank's view
   PlanScalars* scalars;
-  long long* counts_dev;                 // [2*world + 1]: send counts, recv counts, migrated
+  long long* counts_dev;                 // [4*world + 1]: my send counts, my recv counts, migrated, every rank's recv / send totals
 };
 
 // rec_off: first free record of the (persisting) receive buffer; imports get bank index nl + rec_off + position

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -90,17 +91,17 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     s->recsz += s->recsz & 1;
   }
   if (world > 1) {
-    // A rank receives at most one record per physical slot (N_local); it may have to send its particles to
-    // every other rank ((world-1)*N_local records in the degenerate case).  Take the worst case when it fits
-    // in half of the free memory, otherwise 2*N_local; the host side reports a step that needs more.
-    s->recv_cap = Nloc;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-    const size_t per = s->recsz * sizeof(double);
-    const size_t budget = free_b / 2 > s->recv_cap * per ? free_b / 2 - s->recv_cap * per : 0;
-    const size_t fit = per ? budget / per : 0;
-    s->send_cap = std::min(Nloc * (size_t)(world - 1), std::max(Nloc, fit));
+    // Exchange buffers, sized identically on every rank (a deterministic function of the problem and the options, never
+    // of the free memory, so that every rank reaches the same verdict about a step's exchange): `step_cap` records may
+    // leave / enter a rank per time step; received records stay alive until the next flush of the lazy update.  With
+    // owner-computes placement a step moves the load imbalance only -- and one record per (destination, ancestor) pair,
+    // however many children it has -- so the default is a quarter of the local particles.
+    const size_t dflt = std::min(Nloc, std::max<size_t>(1024, Nloc / 4));
+    s->step_cap = o.exchange_capacity > 0 ? std::min<size_t>((size_t)o.exchange_capacity, Nloc * (size_t)(world - 1)) : dflt;
+    s->send_cap = s->step_cap;
+    s->recv_cap = std::min(s->step_cap, Nloc) * (size_t)std::max(c->lazy_depth, 1);
   }
+  s->rec_used_all.assign((size_t)world, 0);
   int st = RBPF_OK;
   auto A = [&](int r) { if (st == RBPF_OK) st = r; };
   A(dmalloc(&s->fwd_local, Nloc * (nN + 1)));
@@ -122,17 +123,22 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     A(dmalloc(&s->pb.fill, Ng)); A(dmalloc(&s->pb.tmp, Ng)); A(dmalloc(&s->pb.order, Ng));
     A(dmalloc(&s->pb.mv_child, Ng)); A(dmalloc(&s->pb.mv_src, Ng)); A(dmalloc(&s->pb.mv_q, Ng)); A(dmalloc(&s->pb.pref, Ng));
     A(dmalloc(&s->pb.slot_ids, Nloc)); A(dmalloc(&s->pb.anc_bank, Nloc)); A(dmalloc(&s->pb.send_idx, Ng));
-    A(dmalloc(&s->pb.scalars, 1)); A(dmalloc(&s->pb.counts_dev, (size_t)2 * world + 1));
+    A(dmalloc(&s->pb.scalars, 1)); A(dmalloc(&s->pb.counts_dev, (size_t)4 * world + 1));
     A(dmalloc(&s->gid_buf[0], Ng)); A(dmalloc(&s->gid_buf[1], Ng));
-    if (st == RBPF_OK && hipHostMalloc((void**)&s->counts_pin, ((size_t)2 * world + 1) * sizeof(long long)) != hipSuccess) st = RBPF_ERR_OUT_OF_MEMORY;
+    if (st == RBPF_OK && hipHostMalloc((void**)&s->counts_pin, ((size_t)4 * world + 1) * sizeof(long long)) != hipSuccess) st = RBPF_ERR_OUT_OF_MEMORY;
   }
-  if (smoother) {
+  if (smoother || (opt && opt->keep_history)) {
+    // global history (replicated): states and ancestors of every step in logical order, for the trajectory draws
     const size_t Ng = (size_t)s->Nglob, T = (size_t)prob->N_T;
     A(dmalloc(&s->Xhist, T * nN * Ng)); A(dmalloc(&s->Ahist, T * Ng));
-    A(dmalloc(&s->anc_local, Nloc)); A(dmalloc(&s->anc_gather, Ng)); A(dmalloc(&s->anc_glob, Ng));
-    A(dmalloc(&s->anc_w, Ng)); A(dmalloc(&s->anc_wc, Ng)); A(dmalloc(&s->w_local, Nloc)); A(dmalloc(&s->ident_bank, Nloc));
     if (st == RBPF_OK && hipMemset(s->Ahist, 0, T * Ng * sizeof(int)) != hipSuccess) st = RBPF_ERR_HIP;
   }
+  if (smoother) {
+    const size_t Ng = (size_t)s->Nglob;
+    A(dmalloc(&s->anc_local, Nloc)); A(dmalloc(&s->anc_gather, Ng)); A(dmalloc(&s->anc_glob, Ng));
+    A(dmalloc(&s->anc_w, Ng)); A(dmalloc(&s->anc_wc, Ng)); A(dmalloc(&s->ident_bank, Nloc));
+  }
+  A(dmalloc(&s->w_local, Nloc));
   if (st != RBPF_OK) { ctx_free(c); return st; }
   *out = c;
   return RBPF_OK;
@@ -243,7 +249,7 @@ int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
                                c->stream, s->recsz, c->fp32 ? 1 : 0));
   }
   if (s->smoother) RB_TRY(shard_smoother_pack_info(c, idx, count));
-  HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
+  if (!s->async) HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
   return RBPF_OK;
 }
 
@@ -348,7 +354,7 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
   HIPCHK(launch_step(a, c->stream));
   if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); ctx_account_launch(c, a); }
-  HIPCHK(hipStreamSynchronize(c->stream));     // fwd_local feeds the next collective
+  if (!s->async) HIPCHK(hipStreamSynchronize(c->stream));     // fwd_local feeds the next collective
   if (dev_plan) {                                           // commit the placement of the new generation
     s->cur_gid = s->pb.new_gid;
     s->gid_cur ^= 1;
@@ -358,6 +364,8 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   if (lazy) {
     // records received for this step stay alive (imported lineages keep them as base) until the next flush
     s->rec_used = flush ? 0 : s->rec_used + s->plan_recv;
+    for (int q = 0; q < s->world; ++q)
+      s->rec_used_all[q] = flush ? 0 : s->rec_used_all[q] + (dev_plan ? (int)s->counts_pin[2 * s->world + 1 + q] : 0);
     s->plan_recv = 0;
     c->tcur = tnew;
   }
@@ -380,13 +388,27 @@ int rbpf_shard_plan(rbpf_ctx* c, int64_t* counts_host) {
   s->pb.new_gid = s->gid_buf[s->gid_cur ^ 1];
   const int rec_off = (c->lazy_depth >= 2) ? s->rec_used : 0;
   HIPCHK(plan_run(s->pb, s->Nglob, s->world, s->Nloc, s->rank, s->ai_glob, s->placed ? s->cur_gid : nullptr, rec_off, c->stream));
-  HIPCHK(hipMemcpyAsync(s->counts_pin, s->pb.counts_dev, ((size_t)2 * s->world + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipMemcpyAsync(s->counts_pin, s->pb.counts_dev, ((size_t)4 * s->world + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   for (int q = 0; q < 2 * s->world + 1; ++q) counts_host[q] = (int64_t)s->counts_pin[q];
   counts_host[2 * s->world + 1] = rec_off;                 // first record of recv_rec the exchange may write
   s->plan_recv = 0;
   for (int q = 0; q < s->world; ++q) s->plan_recv += (int)s->counts_pin[s->world + q];
-  if ((size_t)(rec_off + s->plan_recv) > s->recv_cap) { set_error("receive buffer too small for the records alive in this lazy cycle"); return RBPF_ERR_OUT_OF_MEMORY; }
+  // Capacity verdict, identical on every rank: the plan and the buffer sizes are replicated, so every rank checks every
+  // rank's exchange BEFORE a collective is issued -- a step that does not fit is an error everywhere, not a hang.
+  if (s->world > 1) {
+    for (int q = 0; q < s->world; ++q) {
+      const long long rcv = s->counts_pin[2 * s->world + 1 + q], snd = s->counts_pin[3 * s->world + 1 + q];
+      const long long alive = (c->lazy_depth >= 2) ? s->rec_used_all[q] : 0;
+      if ((size_t)(alive + rcv) > s->recv_cap || (size_t)snd > s->send_cap) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "exchange of step %d does not fit: rank %d would send %lld and hold %lld received records "
+                 "(capacity %zu / %zu); raise rbpf_options.exchange_capacity", c->t, q, snd, alive + rcv, s->send_cap, s->recv_cap);
+        set_error(buf);
+        return RBPF_ERR_OUT_OF_MEMORY;
+      }
+    }
+  }
   s->plan_ready = true;
   return RBPF_OK;
 }
@@ -400,6 +422,165 @@ int rbpf_shard_plan_read(rbpf_ctx* c, int32_t* slot_ids, int32_t* anc_bank, int3
   if (anc_bank) HIPCHK(hipMemcpy(anc_bank, s->pb.anc_bank, (size_t)s->Nloc * 4, hipMemcpyDeviceToHost));
   if (send_idx && n_send > 0) HIPCHK(hipMemcpy(send_idx, s->pb.send_idx, (size_t)n_send * 4, hipMemcpyDeviceToHost));
   if (new_gid) HIPCHK(hipMemcpy(new_gid, s->pb.new_gid, (size_t)s->Nglob * 4, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_stream_get(rbpf_ctx* c, void** hip_stream) {
+  if (!c || !hip_stream) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  *hip_stream = reinterpret_cast<void*>(c->stream);
+  return RBPF_OK;
+}
+
+int rbpf_shard_set_async(rbpf_ctx* c, int32_t on) {
+  if (!c || !c->sh) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  c->sh->async = on != 0;
+  return RBPF_OK;
+}
+
+int rbpf_shard_set_ancestors(rbpf_ctx* c, const int32_t* ai) {
+  if (!c || !c->sh || !ai) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  ShardState* s = c->sh;
+  for (int i = 0; i < s->Nglob; ++i)
+    if (ai[i] < 0 || ai[i] >= s->Nglob) { set_error("ancestor out of range"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipMemcpy(s->ai_glob, ai, (size_t)s->Nglob * sizeof(int), hipMemcpyHostToDevice));
+  if (s->Ahist && c->t < c->T) HIPCHK(hipMemcpy(s->Ahist + (size_t)c->t * s->Nglob, ai, (size_t)s->Nglob * sizeof(int), hipMemcpyHostToDevice));
+  return RBPF_OK;
+}
+
+}  // extern "C"
+
+namespace rbpf {
+// w_local[p] = w_glob[logical id of physical slot p]
+__global__ void shard_w_local_kernel(int Nloc, int slot0, const int* __restrict__ slot_ids, const double* __restrict__ w_glob,
+                                     double* __restrict__ w_local) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < Nloc) w_local[p] = w_glob[slot_ids ? slot_ids[p] : slot0 + p];
+}
+}  // namespace rbpf
+
+// Covariance of local particle `idx` as of the last finished step in MATLAB layout (every pending downdate applied; the
+// stored matrix of its lineage may sit in a received record), into the device buffer dP [n x n].
+static int shard_unpack_particle(rbpf_ctx* c, int idx, double* dP) {
+  ShardState* s = c->sh;
+  const Layout& L = c->lay;
+  const int d = c->mdl.d, N = s->Nloc;
+  int* didx = nullptr;
+  RB_TRY(dmalloc(&didx, 1));
+  hipError_t e = hipMemcpyAsync(didx, &idx, sizeof(int), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && c->lazy_depth >= 2) {
+    const int C = c->lazy_depth, B = C + 1, t = c->t;
+    const int ell = (t == 0) ? 0 : ((t - 1) % C) + 1;
+    const double* fset[kMaxSets]; const int* fidx[kMaxSets];
+    for (int q = 0; q < ell; ++q) { const int bank = (t - ell + q) % B; fset[q] = c->Fb[bank]; fidx[q] = c->fidx[c->tcur] + (size_t)bank * N; }
+    double* rec = nullptr;
+    int st = dmalloc(&rec, s->recsz);
+    if (st != RBPF_OK) { hipFree(didx); return st; }
+    e = launch_pack_records_flushed(L, d, didx, 1, c->Pt[c->cur], c->Pb[c->cur], ell, fset, fidx, c->base[c->tcur], N, s->recv_rec,
+                                    s->recsz, c->xl[c->xcur], rec, c->stream, c->fp32 ? 1 : 0);
+    const size_t per = c->fp32 ? 2 : 1;
+    if (e == hipSuccess) e = launch_unpack_P(L, d, rec, rec + L.szT / per, nullptr, nullptr, 1, dP, c->stream, c->fp32 ? 1 : 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(rec);
+  } else if (e == hipSuccess) {
+    e = launch_unpack_P(L, d, c->Pt[c->cur], c->Pb[c->cur], c->t > 0 ? c->F[c->cur] : nullptr, didx, 1, dP, c->stream, c->fp32 ? 1 : 0);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  hipFree(didx);
+  HIPCHK(e);
+  return RBPF_OK;
+}
+
+extern "C" {
+
+int rbpf_shard_finish(rbpf_ctx* c, int32_t phase, double* xl_max, double* P_max, double* xl_mean, double* P_mean,
+                      double* traj_sample_iwmax, int32_t* iw_max) {
+  if (!c || !c->sh || (phase != 0 && phase != 1)) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  ShardState* s = c->sh;
+  if (s->smoother) { set_error("smoother context: use rbpf_shard_smoother_end"); return RBPF_ERR_STATE; }
+  if (c->t < 1 || s->t_norm != c->t) { set_error("finish needs the last finished step gathered and normalised"); return RBPF_ERR_STATE; }
+  RB_TRY(ctx_check_flags(c));
+  const int n = c->mdl.n, nN = c->mdl.nN, N = s->Nglob, Nloc = s->Nloc, Td = c->t;
+  const Layout& L = c->lay;
+  hipStream_t st = c->stream;
+  // where a logical slot's particle lives now
+  auto locate = [&](int logical, int& owner, int& idx) -> int {
+    int gid = logical;
+    if (s->placed) HIPCHK(hipMemcpy(&gid, s->cur_gid + logical, sizeof(int), hipMemcpyDeviceToHost));
+    owner = gid / Nloc; idx = gid % Nloc;
+    return RBPF_OK;
+  };
+  if (phase == 0) {
+    int iw = 0;
+    HIPCHK(hipMemcpy(&iw, c->d_flags + 2, sizeof(int), hipMemcpyDeviceToHost));
+    if (iw_max) *iw_max = iw;
+    int owner = 0, idx = 0;
+    RB_TRY(locate(iw, owner, idx));
+    if (xl_max) {
+      std::memset(xl_max, 0, (size_t)n * sizeof(double));
+      if (owner == s->rank) HIPCHK(hipMemcpy(xl_max, c->xl[c->xcur] + (size_t)idx * L.ldx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    if (P_max) {
+      std::memset(P_max, 0, (size_t)n * n * sizeof(double));
+      if (owner == s->rank) {
+        double* dP = nullptr;
+        RB_TRY(dmalloc(&dP, (size_t)n * n));
+        int rc = shard_unpack_particle(c, idx, dP);
+        hipError_t e = (rc == RBPF_OK) ? hipMemcpy(P_max, dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost) : hipSuccess;
+        hipFree(dP);
+        if (rc != RBPF_OK) return rc;
+        HIPCHK(e);
+      }
+    }
+    if (xl_mean) {                       // my share of sum_i w_i xl_i (particleFilter.m:224)
+      hipLaunchKernelGGL(shard_w_local_kernel, dim3((Nloc + 255) / 256), dim3(256), 0, st, Nloc, s->rank * Nloc,
+                         s->placed ? s->pb.slot_ids : nullptr, s->w_glob, s->w_local);
+      double* dm = nullptr;
+      RB_TRY(dmalloc(&dm, (size_t)n));
+      hipError_t e = launch_weighted_mean_xl(Nloc, n, L.ldx, c->xl[c->xcur], s->w_local, dm, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(xl_mean, dm, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      hipFree(dm);
+      HIPCHK(e);
+    }
+    if (traj_sample_iwmax) {             // :233, back-trace through the replicated history
+      if (!s->Xhist) { set_error("traj_sample_iwmax needs keep_history = 1"); return RBPF_ERR_STATE; }
+      double* dout = nullptr; int* didx = nullptr;
+      RB_TRY(dmalloc(&dout, (size_t)nN * Td));
+      int s2 = dmalloc(&didx, 1);
+      if (s2 != RBPF_OK) { hipFree(dout); return s2; }
+      hipError_t e = hipMemcpy(didx, &iw, sizeof(int), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = launch_backtrace(N, nN, Td, s->Xhist, s->Ahist, didx, 1, dout, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess) e = hipMemcpy(traj_sample_iwmax, dout, (size_t)nN * Td * sizeof(double), hipMemcpyDeviceToHost);
+      hipFree(dout); hipFree(didx);
+      HIPCHK(e);
+    }
+    return RBPF_OK;
+  }
+  // phase 1: quirk Q3 -- P_mean is the LAST particle's term only (particleFilter.m:228-230 assigns instead of accumulating)
+  if (!P_mean || !xl_mean) { set_error("phase 1 needs xl_mean (input) and P_mean"); return RBPF_ERR_INVALID_ARG; }
+  if (c->opt.fix_p_mean) { set_error("fix_p_mean = 1 is not available in the sharded session"); return RBPF_ERR_UNSUPPORTED; }
+  std::memset(P_mean, 0, (size_t)n * n * sizeof(double));
+  int owner = 0, idx = 0;
+  RB_TRY(locate(N - 1, owner, idx));
+  if (owner == s->rank) {
+    double* dP = nullptr;
+    RB_TRY(dmalloc(&dP, (size_t)n * n));
+    std::vector<double> Pl((size_t)n * n), xll(n);
+    double wl = 0.0;
+    int rc = shard_unpack_particle(c, idx, dP);
+    hipError_t e = (rc == RBPF_OK) ? hipMemcpy(Pl.data(), dP, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost) : hipSuccess;
+    hipFree(dP);
+    if (rc != RBPF_OK) return rc;
+    if (e == hipSuccess) e = hipMemcpy(xll.data(), c->xl[c->xcur] + (size_t)idx * L.ldx, (size_t)n * sizeof(double), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&wl, s->w_glob + (N - 1), sizeof(double), hipMemcpyDeviceToHost);
+    HIPCHK(e);
+    for (int cc = 0; cc < n; ++cc)
+      for (int r = 0; r < n; ++r)
+        P_mean[r + (size_t)n * cc] = wl * (Pl[r + (size_t)n * cc] + (xl_mean[r] - xll[r]) * (xl_mean[cc] - xll[cc]));
+  }
   return RBPF_OK;
 }
 

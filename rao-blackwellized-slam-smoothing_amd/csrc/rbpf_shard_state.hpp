@@ -32,6 +32,9 @@ struct ShardState {
   long long* counts_pin = nullptr; // pinned host copy of [send counts | recv counts | migrated]
   int last_send_total = 0;
   // multi-step lazy update: received records persist until the next flush (imported lineages use them as base)
+  std::vector<int> rec_used_all;   // records alive in every rank's receive buffer (replicated bookkeeping)
+  size_t step_cap = 0;             // records one rank may send / receive per step (identical on every rank)
+  bool async = false;              // no stream synchronisation at the end of pack / step (collectives on the same stream)
   int rec_used = 0;                // records currently alive in recv_rec
   int plan_recv = 0;               // records the pending plan will append
   // ---- sharded information-form smoother (rbpf_smoother.hip) ----

@@ -1182,6 +1182,7 @@ int rbpf_shard_smoother_begin(rbpf_ctx* c, int32_t k) {
   RB_TRY(ctx_reset(c));
   sh->t_norm = 0; sh->placed = false; sh->plan_ready = false; sh->gid_cur = 0; sh->cur_gid = nullptr;
   sh->rec_used = 0; sh->plan_recv = 0; sh->k_iter = k;
+  std::fill(sh->rec_used_all.begin(), sh->rec_used_all.end(), 0);
   RB_TRY(info_begin_iteration(c, s->h_ivec0.data(), s->hld0, 0.0, 0.0, s->d_Rinv));
   if (k > 0) {
     HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, c->stream, 1));           // :120
@@ -1231,7 +1232,7 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
   HIPCHK(launch_chol(ca, N, d, st));
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(st));
+  if (!sh->async) HIPCHK(hipStreamSynchronize(st));
   return RBPF_OK;
 }
 
@@ -1246,7 +1247,7 @@ int rbpf_shard_smoother_anc_sample(rbpf_ctx* c) {
   RB_TRY(normalise_draw_one(c, N, t, k, sh->anc_glob, sh->anc_w, sh->anc_wc, N - 1,
                             c->d_U ? c->d_U + ((size_t)k * (c->T - 1) + (t - 1)) * N : nullptr, sh->ai_glob, st));
   HIPCHK(hipMemcpyAsync(sh->Ahist + (size_t)t * N + (N - 1), sh->ai_glob + (N - 1), sizeof(int), hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipStreamSynchronize(st));
+  if (!sh->async) HIPCHK(hipStreamSynchronize(st));
   return RBPF_OK;
 }
 

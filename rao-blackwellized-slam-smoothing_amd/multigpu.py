@@ -167,10 +167,12 @@ class ShardedFilterSession:
     transport="host"  : device -> host -> gloo -> device (lets two ranks share ONE GPU in tests)."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
-                 transport="device", planner="device", lazy_depth=0, storage="fp64"):
+                 transport="device", planner="device", lazy_depth=0, storage="fp64", keep_history=False, exchange_capacity=0,
+                 sync_phases=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
+        self.sync_phases = bool(sync_phases)   # diagnostic: synchronise after every phase so that stats["phase_s"] is GPU time
         self.lib = load_library()
         for name, argt in (("rbpf_shard_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
                                                   C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
@@ -183,7 +185,12 @@ class ShardedFilterSession:
                            ("rbpf_shard_normalise_plan", [C.c_void_p, C.POINTER(C.c_int64)]),
                            ("rbpf_shard_plan_read", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p, _ffi.c_int32_p, C.c_int32,
                                                      _ffi.c_int32_p]),
-                           ("rbpf_shard_trajectories", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p])):
+                           ("rbpf_shard_trajectories", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p]),
+                           ("rbpf_stream_get", [C.c_void_p, C.POINTER(C.c_void_p)]),
+                           ("rbpf_shard_set_async", [C.c_void_p, C.c_int32]),
+                           ("rbpf_shard_finish", [C.c_void_p, C.c_int32, _ffi.c_double_p, _ffi.c_double_p, _ffi.c_double_p,
+                                                  _ffi.c_double_p, _ffi.c_double_p, _ffi.c_int32_p]),
+                           ("rbpf_shard_set_ancestors", [C.c_void_p, _ffi.c_int32_p])):
             getattr(self.lib, name).argtypes = argt
         self.model, self.rank, self.world, self.transport = model, int(rank), int(world), transport
         self.planner = planner          # "device": rbpf_shard_plan (production); "host": the numpy specification
@@ -193,12 +200,18 @@ class ShardedFilterSession:
                                          self.prob.N_T, model.nw, self._n_iter())
         if lazy_depth >= 2 and planner != "device":
             raise ValueError("lazy_depth >= 2 needs planner='device'")
-        self.opt = _ffi.rbpf_options(keep_history=0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
-                                     storage=_storage_code(storage))
+        self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth),
+                                     jitter=0.0, storage=_storage_code(storage), exchange_capacity=int(exchange_capacity))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         self._create()
         self.device = torch.device("cuda", torch.cuda.current_device())
+        # Collectives are issued on the library's own stream: kernels and collectives are then ordered on the device and a
+        # step needs ONE host synchronisation (the split sizes of the all_to_all) instead of one per phase.
+        sp = C.c_void_p()
+        check(self.lib.rbpf_stream_get(self.ctx, C.byref(sp)))
+        self.stream = torch.cuda.ExternalStream(sp.value, device=self.device)
+        check(self.lib.rbpf_shard_set_async(self.ctx, 1 if transport == "device" else 0))
         self.N_local, self.N_global = self.prob.N_P, self.prob.N_P * self.world
         self.t = 0
         self.t_norm = 0
@@ -226,21 +239,28 @@ class ShardedFilterSession:
                                          C.byref(self.opt), self.rank, self.world, C.byref(self.ctx)))
 
     # -- collectives -----------------------------------------------------------------------------
+    def _phase_sync(self):
+        if self.sync_phases or self.transport != "device":
+            self.stream.synchronize()
+
     def _gather(self):
         torch, dist = self.torch, self.dist
-        if self.world == 1:
-            self.t_fwd_gather.copy_(self.t_fwd_local)
-        elif self.transport == "device":
-            dist.all_gather_into_tensor(self.t_fwd_gather, self.t_fwd_local)
-        else:
-            h = torch.empty(self.t_fwd_gather.shape, dtype=torch.float64)
-            dist.all_gather_into_tensor(h, self.t_fwd_local.cpu())
-            self.t_fwd_gather.copy_(h)
-        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            if self.world == 1:
+                self.t_fwd_gather.copy_(self.t_fwd_local)
+            elif self.transport == "device":
+                dist.all_gather_into_tensor(self.t_fwd_gather, self.t_fwd_local)
+            else:
+                h = torch.empty(self.t_fwd_gather.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(h, self.t_fwd_local.cpu())
+                self.t_fwd_gather.copy_(h)
+        self._phase_sync()
 
     def _exchange(self, rp, recv_off=0):
         """rp: RankPlan (host planner) or (send_counts, recv_counts) of the device plan.  recv_off: first record of
-        the receive buffer this exchange writes (records persist during a lazy cycle)."""
+        the receive buffer this exchange writes (records persist during a lazy cycle).  Whether the exchange fits the
+        buffers was decided -- identically on every rank -- by rbpf_shard_plan; the host planner repeats that check here
+        for every rank from the replicated plan."""
         torch, dist = self.torch, self.dist
         send_counts, recv_counts = (rp.send_counts, rp.recv_counts) if isinstance(rp, RankPlan) else rp
         ns, nr = int(send_counts.sum()), int(recv_counts.sum())
@@ -254,15 +274,16 @@ class ShardedFilterSession:
             check(self.lib.rbpf_shard_pack(self.ctx, None, ns))
         rp = RankPlan(None, None, None, send_counts, recv_counts)
         t_recv = self.t_recv[recv_off:]
-        if self.transport == "device":
-            exchange_rows(self.t_send, t_recv, rp.send_counts, rp.recv_counts, dist)
-        else:
-            width = int(self.v.record_doubles)
-            hs, hr = self.t_send[:ns].cpu(), torch.empty((nr, width), dtype=torch.float64)
-            exchange_rows(hs, hr, rp.send_counts, rp.recv_counts, dist)
-            if nr:
-                t_recv[:nr].copy_(hr)
-        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            if self.transport == "device":
+                exchange_rows(self.t_send, t_recv, rp.send_counts, rp.recv_counts, dist)
+            else:
+                width = int(self.v.record_doubles)
+                hs, hr = self.t_send[:ns].cpu(), torch.empty((nr, width), dtype=torch.float64)
+                exchange_rows(hs, hr, rp.send_counts, rp.recv_counts, dist)
+                if nr:
+                    t_recv[:nr].copy_(hr)
+        self._phase_sync()
         self.stats["sent_records"] += ns
         self.stats["recv_records"] += nr
 
@@ -312,6 +333,12 @@ class ShardedFilterSession:
                 t2 = time.perf_counter()
                 plan = plan_generation(self.ai, self.cur_rank, self.cur_idx, self.world, self.N_local)
                 rp = rank_view(plan, self.ai, self.cur_rank, self.cur_idx, self.rank, self.world, self.N_local)
+                if self.world > 1 and plan.pair_dest.size:        # every rank checks every rank (the plan is replicated)
+                    rcv = np.bincount(plan.pair_dest, minlength=self.world)
+                    snd = np.bincount(plan.pair_src // self.N_local, minlength=self.world)
+                    if rcv.max() > self.v.recv_capacity or snd.max() > self.v.send_capacity:
+                        raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, "exchange does not fit the record buffers of rank "
+                                             f"{int(np.argmax(np.maximum(rcv, snd)))}: raise exchange_capacity")
                 t3 = time.perf_counter()
                 if self.world > 1:
                     self._exchange(rp)
@@ -327,6 +354,7 @@ class ShardedFilterSession:
             self.stats["steps"] += 1
 
     def sync(self):
+        self.stream.synchronize()
         self.torch.cuda.synchronize()
 
     def reset(self):
@@ -343,17 +371,52 @@ class ShardedFilterSession:
                     scheduled_bytes_per_launch=tm.scheduled_bytes_per_launch)
 
     def finish(self, want=("traj_max", "traj_mean")):
-        """Normalises the last finished step and returns the global trajectory summaries."""
+        """Normalises the last finished step and returns the requested outputs of src/particleFilter.m:220-233 for the GLOBAL
+        filter, identical on every rank: traj_max, traj_mean, xl_max, P_max, xl_mean, P_mean (quirk Q3, as the reference),
+        traj_sample_iwmax (needs keep_history=True), iw_max.  xl_max / P_max / P_mean come from the rank that holds the particle
+        (one small all_reduce); xl_mean is the sum of the ranks' shares."""
         if self.t_norm < self.t:
             self._gather()
             self._normalise(False)
-        nN, T = self.model.nNonLin, self.prob.N_T
+        self.sync()
+        nN, n, T = self.model.nNonLin, self.model.nLin, self.prob.N_T
         out = dict(traj_max=np.full((nN, T), np.nan, order="F"), traj_mean=np.full((nN, T), np.nan, order="F"))
         check(self.lib.rbpf_shard_trajectories(self.ctx, _dp(out["traj_max"]), _dp(out["traj_mean"])))
-        return out
+        extra = [k for k in want if k not in ("traj_max", "traj_mean")]
+        if extra:
+            need_mean = "xl_mean" in want or "P_mean" in want
+            xl_max, P_max = np.zeros(n), np.zeros((n, n), order="F")
+            xl_mean = np.zeros(n)
+            tsi = np.full((nN, self.t), np.nan, order="F") if "traj_sample_iwmax" in want else None
+            iw = C.c_int32(0)
+            check(self.lib.rbpf_shard_finish(self.ctx, 0, _dp(xl_max) if "xl_max" in want else None,
+                                             _dp(P_max) if "P_max" in want else None, _dp(xl_mean) if need_mean else None, None,
+                                             _dp(tsi) if tsi is not None else None, C.byref(iw)))
+            buf = self._all_reduce_host(np.concatenate((xl_max, P_max.ravel(order="F"), xl_mean)))
+            xl_max, P_max, xl_mean = buf[:n], buf[n:n + n * n].reshape((n, n), order="F"), buf[n + n * n:]
+            out.update(xl_max=xl_max, P_max=P_max, xl_mean=xl_mean, iw_max=int(iw.value))
+            if tsi is not None:
+                out["traj_sample_iwmax"] = tsi
+            if "P_mean" in want:
+                P_mean = np.zeros((n, n), order="F")
+                xm = np.ascontiguousarray(xl_mean)
+                check(self.lib.rbpf_shard_finish(self.ctx, 1, None, None, _dp(xm), _dp(P_mean), None, None))
+                out["P_mean"] = self._all_reduce_host(P_mean.ravel(order="F")).reshape((n, n), order="F")
+        return {k: v for k, v in out.items() if k in want or k == "iw_max"}
+
+    def _all_reduce_host(self, vec):
+        """Sum over ranks of a host vector (final extraction only: a few n^2 doubles, once per run)."""
+        if self.world == 1:
+            return np.array(vec, dtype=np.float64)
+        t = self.torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64))
+        if self.transport == "device":
+            t = t.to(self.device)
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
 
     def close(self):
         if self.ctx:
+            self.sync()
             self.t_fwd_local = self.t_fwd_gather = self.t_send = self.t_recv = None
             self.lib.rbpf_destroy(self.ctx)
             self.ctx = C.c_void_p()
@@ -381,7 +444,7 @@ class ShardedSmootherSession(ShardedFilterSession):
     particles bit for bit."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
-                 transport="device"):
+                 transport="device", exchange_capacity=0, sync_phases=False):
         self.N_K = int(N_K)
         lib = load_library()
         for name, argt in (("rbpf_shard_smoother_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
@@ -397,7 +460,8 @@ class ShardedSmootherSession(ShardedFilterSession):
                                                         _ffi.c_int32_p, _ffi.c_int32_p])):
             getattr(lib, name).argtypes = argt
         super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
-                         transport=transport, planner="device", lazy_depth=0)
+                         transport=transport, planner="device", lazy_depth=0, exchange_capacity=exchange_capacity,
+                         sync_phases=sync_phases)
         sv = rbpf_shard_smoother_views()
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
         self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)
@@ -412,15 +476,16 @@ class ShardedSmootherSession(ShardedFilterSession):
 
     def _gather_anc(self):
         torch, dist = self.torch, self.dist
-        if self.world == 1:
-            self.t_anc_gather.copy_(self.t_anc_local)
-        elif self.transport == "device":
-            dist.all_gather_into_tensor(self.t_anc_gather, self.t_anc_local)
-        else:
-            h = torch.empty(self.t_anc_gather.shape, dtype=torch.float64)
-            dist.all_gather_into_tensor(h, self.t_anc_local.cpu())
-            self.t_anc_gather.copy_(h)
-        torch.cuda.synchronize()
+        with torch.cuda.stream(self.stream):
+            if self.world == 1:
+                self.t_anc_gather.copy_(self.t_anc_local)
+            elif self.transport == "device":
+                dist.all_gather_into_tensor(self.t_anc_gather, self.t_anc_local)
+            else:
+                h = torch.empty(self.t_anc_gather.shape, dtype=torch.float64)
+                dist.all_gather_into_tensor(h, self.t_anc_local.cpu())
+                self.t_anc_gather.copy_(h)
+        self._phase_sync()
 
     def advance(self, n_steps):
         raise NotImplementedError("use run()")
@@ -470,11 +535,7 @@ class ShardedSmootherSession(ShardedFilterSession):
             ak, owner = C.c_int32(0), C.c_int32(0)
             check(lib.rbpf_shard_smoother_end(self.ctx, _dp(xnk), _dp(xlk), _dp(pk), C.byref(ak), C.byref(owner)))
             if W > 1:                                      # the owner's rows reach every rank (zeros elsewhere)
-                buf = self.torch.from_numpy(np.concatenate((xlk, pk.ravel(order="F"))))
-                if self.transport == "device":
-                    buf = buf.to(self.device)
-                self.dist.all_reduce(buf)
-                buf = buf.cpu().numpy()
+                buf = self._all_reduce_host(np.concatenate((xlk, pk.ravel(order="F"))))
                 xlk, pk = buf[:n], buf[n:].reshape((n, n), order="F")
             XNK[:, :, k], XLK[:, k], PK[:, :, k] = xnk, xlk, pk
             self.aks.append(int(ak.value))
@@ -483,5 +544,7 @@ class ShardedSmootherSession(ShardedFilterSession):
         return XNK, XLK, PK
 
     def close(self):
+        if self.ctx:
+            self.sync()
         self.t_anc_local = self.t_anc_gather = None
         super().close()
