@@ -157,9 +157,10 @@ typedef struct {
   int32_t trace;         /* 1: record per-step logw / w / ancestor indices (tests)              */
   int32_t fix_p_mean;    /* 0: reproduce quirk Q3 (particleFilter.m:228-230 overwrites P_mean);  *
                           * 1: accumulate it over the particles (the evident intent)            */
-  int32_t lazy_depth;    /* filter only: C >= 2 keeps up to C pending rank-n_y downdates on the fly and rewrites  *
-                          * the stored covariances every C-th step only (C-1 read-only steps in between);      *
-                          * 0/1: rewrite every step.  Results agree to rounding (same algebra).   max 4       */
+  int32_t lazy_depth;    /* filter and information-form smoother: C >= 2 keeps up to C pending rank-n_y downdates on the    *
+                          * fly and rewrites the stored covariances every C-th step only (C-1 read-only steps in         *
+                          * between); 0/1: rewrite every step.  Results agree to rounding (same algebra).  max 4 (filter) *
+                          * / 3 (information form); ignored by the covariance-form and the sharded smoother             */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
   int32_t inplace;       /* filter with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
                           * every flush (the first child of a stored matrix overwrites it after its siblings    *

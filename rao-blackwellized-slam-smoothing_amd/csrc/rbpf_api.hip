@@ -196,6 +196,8 @@ static int dmalloc(T** p, size_t count) {
 
 #define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
 
+static bool ex_smoother_sharded(const CreateExtras* ex, bool smoother) { return ex != nullptr && smoother; }
+
 static bool have_device() {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess && n > 0;
@@ -326,7 +328,9 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     set_error("unknown rng mode"); return RBPF_ERR_INVALID_ARG;
   }
   // ---- particle banks ----
-  c->lazy_depth = (!smoother && !sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, (int)kMaxSets) : 1;
+  // multi-step lazy update: the filter (up to kMaxSets pending sets) and the information-form smoother (up to 3: its step
+  // kernel carries two more right-hand sides); the covariance-form smoother switches it off (smoother_run)
+  c->lazy_depth = (!sparse && !ex_smoother_sharded(ex, smoother) && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (int)kMaxSets) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     const bool can = !smoother && !ex && c->lazy_depth >= 2;
@@ -354,7 +358,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
-    if (step_lds_bytes(c->mdl, c->lay, 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
     for (int b = 0; b <= c->lazy_depth; ++b) {            // entry N of every bank stays zero (fresh lineages)
       RB_TRY(dmalloc(&c->Fb[b], (size_t)(N + 1) * 2 * d * L.ldx));
       HIPCHK(hipMemsetAsync(c->Fb[b], 0, (size_t)(N + 1) * 2 * d * L.ldx * sizeof(double), c->stream));
@@ -611,7 +615,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     }
   }
   a.xn_old = X_old; a.xn_new = X_new;
-  const bool lazy = c->lazy_depth >= 2 && !info && !xref_t;
+  const bool lazy = c->lazy_depth >= 2;
   const int ob = c->cur;
   int nb = (t == 0) ? 0 : (c->cur ^ 1);          // bank the stored covariances are written to (if at all)
   const int xo = c->xcur, xn = (t == 0) ? 0 : (c->xcur ^ 1);

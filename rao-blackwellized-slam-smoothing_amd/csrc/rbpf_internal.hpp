@@ -146,6 +146,7 @@ struct SearchArgs {
 };
 
 size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0, int n_sets = 1);
+bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets);
 Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
 

@@ -107,21 +107,28 @@ template <> __device__ __forceinline__ void st_stream<float>(float* p, dbl2 v) {
 // layout helpers (host + device)
 // ---------------------------------------------------------------------------------------------
 struct LdsPlan {
-  int off_HK, off_xl, off_PHt, off_parts, off_tab, off_misc, off_red, total;  // in doubles
+  int off_HK, off_xl, off_PHt, off_parts, off_tab, off_misc, off_red, off_kst, total;  // in doubles
 };
 
 __host__ __device__ inline int even_up(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ns, int ldx, int CS, int mc, int ktot) {
+constexpr int kKBlock = 64;        // columns per stage of the blocked pending-factor buffer (KB variants of the step kernel)
+
+// kb != 0: the pending column factors K of the NS sets are NOT kept for all n columns (n * NS * D doubles: 74 KB at n = 1027,
+// NS = 2, and 37 KB on top of the information form's 5 right-hand sides at n = 515 -- one workgroup per CU); they pass through a
+// double-buffered stage of kKBlock columns instead, refilled while the previous block streams.  With one column phase
+// (CS == 1) the per-phase partial sums are not needed either: the accumulators go straight to PHt.
+__host__ __device__ inline LdsPlan lds_plan(int n, int d, int e, int ns, int ldx, int CS, int mc, int ktot, int kb = 0) {
   LdsPlan p;
   int o = 0;
-  p.off_HK = o;    o += even_up(n * (d + e + ns * d));
+  p.off_HK = o;    o += even_up(n * (d + e + (kb ? 0 : ns * d)));
   p.off_xl = o;    o += ldx;
   p.off_PHt = o;   o += (d + e) * ldx;
-  p.off_parts = o; o += CS * (d + e) * mc;
+  p.off_parts = o; o += (kb && CS == 1) ? 0 : CS * (d + e) * mc;
   p.off_tab = o;   o += even_up(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o;  o += 64;
   p.off_red = o;   o += kWaves * 16;
+  p.off_kst = o;   o += kb ? 2 * kKBlock * ns * d : 0;
   p.total = o;
   return p;
 }
@@ -134,8 +141,16 @@ Layout make_layout_low_regs(int n, int d) {
   return L;
 }
 
+// The blocked variant is taken when the plain plan would leave one workgroup per CU (> 80 KB) and the wave decomposition
+// has no remainder chunk (every wave runs the same block loop: it contains workgroup barriers).
+bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
+  if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;
+  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, 0).total * sizeof(double) > 80 * 1024;
+}
+
 size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
-  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot).total * sizeof(double);
+  const int kb = step_use_blocked(m, lay, extra, n_sets) ? 1 : 0;
+  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, kb).total * sizeof(double);
 }
 
 Layout make_layout(int n, int d) {
@@ -315,6 +330,123 @@ __device__ __forceinline__ void stream_core(const TS* __restrict__ src, TS* __re
   }
 }
 
+// The same stream with the pending column factors of the NS sets passing through a double-buffered LDS stage of kKBlock
+// columns (KB variants).  All four waves of the workgroup run the block loop together (it has one barrier per block): the
+// factors of block b + 1 are fetched into registers before block b streams and parked in the other stage afterwards.
+// HK holds [H(D) | X(E)] per column only.  acc_ld: row stride of out_acc (mc for the per-phase partials, ldx when the
+// accumulators go straight to PHt).
+template <typename TS, int D, int E, int CPL, int UC, int NS, bool WR>
+__device__ __forceinline__ void stream_core_blocked(const TS* __restrict__ src, TS* __restrict__ dst,
+                                                    const double* __restrict__ HK, double* __restrict__ Kst,
+                                                    const SetPtrs<(NS > 0 ? NS : 1)> Fsets, int ldx, int n, int nb, int mc,
+                                                    int chunk0, int chunk_stride, int CS, int wc, int lane, int tid,
+                                                    double* __restrict__ out_acc, int acc_ld) {
+  constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1;
+  constexpr int kPer = (NDA + 3) / 4;                                   // staged values per thread and block
+  static_assert(kKBlock == 64, "one lane per column of a block");
+  double acc[CPL][2][DE];
+  double ks[CPL][2][NDA];
+  int r0[CPL];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    r0[q] = (chunk0 + q * chunk_stride) * kChunkRows + 2 * lane;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int k = 0; k < DE; ++k) acc[q][e][k] = 0.0;
+#pragma unroll
+      for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+        for (int k = 0; k < D; ++k) ks[q][e][sset * D + k] = Fsets.p[sset][(size_t)k * ldx + nb + r0[q] + e];
+    }
+  }
+  const size_t colstep = (size_t)CS * mc;
+  const int nblk = (n + kKBlock - 1) / kKBlock;
+  // stage entry (column cc of the block, factor k) at cc * ND + k.  Lane l fetches column l of the block; factor k is
+  // fetched by wave k % 4 (static loop, wave-uniform predicate: no dynamic indexing of the set pointers)
+  const int wave_id = tid >> 6;
+  auto fetch = [&](int b, double (&v)[kPer]) {
+    const int c = min(b * kKBlock + lane, n - 1);
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if ((k & 3) == wave_id) v[k >> 2] = Fsets.p[NS > 0 ? k / D : 0][(size_t)(D + k % D) * ldx + c];
+  };
+  auto park = [&](int b, const double (&v)[kPer]) {
+    double* st = Kst + (size_t)(b & 1) * kKBlock * NDA;
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      if ((k & 3) == wave_id) st[(size_t)lane * NDA + k] = v[k >> 2];
+  };
+  double pre[kPer];
+  fetch(0, pre);
+  park(0, pre);
+  __syncthreads();
+  for (int b = 0; b < nblk; ++b) {
+    if (b + 1 < nblk) fetch(b + 1, pre);
+    const double* st = Kst + (size_t)(b & 1) * kKBlock * NDA;
+    const int cb = b * kKBlock, ce = min(n, cb + kKBlock);
+    // first column of this wave inside the block: the smallest c >= cb with c % CS == wc
+    int c = cb + ((wc - cb % CS) + CS) % CS;
+    const TS* sp = src + (size_t)c * mc;
+    TS* dp = dst + (size_t)c * mc;
+    const double* hk = HK + (size_t)c * DE;
+    const int hkstep = CS * DE;
+    for (; c + (UC - 1) * CS < ce; c += UC * CS) {
+      typename Pair<TS>::type v[UC][CPL];
+#pragma unroll
+      for (int u = 0; u < UC; ++u)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) v[u][q] = ld_stream_raw<TS>(sp + u * colstep + r0[q]);
+#pragma unroll
+      for (int u = 0; u < UC; ++u) {
+        double h[DE], kc[NDA];
+#pragma unroll
+        for (int k = 0; k < DE; ++k) h[k] = hk[u * hkstep + k];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) kc[k] = st[(size_t)(c + u * CS - cb) * NDA + k];
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          double p0 = (double)v[u][q].x, p1 = (double)v[u][q].y;
+#pragma unroll
+          for (int k = 0; k < ND; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+#pragma unroll
+          for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+          if (WR) { dbl2 o; o.x = p0; o.y = p1; st_stream(dp + u * colstep + r0[q], o); }
+        }
+      }
+      sp += UC * colstep; dp += UC * colstep; hk += UC * hkstep;
+    }
+    for (; c < ce; c += CS) {
+      double h[DE], kc[NDA];
+#pragma unroll
+      for (int k = 0; k < DE; ++k) h[k] = hk[k];
+#pragma unroll
+      for (int k = 0; k < ND; ++k) kc[k] = st[(size_t)(c - cb) * NDA + k];
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const dbl2 vv = ld_stream(sp + r0[q]);
+        double p0 = vv.x, p1 = vv.y;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) { p0 = fma(-ks[q][0][k], kc[k], p0); p1 = fma(-ks[q][1][k], kc[k], p1); }
+#pragma unroll
+        for (int k = 0; k < DE; ++k) { acc[q][0][k] = fma(p0, h[k], acc[q][0][k]); acc[q][1][k] = fma(p1, h[k], acc[q][1][k]); }
+        if (WR) { dbl2 o; o.x = p0; o.y = p1; st_stream(dp + r0[q], o); }
+      }
+      sp += colstep; dp += colstep; hk += hkstep;
+    }
+    if (b + 1 < nblk) park(b + 1, pre);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+#pragma unroll
+    for (int k = 0; k < DE; ++k) {
+      out_acc[(size_t)k * acc_ld + r0[q]] = acc[q][0][k];
+      out_acc[(size_t)k * acc_ld + r0[q] + 1] = acc[q][1][k];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // dynModel for every slot, one thread per particle (examples/slam-dense-mag/run_dense3D_magfield.m:301-308,
 // examples/slam-dense-radio/run_dense2D_withHeading.m:75-76; particleFilter.m:108).  Kept out of the step
@@ -400,10 +532,11 @@ hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
 // UFX: extra unroll of the covariance stream for float storage when a wave owns two row chunks of WHOLE columns
 // (RS = 4, CS = 1: n >= 1024); measured at n = 1027: 1: 0.62, 2: 0.39, 3: 0.68, 4: 0.76, 6: 0.67, 8: 0.70 M/s.  With
 // CS = 4 (n = 259) the same factor costs a third of the throughput, hence a launch-time choice.
-template <typename TS, int D, int E, int CPL, int NS, bool WR, int UFX = 1>
+// KB: the pending column factors go through the blocked LDS stage (stream_core_blocked) instead of a record per column.
+template <typename TS, int D, int E, int CPL, int NS, bool WR, int UFX = 1, bool KB = false>
 __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const StepArgs a) {
   extern __shared__ double smem[];
-  constexpr int DE = D + E, ND = NS * D, REC = DE + ND, NSA = NS > 0 ? NS : 1;
+  constexpr int DE = D + E, ND = NS * D, REC = KB ? DE : DE + ND, NSA = NS > 0 ? NS : 1;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
@@ -416,8 +549,8 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[8] : i;                         // bank entry the rewritten matrix goes to
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const LdsPlan lp = lds_plan(n, D, E, NS, ldx, Ly.CS, mc, M.ktot);
-  double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol of every pending set [NS][D]
+  const LdsPlan lp = lds_plan(n, D, E, NS, ldx, Ly.CS, mc, M.ktot, KB ? 1 : 0);
+  double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol of every pending set [NS][D] (not with KB)
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;      // [DE][ldx]
   double* parts = smem + lp.off_parts;  // [CS][DE][mc]
@@ -471,18 +604,22 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
         const int c = min(c0 + u * kThreads, n - 1);
         xv[u] = xl_src[c];
         ivv[u] = (E > 0) ? iv[c] : 0.0;
+        if (!KB) {
 #pragma unroll
-        for (int sset = 0; sset < NS; ++sset)
+          for (int sset = 0; sset < NS; ++sset)
 #pragma unroll
-          for (int k = 0; k < D; ++k) kv[u][sset * D + k] = srcFs.p[sset][(size_t)(D + k) * ldx + c];
+            for (int k = 0; k < D; ++k) kv[u][sset * D + k] = srcFs.p[sset][(size_t)(D + k) * ldx + c];
+        }
       }
 #pragma unroll
       for (int u = 0; u < PB; ++u) {
         const int c = c0 + u * kThreads;
         if (c < n) {
           xls[c] = xv[u];
+          if (!KB) {
 #pragma unroll
-          for (int k = 0; k < ND; ++k) HK[c * REC + DE + k] = kv[u][k];
+            for (int k = 0; k < ND; ++k) HK[c * REC + DE + k] = kv[u][k];
+          }
           if (E > 0) HK[c * REC + D] = ivv[u];
         }
       }
@@ -535,14 +672,22 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   // ---- D: stream the covariance once: apply pending downdate, store, accumulate P+ [H' X] ----
   {
     const int wr = wave % Ly.RS, wc = wave / Ly.RS;
-    if (mc > 0 && wc < Ly.CS) {
-      const TS* src = srcT;
-      TS* dst = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
-      // a float load brings half the bytes: twice the columns in flight keep the same bytes outstanding
 #ifndef RBPF_UF32
 #define RBPF_UF32 2
 #endif
-      constexpr int kUF = ((sizeof(TS) == 4 && CPL <= 1) ? RBPF_UF32 : 1) * UFX;
+    // a float load brings half the bytes: twice the columns in flight keep the same bytes outstanding
+    constexpr int kUF = ((sizeof(TS) == 4 && CPL <= 1) ? RBPF_UF32 : 1) * UFX;
+    if (KB) {
+      // every wave of the workgroup runs the block loop (launch-time guarantee: RS * CS == 4 waves, no remainder chunk)
+      const TS* src = srcT;
+      TS* dst = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
+      const bool direct = Ly.CS == 1;                       // one column phase: accumulators go straight to PHt
+      double* out_acc = direct ? PHt + nb : parts + (size_t)wc * DE * mc;
+      stream_core_blocked<TS, D, E, (CPL > 0 ? CPL : 1), kUF * (CPL <= 1 ? RBPF_UC : (CPL == 2 ? RBPF_UC2 : RBPF_UC3)), NS, WR>(
+          src, dst, HK, smem + lp.off_kst, srcFs, ldx, n, nb, mc, wr, Ly.RS, Ly.CS, wc, lane, tid, out_acc, direct ? ldx : mc);
+    } else if (mc > 0 && wc < Ly.CS) {
+      const TS* src = srcT;
+      TS* dst = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
       double* out_acc = parts + (size_t)wc * DE * mc;
       // CPL full rounds of RS chunks (every wave), then one remainder chunk for the first CH % RS waves:
       // both decisions are wave-uniform, so the streaming loops are branch-free
@@ -572,7 +717,11 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
           const int cc = c + e;
           if (cc < n) {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) p[e] = fma(-ksb[k], HK[cc * REC + DE + k], p[e]);
+            for (int k = 0; k < ND; ++k) {
+              // pending column factor K(cc, k): from the per-column record, or (KB) straight from the factor set
+              const double kcv = KB ? srcFs.p[NS > 0 ? k / D : 0][(size_t)(D + k % D) * ldx + cc] : HK[cc * REC + DE + k];
+              p[e] = fma(-ksb[k], kcv, p[e]);
+            }
 #pragma unroll
             for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], HK[cc * REC + k], accb[k]);
           }
@@ -587,7 +736,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     }
   }
   __syncthreads();
-  if (mc > 0) {
+  if (mc > 0 && !(KB && Ly.CS == 1)) {
     // fixed-order combine of the column phases (deterministic)
     for (int r = tid; r < mc; r += kThreads) {
 #pragma unroll
@@ -759,6 +908,19 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   RBPF_KSTAMP(6);
 }
 
+template <typename TS, int D, int E, int CPL, int NS, bool WR, int UFX, bool KB>
+static hipError_t launch_step_k(const StepArgs& a, size_t lds, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR, UFX, KB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR, UFX, KB>), dim3(a.N), dim3(kThreads), lds, s, a);
+  return hipGetLastError();
+}
+
 template <typename TS, int D, int E, int CPL, int NS, bool WR>
 static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
   const size_t lds = step_lds_bytes(a.mdl, a.lay, E, NS);
@@ -766,29 +928,17 @@ static hipError_t launch_step_t(const StepArgs& a, hipStream_t s) {
   // columns per wave and two row chunks (n >= 1024) x4; double storage in the 2 x 2 decomposition (the flush kernel of
   // the lazy update at n = 259) x2 (8.2 vs 7.7 M particle-steps/s at N = 8192)
   constexpr int kWide = (sizeof(TS) == 4 && CPL == 2) ? 4 : ((sizeof(TS) == 8 && CPL == 1 && E == 0) ? 2 : 1);
-  if constexpr (kWide > 1) {
-    const bool wide = (sizeof(TS) == 4) ? (a.lay.CS == 1) : (a.lay.CS == 2 && a.lay.RS == 2);
-    if (wide) {
-      static bool attr_wide = false;
-      if (!attr_wide) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR, kWide>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_wide = true;
-      }
-      hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR, kWide>), dim3(a.N), dim3(kThreads), lds, s, a);
-      return hipGetLastError();
+  bool wide = false;
+  if constexpr (kWide > 1) wide = (sizeof(TS) == 4) ? (a.lay.CS == 1) : (a.lay.CS == 2 && a.lay.RS == 2);
+  // pending factors through the blocked LDS stage when the per-column records would leave one workgroup per CU
+  if constexpr (NS >= 1 && CPL >= 1 && CPL <= 2) {
+    if (step_use_blocked(a.mdl, a.lay, E, NS)) {
+      if constexpr (kWide > 1) { if (wide) return launch_step_k<TS, D, E, CPL, NS, WR, kWide, true>(a, lds, s); }
+      return launch_step_k<TS, D, E, CPL, NS, WR, 1, true>(a, lds, s);
     }
   }
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
-  return hipGetLastError();
+  if constexpr (kWide > 1) { if (wide) return launch_step_k<TS, D, E, CPL, NS, WR, kWide, false>(a, lds, s); }
+  return launch_step_k<TS, D, E, CPL, NS, WR, 1, false>(a, lds, s);
 }
 
 template <typename TS, int D, int E, int NS, bool WR>
@@ -802,15 +952,20 @@ static hipError_t launch_step_cpl(const StepArgs& a, hipStream_t s) {
   }
 }
 
-// multi-step lazy variants (filter only, E = 0): up to kMaxSets pending sets, light (read-only) or flush
-template <typename TS, int D>
+// multi-step lazy variants: up to kMaxSets pending sets (3 for the information form, E = 2), light (read-only) or flush
+template <typename TS, int D, int E>
 static hipError_t launch_step_lazy(const StepArgs& a, hipStream_t s) {
   if (a.lay.CPL < 1 || a.lay.CPL > 2) return hipErrorInvalidValue;
-#define RBPF_LZ(NS_, WR_) (a.lay.CPL == 1 ? launch_step_t<TS, D, 0, 1, NS_, WR_>(a, s) : launch_step_t<TS, D, 0, 2, NS_, WR_>(a, s))
+#define RBPF_LZ(NS_, WR_) (a.lay.CPL == 1 ? launch_step_t<TS, D, E, 1, NS_, WR_>(a, s) : launch_step_t<TS, D, E, 2, NS_, WR_>(a, s))
   if (a.write_base) {
-    switch (a.n_sets) { case 2: return RBPF_LZ(2, true); case 3: return RBPF_LZ(3, true); case 4: return RBPF_LZ(4, true); default: break; }
+    switch (a.n_sets) {
+      case 2: return RBPF_LZ(2, true);
+      case 3: return RBPF_LZ(3, true);
+      case 4: if constexpr (E == 0) return RBPF_LZ(4, true); else break;
+      default: break;
+    }
   } else {
-    switch (a.n_sets) { case 1: return RBPF_LZ(1, false); case 2: return RBPF_LZ(2, false); case 3: return RBPF_LZ(3, false); default: break; }
+    switch (a.n_sets) { case 1: return RBPF_LZ(1, false); case 2: return RBPF_LZ(2, false); case 3: if constexpr (E == 0) return RBPF_LZ(3, false); else break; default: break; }
   }
 #undef RBPF_LZ
   return hipErrorInvalidValue;
@@ -823,13 +978,17 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   if (a.fp32) {
     // fp32 storage of the covariance banks: filter only (E = 0), dense-mag outputs (D = 3)
     if (a.info || D != 3) return hipErrorInvalidValue;
-    if (!legacy) return launch_step_lazy<float, 3>(a, s);
+    if (!legacy) return launch_step_lazy<float, 3, 0>(a, s);
     return a.n_sets ? launch_step_cpl<float, 3, 0, 1, true>(a, s) : launch_step_cpl<float, 3, 0, 0, true>(a, s);
   }
   if (!legacy) {
-    if (a.info) return hipErrorInvalidValue;
-    if (D == 3) return launch_step_lazy<double, 3>(a, s);
-    if (D == 1) return launch_step_lazy<double, 1>(a, s);
+    if (a.info) {                                          // information form: lazy_depth <= 3 (flush with 2 or 3 sets)
+      if (D == 3) return launch_step_lazy<double, 3, 2>(a, s);
+      if (D == 1) return launch_step_lazy<double, 1, 2>(a, s);
+      return hipErrorInvalidValue;
+    }
+    if (D == 3) return launch_step_lazy<double, 3, 0>(a, s);
+    if (D == 1) return launch_step_lazy<double, 1, 0>(a, s);
     return hipErrorInvalidValue;
   }
   if (a.info) {

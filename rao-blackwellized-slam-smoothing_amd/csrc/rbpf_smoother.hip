@@ -785,6 +785,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   hipStream_t st = c->stream;
   SmootherState* s = new SmootherState();
   c->sm = s;
+  if (!info_form) c->lazy_depth = 1;          // the covariance form reads the flushed covariances of every particle every step
   const bool generic = c->mdl.kind == RBPF_MODEL_GENERIC_DENSE;
   const bool drn_cb = generic && c->cb.dyn_res_norm != nullptr;      // the handle; otherwise isempty(dynResNorm)
   if (generic) c->mdl.use_dyn_res_norm = 0;                          // device side: only the additive default exists
@@ -1001,11 +1002,12 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       const int cur = c->cur;
       HIPCHK(hipMemcpy(xnk_h.data(), s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
       if (out->XNK) std::memcpy(out->XNK + (size_t)k * nN * T, xnk_h.data(), (size_t)nN * T * 8);
-      if (out->XLK) HIPCHK(hipMemcpy(out->XLK + (size_t)k * n, c->xl[cur] + (size_t)ak * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
+      (void)cur;
+      if (out->XLK) HIPCHK(hipMemcpy(out->XLK + (size_t)k * n, c->xl[c->xcur] + (size_t)ak * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
       if (out->PK) {
         double* dP = nullptr;
         RB_TRY(dmalloc(&dP, (size_t)n * n));
-        hipError_t e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], s->d_ak, 1, dP, st);
+        hipError_t e = (ctx_unpack(c, s->d_ak, 1, dP) == RBPF_OK) ? hipSuccess : hipErrorUnknown;   // pending downdates applied
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e == hipSuccess) e = hipMemcpy(out->PK + (size_t)k * n * n, dP, (size_t)n * n * 8, hipMemcpyDeviceToHost);
         hipFree(dP);

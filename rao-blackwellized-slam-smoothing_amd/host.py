@@ -650,7 +650,7 @@ def model_dyn_res_norm(dynModel):
 
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-              sparseFeatures, makePlots, rng, extras, chol_variant=0):
+              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -669,7 +669,7 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
     if isinstance(model, GenericDenseModel) and isinstance(rng, ReplayRNG) and (rng.Z is None or rng.Z.size == 0):
         rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
-    opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=0, jitter=0.0,
+    opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
                             chol_variant=int(chol_variant))
     mdesc = model.descriptor(use_dyn_res_norm=use_drn)
     o = _ffi.rbpf_smoother_out()
@@ -718,10 +718,11 @@ def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
-                                    chol_variant=0):
-    """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK)."""
+                                    chol_variant=0, lazy_depth=0):
+    """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
+    covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth)
 
 
 def sample(w, u):

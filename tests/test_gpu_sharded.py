@@ -196,12 +196,14 @@ def _worker_full(rank, world, port, T, m, n_local, lazy_depth, q):
             s.advance(T)
             out = s.finish(want=FULL)
         q.put((rank, out))
+    except Exception as exc:                                   # fail fast instead of letting the parent time out
+        q.put((rank, exc))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lazy_depth", [0, 3])
-@pytest.mark.parametrize("m,n_local", [(130, 24), (16, 200)])
+@pytest.mark.parametrize("m,n_local,lazy_depth", [(130, 24, 0), (16, 200, 0), (130, 24, 3), (125, 160, 2)])
 def test_two_ranks_return_the_full_particle_filter_output_set(m, n_local, lazy_depth):
     """xl_max, P_max, xl_mean, P_mean (quirk Q3: the last logical particle's term) and traj_sample_iwmax of the GLOBAL filter
     from the sharded session, on every rank, against the single-GPU run with N = 2 * N_local particles."""
@@ -215,7 +217,8 @@ def test_two_ranks_return_the_full_particle_filter_output_set(m, n_local, lazy_d
     res = dict(q.get(timeout=240) for _ in range(2))
     for p in procs:
         p.join(120)
-        assert p.exitcode == 0
+    for r in (0, 1):
+        assert not isinstance(res[r], Exception), res[r]
     rbpf, d, mdl, x0, P0, R = _problem(T, m)
     with rbpf.FilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, 2 * n_local, 0.01, rng=rbpf.PhiloxRNG(11),
                             keep_history=True) as s:
@@ -249,9 +252,13 @@ def _worker_skew(rank, world, port, n_local, cap, q):
         with mg.ShardedFilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, n_local, 0.01, rng=rbpf.PhiloxRNG(11),
                                      rank=rank, world=world, transport="host", exchange_capacity=cap) as s:
             s.advance(2)
-            # every child descends from a DISTINCT particle of rank 0: rank 0 keeps n_local children, the other n_local
-            # migrate to rank 1 with n_local distinct records -- the worst case for the record buffers
-            ai = (np.arange(N) % n_local).astype(np.int32)
+            # every child descends from a DISTINCT particle that currently lives on rank 0: rank 0 keeps n_local children,
+            # the other n_local migrate to rank 1 with n_local distinct records -- the worst case for the record buffers
+            gid = np.empty(N, dtype=np.int32)
+            mg.check(s.lib.rbpf_shard_plan_read(s.ctx, None, None, None, 0, gid.ctypes.data_as(C.POINTER(C.c_int32))))
+            on0 = np.nonzero(gid // n_local == 0)[0]
+            assert on0.size == n_local
+            ai = on0[np.arange(N) % n_local].astype(np.int32)
             s._gather()
             mg.check(s.lib.rbpf_shard_normalise_search(s.ctx, None, s.ai.ctypes.data_as(C.POINTER(C.c_int32))))
             s.t_norm += 1
@@ -269,6 +276,9 @@ def _worker_skew(rank, world, port, n_local, cap, q):
             except rbpf.RBPFError as exc:
                 status, msg, ok = exc.status, str(exc), False
             q.put((rank, status, msg, ok, cnt.tolist()))
+    except Exception as exc:
+        q.put((rank, -1, repr(exc), False, []))
+        raise
     finally:
         dist.destroy_process_group()
 

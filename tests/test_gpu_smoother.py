@@ -172,3 +172,20 @@ def test_smoother_makePlots_runs_after_every_iteration(rbpf):
     with pytest.raises(KeyError):
         rbpf.particleSmoother(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
                               c["N_P"], 2, c["dt"], False, bad, rng=cases.device_rng(rbpf, c))
+
+
+@pytest.mark.parametrize("lazy_depth", [2, 3])
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 7, 8, 130), ("mag", 6, 7, 256), ("mag", 6, 7, 512), ("radio", 9, 9, 128),
+                                            ("radio", 8, 8, 140)])
+def test_information_form_smoother_with_the_lazy_covariance_update(rbpf, kind, N_P, N_T, m, lazy_depth):
+    """rbpf_options.lazy_depth in particleSmootherInformationForm: the stored covariances are rewritten every C-th step only,
+    the pending rank-ny downdates of :331 applied on the fly (at nLin = 515 with the pending factors passing through the
+    blocked LDS stage).  Same algebra -> the oracle's ancestors bit for bit and its numbers to 1e-9."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=53, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    out = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
+                                               c["Q"], R, N_P, 3, c["dt"], rng=cases.device_rng(rbpf, c), extras=True,
+                                               lazy_depth=lazy_depth)
+    check(ref, out, 3)
