@@ -286,9 +286,10 @@ def _worker_skew(rank, world, port, n_local, cap, q):
 @pytest.mark.parametrize("cap,fits", [(0, True), (8, False)])
 def test_skewed_exchange_is_agreed_on_by_every_rank(cap, fits):
     """an exchange that does not fit a rank's record buffers must fail on EVERY rank before any collective is
-    issued (the plan is replicated), never hang the peers in all_to_all.  All 32 children of a step descend from the 32
-    particles of rank 0, so 32 records have to reach rank 1: fine with the default capacity, an error on both ranks --
-    also on rank 0, whose own buffers would do -- with exchange_capacity = 8."""
+    issued (the plan is replicated), never hang the peers in all_to_all.  All 64 children of a step descend from the 32
+    particles of rank 0 (two each); the 32 children of the last 16 of them migrate, so 16 distinct records have to reach
+    rank 1: fine with the default capacity, an error on both ranks -- also on rank 1, which only receives -- with
+    exchange_capacity = 8."""
     n_local = 32
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -309,4 +310,5 @@ def test_skewed_exchange_is_agreed_on_by_every_rank(cap, fits):
         else:
             assert status == rbpf.RBPF_ERR_OUT_OF_MEMORY and "exchange_capacity" in msg, msg
     if fits:
-        assert res[0][4][1] == n_local and res[1][4][2] == n_local                # rank 0 sends 32 records to rank 1
+        assert res[0][4][1] == n_local // 2 and res[1][4][2] == n_local // 2      # rank 0 sends 16 records to rank 1
+        assert res[0][4][4] == n_local                                            # 32 children migrate
