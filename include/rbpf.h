@@ -174,6 +174,13 @@ typedef struct {
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
                           * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 as  *
                           * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
+  int32_t chol_refresh;  /* information-form smoother: 0 / 1 = factorise Imat_i + ImatAddt from scratch at every step, as           *
+                          * particleSmootherInformationForm.m:228 does (default).  K > 1: CARRY the factor along every lineage   *
+                          * -- per step n_y rank-1 updates (the particle's own H' R^-1 H) and n_y rank-1 downdates (the reference *
+                          * trajectory's term leaving ImatAddt) of the ancestor's factor, O(n^2) instead of n^3/3, the forward     *
+                          * solve carried as an augmented row -- and refactorise from the exactly carried Imat every K-th step.     *
+                          * Same algebra, different arithmetic: ancestor probabilities agree with the default to ~1e-10 (measured   *
+                          * bounds in tests/test_gpu_chol_carry.py and DESIGN.md), not bit-wise.  nLin <= 575, unsharded.           */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
                           * 0: min(N_local, max(1024, N_local / 4)).  A step that needs more fails on EVERY rank with         *

@@ -1195,3 +1195,59 @@ def ekf_dense(model, LL, odometry, y, x0, q0, P0, Q, R, dt):
         xf[3:6] = 0.0
         xf_traj[:, t], Pf_traj[:, :, t], qnb_traj[:, t] = xf, Pf, q_nb
     return xf_traj, qnb_traj, Pf_traj
+
+
+# --------------------------------------------------------------------------------------
+# acceptance metrics of the example scripts
+# --------------------------------------------------------------------------------------
+def procrustes_oracle(X, Y):
+    """MATLAB's procrustes(X, Y) with its default options (scaling and reflection allowed), the function
+    examples/slam-sparse-visual/calc_rmses.m:38 and run_dense3D_magfield.m:160-161 call.  It is a Statistics-Toolbox
+    function, absent from the reference tree; this restates its published definition by a route of its own -- the orthogonal
+    factor of the polar decomposition via the symmetric eigenproblem of A'A instead of an SVD: with X0, Y0 centred and scaled
+    to unit Frobenius norm and A = X0'Y0, T = (A'A)^(-1/2) A' maximises trace(T A), b = trace((A'A)^(1/2)) |X| / |Y|,
+    d = 1 - trace((A'A)^(1/2))^2, Z = |X| trace(.) Y0 T + mean(X), c = mean(X) - b mean(Y) T.  Needs X0'Y0 of full rank
+    (a planar truth against a 3-D estimate leaves the rotation about the plane's normal undetermined in any formulation)."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    muX, muY = X.mean(axis=0), Y.mean(axis=0)
+    X0, Y0 = X - muX, Y - muY
+    nX, nY = math.sqrt(float(np.sum(X0 * X0))), math.sqrt(float(np.sum(Y0 * Y0)))
+    X0, Y0 = X0 / nX, Y0 / nY
+    A = X0.T @ Y0
+    lam, V = np.linalg.eigh(A.T @ A)
+    root = np.sqrt(np.maximum(lam, 0.0))
+    T = V @ np.diag(1.0 / root) @ V.T @ A.T                   # (A'A)^(-1/2) A'
+    tr = float(np.sum(root))
+    b = tr * nX / nY
+    d = 1.0 - tr * tr
+    Z = nX * tr * (Y0 @ T) + muX
+    c = muX - b * (muY @ T)
+    return d, Z, dict(b=b, T=T, c=c)
+
+
+def calc_rmses_oracle(truth, estimate, map_true, map_est, traj, traj_est):
+    """examples/slam-sparse-visual/calc_rmses.m:35-55 -> (rmse_path, rmse_map); the angle RMSE is NaN by construction (:44)."""
+    _, _, tr = procrustes_oracle(truth, estimate)                                       # :38
+    Z = tr["b"] * np.asarray(traj_est)[:, 0:2] @ tr["T"] + tr["c"]                       # :41
+    Zm = tr["b"] * np.asarray(map_est) @ tr["T"] + tr["c"]                               # :47
+    d = np.sqrt(np.sum((np.asarray(traj)[:, 0:2] - Z) ** 2, axis=1))                     # :50
+    dm = np.sqrt(np.sum((np.asarray(map_true) - Zm) ** 2, axis=1))                       # :57
+    return math.sqrt(float(np.mean(d ** 2))), math.sqrt(float(np.mean(dm ** 2)))
+
+
+def quat2euler_oracle(q):
+    """tools/quat2euler.m:26-34, one quaternion, degrees."""
+    q0, q1, q2, q3 = (float(v) for v in np.asarray(q, dtype=np.float64).ravel())
+    return 180.0 / math.pi * np.array([math.atan2(2 * q2 * q3 - 2 * q0 * q1, 2 * q0 ** 2 + 2 * q3 ** 2 - 1),
+                                       -math.asin(max(-1.0, min(1.0, 2 * q1 * q3 + 2 * q0 * q2))),
+                                       math.atan2(2 * q1 * q2 - 2 * q0 * q3, 2 * q0 ** 2 + 2 * q1 ** 2 - 1)])
+
+
+def rmse_dense_mag_oracle(pos_true, quat_true, traj):
+    """run_dense3D_magfield.m:160-181 for one trajectory estimate [7 x T]."""
+    pos_true = np.asarray(pos_true, dtype=np.float64)
+    _, Z, _ = procrustes_oracle(pos_true.T, np.asarray(traj)[0:3, :].T)
+    rmse_pos = np.sqrt(np.mean((pos_true.T - Z) ** 2, axis=0))
+    err = np.stack([quat2euler_oracle(qLeft(np.asarray(traj)[3:7, ii]) @ qInv(np.asarray(quat_true)[ii])) for ii in range(np.asarray(traj).shape[1])])
+    return rmse_pos, np.sqrt(np.mean(err ** 2, axis=0))

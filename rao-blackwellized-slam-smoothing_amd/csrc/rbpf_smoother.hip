@@ -42,6 +42,11 @@ struct SmootherState {
   int* d_ak = nullptr;
   double* d_ivec0 = nullptr;    // [ldx] initial information vector (:110)
   double* d_hld0 = nullptr;     // [1]
+  // carried ancestor-weight factors (rbpf_options.chol_refresh > 1)
+  double* d_Lsw[2] = {nullptr, nullptr};    // [N][sweep_factor_doubles(n)] factor banks in sweep layout, ping-pong
+  double* d_W = nullptr;        // [d x d] whitening factor: W' W = R^-1
+  int sw_cur = 0;
+  int refresh = 0;              // K (0 / 1: off)
   int icur = 0;                 // ping-pong index of ivec / hld / qf / Hb
   int imat_cur = 0;
   bool imat_valid = false;      // false until the first gather of an iteration (Imat = Imat0)
@@ -60,7 +65,7 @@ void smoother_free(rbpf_ctx* c) {
   hipFree(s->d_Pfull); hipFree(s->d_G); hipFree(s->d_S); hipFree(s->d_L); hipFree(s->d_e);
   for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
   hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
-  hipFree(s->d_Rinv);
+  hipFree(s->d_Rinv); hipFree(s->d_Lsw[0]); hipFree(s->d_Lsw[1]); hipFree(s->d_W);
   delete s;
   c->sm = nullptr;
 }
@@ -586,6 +591,7 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 
 #include "rbpf_chol64.hpp"
 #include "rbpf_chol_small.hpp"
+#include "rbpf_chol_sweep.hpp"
 
 // batched ancestor-weight factorisation: d_lds = number of pending-update rows kept in LDS (mode 1: n_y, mode 0: 0).
 // Matrices of more than 11 row tiles (n >= 176) take the 64-column kernel (rbpf_chol64.hpp; 4 waves and two workgroups per
@@ -870,6 +876,31 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
     RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
     RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
+    s->refresh = c->opt.chol_refresh > 1 ? c->opt.chol_refresh : 0;
+    if (s->refresh) {
+      if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds) { set_error("chol_refresh > 1 supports nLin <= 575"); return RBPF_ERR_UNSUPPORTED; }
+      for (int b = 0; b < 2; ++b) RB_TRY(dmalloc(&s->d_Lsw[b], (size_t)N * sweep_factor_doubles(n)));
+      RB_TRY(dmalloc(&s->d_W, (size_t)d * d));
+      // W = inv(chol(R,'lower')): W' W = R^-1, so H' R^-1 H = sum_a (W H)_a' (W H)_a
+      std::vector<double> Lr((size_t)d * d, 0.0), Wm((size_t)d * d, 0.0);
+      for (int j = 0; j < d; ++j) {
+        double sd = Rh[j + (size_t)d * j];
+        for (int q = 0; q < j; ++q) sd -= Lr[j + (size_t)d * q] * Lr[j + (size_t)d * q];
+        Lr[j + (size_t)d * j] = std::sqrt(sd);
+        for (int i = j + 1; i < d; ++i) {
+          double v = Rh[i + (size_t)d * j];
+          for (int q = 0; q < j; ++q) v -= Lr[i + (size_t)d * q] * Lr[j + (size_t)d * q];
+          Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
+        }
+      }
+      for (int col = 0; col < d; ++col)
+        for (int i = 0; i < d; ++i) {
+          double v = (i == col);
+          for (int q = 0; q < i; ++q) v -= Lr[i + (size_t)d * q] * Wm[q + (size_t)d * col];
+          Wm[i + (size_t)d * col] = v / Lr[i + (size_t)d * i];
+        }
+      HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+    }
   }
   // information-form initial values (quirk Q5: diagonal of P0 only, :110-115)
   std::vector<double> ivec0(L.ldx, 0.0), Imat0((size_t)n * n, 0.0);
@@ -967,10 +998,35 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d,
                              t - 1, t, -1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
           HIPCHK(hipGetLastError());
-          RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
+          const bool carry = s->refresh > 1;
+          const bool fresh = !carry || t == 1 || ((t - 1) % s->refresh) == 0;
+          if (carry && !fresh) {
+            // carried factors: the exactly carried Imat is advanced on its own (the refresh reads it), then one sweep per
+            // particle turns the ancestor's factor into this particle's and adds logwMeas (rbpf_chol_sweep.hpp)
+            const int ni = s->imat_cur ^ 1;
+            HIPCHK(launch_imat_gather(n, d, L.ldx, N, s->d_Imat[s->imat_cur], (long)((size_t)n * n), c->A + (size_t)(t - 1) * N,
+                                      s->d_Hb[s->icur], d_Rinv, s->d_Imat[ni], st));
+            s->imat_cur = ni;
+            SweepArgs sw;
+            sw.n = n; sw.d = d; sw.ldx = L.ldx; sw.NS = sweep_slots(n); sw.N = N; sw.ref_slot = N - 1;
+            sw.Lold = s->d_Lsw[s->sw_cur]; sw.Lnew = s->d_Lsw[s->sw_cur ^ 1]; sw.stride = sweep_factor_doubles(n);
+            sw.anc = c->A + (size_t)(t - 1) * N; sw.Hb = s->d_Hb[s->icur]; sw.Href = s->d_dyref + (size_t)(t - 1) * d * n;
+            sw.W = s->d_W; sw.yt = c->d_y + (size_t)(t - 1) * d; sw.qf = s->d_qf[s->icur]; sw.hld = s->d_hld[s->icur];
+            sw.pant_log = s->d_pant_log; sw.status = c->d_flags;
+            HIPCHK(launch_chol_sweep(sw, st));
+            s->sw_cur ^= 1;
+            skip_chol = true;
+          } else {
+            RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
+            if (carry) ca.variant = 64;            // the refresh reads the factor back in the 64-column kernel's layout
+          }
         }
         if (!skip_chol) HIPCHK(launch_chol(ca, N, ca.mode == 1 ? d : 0, st));
         HIPCHK(hipGetLastError());
+        if (info_form && s->refresh > 1 && !skip_chol) {                    // fresh factors -> sweep layout
+          HIPCHK(launch_sweep_from_chol64(n, N, s->d_L, chol_factor_doubles(n), s->d_Lsw[s->sw_cur ^ 1], sweep_factor_doubles(n), st));
+          s->sw_cur ^= 1;
+        }
         // normalise (:236-238), sample ai(N_P) (:241)
         RB_TRY(normalise_draw_one(c, N, t, k, s->d_pant_log, s->d_pant + (c->opt.trace ? ((size_t)k * T + t) * N : 0), s->d_wc2, N - 1,
                                   c->d_U ? c->d_U + ((size_t)k * (T - 1) + (t - 1)) * N : nullptr, c->A + (size_t)t * N, st));
@@ -1136,6 +1192,7 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     return RBPF_ERR_INVALID_ARG;
   }
   if (n > 1023) { set_error("information-form smoother supports nLin <= 1023"); return RBPF_ERR_UNSUPPORTED; }
+  if (opt && opt->chol_refresh > 1) { set_error("chol_refresh > 1 (carried factors) is not available in the sharded smoother"); return RBPF_ERR_UNSUPPORTED; }
   SmootherState* s = new SmootherState();
   c->sm = s;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));

@@ -53,9 +53,30 @@ def _axis_tables(NN, L, x):
     return S, Cc
 
 
-def curl_free_field_draw(x, m, LL, theta, rs):
+def _device_field(kind, NN, L, x, foo, chunk=512):
+    """The reduced-rank field at the points x from the DEVICE basis kernels: the simulation basis (2000
+    functions in the reference) is just another measModel of the family -- H(x) @ foo with the identity attitude -- so the
+    a7 / a8 kernels evaluate it (rbpf_meas_model); the host only draws the coefficients and adds the noise."""
+    from . import host
+    if kind == "mag":
+        mdl = host.DenseMagModel(NN, L)
+        xn = np.zeros((7, x.shape[0]))
+        xn[0:3], xn[3] = x.T, 1.0                               # q = [1 0 0 0]: Rnb = I
+    else:
+        mdl = host.DenseRadioModel(NN, L)
+        xn = np.zeros((3, x.shape[0]))
+        xn[0:2] = x.T
+    out = []
+    for i0 in range(0, x.shape[0], chunk):                        # [npts x ny x nLin] in chunks: 48 KB per point at m = 2000
+        dy = mdl.measModel(xn[:, i0:i0 + chunk])
+        out.append(dy @ foo)
+    return np.concatenate(out, axis=0)
+
+
+def curl_free_field_draw(x, m, LL, theta, rs, device=False):
     """Gradient-field draw of tools/gp_rnd_scalar_potential_fast.m:42-102 at points x [npts x 3]:
-    returns (df, y) = (true field, field + sqrt(sigma2) * noise)."""
+    returns (df, y) = (true field, field + sqrt(sigma2) * noise).  device=True evaluates the m basis functions with the HIP
+    measurement-model kernel instead of the numpy tables (same numbers to ~1e-12)."""
     LL = np.asarray(LL, dtype=np.float64)
     x = np.asarray(x, dtype=np.float64) - LL.mean(axis=0)
     L, NN = domain_cartesian_dx(m, 3, (LL.max(axis=0) - LL.min(axis=0))[None, :] / 2.0)
@@ -63,6 +84,9 @@ def curl_free_field_draw(x, m, LL, theta, rs):
     linSigma2, lengthScale, magnSigma2, sigma2 = (float(t) for t in np.asarray(theta).ravel())
     Sse = magnSigma2 * math.sqrt(2 * math.pi) ** 3 * lengthScale ** 3 * np.exp(-lam * lengthScale ** 2 / 2)
     foo = np.sqrt(np.concatenate(([linSigma2] * 3, Sse))) * rs.standard_normal(m + 3)
+    if device:
+        df = _device_field("mag", NN, L, x, foo)
+        return df, df + math.sqrt(sigma2) * rs.standard_normal(df.shape)
     S, Cc = _axis_tables(NN, L, x)
     amp = 1.0 / np.sqrt(L)
     dfac = np.pi * NN / (2.0 * L * np.sqrt(L))                      # [m x 3]
@@ -76,8 +100,9 @@ def curl_free_field_draw(x, m, LL, theta, rs):
     return df, y
 
 
-def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0):
-    """generateData_dense.m 'bean_6D' scaled to N_T samples -> dict(dx, initState, y, LL, pos, quat)."""
+def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0, device=False):
+    """generateData_dense.m 'bean_6D' scaled to N_T samples -> dict(dx, initState, y, LL, pos, quat).  device=True: the field
+    draw's m_sim basis functions are evaluated by the HIP kernels."""
     rs = np.random.RandomState(seed)
     psi = np.linspace(0.0, laps * np.pi, N_T)
     r = a * np.sin(psi) ** 3 + a * np.cos(psi) ** 3
@@ -95,7 +120,7 @@ def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0):
     ls = float(np.asarray(theta).ravel()[1])
     LL = np.array([[pos[0].min() - nLL * ls, pos[1].min() - nLL * ls, -nLL * ls],
                    [pos[0].max() + nLL * ls, pos[1].max() + nLL * ls, nLL * ls]])
-    _, yn = curl_free_field_draw(pos.T, m_sim, LL, theta, rs)
+    _, yn = curl_free_field_draw(pos.T, m_sim, LL, theta, rs, device=device)
     y = np.stack([_quat2rmat(quat[i]).T @ yn[i] for i in range(N_T)], axis=0)
     # noisy odometry: push the truth through dynModel (run_dense3D_magfield.m:301-308)
     Q = np.asarray(Q, dtype=np.float64)
@@ -113,8 +138,9 @@ def bean_6D(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=2, laps=3, a=15.0):
     return dict(dx=dx, initState=initState, y=y, LL=LL, pos=pos, quat=quat)
 
 
-def scalar_field_draw(x, m, LL, theta, rs):
-    """Scalar-field draw of tools/gp_rnd_SE1D_fast.m:44-85 at points x [npts x 2]: returns (f, y)."""
+def scalar_field_draw(x, m, LL, theta, rs, device=False):
+    """Scalar-field draw of tools/gp_rnd_SE1D_fast.m:44-85 at points x [npts x 2]: returns (f, y).  device=True: basis on the
+    HIP kernels."""
     LL = np.asarray(LL, dtype=np.float64)
     x = np.asarray(x, dtype=np.float64) - LL.mean(axis=0)
     L, NN = domain_cartesian_dx(m, 2, (LL.max(axis=0) - LL.min(axis=0))[None, :] / 2.0)
@@ -123,6 +149,9 @@ def scalar_field_draw(x, m, LL, theta, rs):
     k = magnSigma2 * math.sqrt(2 * math.pi) ** 2 * lengthScale ** 2 * np.exp(-lam * lengthScale ** 2 / 2)
     foo = np.sqrt(k) * rs.standard_normal(m)
     noise = rs.standard_normal(x.shape[0])
+    if device:
+        f = _device_field("radio", NN, L, x, foo)
+        return f, f + math.sqrt(sigma2) * noise
     S, _ = _axis_tables(NN, L, x)
     amp = 1.0 / np.sqrt(L)
     f = ((S[0][:, NN[:, 0]] * amp[0]) * (S[1][:, NN[:, 1]] * amp[1])) @ foo
@@ -140,7 +169,7 @@ def radio_Q(N_T, traj="line_3D"):
     return Q.reshape(1, 1, N_T)
 
 
-def planar_heading(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=4, traj="line_3D"):
+def planar_heading(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=4, traj="line_3D", device=False):
     """generateData_dense.m 'line_3D' (:113-132) / 'square_3D' (:101-112) with N = N_T points, scalar field
     (:258-290), odometry noise on the heading by running dynModel forward (:310-323;
     run_dense2D_withHeading.m:75-76) -> dict(dx, initState, y [N_T x 1], LL, pos)."""
@@ -160,7 +189,7 @@ def planar_heading(N_T, Q, theta, dt, seed=1, m_sim=2000, nLL=4, traj="line_3D")
     ls = float(np.asarray(theta).ravel()[0])
     LL = np.array([[pos[0].min() - nLL * ls, pos[1].min() - nLL * ls],
                    [pos[0].max() + nLL * ls, pos[1].max() + nLL * ls]])
-    _, y = scalar_field_draw(pos.T, m_sim, LL, theta, rs)
+    _, y = scalar_field_draw(pos.T, m_sim, LL, theta, rs, device=device)
     Q = np.asarray(Q, dtype=np.float64).reshape(1, 1, -1)
     dtv = np.broadcast_to(np.asarray(dt, dtype=np.float64).ravel(), (1,)) if np.ndim(dt) == 0 else np.asarray(dt)
     zo = rs.standard_normal(N - 1)

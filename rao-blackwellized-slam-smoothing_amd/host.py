@@ -650,7 +650,7 @@ def model_dyn_res_norm(dynModel):
 
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0):
+              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -670,7 +670,7 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
         rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
-                            chol_variant=int(chol_variant))
+                            chol_variant=int(chol_variant), chol_refresh=int(chol_refresh))
     mdesc = model.descriptor(use_dyn_res_norm=use_drn)
     o = _ffi.rbpf_smoother_out()
     b = dict(XNK=np.full((nN, T, N_K), np.nan, order="F"), XLK=np.full((n, N_K), np.nan, order="F"),
@@ -718,11 +718,13 @@ def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
-                                    chol_variant=0, lazy_depth=0):
+                                    chol_variant=0, lazy_depth=0, chol_refresh=0):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
-    covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding)."""
+    covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
+    chol_refresh = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1 up/down-dates and
+    recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh)
 
 
 def sample(w, u):

@@ -126,3 +126,40 @@ def test_procrustes_recovers_a_similarity_transform(rbpf):
     np.testing.assert_allclose(tr["T"], T, atol=1e-12)
     rp, rm = mt.calc_rmses(X, Y, X[:5], Y[:5])
     assert rp < 1e-12 and rm < 1e-12
+
+
+def test_acceptance_metrics_match_the_oracle(rbpf, oracle):
+    """the product's Procrustes-aligned RMSEs (examples/slam-sparse-visual/calc_rmses.m:35-55,
+    run_dense3D_magfield.m:155-181) against the oracle's restatement (a different route to the same definition), and a
+    known answer: a similarity transform of the truth is undone exactly."""
+    import importlib
+    M = importlib.import_module(rbpf.__name__ + ".metrics")
+    rs = np.random.RandomState(8)
+    mp = rs.standard_normal((20, 2)) * 3
+    th = 0.7
+    Rm = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    traj = np.column_stack((np.cumsum(rs.standard_normal((50, 2)) * 0.2, axis=0), rs.standard_normal(50)))
+    map_est = 1.7 * mp @ Rm + np.array([0.3, -2.0]) + 0.05 * rs.standard_normal(mp.shape)
+    traj_est = np.column_stack((1.7 * traj[:, 0:2] @ Rm + np.array([0.3, -2.0]) + 0.05 * rs.standard_normal((50, 2)), traj[:, 2]))
+    got = M.calc_rmses(mp, map_est, traj, traj_est)
+    want = oracle.calc_rmses_oracle(mp, map_est, mp, map_est, traj, traj_est)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    d, Z, tr = M.procrustes(mp, 1.7 * mp @ Rm + np.array([0.3, -2.0]))                  # exact similarity: undone exactly
+    assert d < 1e-14 and np.max(np.abs(Z - mp)) < 1e-12 and abs(tr["b"] - 1 / 1.7) < 1e-12
+    d2, Z2, tr2 = oracle.procrustes_oracle(mp, map_est)
+    d1, Z1, tr1 = M.procrustes(mp, map_est)
+    assert abs(d1 - d2) < 1e-12 and np.max(np.abs(Z1 - Z2)) < 1e-10 and np.max(np.abs(tr1["T"] - tr2["T"])) < 1e-10
+    # dense-mag acceptance numbers on a synthetic estimate
+    c = cases.mag_case(4, 30, 16, seed=12)
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    dd = dg.bean_6D(30, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=5, m_sim=100)
+    dd["pos"][2] = 0.4 * np.sin(np.linspace(0, 5, 30))         # a non-planar path: the alignment is unique (full-rank X0'Y0)
+    est = np.vstack((dd["pos"] + 0.1 * rs.standard_normal(dd["pos"].shape), dd["quat"].T))
+    qn = rs.standard_normal(4) * 0.02 + np.array([1.0, 0, 0, 0])
+    est[3:7] = np.stack([oracle.qLeft(qn / np.linalg.norm(qn)) @ est[3:7, i] for i in range(30)], axis=1)
+    gp, go = M.rmse_dense_mag(dd["pos"], dd["quat"], est)
+    wp, wo = oracle.rmse_dense_mag_oracle(dd["pos"], dd["quat"], est)
+    np.testing.assert_allclose(gp, wp, rtol=1e-9)
+    np.testing.assert_allclose(go, wo, rtol=1e-9)
+    assert np.all(gp < 0.3) and np.all(go < 10.0)
+    del c

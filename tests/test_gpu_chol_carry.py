@@ -1,0 +1,60 @@
+"""rbpf_options.chol_refresh = K > 1: the ancestor-weight factors of particleSmootherInformationForm.m:224-236 are carried
+along the lineages (ny rank-1 updates + ny rank-1 downdates per step, rbpf_chol_sweep.hpp) and recomputed from the exactly
+carried Imat every K-th step, instead of a fresh chol(Imat_i + ImatAddt) per particle and step.  Same algebra, different
+arithmetic.  Stated tolerance: ancestor probabilities paNt within 1e-9 (absolute, they are <= 1) of the numpy oracle's, which
+factorises from scratch as the reference does; every ancestor index and every output equal to the oracle's as in the default
+mode.  K = 1000 never refreshes after the first step: the drift over the whole run stays inside the same bound."""
+import numpy as np
+import pytest
+
+import cases
+import test_gpu_smoother as ts
+
+pytestmark = pytest.mark.gpu
+
+
+def run(rbpf, c, **kw):
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    return rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
+                                                c["Q"], R, c["N_P"], c["N_K"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, **kw)
+
+
+@pytest.mark.parametrize("K", [2, 5, 1000])
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 8, 14, 130), ("mag", 6, 12, 512), ("mag", 7, 10, 40), ("radio", 10, 16, 128),
+                                            ("radio", 9, 12, 24)])
+def test_carried_factors_match_the_oracle(rbpf, kind, N_P, N_T, m, K):
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=71, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    out = run(rbpf, c, chol_refresh=K)
+    ts.check(ref, out, 3)                                  # ancestors bit-exact, paNt / weights / outputs to 1e-9
+
+
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 64, 60, 130), ("radio", 96, 80, 128)])
+def test_drift_of_the_carried_factors_over_a_long_run(rbpf, kind, N_P, N_T, m):
+    """60 / 80 steps without a refresh against the default (fresh factorisation every step) on the same random numbers: the
+    ancestor probabilities stay within 1e-9, so every index and every output is identical or within 1e-9."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=73, N_K=2)
+    a = run(rbpf, c)
+    b = run(rbpf, c, chol_refresh=1000)
+    pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
+    drift = float(np.max(np.abs(pa - pb)))
+    assert drift <= 1e-9, drift
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
+
+
+def test_carried_factors_with_the_lazy_covariance_update(rbpf):
+    c = cases.mag_case(7, 11, 256, seed=75, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    out = run(rbpf, c, chol_refresh=4, lazy_depth=3)
+    ts.check(ref, out, 3)
+
+
+def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
+    c = cases.mag_case(4, 4, 600, seed=1, N_K=2)             # nLin = 603 > 575
+    with pytest.raises(rbpf.RBPFError) as ei:
+        run(rbpf, c, chol_refresh=8)
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED

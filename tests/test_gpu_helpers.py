@@ -203,3 +203,24 @@ def test_quaternion_helpers_match_oracle(rbpf, oracle):
     mid = phi[(nrm > 0.05) & (nrm < np.pi / 2)]
     assert np.max(np.abs(rbpf.quat_helper("logq", rbpf.quat_helper("expq", mid)) - mid)) <= 1e-13
     assert np.max(np.abs(np.einsum("nij,nkj->nik", gr, gr) - np.eye(3))) <= 1e-14                     # orthonormal
+
+
+@pytest.mark.gpu
+def test_synthetic_data_generators_on_the_device(rbpf, oracle):
+    """the field draws of generateData_dense.m:216-257 (tools/gp_rnd_scalar_potential_fast.m:42-102,
+    gp_rnd_SE1D_fast.m:44-85) with the 2000-function simulation basis evaluated by the HIP measurement-model kernel,
+    against the host tables and against the oracle's generator (same seeded stream)."""
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    a = dg.bean_6D(60, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=7, m_sim=2000)
+    b = dg.bean_6D(60, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=7, m_sim=2000, device=True)
+    for k in ("dx", "initState", "LL", "pos", "quat"):
+        np.testing.assert_array_equal(a[k], b[k])
+    assert np.max(np.abs(a["y"] - b["y"])) <= 1e-10 * np.max(np.abs(a["y"]))
+    o = oracle.generate_bean_6D(60, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=7, m_sim=2000)
+    assert np.max(np.abs(o["y"] - b["y"])) <= 1e-9 * np.max(np.abs(o["y"]))
+    Qr = dg.radio_Q(48, "square_3D")
+    ra = dg.planar_heading(48, Qr, cases.THETA_RADIO, 1.0, seed=3, nLL=4, traj="square_3D", m_sim=2000)
+    rb = dg.planar_heading(48, Qr, cases.THETA_RADIO, 1.0, seed=3, nLL=4, traj="square_3D", m_sim=2000, device=True)
+    np.testing.assert_array_equal(ra["dx"], rb["dx"])
+    assert np.max(np.abs(ra["y"] - rb["y"])) <= 1e-10 * np.max(np.abs(ra["y"]))
