@@ -220,10 +220,11 @@ def smoother_reference_size(pkg, datagen):
     return out
 
 
-def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed):
+def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed, **opts):
     """The metric's smoother: particleSmootherInformationForm on slam-dense-mag m=512, T=3000, complete, for the per-GPU share
     of N=65 536 at 8 GPUs (N_share = 8192 particles; the information-form state of all 65 536 -- 2 x 139 GB of Imat next to
-    the covariances -- does not fit one GPU).  Wall clock of the whole call, N_K iterations."""
+    the covariances -- does not fit one GPU).  Wall clock of the whole call, N_K iterations.
+    opts: rbpf_options of the information form (lazy_depth, chol_refresh)."""
     import numpy as np
     Q = q_mag()
     d = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=seed)
@@ -232,11 +233,11 @@ def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed):
     t0 = time.perf_counter()
     XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0,
                                                     Q, R, N_share, N_K, 0.01, False, lambda *a: marks.append(time.perf_counter()),
-                                                    rng=pkg.PhiloxRNG(3))
+                                                    rng=pkg.PhiloxRNG(3), **opts)
     secs = time.perf_counter() - t0
     its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
     return {"workload": f"slam-dense-mag N_P={N_share} (1/8 of N=65536) T={T} m={m} N_K={N_K} fp64, information form, complete run",
-            "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
+            "options": opts, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
             "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
             "finite": bool(np.all(np.isfinite(XNK))),
             "pos_rmse_m_last_iteration": round(float(np.sqrt(np.mean((XNK[0:3, :, -1] - d["pos"]) ** 2))), 4)}
@@ -374,7 +375,24 @@ def main():
         chk = sess.finish(want=("traj_mean",))
         if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
             raise SystemExit("non-finite filter output")
-        shard_stats = getattr(sess, "stats", None)
+        shard_stats = dict(getattr(sess, "stats", None) or {})
+        shard_stats.pop("phase_s", None)                  # host enqueue times only: the timed run has one sync per step
+        sess.close()
+        # diagnostic pass (not timed into `value`): the same steps with a stream synchronisation after every phase, so that
+        # the first multi-GPU run shows where a step's time goes (gather / normalise+plan / exchange / step kernel)
+        diag_steps = min(24, K)
+        sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
+                                       N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world,
+                                       lazy_depth=args.lazy_depth, storage=args.storage, sync_phases=True)
+        sess.advance(6)
+        sess.sync()
+        sess.stats["phase_s"] = dict(gather=0.0, normalise=0.0, plan=0.0, exchange=0.0, step=0.0)
+        sess.stats["steps"] = 0
+        barrier()
+        sess.advance(diag_steps)
+        sess.sync()
+        ph = sess.stats.get("phase_s", {})
+        shard_stats["phase_ms_per_step_synchronised"] = {k: round(v / max(diag_steps, 1) * 1e3, 4) for k, v in ph.items()}
         sess.close()
         head = {"value": N_total * K / dt_s, "ms_per_step": dt_s / K * 1e3, "roofline": roofline_of(tm)}
         single_bank = False
@@ -401,10 +419,7 @@ def main():
             "roofline": head["roofline"],
         }
         if shard_stats:
-            st = dict(shard_stats)
-            ph = st.pop("phase_s", {})
-            st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 4) for k, v in ph.items()}
-            line["config"]["sharding"] = st
+            line["config"]["sharding"] = shard_stats
         solo = world == 1 and not args.force_sharded
         if solo and not args.no_traffic:
             tr, why = measure_traffic(args, args.lazy_depth)
@@ -418,10 +433,18 @@ def main():
             sm = {"reference_size": guarded(smoother_reference_size, pkg, datagen),
                   "kernel_roofline": guarded(smoother_kernel_roofline, pkg)}
             if not args.no_smoother_full:
-                sm["share_full"] = guarded(smoother_share_full, pkg, datagen, 8192, 3000, 512, 2, args.seed)
+                # the reference's arithmetic (a fresh factorisation per particle and step, :228), covariances rewritten every
+                # third step -- and the same run with the ancestor-weight factors carried along the lineages (option
+                # chol_refresh: rank-1 up/down-dates, refactorised every 32nd step; ancestor probabilities within 1e-9 of the
+                # fresh factorisation's, tests/test_gpu_chol_carry.py)
+                sm["share_full"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3))
+                sm["share_full_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3,
+                                                                                       chol_refresh=32))
                 if "seconds" in sm["share_full"]:
                     line["smoother_wall_clock_s"] = sm["share_full"]["seconds"]
-                    line["smoother_wall_clock_workload"] = sm["share_full"]["workload"]
+                    line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3, fresh factorisation every step"
+                if "seconds" in sm["share_full_carried_factors"]:
+                    line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
             if not args.no_large:
                 sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
             line["smoother"] = sm

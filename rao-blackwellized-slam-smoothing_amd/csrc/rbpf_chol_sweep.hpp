@@ -203,6 +203,52 @@ static hipError_t launch_sweep_from_chol64(int n, int batch, const double* Lfrag
   return hipGetLastError();
 }
 
+// ---- refresh from the state history ------------------------------------------------------------------------------
+// Between two refreshes nothing reads Imat, so it is not advanced at all: at a refresh step the information matrix of every
+// particle is rebuilt from the last materialised generation t0 ("base") and the measurement Jacobians along its ancestral
+// path,  Imat_i(t-1) = Imat_base(anc_{t0}(i)) + sum_{s = t0+1}^{t-1} H(x_{path_i(s), s})' R^-1 H(...),  the H recomputed from
+// the state history (basis evaluation is cheap) and the sum formed as G' G on the matrix cores, G = [W H_s] stacked.
+// Exactly the terms :334 adds step by step, in another summation order.
+
+// thread per particle: walk the ancestor table back from generation t_last to t0 + 1, collecting the states on the way
+__global__ void sweep_path_kernel(int N, int nN, int Kp, int t_last, int t0, const int* __restrict__ A, const double* __restrict__ X,
+                                  int* __restrict__ base_slot, double* __restrict__ Xp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int slot = i;
+  for (int s = t_last; s > t0; --s) {
+    const double* Xs = X + (size_t)s * nN * N;
+    double* col = Xp + ((size_t)i * Kp + (s - t0 - 1)) * nN;
+    for (int c = 0; c < nN; ++c) col[c] = Xs[(size_t)c * N + slot];
+    if (s > 0) slot = A[(size_t)s * N + slot];          // ancestor in generation s - 1
+  }
+  base_slot[i] = slot;
+}
+
+// G = W H in place: H [rows][d][n] (rows of H contiguous), W [d x d] column-major
+__global__ void sweep_whiten_kernel(size_t rows, int d, int n, const double* __restrict__ W, double* __restrict__ H) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= rows * n) return;
+  const size_t row = q / n; const int c = (int)(q % n);
+  double* h = H + row * d * n + c;
+  double v[3], o[3];
+  for (int b = 0; b < d; ++b) v[b] = h[(size_t)b * n];
+  for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s = fma(W[a + d * b], v[b], s); o[a] = s; }
+  for (int a = 0; a < d; ++a) h[(size_t)a * n] = o[a];
+}
+
+// Imat_new[i] += base[base_slot[i]] over the block-lower part the factorisation kernels read
+__global__ __launch_bounds__(256) void sweep_add_base_kernel(int n, const double* __restrict__ base, long base_stride,
+                                                             const int* __restrict__ base_slot, double* __restrict__ Imat) {
+  const int p = blockIdx.x;
+  const double* src = base + (size_t)(base_slot ? base_slot[p] : 0) * base_stride;
+  double* dst = Imat + (size_t)p * n * n;
+  for (int c = blockIdx.y; c < n; c += gridDim.y) {
+    const int r0 = (c >> 6) << 6;
+    for (int r = r0 + threadIdx.x; r < n; r += blockDim.x) dst[(size_t)r + (size_t)n * c] += src[(size_t)r + (size_t)n * c];
+  }
+}
+
 // Imat(:,:,i) of the new generation = ancestor's stored matrix + the particle's own last update (InformationForm.m:170,334),
 // on its own (the steps between two refreshes: the factorisation kernels, which otherwise do this while loading, do not run).
 // Covers the block-lower part the factorisation kernels read (rows >= 64 * (column / 64)).

@@ -47,6 +47,10 @@ struct SmootherState {
   double* d_W = nullptr;        // [d x d] whitening factor: W' W = R^-1
   int sw_cur = 0;
   int refresh = 0;              // K (0 / 1: off)
+  bool lazy_imat = false;       // Imat is rebuilt from the state history at the refreshes only (recognised families)
+  int base_gen = -1;            // generation the Imat bank holds (-1: Imat0)
+  int* d_base_slot = nullptr;   // [N]
+  double* d_Xp = nullptr;       // [N * K][nN] states along the ancestral paths (d_G then holds [N * K][d][n] whitened Jacobians)
   int icur = 0;                 // ping-pong index of ivec / hld / qf / Hb
   int imat_cur = 0;
   bool imat_valid = false;      // false until the first gather of an iteration (Imat = Imat0)
@@ -66,6 +70,7 @@ void smoother_free(rbpf_ctx* c) {
   for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
   hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
   hipFree(s->d_Rinv); hipFree(s->d_Lsw[0]); hipFree(s->d_Lsw[1]); hipFree(s->d_W);
+  hipFree(s->d_base_slot); hipFree(s->d_Xp);
   delete s;
   c->sm = nullptr;
 }
@@ -900,6 +905,12 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           Wm[i + (size_t)d * col] = v / Lr[i + (size_t)d * i];
         }
       HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+      s->lazy_imat = c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;     // needs measModel on the device
+      if (s->lazy_imat) {
+        RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
+        RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
+        RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
+      }
     }
   }
   // information-form initial values (quirk Q5: diagonal of P0 only, :110-115)
@@ -1001,12 +1012,15 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
           const bool carry = s->refresh > 1;
           const bool fresh = !carry || t == 1 || ((t - 1) % s->refresh) == 0;
           if (carry && !fresh) {
-            // carried factors: the exactly carried Imat is advanced on its own (the refresh reads it), then one sweep per
-            // particle turns the ancestor's factor into this particle's and adds logwMeas (rbpf_chol_sweep.hpp)
-            const int ni = s->imat_cur ^ 1;
-            HIPCHK(launch_imat_gather(n, d, L.ldx, N, s->d_Imat[s->imat_cur], (long)((size_t)n * n), c->A + (size_t)(t - 1) * N,
-                                      s->d_Hb[s->icur], d_Rinv, s->d_Imat[ni], st));
-            s->imat_cur = ni;
+            // carried factors: one sweep per particle turns the ancestor's factor into this particle's and adds logwMeas
+            // (rbpf_chol_sweep.hpp).  Host-callback models cannot rebuild Imat from the state history at a refresh, so for
+            // them the exactly carried Imat is advanced every step by a copy kernel.
+            if (!s->lazy_imat) {
+              const int ni = s->imat_cur ^ 1;
+              HIPCHK(launch_imat_gather(n, d, L.ldx, N, s->d_Imat[s->imat_cur], (long)((size_t)n * n), c->A + (size_t)(t - 1) * N,
+                                        s->d_Hb[s->icur], d_Rinv, s->d_Imat[ni], st));
+              s->imat_cur = ni;
+            }
             SweepArgs sw;
             sw.n = n; sw.d = d; sw.ldx = L.ldx; sw.NS = sweep_slots(n); sw.N = N; sw.ref_slot = N - 1;
             sw.Lold = s->d_Lsw[s->sw_cur]; sw.Lnew = s->d_Lsw[s->sw_cur ^ 1]; sw.stride = sweep_factor_doubles(n);
@@ -1016,6 +1030,29 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             HIPCHK(launch_chol_sweep(sw, st));
             s->sw_cur ^= 1;
             skip_chol = true;
+          } else if (carry && s->lazy_imat) {
+            // refresh: Imat of generation t-1 from the base generation + G'G along the ancestral paths, then factorise it
+            const int t0 = s->base_gen, Kp = t - 1 - t0;
+            if (Kp < 1 || Kp > s->refresh) { set_error("internal: refresh window"); return RBPF_ERR_STATE; }
+            const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
+            hipLaunchKernelGGL(sweep_path_kernel, dim3((N + 127) / 128), dim3(128), 0, st, N, nN, Kp, t - 1, t0, c->A, c->X, s->d_base_slot, s->d_Xp);
+            HIPCHK(hipGetLastError());
+            HIPCHK(launch_meas_model(c->mdl, N * Kp, s->d_Xp, s->d_G, st, 1));
+            const size_t rows = (size_t)N * Kp;
+            hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, st, rows, d, n, s->d_W, s->d_G);
+            HIPCHK(hipGetLastError());
+            const long Kd = (long)Kp * d;
+            GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
+            HIPCHK(launch_gemm(gg, N, st));                                   // G' G
+            hipLaunchKernelGGL(sweep_add_base_kernel, dim3(N, 4), dim3(256), 0, st, n, t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur],
+                               t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni]);
+            HIPCHK(hipGetLastError());
+            s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
+            ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
+            ca.Imat = s->d_Imat[ni]; ca.imat_stride = (long)((size_t)n * n); ca.imat_anc = nullptr; ca.ImatOut = nullptr;
+            ca.Hb = nullptr; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
+            ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
+            ca.variant = 64;
           } else {
             RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
             if (carry) ca.variant = 64;            // the refresh reads the factor back in the 64-column kernel's layout
@@ -1096,6 +1133,7 @@ static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, d
   s->icur = 0;
   s->imat_cur = 0;
   s->imat_valid = false;
+  s->base_gen = -1;
   return RBPF_OK;
 }
 

@@ -322,6 +322,8 @@ class ShardedFilterSession:
                         self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]), int(cnt[2 * self.world + 1]))
                     t4 = time.perf_counter()
                     check(self.lib.rbpf_shard_step(self.ctx, None, None))
+                    if self.sync_phases:
+                        self.stream.synchronize()
                     t5 = time.perf_counter()
                     self.stats["migrated"] += int(cnt[2 * self.world])
                     tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["plan"] += t3 - t2
@@ -344,6 +346,8 @@ class ShardedFilterSession:
                     self._exchange(rp)
                 t4 = time.perf_counter()
                 check(self.lib.rbpf_shard_step(self.ctx, _ip(rp.anc_bank), _ip(rp.slot_ids)))
+                if self.sync_phases:
+                    self.stream.synchronize()
                 t5 = time.perf_counter()
                 tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["plan"] += t3 - t2
                 tm["exchange"] += t4 - t3; tm["step"] += t5 - t4
