@@ -2,7 +2,9 @@
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 from . import _build
 
@@ -116,11 +118,31 @@ class RBPFError(RuntimeError):
         self.status = status
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch wheel carries its own libamdhip64 / libhsa-runtime64 (soname
+    libamdhip64.so.7, the soname librbpf_hip.so asks for); if /opt/rocm's copy is mapped first and torch is imported later
+    (ShardedFilterSession after a single-GPU call, say) the process holds two runtimes and the second one finds no device
+    ("No HIP GPUs are available").  Mapping the wheel's copy first -- without importing torch -- makes the dynamic linker
+    hand the same runtime to both; without a torch wheel the library binds /opt/rocm's as usual."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library(build_if_missing: bool = True):
     """dlopen the in-tree HIP library.  Fails loudly when it is missing: there is no CPU fallback."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     path = os.environ.get("RBPF_LIB_PATH") or _build.LIBPATH     # RBPF_LIB_PATH: tuning variants only
     if not os.path.exists(path):
         if not build_if_missing:

@@ -415,6 +415,7 @@ int ctx_reset(rbpf_ctx* c) {
   c->tcur = 0;
   c->ready_step = -1;
   c->drawn_step = -1;
+  c->order_step = -1;
   if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) {              // particleFilter.m:59: xn = repmat(x0_nonLin, 1, N_P)
     c->h_xn.resize((size_t)c->mdl.nN * c->N);
     for (int i = 0; i < c->N; ++i) for (int q = 0; q < c->mdl.nN; ++q) c->h_xn[q + (size_t)c->mdl.nN * i] = c->h_x0n[q];
@@ -540,6 +541,13 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
 
   const bool pre_drawn = (c->ready_step == t);       // ancestors + order came from the fused kernel of step t-1
   if (t > 0 && n_draw > 0 && !pre_drawn && c->drawn_step != t) RB_TRY(ctx_draw_ancestors(c, k_iter, n_draw));
+  if (c->sort_steps && t > 0 && !pre_drawn && c->mdl.kind != RBPF_MODEL_SPARSE_VISUAL_2D) {
+    // smoothers: every ancestor of this step is known now (slot N-1's came from the ancestor weights); process the children
+    // in the order of the stored matrix they read, so that siblings share it through the caches as in the filter
+    const int* remap = (c->lazy_depth >= 2) ? c->base[c->tcur] : nullptr;
+    HIPCHK(launch_order(N, N, A_t, c->d_order, c->d_counts, c->stream, remap));
+    c->order_step = t;
+  }
   if (c->mdl.kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
     // sparseFeatures branch: one small kernel does gather, dynModel, EKF weight and update (rbpf_sparse.hip);
     // the update is applied at once, so the pending-factor banks stay zero
@@ -580,7 +588,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.mdl = c->mdl; a.lay = L; a.N = N; a.t = t; a.propagate = (t > 0);
   a.ai = (t > 0) ? A_t : nullptr;
   a.ai_bank = nullptr; a.slot_offset = 0; a.xn_old_stride = (size_t)N; a.xn_new_stride = (size_t)N;
-  a.order = (pre_drawn && t > 0) ? c->d_order : nullptr;
+  a.order = ((pre_drawn || c->order_step == t) && t > 0) ? c->d_order : nullptr;
   a.zero_set_idx = N;
   a.slot_ids = nullptr; a.n_bank_local = 0; a.rec = nullptr; a.rec_stride = 0; a.rec_off_B = a.rec_off_F = a.rec_off_X = 0;
   a.rec_off_I = a.rec_off_hld = 0;

@@ -16,6 +16,10 @@
 // Sweep layout of a factor (per particle): rows 0..n-1 and the augmented row n, padded to NS slots of 64 rows; column k
 // keeps the slots k/64 .. NS-1 only (the rows above its diagonal block are zero), slot q at row 64 q + lane:
 //     off(k) = 64 * (64 * (b NS - b (b - 1) / 2) + r (NS - b)),   b = k / 64, r = k % 64       [doubles]
+// Compact tail: when the last slot holds at most 8 rows (nLin = 515: the 3 border rows + the augmented row; nLin = 128: the
+// augmented row) it is STORED as 8 doubles (one 64-byte sector, lanes 0..7) instead of 64 -- 18 % / 33 % less traffic; in
+// registers it stays a slot like the others:
+//     off(k) = 64 * (64 * (b M - b (b - 1) / 2) + r (M - b)) + 8 k   for k <= 64 M (M = NS - 1),   off(64 M) + 8 (k - 64 M) beyond
 // One wave64 owns one particle: the column and the 2 ny vectors live in registers (lane = row within a slot), the pivots are
 // broadcast with v_readlane, so there is no LDS and no barrier; the next column's loads are issued before the rotations of
 // the current one.
@@ -23,18 +27,27 @@
 
 constexpr int kSweepMaxSlots = 9;                    // rows n + 1 <= 576: nLin <= 575 (dense-mag m = 512 is 515)
 
-__host__ __device__ inline size_t sweep_col_offset(int k, int NS) {
-  const size_t b = (size_t)(k >> 6), r = (size_t)(k & 63);
-  return 64 * (64 * (b * NS - b * (b - 1) / 2) + r * (NS - b));
-}
 __host__ __device__ inline int sweep_slots(int n) { return (n + 1 + 63) >> 6; }
-__host__ __device__ inline size_t sweep_factor_doubles(int n) { return sweep_col_offset(n, sweep_slots(n)); }
+__host__ __device__ inline int sweep_tail_compact(int n) { const int t = (n + 1) & 63; return (t >= 1 && t <= 8 && n + 1 > 64) ? 1 : 0; }
+__host__ __device__ inline size_t sweep_col_offset(int k, int NS, int tailc) {
+  if (!tailc) {
+    const size_t b = (size_t)(k >> 6), r = (size_t)(k & 63);
+    return 64 * (64 * (b * NS - b * (b - 1) / 2) + r * (NS - b));
+  }
+  const int M = NS - 1;
+  const int kk = k < 64 * M ? k : 64 * M;
+  const size_t b = (size_t)(kk >> 6), r = (size_t)(kk & 63);
+  return 64 * (64 * (b * M - b * (b - 1) / 2) + r * (M - b)) + 8 * (size_t)k;
+}
+__host__ __device__ inline size_t sweep_factor_doubles(int n) { return sweep_col_offset(n, sweep_slots(n), sweep_tail_compact(n)); }
 
 struct SweepArgs {
   int n, d, ldx, NS, N;
+  int tailc;                        // compact tail: the last slot is stored as 8 doubles
   int ref_slot;                     // particle that carries the reference trajectory (its update and downdate cancel: copy), or -1
   const double* Lold; double* Lnew; size_t stride;      // factor banks (sweep layout), doubles per particle
   const int* anc;                   // [N] bank entry of each particle's ancestor (null: identity)
+  const int* order;                 // [N] processing order (ancestor-sorted: siblings read their ancestor's factor together) or null
   const double* Hb;                 // [N][d][ldx] H of each particle's last update
   const double* Href;               // [d][n] H along the reference trajectory at the step that leaves the suffix sums
   const double* W;                  // [d x d] column-major whitening factor: W' W = R^-1 (W = inv(chol(R,'lower')))
@@ -45,7 +58,7 @@ struct SweepArgs {
 };
 
 // fragment-order factor of the 64-column kernel (row-tile major: ((rt * 4 RT + kg) * 64 + kk * 16 + r)) -> sweep layout
-__global__ void sweep_from_chol64_kernel(int n, int NS, const double* __restrict__ Lfrag, size_t frag_stride,
+__global__ void sweep_from_chol64_kernel(int n, int NS, int tailc, const double* __restrict__ Lfrag, size_t frag_stride,
                                          double* __restrict__ Lsw, size_t sw_stride) {
   const int p = blockIdx.x;
   const int RT = (n + 1 + 15) >> 4;
@@ -54,93 +67,145 @@ __global__ void sweep_from_chol64_kernel(int n, int NS, const double* __restrict
   double* dst = Lsw + (size_t)p * sw_stride;
   for (int k = blockIdx.y; k < n; k += gridDim.y) {
     const int b = k >> 6;
-    double* col = dst + sweep_col_offset(k, NS);
+    double* col = dst + sweep_col_offset(k, NS, tailc);
     for (int e = threadIdx.x; e < (NS - b) * 64; e += blockDim.x) {
-      const int row = 64 * b + e;
+      const int q = b + (e >> 6), ln = e & 63, row = 64 * q + ln;
+      if (tailc && q == NS - 1 && ln >= 8) continue;                    // the compact tail keeps lanes 0..7 only
       double v = 0.0;
       if (row >= k && row <= n) v = src[((size_t)(row >> 4) * KGS + (size_t)(k >> 2)) * 64 + (size_t)(k & 3) * 16 + (row & 15)];
-      col[e] = v;
+      col[(size_t)(q - b) * 64 + ln] = v;
     }
   }
 }
 
-// One rank-1 rotation of column k against vector x (SIGN = +1 update, -1 downdate), slots B.. of the column.
-//   r = sqrt(Lkk^2 +- xk^2); c = r / Lkk; s = xk / Lkk;  L_ik = (L_ik +- s x_i) / c;  x_i = c x_i - s L_ik
-// linv = 1 / Lkk on entry, 1 / r on exit (the next rotation's pivot is r).  Returns false when a downdate loses definiteness.
-template <int NS, int B, int SIGN>
-__device__ __forceinline__ bool sweep_rotate(double (&col)[NS], double (&x)[NS], int r_lane, int lane, double& Lkk, double& linv) {
-  const double xk = readlane_f64(x[B], r_lane);
-  const double t = fma((double)SIGN * xk, xk, Lkk * Lkk);
-  if (!(t > 0.0)) return false;
-  double rr, rinv;
-  sqrt_rsqrt(t, rr, rinv);
-  const double c = rr * linv, s = xk * linv, cinv = Lkk * rinv;
+// The D downdate vectors of a particle: in registers, or -- VLDS, the large sizes, where 2 D NS doubles of vectors plus the
+// column leave one wave per SIMD -- in LDS (lane-private slices, [a][q][lane]; the pivot read is a broadcast).  With the
+// downdate vectors out of the register file two waves fit a SIMD and overlap each other's load latency.
+template <int D, int NS, bool VLDS>
+struct SweepV {
+  double r[VLDS ? 1 : D][VLDS ? 1 : NS];
+  double* s;                                            // LDS slice of this wave (VLDS)
+  int lane;
+  __device__ __forceinline__ double get(int a, int q) const { if constexpr (VLDS) return s[(a * NS + q) * 64 + lane]; else return r[a][q]; }
+  __device__ __forceinline__ void set(int a, int q, double x) { if constexpr (VLDS) s[(a * NS + q) * 64 + lane] = x; else r[a][q] = x; }
+  __device__ __forceinline__ double pivot(int a, int q, int r_lane) const {
+    if constexpr (VLDS) return s[(a * NS + q) * 64 + r_lane]; else return readlane_f64(r[a][q], r_lane);
+  }
+};
+
+// The 2 D rank-1 rotations of column k (D updates with u_a, then D downdates with v_a), slots B.. of the column:
+//   r_a = sqrt(r_{a-1}^2 +- x_a(k)^2),  c_a = r_a / r_{a-1},  s_a = x_a(k) / r_{a-1}     (r_0 = L_kk)
+//   L_ik = (L_ik +- s_a x_a(i)) / c_a;  x_a(i) = c_a x_a(i) - s_a L_ik
+// A rotation changes only its own vector and the column, so the pivots x_a(k) of all 2 D vectors are read first and the
+// squared pivots t_a = L_kk^2 +- ... are accumulated directly: the 2 D reciprocal square roots are then independent of
+// each other (one exposed latency chain per column instead of 2 D), and only the column updates are sequential across a,
+// with the slots as independent work in between.  Returns false when a downdate loses definiteness.
+template <int D, int NS, int B, bool VLDS>
+__device__ __forceinline__ bool sweep_rotate_all(double (&col)[NS], double (&u)[D][NS], SweepV<D, NS, VLDS>& v, int r_lane, int lane,
+                                                 double& Lkk) {
+  double xk[2 * D], t[2 * D + 1];
 #pragma unroll
-  for (int q = B; q < NS; ++q) {
-    const double lq = fma((double)SIGN * s, x[q], col[q]) * cinv;
-    x[q] = fma(c, x[q], -s * lq);
-    col[q] = lq;
+  for (int a = 0; a < D; ++a) { xk[a] = readlane_f64(u[a][B], r_lane); xk[D + a] = v.pivot(a, B, r_lane); }
+  t[0] = Lkk * Lkk;
+#pragma unroll
+  for (int a = 0; a < 2 * D; ++a) t[a + 1] = fma(a < D ? xk[a] : -xk[a], xk[a], t[a]);
+  bool ok = true;
+#pragma unroll
+  for (int a = 0; a <= 2 * D; ++a) ok = ok && (t[a] > 0.0);
+  if (!ok) return false;
+  double rt[2 * D + 1], ri[2 * D + 1];                 // sqrt(t_a), 1 / sqrt(t_a)
+#pragma unroll
+  for (int a = 0; a <= 2 * D; ++a) sqrt_rsqrt(t[a], rt[a], ri[a]);
+#pragma unroll
+  for (int a = 0; a < 2 * D; ++a) {
+    const double c = rt[a + 1] * ri[a], s = xk[a] * ri[a], cinv = rt[a] * ri[a + 1];
+    const double ss = (a < D) ? s : -s;
+    if (a < D) {
+#pragma unroll
+      for (int q = B; q < NS; ++q) {
+        const double lq = fma(ss, u[a][q], col[q]) * cinv;
+        u[a][q] = fma(c, u[a][q], -s * lq);
+        col[q] = lq;
+      }
+    } else {
+#pragma unroll
+      for (int q = B; q < NS; ++q) {
+        const double vq = v.get(a - D, q);
+        const double lq = fma(ss, vq, col[q]) * cinv;
+        v.set(a - D, q, fma(c, vq, -s * lq));
+        col[q] = lq;
+      }
+    }
   }
   // rows above the pivot inside the diagonal slot are structurally zero
   col[B] = (lane >= r_lane) ? col[B] : 0.0;
-  Lkk = rr; linv = rinv;
+  Lkk = rt[2 * D];
   return true;
 }
 
-template <int D, int NS, int B>
+template <int D, int NS, int B, bool VLDS>
 __device__ __forceinline__ bool sweep_block(const SweepArgs& a, const double* __restrict__ src, double* __restrict__ dst,
-                                            double (&u)[D][NS], double (&v)[D][NS], int lane, bool plain_copy,
+                                            double (&u)[D][NS], SweepV<D, NS, VLDS>& v, int lane, bool plain_copy,
                                             double& sumlog, double& vv) {
   const int k0 = 64 * B, k1 = min(a.n, k0 + 64);
   if (k0 >= a.n) return true;
   double col[NS], nxt[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) { col[q] = 0.0; nxt[q] = 0.0; }
+  const bool tailc = a.tailc != 0;
+  // slot q of a column sits at (q - B) * 64 + lane; with the compact tail the last slot is 8 doubles, lanes 0..7
+#define RBPF_SW_LOAD(dst_, base_)                                                                          \
+  _Pragma("unroll") for (int q = B; q < NS; ++q) {                                                         \
+    if (q == NS - 1 && tailc) dst_[q] = (lane < 8) ? (base_)[(size_t)(q - B) * 64 + lane] : 0.0;            \
+    else dst_[q] = (base_)[(size_t)(q - B) * 64 + lane];                                                   \
+  }
   {
-    const double* c0 = src + sweep_col_offset(k0, NS);
-#pragma unroll
-    for (int q = B; q < NS; ++q) nxt[q] = c0[(size_t)(q - B) * 64 + lane];
+    const double* c0 = src + sweep_col_offset(k0, NS, a.tailc);
+    RBPF_SW_LOAD(nxt, c0)
   }
   for (int k = k0; k < k1; ++k) {
     const int r_lane = k - k0;
 #pragma unroll
     for (int q = B; q < NS; ++q) col[q] = nxt[q];
     if (k + 1 < k1) {                                     // the next column of this block (same slot range)
-      const double* cn = src + sweep_col_offset(k + 1, NS);
-#pragma unroll
-      for (int q = B; q < NS; ++q) nxt[q] = cn[(size_t)(q - B) * 64 + lane];
+      const double* cn = src + sweep_col_offset(k + 1, NS, a.tailc);
+      RBPF_SW_LOAD(nxt, cn)
     }
+
     double Lkk = readlane_f64(col[B], r_lane);
     if (!plain_copy) {
-      double linv = 1.0 / Lkk;
-#pragma unroll
-      for (int aa = 0; aa < D; ++aa)
-        if (!sweep_rotate<NS, B, 1>(col, u[aa], r_lane, lane, Lkk, linv)) return false;
-#pragma unroll
-      for (int aa = 0; aa < D; ++aa)
-        if (!sweep_rotate<NS, B, -1>(col, v[aa], r_lane, lane, Lkk, linv)) return false;
+      if (!sweep_rotate_all<D, NS, B, VLDS>(col, u, v, r_lane, lane, Lkk)) return false;
     }
     if (!(Lkk > 0.0)) return false;
-    double* cd = dst + sweep_col_offset(k, NS);
+    double* cd = dst + sweep_col_offset(k, NS, a.tailc);
 #pragma unroll
-    for (int q = B; q < NS; ++q) __builtin_nontemporal_store(col[q], &cd[(size_t)(q - B) * 64 + lane]);
+    for (int q = B; q < NS; ++q) {
+      if (q == NS - 1 && tailc) { if (lane < 8) __builtin_nontemporal_store(col[q], &cd[(size_t)(q - B) * 64 + lane]); }
+      else __builtin_nontemporal_store(col[q], &cd[(size_t)(q - B) * 64 + lane]);
+    }
     if (lane == r_lane) sumlog += log(Lkk);
     if (lane == (a.n & 63)) vv = fma(col[NS - 1], col[NS - 1], vv);    // z_k = L(n, k): the augmented row sits in the last slot
   }
+#undef RBPF_SW_LOAD
   return true;
 }
 
-template <int D, int NS>
-__global__ __launch_bounds__(256) void chol_sweep_kernel(const SweepArgs a) {
+template <int D, int NS, bool VLDS>
+__global__ __launch_bounds__(256, VLDS ? 2 : 1) void chol_sweep_kernel(const SweepArgs a) {
+  extern __shared__ double sweep_lds[];
   const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (p >= a.N) return;                                  // wave-uniform
+  const int pb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (pb >= a.N) return;                                 // wave-uniform
+  const int p = a.order ? a.order[pb] : pb;
   const int src_p = a.anc ? a.anc[p] : p;
   const double* src = a.Lold + (size_t)src_p * a.stride;
   double* dst = a.Lnew + (size_t)p * a.stride;
   const bool plain_copy = (p == a.ref_slot);
   // update vectors u_a = (W H_p)_a, downdate vectors v_a = (W H_ref)_a, both augmented by eta_a = (W y)_a in row n
-  double u[D][NS], v[D][NS];
+  double u[D][NS];
+  SweepV<D, NS, VLDS> v;
+  v.lane = lane;
+  v.s = VLDS ? sweep_lds + (size_t)(threadIdx.x >> 6) * D * NS * 64 : nullptr;
   {
     double Wm[D * D], eta[D];
 #pragma unroll
@@ -161,13 +226,13 @@ __global__ __launch_bounds__(256) void chol_sweep_kernel(const SweepArgs a) {
 #pragma unroll
         for (int bb = 0; bb < D; ++bb) { su = fma(Wm[aa + D * bb], h[bb], su); sv = fma(Wm[aa + D * bb], hr[bb], sv); }
         u[aa][q] = (row < a.n) ? su : (row == a.n ? eta[aa] : 0.0);
-        v[aa][q] = (row < a.n) ? sv : (row == a.n ? eta[aa] : 0.0);
+        v.set(aa, q, (row < a.n) ? sv : (row == a.n ? eta[aa] : 0.0));
       }
     }
   }
   double sumlog = 0.0, vv = 0.0;
   bool ok = true;
-#define RBPF_SWEEP_BLOCK(B_) if constexpr (NS > B_) { if (ok) ok = sweep_block<D, NS, B_>(a, src, dst, u, v, lane, plain_copy, sumlog, vv); }
+#define RBPF_SWEEP_BLOCK(B_) if constexpr (NS > B_) { if (ok) ok = sweep_block<D, NS, B_, VLDS>(a, src, dst, u, v, lane, plain_copy, sumlog, vv); }
   RBPF_SWEEP_BLOCK(0) RBPF_SWEEP_BLOCK(1) RBPF_SWEEP_BLOCK(2) RBPF_SWEEP_BLOCK(3) RBPF_SWEEP_BLOCK(4)
   RBPF_SWEEP_BLOCK(5) RBPF_SWEEP_BLOCK(6) RBPF_SWEEP_BLOCK(7) RBPF_SWEEP_BLOCK(8)
 #undef RBPF_SWEEP_BLOCK
@@ -183,7 +248,11 @@ template <int D>
 static hipError_t launch_chol_sweep_d(const SweepArgs& a, hipStream_t st) {
   const dim3 grid((a.N + 3) / 4), block(256);
   switch (a.NS) {
-#define RBPF_SW(NS_) case NS_: hipLaunchKernelGGL((chol_sweep_kernel<D, NS_>), grid, block, 0, st, a); break;
+  // downdate vectors in LDS where D * NS is large (two waves per SIMD instead of one): 4 waves x D x NS x 512 B per workgroup
+#define RBPF_SW(NS_) case NS_:                                                                                          \
+    if constexpr (D * NS_ >= 21) hipLaunchKernelGGL((chol_sweep_kernel<D, NS_, true>), grid, block, (size_t)4 * D * NS_ * 64 * sizeof(double), st, a); \
+    else hipLaunchKernelGGL((chol_sweep_kernel<D, NS_, false>), grid, block, 0, st, a);                                    \
+    break;
     RBPF_SW(1) RBPF_SW(2) RBPF_SW(3) RBPF_SW(4) RBPF_SW(5) RBPF_SW(6) RBPF_SW(7) RBPF_SW(8) RBPF_SW(9)
 #undef RBPF_SW
     default: return hipErrorInvalidValue;
@@ -199,7 +268,8 @@ static hipError_t launch_chol_sweep(const SweepArgs& a, hipStream_t st) {
 
 static hipError_t launch_sweep_from_chol64(int n, int batch, const double* Lfrag, size_t frag_stride, double* Lsw, size_t sw_stride,
                                            hipStream_t st) {
-  hipLaunchKernelGGL(sweep_from_chol64_kernel, dim3(batch, 8), dim3(256), 0, st, n, sweep_slots(n), Lfrag, frag_stride, Lsw, sw_stride);
+  hipLaunchKernelGGL(sweep_from_chol64_kernel, dim3(batch, 8), dim3(256), 0, st, n, sweep_slots(n), sweep_tail_compact(n), Lfrag, frag_stride,
+                     Lsw, sw_stride);
   return hipGetLastError();
 }
 

@@ -109,6 +109,8 @@ struct rbpf_ctx {
   int* d_counts = nullptr;  // [2N] counting-sort scratch
   int ready_step = -1;      // step whose ancestors (and order) were already drawn by the fused resample kernel
   bool fuse_resample = false;
+  bool sort_steps = false;  // smoothers: process every step in ancestor order too (the filter's fused resample kernel does it there)
+  int order_step = -1;      // step d_order was computed for by ctx_step (smoothers)
   size_t bank_cap = 0;      // particles per bank incl. the recv region
   size_t rng_slots = 0;     // slots per step in d_U / d_Z
 };

@@ -159,7 +159,9 @@ hipError_t launch_cumsum(int N, const double* w, double* wc, hipStream_t s);
 // normalise step t and, fused, draw the ancestors of step t+1 (+ their ancestor-sorted processing order)
 hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, int* order, int* counts, hipStream_t s,
                                      const int* remap = nullptr);
-hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s);
+hipError_t launch_order_large(int n_slots, int range, const int* key, const int* remap, int* order, int* counts, hipStream_t s);
+// counting sort of the slots by remap[key[i]] (remap null: key[i]); range: number of distinct key values
+hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s, const int* remap = nullptr);
 // plan of a single-bank flush: order [N] lists the slots sorted by the entry base[ai[.]] of their ancestor's stored
 // matrix.  dst [N] / phase [N] out; scratch: 3 N ints.
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase,

@@ -1378,10 +1378,11 @@ __global__ __launch_bounds__(kNormThreads) void normalise_resample_kernel(const 
   RBPF_STAMP(3);
 }
 
-__global__ __launch_bounds__(kNormThreads) void order_kernel(int n_slots, int range, const int* key, int* order, int* counts) {
+__global__ __launch_bounds__(kNormThreads) void order_kernel(int n_slots, int range, const int* key, int* order, int* counts,
+                                                             const int* remap) {
   __shared__ int sidx[16];
   __shared__ int scnt[2 * kScanChunk];
-  order_block(n_slots, range, key, order, counts, sidx, scnt, 2 * kScanChunk);
+  order_block(n_slots, range, key, order, counts, sidx, scnt, 2 * kScanChunk, remap);
 }
 
 hipError_t launch_normalise_scan(const NormArgs& a, hipStream_t s) {
@@ -1395,8 +1396,9 @@ hipError_t launch_normalise_resample(const NormArgs& a, const SearchArgs& sa, in
   return hipGetLastError();
 }
 
-hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s) {
-  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kNormThreads), 0, s, n_slots, range, key, order, counts);
+hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s, const int* remap) {
+  if (range > kSingleWgResampleMaxN) return launch_order_large(n_slots, range, key, remap, order, counts, s);   // no LDS histogram
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(kNormThreads), 0, s, n_slots, range, key, order, counts, remap);
   return hipGetLastError();
 }
 

@@ -219,6 +219,18 @@ hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, in
   return e;
 }
 
+// counting sort of n_slots slots by remap[key[i]] over `range` key values, multi-workgroup (histogram, scan, scatter);
+// counts: >= range ints of scratch
+hipError_t launch_order_large(int n_slots, int range, const int* key, const int* remap, int* order, int* counts, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(counts, 0, (size_t)range * sizeof(int), s);
+  if (e != hipSuccess) return e;
+  const int nb = (n_slots + 255) / 256;
+  hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(256), 0, s, n_slots, key, remap, counts);
+  hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRB), 0, s, range, counts);
+  hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(256), 0, s, n_slots, key, remap, counts, order);
+  return hipGetLastError();
+}
+
 // ---- plan of a single-bank ("in place") flush ---------------------------------------------------------------
 // Every stored matrix with children keeps its bank entry for its first child (in the ancestor-sorted processing
 // order); the other children take the entries no child refers to, the k-th of them the k-th free entry.

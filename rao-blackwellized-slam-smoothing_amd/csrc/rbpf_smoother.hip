@@ -797,6 +797,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   SmootherState* s = new SmootherState();
   c->sm = s;
   if (!info_form) c->lazy_depth = 1;          // the covariance form reads the flushed covariances of every particle every step
+  c->sort_steps = true;
   const bool generic = c->mdl.kind == RBPF_MODEL_GENERIC_DENSE;
   const bool drn_cb = generic && c->cb.dyn_res_norm != nullptr;      // the handle; otherwise isempty(dynResNorm)
   if (generic) c->mdl.use_dyn_res_norm = 0;                          // device side: only the additive default exists
@@ -1022,11 +1023,12 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
               s->imat_cur = ni;
             }
             SweepArgs sw;
-            sw.n = n; sw.d = d; sw.ldx = L.ldx; sw.NS = sweep_slots(n); sw.N = N; sw.ref_slot = N - 1;
+            sw.n = n; sw.d = d; sw.ldx = L.ldx; sw.NS = sweep_slots(n); sw.tailc = sweep_tail_compact(n); sw.N = N; sw.ref_slot = N - 1;
             sw.Lold = s->d_Lsw[s->sw_cur]; sw.Lnew = s->d_Lsw[s->sw_cur ^ 1]; sw.stride = sweep_factor_doubles(n);
             sw.anc = c->A + (size_t)(t - 1) * N; sw.Hb = s->d_Hb[s->icur]; sw.Href = s->d_dyref + (size_t)(t - 1) * d * n;
             sw.W = s->d_W; sw.yt = c->d_y + (size_t)(t - 1) * d; sw.qf = s->d_qf[s->icur]; sw.hld = s->d_hld[s->icur];
             sw.pant_log = s->d_pant_log; sw.status = c->d_flags;
+            sw.order = (c->order_step == t - 1) ? c->d_order : nullptr;     // generation t-1 in the order its step ran in
             HIPCHK(launch_chol_sweep(sw, st));
             s->sw_cur ^= 1;
             skip_chol = true;

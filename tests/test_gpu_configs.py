@@ -196,3 +196,31 @@ def test_radio_filter_against_the_c_restatement(rbpf):
                               rng=cases.device_rng(rbpf, c), want_xn_traj=False)
     assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
     assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
+
+
+@pytest.mark.parametrize("kind,N,T,m", [("radio", 65536, 8, 128), ("mag", 8192, 8, 512)])
+def test_carried_factors_and_lazy_update_at_the_configuration_sizes(rbpf, kind, N, T, m):
+    """The options the bench's second smoother number uses (lazy_depth = 3, chol_refresh) at configs[3]'s size and at the
+    per-GPU share of configs[2] (N_P = 8192, nLin = 515) against the default arithmetic on the same Philox streams: same
+    ancestors and trajectory draws, ancestor probabilities within 1e-9, outputs within 1e-9."""
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    if kind == "radio":
+        Q = dg.radio_Q(T, "square_3D")
+        th = [0.25, 2.0, 0.01]
+        d = dg.planar_heading(T, Q, th, 1.0, seed=1, nLL=4, traj="square_3D")
+        mdl, x0, P0, R = rbpf.dense_radio_prior(m, d["LL"], th)
+        dt = 1.0
+    else:
+        Q, dt = cases.Q_MAG, 0.01
+        d = dg.bean_6D(T, Q, cases.THETA_MAG, dt, seed=1)
+        mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    run = lambda **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
+                                                            x0, P0, Q, R, N, 2, dt, rng=rbpf.PhiloxRNG(9), extras=True, **kw)
+    a = run()
+    b = run(lazy_depth=3, chol_refresh=3)
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
+    assert np.max(np.abs(pa - pb)) <= 1e-9
+    assert rel(b[3]["w"], a[3]["w"]) <= 1e-9
+    assert rel(b[0], a[0]) <= RTOL and rel(b[1], a[1]) <= RTOL and rel(b[2], a[2]) <= RTOL

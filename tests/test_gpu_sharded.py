@@ -312,3 +312,31 @@ def test_skewed_exchange_is_agreed_on_by_every_rank(cap, fits):
     if fits:
         assert res[0][4][1] == n_local // 2 and res[1][4][2] == n_local // 2      # rank 0 sends 16 records to rank 1
         assert res[0][4][4] == n_local                                            # 32 children migrate
+
+
+_LIB_THEN_TORCH = r"""
+import importlib, sys
+sys.path[:0] = [{root!r}, {root!r} + "/tests", {root!r} + "/oracle"]
+import cases
+rbpf = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+assert "torch" not in sys.modules
+c = cases.radio_case(64, 10, 128, seed=1, N_K=2)
+mdl, x0, P0, R = cases.device_model(rbpf, c)
+rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 64, c["dt"],
+                    rng=cases.device_rng(rbpf, c))
+import torch
+torch.cuda.init()
+x = torch.ones(4, device="cuda") * 2
+assert float(x.sum()) == 8.0
+print("one runtime", sum("libamdhip64" in ln and " r-xp " in ln for ln in open("/proc/self/maps")))
+"""
+
+
+def test_torch_initialises_after_the_library_has_used_the_gpu():
+    """A single-GPU call followed by a sharded session in the same process: the library and torch must share one HIP runtime
+    (_ffi._share_hip_runtime_with_torch); with two copies mapped the later one finds no device."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LIB_THEN_TORCH.format(root=root)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "one runtime 1" in r.stdout, r.stdout
