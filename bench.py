@@ -261,6 +261,42 @@ def smoother_radio_large(pkg, datagen):
             "seconds": min(runs), "runs": runs, "unit": "s", "finite": bool(np.all(np.isfinite(XNK)))}
 
 
+def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full, N_K, seed, rank, world, lazy_depth):
+    """The metric's smoother as the N-GPU job runs it: particleSmootherInformationForm with world * N_local particles sharded over
+    the ranks (ShardedSmootherSession: all_gather of the forward bank and of the ancestor log-weights, all_to_all of the migrating
+    particle records), timed over the first T_s of the T_full time steps of both CPF-AS iterations; max over ranks.  The full-length
+    figure is an extrapolation by time steps (every step of an iteration costs the same) and is labelled as one."""
+    Q = q_mag()
+    d = datagen.bean_6D(T_s, Q, THETA_MAG, 0.01, seed=seed)
+    model, x0_lin, P0, R = pkg.dense_mag_prior(m, d["LL"], THETA_MAG)
+    sess = mg.ShardedSmootherSession(model, d["dx"], d["y"], d["initState"], x0_lin, P0, Q, R, N_local, N_K, 0.01,
+                                     rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth)
+    try:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        XNK, XLK, PK = sess.run()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        it = list(sess.stats.get("iter_s", []))
+        st = {k: v for k, v in sess.stats.items() if k not in ("phase_s", "iter_s")}
+    finally:
+        sess.close()
+    tt = torch.tensor([dt_s] + it, dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    tt = [float(v) for v in tt.tolist()]
+    import numpy as np
+    if not (np.all(np.isfinite(XNK)) and np.all(np.isfinite(PK))):
+        raise RuntimeError("non-finite smoother output")
+    per_step = [v / T_s for v in tt[1:]]
+    return {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_local * world} ({N_local} per GPU x {world}) m={m} N_K={N_K}, "
+                        f"first {T_s} of {T_full} time steps of every iteration, lazy_depth {lazy_depth}, fresh factorisation every step",
+            "seconds": tt[0], "seconds_per_iteration": tt[1:], "ms_per_time_step_per_iteration": [v * 1e3 for v in per_step],
+            "extrapolated_full_T_seconds": sum(per_step) * T_full, "sharding": st}
+
+
 def smoother_kernel_roofline(pkg):
     """The smoothers' dominant kernel on its own: the batched ancestor-weight factorisation (particleSmoother.m:221-229,
     particleSmootherInformationForm.m:224-236) of 2048 matrices of the m=512 size (n=515), timed with HIP events inside
@@ -307,6 +343,9 @@ def main():
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
     ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
+    ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
+    ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
+    ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of the sharded smoother leg, seconds")
     args = ap.parse_args()
 
     if args.traffic_child:
@@ -464,6 +503,33 @@ def main():
             except Exception as exc:                                  # report, never hide
                 line["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": None, "kind": "port",
                                         "sample": f"failed: {exc}"}
+    else:
+        line = None
+    if sharded and not args.no_smoother:
+        # The smoother as the N-GPU job runs it.  Every rank takes part (collectives), so the leg runs under a watchdog: if it
+        # does not come back in time, rank 0 prints the line it already has (the filter measurement) and every rank leaves.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                line["smoother_sharded"] = {"error": f"no result within {args.smoother_timeout} s"}
+                print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+        dog = threading.Timer(args.smoother_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = smoother_sharded_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.m, min(args.smoother_steps, T), T, 2,
+                                       args.seed, rank, world, min(args.lazy_depth, 3))
+        except Exception as exc:
+            res = {"error": f"{type(exc).__name__}: {exc}"}
+        dog.cancel()
+        if rank == 0:
+            line["smoother_sharded"] = res
+            if "extrapolated_full_T_seconds" in res:
+                line["smoother_wall_clock_extrapolated_s"] = res["extrapolated_full_T_seconds"]
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -196,7 +196,6 @@ static int dmalloc(T** p, size_t count) {
 
 #define RB_TRY(x) do { int _s = (x); if (_s != RBPF_OK) return _s; } while (0)
 
-static bool ex_smoother_sharded(const CreateExtras* ex, bool smoother) { return ex != nullptr && smoother; }
 
 static bool have_device() {
   int n = 0;
@@ -330,7 +329,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   // ---- particle banks ----
   // multi-step lazy update: the filter (up to kMaxSets pending sets) and the information-form smoother (up to 3: its step
   // kernel carries two more right-hand sides); the covariance-form smoother switches it off (smoother_run)
-  c->lazy_depth = (!sparse && !ex_smoother_sharded(ex, smoother) && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (int)kMaxSets) : 1;
+  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (int)kMaxSets) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     const bool can = !smoother && !ex && c->lazy_depth >= 2;

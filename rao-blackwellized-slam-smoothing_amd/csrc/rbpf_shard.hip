@@ -66,7 +66,6 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   if (opt) o = *opt; else std::memset(&o, 0, sizeof(o));
   o.keep_history = 0;
   o.trace = 0;
-  if (smoother) o.lazy_depth = 0;
   rbpf_ctx* c = nullptr;
   RB_TRY(ctx_create(model, prob, rng, &o, smoother, N_K, &c, &ex));
   ShardState* s = new ShardState();
@@ -338,7 +337,6 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.xref = xref_t; a.xref_gslot = s->Nglob - 1;
   a.info = info ? 1 : 0;
   if (info) {
-    if (lazy) { set_error("the information form has no lazy update"); return RBPF_ERR_UNSUPPORTED; }
     a.ivec_old = info->ivec_old; a.ivec_old_stride = info->ivec_old_stride; a.ivec_new = info->ivec_new;
     a.hld_old = info->hld_old; a.hld_old_stride = info->hld_old_stride; a.hld_new = info->hld_new;
     a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
@@ -461,7 +459,7 @@ __global__ void shard_w_local_kernel(int Nloc, int slot0, const int* __restrict_
 
 // Covariance of local particle `idx` as of the last finished step in MATLAB layout (every pending downdate applied; the
 // stored matrix of its lineage may sit in a received record), into the device buffer dP [n x n].
-static int shard_unpack_particle(rbpf_ctx* c, int idx, double* dP) {
+int rbpf::shard_unpack_particle(rbpf_ctx* c, int idx, double* dP) {
   ShardState* s = c->sh;
   const Layout& L = c->lay;
   const int d = c->mdl.d, N = s->Nloc;

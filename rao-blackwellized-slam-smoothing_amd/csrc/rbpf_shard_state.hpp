@@ -64,5 +64,6 @@ int shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* sl
 int shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host, int k_iter, int n_draw);
 // information part of the send records (ivec, halfLogDetP, pending H, Imat) of `count` local particles
 int shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count);
+int shard_unpack_particle(rbpf_ctx* c, int idx, double* dP);
 
 }  // namespace rbpf

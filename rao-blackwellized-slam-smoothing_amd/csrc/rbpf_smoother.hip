@@ -1401,23 +1401,19 @@ int rbpf_shard_smoother_end(rbpf_ctx* c, double* XNK_k, double* XLK_k, double* P
   if (ak_out) *ak_out = ak;
   if (owner_rank) *owner_rank = owner;
   if (XNK_k) HIPCHK(hipMemcpy(XNK_k, s->d_xnk, (size_t)nN * T * 8, hipMemcpyDeviceToHost));
-  const int cur = c->cur;
   if (XLK_k) {
     std::memset(XLK_k, 0, (size_t)n * 8);
-    if (owner == sh->rank) HIPCHK(hipMemcpy(XLK_k, c->xl[cur] + (size_t)idx * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (owner == sh->rank) HIPCHK(hipMemcpy(XLK_k, c->xl[c->xcur] + (size_t)idx * L.ldx, (size_t)n * 8, hipMemcpyDeviceToHost));
   }
   if (PK_k) {
     std::memset(PK_k, 0, (size_t)n * n * 8);
     if (owner == sh->rank) {
-      double* dP = nullptr; int* didx = nullptr;
+      double* dP = nullptr;
       RB_TRY(dmalloc(&dP, (size_t)n * n));
-      int s2 = dmalloc(&didx, 1);
-      if (s2 != RBPF_OK) { hipFree(dP); return s2; }
-      hipError_t e = hipMemcpy(didx, &idx, 4, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = launch_unpack_P(L, d, c->Pt[cur], c->Pb[cur], c->F[cur], didx, 1, dP, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e == hipSuccess) e = hipMemcpy(PK_k, dP, (size_t)n * n * 8, hipMemcpyDeviceToHost);
-      hipFree(dP); hipFree(didx);
+      int rc = shard_unpack_particle(c, idx, dP);                 // pending downdates applied, lineage base in a record or the bank
+      hipError_t e = (rc == RBPF_OK) ? hipMemcpy(PK_k, dP, (size_t)n * n * 8, hipMemcpyDeviceToHost) : hipSuccess;
+      hipFree(dP);
+      if (rc != RBPF_OK) return rc;
       HIPCHK(e);
     }
   }

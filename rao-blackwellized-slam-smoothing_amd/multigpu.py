@@ -448,7 +448,7 @@ class ShardedSmootherSession(ShardedFilterSession):
     particles bit for bit."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
-                 transport="device", exchange_capacity=0, sync_phases=False):
+                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0):
         self.N_K = int(N_K)
         lib = load_library()
         for name, argt in (("rbpf_shard_smoother_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
@@ -464,7 +464,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                                                         _ffi.c_int32_p, _ffi.c_int32_p])):
             getattr(lib, name).argtypes = argt
         super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
-                         transport=transport, planner="device", lazy_depth=0, exchange_capacity=exchange_capacity,
+                         transport=transport, planner="device", lazy_depth=lazy_depth, exchange_capacity=exchange_capacity,
                          sync_phases=sync_phases)
         sv = rbpf_shard_smoother_views()
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
@@ -503,7 +503,9 @@ class ShardedSmootherSession(ShardedFilterSession):
         PK = np.zeros((n, n, self.N_K), order="F")
         self.aks = []
         tm = self.stats.setdefault("phase_s", dict(gather=0.0, normalise=0.0, anc=0.0, plan=0.0, exchange=0.0, step=0.0))
+        self.stats["iter_s"] = []
         for k in range(self.N_K):
+            t_iter = time.perf_counter()
             check(lib.rbpf_shard_smoother_begin(self.ctx, k))
             for t in range(T):
                 if t == 0:
@@ -543,6 +545,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                 xlk, pk = buf[:n], buf[n:].reshape((n, n), order="F")
             XNK[:, :, k], XLK[:, k], PK[:, :, k] = xnk, xlk, pk
             self.aks.append(int(ak.value))
+            self.stats["iter_s"].append(time.perf_counter() - t_iter)     # rbpf_shard_smoother_end synchronised
             if progress:
                 progress(k)
         return XNK, XLK, PK

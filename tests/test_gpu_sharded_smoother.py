@@ -26,7 +26,7 @@ def _case(kind, N, T, m, N_K):
     return mk(N, T, m, seed=31, N_K=N_K)
 
 
-def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q):
+def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth=0):
     import importlib
     import torch
     import torch.distributed as dist
@@ -41,7 +41,8 @@ def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q):
         c = _case(kind, world * n_local, T, m, N_K)
         mdl, x0, P0, R = cases.device_model(rbpf, c)
         s = mg.ShardedSmootherSession(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, n_local, N_K, c["dt"],
-                                      rng=cases.device_rng(rbpf, c), rank=rank, world=world, transport=transport)
+                                      rng=cases.device_rng(rbpf, c), rank=rank, world=world, transport=transport,
+                                      lazy_depth=lazy_depth)
         XNK, XLK, PK = s.run()
         stats = dict(s.stats)
         aks = list(s.aks)
@@ -51,11 +52,11 @@ def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q):
         dist.destroy_process_group()
 
 
-def _run(world, backend, transport, kind, n_local, T, m, N_K):
+def _run(world, backend, transport, kind, n_local, T, m, N_K, lazy_depth=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, kind, n_local, T, m, N_K, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -90,6 +91,26 @@ def test_two_ranks_equal_single_gpu_smoother(rbpf, kind, n_local, T, m, N_K):
     orc = cases.oracle_smoother(c, info_form=True)
     np.testing.assert_allclose(res[0][1], orc["XNK"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(res[0][2], orc["XLK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["XLK"])))
+    np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
+
+
+@pytest.mark.parametrize("kind,n_local,T,m,N_K,lazy_depth", [("mag", 24, 11, 130, 3, 3), ("mag", 16, 9, 256, 2, 2), ("radio", 40, 12, 128, 3, 3)])
+def test_two_ranks_with_lazy_update_match_single_gpu_smoother(rbpf, kind, n_local, T, m, N_K, lazy_depth):
+    """Sharded information-form smoother + multi-step lazy covariance update: a migrating particle's record carries its
+    covariance with the pending downdates applied (another rounding point than the single-GPU flush), so the two agree to
+    1e-9 instead of bit for bit; the oracle bounds both."""
+    res = _run(2, "gloo", "host", kind, n_local, T, m, N_K, lazy_depth)
+    c, ref = _single(rbpf, kind, 2 * n_local, T, m, N_K)
+    for rank, XNK, XLK, PK, aks, stats in res:
+        np.testing.assert_array_equal(np.asarray(aks), ref[3]["ak"])
+        np.testing.assert_allclose(XNK, ref[0], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(XLK, ref[1], rtol=1e-9, atol=1e-9 * np.max(np.abs(ref[1])))
+        np.testing.assert_allclose(PK, ref[2], rtol=1e-9, atol=1e-9 * np.max(np.abs(ref[2])))
+    np.testing.assert_array_equal(res[0][1], res[1][1])        # the ranks agree with each other exactly
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    assert res[0][5]["migrated"] > 0
+    orc = cases.oracle_smoother(c, info_form=True)
+    np.testing.assert_allclose(res[0][1], orc["XNK"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
 
 
