@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 4
+#define RBPF_ABI_VERSION 5
 
 typedef enum {
   RBPF_OK = 0,
@@ -375,6 +375,12 @@ int rbpf_shard_set_ancestors(rbpf_ctx* ctx, const int32_t* ai);
 typedef struct {
   double* anc_local;           /* [N_local] ancestor log-weights of my particles (physical order)          */
   double* anc_gather;          /* [world][N_local] all_gather target                                      */
+  /* carried factors (chol_refresh > 1): base matrices exchanged at a refresh, [refresh_capacity][matrix_doubles]; NULL / 0
+   * otherwise                                                                                                */
+  double* refresh_send;
+  double* refresh_recv;
+  int64_t refresh_capacity;
+  int64_t matrix_doubles;      /* n_lin * n_lin                                                            */
 } rbpf_shard_smoother_views;
 
 int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
@@ -388,6 +394,21 @@ int rbpf_shard_smoother_normalise(rbpf_ctx* ctx, int32_t want_draw);
 int rbpf_shard_smoother_anc_weights(rbpf_ctx* ctx);
 /* After the all_gather of anc_local: normalise (:243-245) and draw ai(N_P) (:248).                                */
 int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx);
+/* Carried ancestor-weight factors in the sharded smoother (rbpf_options.chol_refresh = K > 1, lazy_depth as usual): between
+ * refreshes rbpf_shard_smoother_anc_weights runs one up/down-date sweep per particle over its ancestor's factor, which migrates
+ * inside the particle records in place of Imat.  At the steps t = 1 and (t - 1) % K == 0 of an iteration k > 0 the factors are
+ * refreshed INSTEAD of rbpf_shard_smoother_anc_weights:
+ *   rbpf_shard_smoother_refresh_begin(ctx, owner_now, base_loc)   both [N_global] int32, identical on every rank:
+ *        owner_now[j] = rank * N_local + slot of logical slot j's particle, base_loc[j] = the same for the ancestor its
+ *        information matrix is rebuilt from (-1: the common initial matrix, nothing to fetch)
+ *   the host mirror derives the fetch plan from the two tables (multigpu.plan_refresh: unique (destination, matrix) pairs),
+ *   rbpf_shard_smoother_refresh_pack(ctx, slots, count); all_to_all_single(refresh_send -> refresh_recv);
+ *   rbpf_shard_smoother_refresh_end(ctx, base_index, n_recv)      base_index [N_local]: bank slot or N_local + position in
+ *        refresh_recv
+ * then all_gather(anc_local) and rbpf_shard_smoother_anc_sample as usual.                                            */
+int rbpf_shard_smoother_refresh_begin(rbpf_ctx* ctx, int32_t* owner_now, int32_t* base_loc);
+int rbpf_shard_smoother_refresh_pack(rbpf_ctx* ctx, const int32_t* slots, int32_t count);
+int rbpf_shard_smoother_refresh_end(rbpf_ctx* ctx, const int32_t* base_index, int32_t n_recv);
 /* One information-form time step of my particles (:256-335), using the plan of rbpf_shard_plan for t > 0.        */
 int rbpf_shard_smoother_step(rbpf_ctx* ctx);
 /* End of iteration (:346-354): ak = sample(w), new reference trajectory -> XNK_k [n_nonlin x N_T] (every rank);

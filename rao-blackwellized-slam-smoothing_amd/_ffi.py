@@ -106,6 +106,7 @@ EXPORTS = [
     "rbpf_stream_get", "rbpf_shard_set_async", "rbpf_shard_finish", "rbpf_shard_set_ancestors",
     "rbpf_shard_smoother_create", "rbpf_shard_smoother_views_get", "rbpf_shard_smoother_begin",
     "rbpf_shard_smoother_normalise", "rbpf_shard_smoother_anc_weights", "rbpf_shard_smoother_anc_sample",
+    "rbpf_shard_smoother_refresh_begin", "rbpf_shard_smoother_refresh_pack", "rbpf_shard_smoother_refresh_end",
     "rbpf_shard_smoother_step", "rbpf_shard_smoother_end",
 ]
 
@@ -184,8 +185,8 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_chol_weights.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p, C.c_double, C.c_int32, C.c_int32,
                                       c_double_p, c_int32_p, c_double_p]
     lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
-    if lib.rbpf_abi_version() != 4:
-        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 4 (rebuild)")
+    if lib.rbpf_abi_version() != 5:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 5 (rebuild)")
     _lib = lib
     return lib
 

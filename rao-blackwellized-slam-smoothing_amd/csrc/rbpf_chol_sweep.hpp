@@ -55,6 +55,10 @@ struct SweepArgs {
   const double* qf; const double* hld;    // [N] ivec' P ivec and halfLogDetP after the last update
   double* pant_log;                 // += logwMeas
   int* status;
+  // particle-sharded smoother: ancestors with a bank entry >= n_bank read their factor from a received particle record, and
+  // the reference trajectory is the particle whose LOGICAL slot (slot_ids[p]) is ref_logical
+  const double* rec = nullptr; size_t rec_stride = 0, rec_off = 0; int n_bank = 0;
+  const int* slot_ids = nullptr; int ref_logical = -1;
 };
 
 // fragment-order factor of the 64-column kernel (row-tile major: ((rt * 4 RT + kg) * 64 + kk * 16 + r)) -> sweep layout
@@ -198,9 +202,10 @@ __global__ __launch_bounds__(256, VLDS ? 2 : 1) void chol_sweep_kernel(const Swe
   if (pb >= a.N) return;                                 // wave-uniform
   const int p = a.order ? a.order[pb] : pb;
   const int src_p = a.anc ? a.anc[p] : p;
-  const double* src = a.Lold + (size_t)src_p * a.stride;
+  const double* src = (a.rec && src_p >= a.n_bank) ? a.rec + (size_t)(src_p - a.n_bank) * a.rec_stride + a.rec_off
+                                                   : a.Lold + (size_t)src_p * a.stride;
   double* dst = a.Lnew + (size_t)p * a.stride;
-  const bool plain_copy = (p == a.ref_slot);
+  const bool plain_copy = a.slot_ids ? (a.slot_ids[p] == a.ref_logical) : (p == a.ref_slot);
   // update vectors u_a = (W H_p)_a, downdate vectors v_a = (W H_ref)_a, both augmented by eta_a = (W y)_a in row n
   double u[D][NS];
   SweepV<D, NS, VLDS> v;
@@ -295,6 +300,40 @@ __global__ void sweep_path_kernel(int N, int nN, int Kp, int t_last, int t0, con
   base_slot[i] = slot;
 }
 
+// Particle-sharded smoother: the same walk over the replicated global history (logical slot ids), for every logical slot j:
+// owner_now[j] = where its particle lives now (rank * Nloc + physical slot), base_loc[j] = where the particle of its ancestor
+// in generation t0 lived when that generation was materialised (-1: t0 < 0, the common initial matrix).  The path states are
+// written for the particles of this rank only, at their physical slot.
+__global__ void shard_path_kernel(int Nglob, int Nloc, int rank, int nN, int Kp, int t_last, int t0, const int* __restrict__ A,
+                                  const double* __restrict__ X, const int* __restrict__ cur_gid, const int* __restrict__ base_gid,
+                                  int* __restrict__ owner_now, int* __restrict__ base_loc, double* __restrict__ Xp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= Nglob) return;
+  const int gid = cur_gid ? cur_gid[j] : j;
+  const bool mine = (gid / Nloc) == rank;
+  const int p = gid % Nloc;
+  int slot = j;
+  for (int s = t_last; s > t0; --s) {
+    if (mine) {
+      const double* Xs = X + (size_t)s * nN * Nglob;
+      double* col = Xp + ((size_t)p * Kp + (s - t0 - 1)) * nN;
+      for (int c = 0; c < nN; ++c) col[c] = Xs[(size_t)c * Nglob + slot];
+    }
+    if (s > 0) slot = A[(size_t)s * Nglob + slot];
+  }
+  owner_now[j] = gid;
+  base_loc[j] = (t0 < 0) ? -1 : (base_gid ? base_gid[slot] : slot);
+}
+
+// rows of `count` matrices [n x n] out of a bank into a contiguous buffer (the base matrices other ranks asked for)
+__global__ __launch_bounds__(256) void gather_matrices_kernel(size_t nn, const int* __restrict__ idx, const double* __restrict__ bank,
+                                                              double* __restrict__ out) {
+  const double* src = bank + (size_t)idx[blockIdx.x] * nn;
+  double* dst = out + (size_t)blockIdx.x * nn;
+  const size_t per = (nn + gridDim.y - 1) / gridDim.y, q0 = (size_t)blockIdx.y * per, q1 = q0 + per < nn ? q0 + per : nn;
+  for (size_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) dst[q] = src[q];
+}
+
 // G = W H in place: H [rows][d][n] (rows of H contiguous), W [d x d] column-major
 __global__ void sweep_whiten_kernel(size_t rows, int d, int n, const double* __restrict__ W, double* __restrict__ H) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,10 +347,13 @@ __global__ void sweep_whiten_kernel(size_t rows, int d, int n, const double* __r
 }
 
 // Imat_new[i] += base[base_slot[i]] over the block-lower part the factorisation kernels read
+// (sharded smoother: entries >= n_bank are matrices fetched from other ranks, rec [..][n*n])
 __global__ __launch_bounds__(256) void sweep_add_base_kernel(int n, const double* __restrict__ base, long base_stride,
-                                                             const int* __restrict__ base_slot, double* __restrict__ Imat) {
+                                                             const int* __restrict__ base_slot, double* __restrict__ Imat,
+                                                             const double* __restrict__ rec, int n_bank) {
   const int p = blockIdx.x;
-  const double* src = base + (size_t)(base_slot ? base_slot[p] : 0) * base_stride;
+  const int bs = base_slot ? base_slot[p] : 0;
+  const double* src = (rec && bs >= n_bank) ? rec + (size_t)(bs - n_bank) * n * n : base + (size_t)bs * base_stride;
   double* dst = Imat + (size_t)p * n * n;
   for (int c = blockIdx.y; c < n; c += gridDim.y) {
     const int r0 = (c >> 6) << 6;

@@ -80,13 +80,14 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   s->recsz_base = s->recsz;
   s->smoother = smoother;
   if (smoother) {
-    // information part of a record: [ivec ldx | halfLogDetP, pad | pending H d*ldx | Imat n*n], 16-byte aligned
+    // information part of a record: [ivec ldx | halfLogDetP, pad | pending H d*ldx | Imat n*n], 16-byte aligned; with carried
+    // factors (chol_refresh > 1) the matrix part is the ancestor-weight factor in sweep layout instead of Imat
     const size_t n = (size_t)c->mdl.n;
     s->rec_off_I = s->recsz_base;
     s->rec_off_hld = s->rec_off_I + L.ldx;
     s->rec_off_Hb = s->rec_off_hld + 2;
     s->rec_off_Imat = s->rec_off_Hb + (size_t)d * L.ldx;
-    s->recsz = s->rec_off_Imat + n * n;
+    s->recsz = s->rec_off_Imat + smoother_record_matrix_doubles((int)n, o.chol_refresh);
     s->recsz += s->recsz & 1;
   }
   if (world > 1) {

@@ -60,6 +60,18 @@ struct SmootherState {
   std::vector<double> h_ivec0;  // [ldx]
   double hld0 = 0.0;
   std::vector<int> h_ai;        // [Nglob] D2H target of the global ancestor draw
+  // sharded smoother with carried factors: where every logical slot's particle lives now / lived when the Imat bank was
+  // materialised, and the base matrices fetched from (packed for) other ranks at a refresh
+  int* d_owner_now = nullptr;   // [Nglob] rank * Nloc + physical slot
+  int* d_base_gid = nullptr;    // [Nglob] the same table of generation base_gen
+  int* d_base_loc = nullptr;    // [Nglob] location of each logical slot's ancestor of generation base_gen at that time (-1: Imat0)
+  double* d_rf_send = nullptr;  // [rf_cap][n*n]
+  double* d_rf_recv = nullptr;  // [rf_cap][n*n]
+  int* d_rf_idx = nullptr;      // [rf_cap]
+  size_t rf_cap = 0;
+  int rf_stage = 0;             // 1 between refresh_begin and refresh_end
+  int rf_Kp = 0;
+  bool sw_valid = false;        // the factor bank holds the current generation
 };
 
 void smoother_free(rbpf_ctx* c) {
@@ -71,6 +83,7 @@ void smoother_free(rbpf_ctx* c) {
   hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
   hipFree(s->d_Rinv); hipFree(s->d_Lsw[0]); hipFree(s->d_Lsw[1]); hipFree(s->d_W);
   hipFree(s->d_base_slot); hipFree(s->d_Xp);
+  hipFree(s->d_owner_now); hipFree(s->d_base_gid); hipFree(s->d_base_loc); hipFree(s->d_rf_send); hipFree(s->d_rf_recv); hipFree(s->d_rf_idx);
   delete s;
   c->sm = nullptr;
 }
@@ -686,7 +699,7 @@ __global__ void fill_kernel(size_t count, double v, double* p) {
 __global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, const int* __restrict__ idx,
                                                         const double* __restrict__ ivec, const double* __restrict__ hld,
                                                         const double* __restrict__ Hb, const double* __restrict__ Imat,
-                                                        size_t imat_stride, double* __restrict__ rec, size_t rec_stride,
+                                                        size_t imat_stride, size_t imat_len, double* __restrict__ rec, size_t rec_stride,
                                                         size_t off_I, size_t off_hld, size_t off_Hb, size_t off_Imat) {
   const int p = blockIdx.x, src = idx[p];
   double* r = rec + (size_t)p * rec_stride;
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, c
     if (threadIdx.x == 0) { r[off_hld] = hld[src]; r[off_hld + 1] = 0.0; }
   }
   if (Imat) {
-    const size_t nn = (size_t)n * n, per = (nn + gridDim.y - 1) / gridDim.y;
+    const size_t nn = imat_len, per = (nn + gridDim.y - 1) / gridDim.y;
     const size_t q0 = (size_t)blockIdx.y * per, q1 = q0 + per < nn ? q0 + per : nn;
     const double* im = Imat + (size_t)src * imat_stride;
     for (size_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) r[off_Imat + q] = im[q];
@@ -788,6 +801,28 @@ static void info_initial_values(rbpf_ctx* c, std::vector<double>& ivec0, std::ve
     ivec0[r] = (1.0 / pd) * c->h_x0l[r];
     hld0 += std::log(std::sqrt(pd));
   }
+}
+
+// W = inv(chol(R,'lower')): W' W = R^-1, so H' R^-1 H = sum_a (W H)_a' (W H)_a
+static void whitening_factor(const std::vector<double>& Rh, int d, std::vector<double>& Wm) {
+  std::vector<double> Lr((size_t)d * d, 0.0);
+  Wm.assign((size_t)d * d, 0.0);
+  for (int j = 0; j < d; ++j) {
+    double sd = Rh[j + (size_t)d * j];
+    for (int q = 0; q < j; ++q) sd -= Lr[j + (size_t)d * q] * Lr[j + (size_t)d * q];
+    Lr[j + (size_t)d * j] = std::sqrt(sd);
+    for (int i = j + 1; i < d; ++i) {
+      double v = Rh[i + (size_t)d * j];
+      for (int q = 0; q < j; ++q) v -= Lr[i + (size_t)d * q] * Lr[j + (size_t)d * q];
+      Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
+    }
+  }
+  for (int col = 0; col < d; ++col)
+    for (int i = 0; i < d; ++i) {
+      double v = (i == col);
+      for (int q = 0; q < i; ++q) v -= Lr[i + (size_t)d * q] * Wm[q + (size_t)d * col];
+      Wm[i + (size_t)d * col] = v / Lr[i + (size_t)d * i];
+    }
 }
 
 static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* out) {
@@ -887,24 +922,8 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds) { set_error("chol_refresh > 1 supports nLin <= 575"); return RBPF_ERR_UNSUPPORTED; }
       for (int b = 0; b < 2; ++b) RB_TRY(dmalloc(&s->d_Lsw[b], (size_t)N * sweep_factor_doubles(n)));
       RB_TRY(dmalloc(&s->d_W, (size_t)d * d));
-      // W = inv(chol(R,'lower')): W' W = R^-1, so H' R^-1 H = sum_a (W H)_a' (W H)_a
-      std::vector<double> Lr((size_t)d * d, 0.0), Wm((size_t)d * d, 0.0);
-      for (int j = 0; j < d; ++j) {
-        double sd = Rh[j + (size_t)d * j];
-        for (int q = 0; q < j; ++q) sd -= Lr[j + (size_t)d * q] * Lr[j + (size_t)d * q];
-        Lr[j + (size_t)d * j] = std::sqrt(sd);
-        for (int i = j + 1; i < d; ++i) {
-          double v = Rh[i + (size_t)d * j];
-          for (int q = 0; q < j; ++q) v -= Lr[i + (size_t)d * q] * Lr[j + (size_t)d * q];
-          Lr[i + (size_t)d * j] = v / Lr[j + (size_t)d * j];
-        }
-      }
-      for (int col = 0; col < d; ++col)
-        for (int i = 0; i < d; ++i) {
-          double v = (i == col);
-          for (int q = 0; q < i; ++q) v -= Lr[i + (size_t)d * q] * Wm[q + (size_t)d * col];
-          Wm[i + (size_t)d * col] = v / Lr[i + (size_t)d * i];
-        }
+      std::vector<double> Wm;
+      whitening_factor(Rh, d, Wm);
       HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
       s->lazy_imat = c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;     // needs measModel on the device
       if (s->lazy_imat) {
@@ -1047,7 +1066,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
             HIPCHK(launch_gemm(gg, N, st));                                   // G' G
             hipLaunchKernelGGL(sweep_add_base_kernel, dim3(N, 4), dim3(256), 0, st, n, t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur],
-                               t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni]);
+                               t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni], (const double*)nullptr, 0);
             HIPCHK(hipGetLastError());
             s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
             ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
@@ -1198,6 +1217,10 @@ extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_proble
 // on the rank that holds each particle, all-gathered (N doubles), and normalised / sampled identically on every
 // rank, so a W-rank run equals the single-GPU smoother with N = W * N_local particles bit for bit.
 // =============================================================================================================
+size_t rbpf::smoother_record_matrix_doubles(int n, int chol_refresh) {
+  return chol_refresh > 1 ? sweep_factor_doubles(n) : (size_t)n * n;
+}
+
 int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
   SmootherState* s = c->sm;
   ShardState* sh = c->sh;
@@ -1207,11 +1230,13 @@ int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
   // iteration 1 never reads Imat (:157: k > 1 only); later the ancestor-weight factorisation of this step has just
   // stored the matrices of the current generation (own updates included), so the records carry them complete
   const bool with_imat = sh->k_iter > 0;
-  if (with_imat && !s->imat_valid) { set_error("pack before the ancestor weights of this step"); return RBPF_ERR_STATE; }
-  const double* im = with_imat ? s->d_Imat[s->imat_cur] : nullptr;
-  const size_t stride = (size_t)n * n;
+  const bool carry = s->refresh > 1;
+  if (with_imat && !(carry ? s->sw_valid : s->imat_valid)) { set_error("pack before the ancestor weights of this step"); return RBPF_ERR_STATE; }
+  // carried factors: the record takes the particle's factor (sweep layout) along instead of Imat, which is rebuilt at refreshes
+  const double* im = !with_imat ? nullptr : (carry ? s->d_Lsw[s->sw_cur] : s->d_Imat[s->imat_cur]);
+  const size_t stride = carry ? sweep_factor_doubles(n) : (size_t)n * n;
   hipLaunchKernelGGL(pack_info_kernel, dim3(count, with_imat ? 8 : 1), dim3(256), 0, c->stream, n, d, L.ldx, d_idx,
-                     s->d_ivec[s->icur], s->d_hld[s->icur], s->d_Hb[s->icur], im, stride, sh->send_rec, sh->recsz,
+                     s->d_ivec[s->icur], s->d_hld[s->icur], s->d_Hb[s->icur], im, stride, stride, sh->send_rec, sh->recsz,
                      sh->rec_off_I, sh->rec_off_hld, sh->rec_off_Hb, sh->rec_off_Imat);
   HIPCHK(hipGetLastError());
   return RBPF_OK;
@@ -1232,9 +1257,9 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     return RBPF_ERR_INVALID_ARG;
   }
   if (n > 1023) { set_error("information-form smoother supports nLin <= 1023"); return RBPF_ERR_UNSUPPORTED; }
-  if (opt && opt->chol_refresh > 1) { set_error("chol_refresh > 1 (carried factors) is not available in the sharded smoother"); return RBPF_ERR_UNSUPPORTED; }
   SmootherState* s = new SmootherState();
   c->sm = s;
+  s->refresh = c->opt.chol_refresh > 1 ? c->opt.chol_refresh : 0;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
   RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
   RB_TRY(dmalloc(&s->d_ak, 4));
@@ -1258,6 +1283,31 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   HIPCHK(hipMemcpy(s->d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
   s->h_ai.assign((size_t)c->sh->Nglob, 0);
+  if (s->refresh) {
+    // carried ancestor-weight factors (rbpf_chol_sweep.hpp): factor banks, the buffers of the refresh from the state history,
+    // and the exchange buffers for base matrices that sit on another rank
+    if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds) { set_error("chol_refresh > 1 supports nLin <= 575"); return RBPF_ERR_UNSUPPORTED; }
+    if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) { set_error("chol_refresh > 1 in the sharded smoother needs measModel on the device"); return RBPF_ERR_UNSUPPORTED; }
+    ShardState* sh = c->sh;
+    for (int b = 0; b < 2; ++b) RB_TRY(dmalloc(&s->d_Lsw[b], (size_t)N * sweep_factor_doubles(n)));
+    RB_TRY(dmalloc(&s->d_W, (size_t)d * d));
+    std::vector<double> Wm;
+    whitening_factor(c->h_R, d, Wm);
+    HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
+    s->lazy_imat = true;
+    RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
+    RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
+    RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
+    RB_TRY(dmalloc(&s->d_owner_now, (size_t)sh->Nglob));
+    RB_TRY(dmalloc(&s->d_base_gid, (size_t)sh->Nglob));
+    RB_TRY(dmalloc(&s->d_base_loc, (size_t)sh->Nglob));
+    // every particle needs one base matrix at most; half of the local particles importing theirs is far beyond what the
+    // owner-computes placement produces between two refreshes (identical on every rank: a function of the options only)
+    s->rf_cap = (world > 1) ? std::min<size_t>((size_t)N, std::max<size_t>(2 * sh->step_cap, 64)) : 1;
+    RB_TRY(dmalloc(&s->d_rf_send, s->rf_cap * (size_t)n * n));
+    RB_TRY(dmalloc(&s->d_rf_recv, s->rf_cap * (size_t)n * n));
+    RB_TRY(dmalloc(&s->d_rf_idx, s->rf_cap));
+  }
   guard.release();
   *out = c;
   return RBPF_OK;
@@ -1266,6 +1316,8 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
 int rbpf_shard_smoother_views_get(rbpf_ctx* c, rbpf_shard_smoother_views* v) {
   if (!c || !c->sh || !c->sm || !v) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
   v->anc_local = c->sh->anc_local; v->anc_gather = c->sh->anc_gather;
+  v->refresh_send = c->sm->d_rf_send; v->refresh_recv = c->sm->d_rf_recv;
+  v->refresh_capacity = (int64_t)c->sm->rf_cap; v->matrix_doubles = (int64_t)c->mdl.n * c->mdl.n;
   return RBPF_OK;
 }
 
@@ -1283,6 +1335,7 @@ int rbpf_shard_smoother_begin(rbpf_ctx* c, int32_t k) {
   sh->rec_used = 0; sh->plan_recv = 0; sh->k_iter = k;
   std::fill(sh->rec_used_all.begin(), sh->rec_used_all.end(), 0);
   RB_TRY(info_begin_iteration(c, s->h_ivec0.data(), s->hld0, 0.0, 0.0, s->d_Rinv));
+  s->sw_valid = false; s->rf_stage = 0;
   if (k > 0) {
     HIPCHK(launch_meas_model(c->mdl, T, s->d_xnk, s->d_dyref, c->stream, 1));           // :120
     HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, c->stream));
@@ -1305,9 +1358,9 @@ int rbpf_shard_smoother_normalise(rbpf_ctx* c, int32_t want_draw) {
 
 // k > 1, t > 1: ancestor log-weights of my particles against the reference state of the step about to run
 // (:205-240) -> anc_local [N_local] (physical order).  Synchronises: the all_gather follows.
-int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
-  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
-  HIPCHK(hipSetDevice(c->device));
+// dynResNorm part of the weights into anc_local and the (t-1) term out of the suffix sums: common to the fresh factorisation,
+// the sweep and the refresh
+static int shard_anc_head(rbpf_ctx* c) {
   SmootherState* s = c->sm;
   ShardState* sh = c->sh;
   const int t = c->t, k = sh->k_iter, N = sh->Nloc, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
@@ -1323,15 +1376,135 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, t - 1, t, -1.0,
                      s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
   HIPCHK(hipGetLastError());
+  return RBPF_OK;
+}
+
+static bool shard_refresh_due(const SmootherState* s, int t) { return s->refresh > 1 && (t == 1 || ((t - 1) % s->refresh) == 0); }
+
+int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  const int t = c->t, N = sh->Nloc, n = c->mdl.n, d = c->mdl.d;
+  hipStream_t st = c->stream;
+  if (shard_refresh_due(s, t)) { set_error("carried factors: this step refreshes them (rbpf_shard_smoother_refresh_begin / _pack / _end)"); return RBPF_ERR_STATE; }
+  RB_TRY(shard_anc_head(c));
+  if (s->refresh > 1) {
+    // carried factors: one sweep turns the ancestor's factor -- bank entry or received record -- into this particle's
+    if (!s->sw_valid || !sh->placed) { set_error("carried factors: no factor bank for the previous generation"); return RBPF_ERR_STATE; }
+    SweepArgs sw;
+    sw.n = n; sw.d = d; sw.ldx = c->lay.ldx; sw.NS = sweep_slots(n); sw.tailc = sweep_tail_compact(n); sw.N = N; sw.ref_slot = -1;
+    sw.Lold = s->d_Lsw[s->sw_cur]; sw.Lnew = s->d_Lsw[s->sw_cur ^ 1]; sw.stride = sweep_factor_doubles(n);
+    sw.anc = sh->pb.anc_bank; sw.order = nullptr;             // the planner lays the generation out in ancestor order
+    sw.Hb = s->d_Hb[s->icur]; sw.Href = s->d_dyref + (size_t)(t - 1) * d * n;
+    sw.W = s->d_W; sw.yt = c->d_y + (size_t)(t - 1) * d; sw.qf = s->d_qf[s->icur]; sw.hld = s->d_hld[s->icur];
+    sw.pant_log = sh->anc_local; sw.status = c->d_flags;
+    sw.rec = sh->recv_rec; sw.rec_stride = sh->recsz; sw.rec_off = sh->rec_off_Imat; sw.n_bank = N;
+    sw.slot_ids = sh->pb.slot_ids; sw.ref_logical = sh->Nglob - 1;
+    HIPCHK(launch_chol_sweep(sw, st));
+    s->sw_cur ^= 1;
+  } else {
+    CholArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
+    ca.variant = c->opt.chol_variant;
+    RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv, sh->pb.anc_bank));     // plan of the step that made this generation
+    ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
+    HIPCHK(launch_chol(ca, N, d, st));
+    HIPCHK(hipGetLastError());
+  }
+  if (!sh->async) HIPCHK(hipStreamSynchronize(st));
+  return RBPF_OK;
+}
+
+// ---- refresh of the carried factors (chol_refresh = K: the steps t = 1 and (t - 1) % K == 0 of an iteration k > 0) -------------
+// The information matrix of every particle of generation t-1 is rebuilt from the last materialised generation ("base") and the
+// measurement Jacobians along its ancestral path (rbpf_chol_sweep.hpp), then factorised.  The walk runs over the replicated
+// global history; the base matrix of a lineage sits on the rank that held that ancestor when the base was materialised, so the
+// host mirror fetches the ones on other ranks with one all_to_all between _pack and _end (unique per destination and matrix;
+// the plan is a function of the two replicated tables this call returns, hence identical on every rank).
+int rbpf_shard_smoother_refresh_begin(rbpf_ctx* c, int32_t* owner_now, int32_t* base_loc) {
+  if (!c || !c->sh || !c->sm || !owner_now || !base_loc) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  const int t = c->t, nN = c->mdl.nN;
+  if (!shard_refresh_due(s, t)) { set_error("no refresh is due at this step"); return RBPF_ERR_STATE; }
+  RB_TRY(shard_anc_head(c));
+  const int t0 = s->base_gen, Kp = t - 1 - t0;
+  if (Kp < 1 || Kp > s->refresh) { set_error("internal: refresh window"); return RBPF_ERR_STATE; }
+  hipStream_t st = c->stream;
+  hipLaunchKernelGGL(shard_path_kernel, dim3((sh->Nglob + 127) / 128), dim3(128), 0, st, sh->Nglob, sh->Nloc, sh->rank, nN, Kp, t - 1, t0,
+                     sh->Ahist, sh->Xhist, sh->placed ? sh->cur_gid : (const int*)nullptr, s->d_base_gid, s->d_owner_now, s->d_base_loc, s->d_Xp);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(owner_now, s->d_owner_now, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(base_loc, s->d_base_loc, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  s->rf_stage = 1; s->rf_Kp = Kp;
+  return RBPF_OK;
+}
+
+// Base matrices other ranks asked for: slots [count] of the materialised Imat bank -> refresh_send, in the order given.
+int rbpf_shard_smoother_refresh_pack(rbpf_ctx* c, const int32_t* slots, int32_t count) {
+  if (!c || !c->sh || !c->sm || count < 0 || (count > 0 && !slots)) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  if (s->rf_stage != 1 || s->base_gen < 0) { set_error("refresh_pack outside a refresh with a materialised base"); return RBPF_ERR_STATE; }
+  if ((size_t)count > s->rf_cap) { set_error("refresh exchange above its capacity"); return RBPF_ERR_OUT_OF_MEMORY; }
+  if (count == 0) return RBPF_OK;
+  for (int q = 0; q < count; ++q) if (slots[q] < 0 || slots[q] >= c->sh->Nloc) { set_error("refresh_pack: slot out of range"); return RBPF_ERR_INVALID_ARG; }
+  const size_t nn = (size_t)c->mdl.n * c->mdl.n;
+  HIPCHK(hipMemcpyAsync(s->d_rf_idx, slots, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(gather_matrices_kernel, dim3(count, 8), dim3(256), 0, c->stream, nn, s->d_rf_idx, s->d_Imat[s->imat_cur], s->d_rf_send);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(c->stream));                 // `slots` is caller memory; the collective may run on another stream
+  return RBPF_OK;
+}
+
+// base_index [N_local]: where each of my particles finds its base matrix -- a slot of my bank (< N_local) or N_local + the
+// position of the fetched matrix in refresh_recv; ignored (may be NULL) while the base is the common initial matrix.
+// n_recv: matrices in refresh_recv.
+int rbpf_shard_smoother_refresh_end(rbpf_ctx* c, const int32_t* base_index, int32_t n_recv) {
+  if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  ShardState* sh = c->sh;
+  if (s->rf_stage != 1) { set_error("refresh_end without refresh_begin"); return RBPF_ERR_STATE; }
+  const int t = c->t, N = sh->Nloc, n = c->mdl.n, d = c->mdl.d, Kp = s->rf_Kp, t0 = s->base_gen;
+  hipStream_t st = c->stream;
+  if (t0 >= 0) {
+    if (!base_index || n_recv < 0 || (size_t)n_recv > s->rf_cap) { set_error("refresh_end: base_index / n_recv"); return RBPF_ERR_INVALID_ARG; }
+    for (int p = 0; p < N; ++p) if (base_index[p] < 0 || base_index[p] >= N + n_recv) { set_error("refresh_end: base_index out of range"); return RBPF_ERR_INVALID_ARG; }
+    HIPCHK(hipMemcpyAsync(s->d_base_slot, base_index, (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
+  HIPCHK(launch_meas_model(c->mdl, N * Kp, s->d_Xp, s->d_G, st, 1));
+  const size_t rows = (size_t)N * Kp;
+  hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, st, rows, d, n, s->d_W, s->d_G);
+  HIPCHK(hipGetLastError());
+  const long Kd = (long)Kp * d;
+  GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
+  HIPCHK(launch_gemm(gg, N, st));                                   // G' G
+  hipLaunchKernelGGL(sweep_add_base_kernel, dim3(N, 4), dim3(256), 0, st, n, t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur],
+                     t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni],
+                     t0 < 0 ? (const double*)nullptr : s->d_rf_recv, N);
+  HIPCHK(hipGetLastError());
+  s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
+  HIPCHK(hipMemcpyAsync(s->d_base_gid, s->d_owner_now, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToDevice, st));
   CholArgs ca;
   std::memset(&ca, 0, sizeof(ca));
   ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
-  ca.variant = c->opt.chol_variant;
-  RB_TRY(info_fill_chol_args(c, ca, s->d_Rinv, sh->pb.anc_bank));     // plan of the step that made this generation
-  ca.n_bank_local = N; ca.rec = sh->recv_rec; ca.rec_stride = sh->recsz; ca.rec_off_Imat = sh->rec_off_Imat;
+  ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
+  ca.Imat = s->d_Imat[ni]; ca.imat_stride = (long)((size_t)n * n); ca.imat_anc = nullptr; ca.ImatOut = nullptr;
+  ca.Hb = nullptr; ca.Rinv = s->d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
+  ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
+  ca.variant = 64;
   HIPCHK(launch_chol(ca, N, d, st));
   HIPCHK(hipGetLastError());
-  if (!sh->async) HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(launch_sweep_from_chol64(n, N, s->d_L, chol_factor_doubles(n), s->d_Lsw[s->sw_cur ^ 1], sweep_factor_doubles(n), st));
+  s->sw_cur ^= 1; s->sw_valid = true; s->rf_stage = 0;
+  HIPCHK(hipStreamSynchronize(st));              // base_index is caller memory
   return RBPF_OK;
 }
 

@@ -201,7 +201,8 @@ class ShardedFilterSession:
         if lazy_depth >= 2 and planner != "device":
             raise ValueError("lazy_depth >= 2 needs planner='device'")
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth),
-                                     jitter=0.0, storage=_storage_code(storage), exchange_capacity=int(exchange_capacity))
+                                     jitter=0.0, storage=_storage_code(storage), exchange_capacity=int(exchange_capacity),
+                                     chol_refresh=int(getattr(self, "chol_refresh", 0)))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         self._create()
@@ -436,7 +437,51 @@ class ShardedFilterSession:
 # particle-sharded information-form smoother
 # ------------------------------------------------------------------------------------------------
 class rbpf_shard_smoother_views(C.Structure):
-    _fields_ = [("anc_local", _ffi.c_double_p), ("anc_gather", _ffi.c_double_p)]
+    _fields_ = [("anc_local", _ffi.c_double_p), ("anc_gather", _ffi.c_double_p),
+                ("refresh_send", _ffi.c_double_p), ("refresh_recv", _ffi.c_double_p),
+                ("refresh_capacity", C.c_int64), ("matrix_doubles", C.c_int64)]
+
+
+class RefreshPlan:
+    """Fetch plan of one refresh of the carried factors, for one rank (see plan_refresh)."""
+    __slots__ = ("send_slots", "send_counts", "recv_counts", "base_index", "send_totals", "recv_totals")
+
+    def __init__(self, send_slots, send_counts, recv_counts, base_index, send_totals, recv_totals):
+        self.send_slots, self.send_counts, self.recv_counts = send_slots, send_counts, recv_counts
+        self.base_index, self.send_totals, self.recv_totals = base_index, send_totals, recv_totals
+
+
+def plan_refresh(owner_now, base_loc, n_local, world, rank):
+    """Which base matrices cross ranks at a refresh of the carried factors (rbpf_shard_smoother_refresh_*).
+
+    owner_now[j] = r * n_local + p: rank and physical slot of logical slot j's particle; base_loc[j] = q * n_local + s: rank
+    and bank slot of the matrix its information matrix is rebuilt from.  Both tables are replicated, so every rank derives the
+    same plan without communicating: rank q sends rank r each matrix some particle on r needs, once (siblings share it), in
+    ascending slot order; a receive buffer therefore holds the matrices of rank 0, 1, ... in that order.  Returns the
+    RefreshPlan of `rank`: send_slots (concatenated per destination), send_counts / recv_counts [world], base_index [n_local]
+    (a slot of the own bank, or n_local + position in the receive buffer), and every rank's totals (capacity check)."""
+    owner_now = np.asarray(owner_now, dtype=np.int64)
+    base_loc = np.asarray(base_loc, dtype=np.int64)
+    r, p = owner_now // n_local, owner_now % n_local
+    q, s = base_loc // n_local, base_loc % n_local
+    remote = r != q
+    key = (r * world + q) * n_local + s                         # sorts by destination, source, slot
+    uniq = np.unique(key[remote])
+    ur, uq, us = uniq // (world * n_local), (uniq // n_local) % world, uniq % n_local
+    mine_out = uq == rank                                       # what I send, ordered by destination then slot
+    send_slots = us[mine_out].astype(np.int32)
+    send_counts = np.bincount(ur[mine_out], minlength=world).astype(np.int64)
+    mine_in = ur == rank                                        # what I receive, ordered by source then slot
+    recv_keys = uniq[mine_in]
+    recv_counts = np.bincount(uq[mine_in], minlength=world).astype(np.int64)
+    base_index = np.zeros(n_local, dtype=np.int32)
+    here = r == rank
+    loc = here & ~remote
+    base_index[p[loc]] = s[loc]
+    imp = here & remote
+    base_index[p[imp]] = n_local + np.searchsorted(recv_keys, key[imp])
+    return RefreshPlan(send_slots, send_counts, recv_counts, base_index,
+                       np.bincount(uq, minlength=world).astype(np.int64), np.bincount(ur, minlength=world).astype(np.int64))
 
 
 class ShardedSmootherSession(ShardedFilterSession):
@@ -448,8 +493,9 @@ class ShardedSmootherSession(ShardedFilterSession):
     particles bit for bit."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
-                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0):
+                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0):
         self.N_K = int(N_K)
+        self.chol_refresh = int(chol_refresh)
         lib = load_library()
         for name, argt in (("rbpf_shard_smoother_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
                                                            C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
@@ -459,6 +505,9 @@ class ShardedSmootherSession(ShardedFilterSession):
                            ("rbpf_shard_smoother_normalise", [C.c_void_p, C.c_int32]),
                            ("rbpf_shard_smoother_anc_weights", [C.c_void_p]),
                            ("rbpf_shard_smoother_anc_sample", [C.c_void_p]),
+                           ("rbpf_shard_smoother_refresh_begin", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p]),
+                           ("rbpf_shard_smoother_refresh_pack", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
+                           ("rbpf_shard_smoother_refresh_end", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
                            ("rbpf_shard_smoother_step", [C.c_void_p]),
                            ("rbpf_shard_smoother_end", [C.c_void_p, _ffi.c_double_p, _ffi.c_double_p, _ffi.c_double_p,
                                                         _ffi.c_int32_p, _ffi.c_int32_p])):
@@ -470,6 +519,14 @@ class ShardedSmootherSession(ShardedFilterSession):
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
         self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)
         self.t_anc_gather = _view(self.torch, sv.anc_gather, (self.N_global,), self.device)
+        self.refresh_capacity = int(sv.refresh_capacity)
+        self.t_rf_send = self.t_rf_recv = None
+        if self.chol_refresh > 1:
+            shape = (self.refresh_capacity, int(sv.matrix_doubles))
+            self.t_rf_send = _view(self.torch, sv.refresh_send, shape, self.device)
+            self.t_rf_recv = _view(self.torch, sv.refresh_recv, shape, self.device)
+        self.stats["refreshes"] = 0
+        self.stats["refresh_fetched"] = 0
 
     def _n_iter(self):
         return self.N_K
@@ -494,6 +551,42 @@ class ShardedSmootherSession(ShardedFilterSession):
     def advance(self, n_steps):
         raise NotImplementedError("use run()")
 
+    def _refresh(self):
+        """Refresh of the carried factors in place of rbpf_shard_smoother_anc_weights: the information matrices of my
+        particles are rebuilt from the last materialised generation, whose matrices may sit on other ranks (one all_to_all of
+        the unique ones; include/rbpf.h)."""
+        torch, dist, lib, W = self.torch, self.dist, self.lib, self.world
+        own = np.empty(self.N_global, dtype=np.int32)
+        bl = np.empty(self.N_global, dtype=np.int32)
+        check(lib.rbpf_shard_smoother_refresh_begin(self.ctx, _ip(own), _ip(bl)))
+        self.stats["refreshes"] += 1
+        if bl[0] < 0:                                    # first refresh of an iteration: the common initial matrix
+            check(lib.rbpf_shard_smoother_refresh_end(self.ctx, None, 0))
+            return
+        rp = plan_refresh(own, bl, self.N_local, W, self.rank)
+        worst = int(max(rp.send_totals.max(), rp.recv_totals.max()))
+        if worst > self.refresh_capacity:                # replicated plan: every rank reaches this verdict
+            raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"refresh of the carried factors moves up to {worst} matrices per rank, "
+                                 f"above the capacity {self.refresh_capacity} (raise exchange_capacity)")
+        ns, nr = int(rp.send_counts.sum()), int(rp.recv_counts.sum())
+        slots = np.ascontiguousarray(rp.send_slots)
+        check(lib.rbpf_shard_smoother_refresh_pack(self.ctx, _ip(slots) if ns else None, ns))
+        if W > 1:
+            plan = RankPlan(None, None, None, rp.send_counts, rp.recv_counts)
+            with torch.cuda.stream(self.stream):
+                if self.transport == "device":
+                    exchange_rows(self.t_rf_send, self.t_rf_recv, plan.send_counts, plan.recv_counts, dist)
+                else:
+                    hs = self.t_rf_send[:ns].cpu()
+                    hr = torch.empty((nr, self.t_rf_recv.shape[1]), dtype=torch.float64)
+                    exchange_rows(hs, hr, plan.send_counts, plan.recv_counts, dist)
+                    if nr:
+                        self.t_rf_recv[:nr].copy_(hr)
+            self._phase_sync()
+        self.stats["refresh_fetched"] += nr
+        bi = np.ascontiguousarray(rp.base_index)
+        check(lib.rbpf_shard_smoother_refresh_end(self.ctx, _ip(bi), nr))
+
     def run(self, progress=None):
         import time
         lib, T, W = self.lib, self.prob.N_T, self.world
@@ -517,7 +610,11 @@ class ShardedSmootherSession(ShardedFilterSession):
                 check(lib.rbpf_shard_smoother_normalise(self.ctx, 1))
                 t2 = time.perf_counter()
                 if k > 0:
-                    check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
+                    K = self.chol_refresh
+                    if K > 1 and (t == 1 or (t - 1) % K == 0):
+                        self._refresh()
+                    else:
+                        check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
                     self._gather_anc()
                     check(lib.rbpf_shard_smoother_anc_sample(self.ctx))
                 t3 = time.perf_counter()
@@ -553,5 +650,5 @@ class ShardedSmootherSession(ShardedFilterSession):
     def close(self):
         if self.ctx:
             self.sync()
-        self.t_anc_local = self.t_anc_gather = None
+        self.t_anc_local = self.t_anc_gather = self.t_rf_send = self.t_rf_recv = None
         super().close()

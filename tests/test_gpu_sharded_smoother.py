@@ -26,7 +26,7 @@ def _case(kind, N, T, m, N_K):
     return mk(N, T, m, seed=31, N_K=N_K)
 
 
-def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth=0):
+def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth=0, chol_refresh=0):
     import importlib
     import torch
     import torch.distributed as dist
@@ -42,7 +42,7 @@ def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, 
         mdl, x0, P0, R = cases.device_model(rbpf, c)
         s = mg.ShardedSmootherSession(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, n_local, N_K, c["dt"],
                                       rng=cases.device_rng(rbpf, c), rank=rank, world=world, transport=transport,
-                                      lazy_depth=lazy_depth)
+                                      lazy_depth=lazy_depth, chol_refresh=chol_refresh)
         XNK, XLK, PK = s.run()
         stats = dict(s.stats)
         aks = list(s.aks)
@@ -52,11 +52,11 @@ def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, 
         dist.destroy_process_group()
 
 
-def _run(world, backend, transport, kind, n_local, T, m, N_K, lazy_depth=0):
+def _run(world, backend, transport, kind, n_local, T, m, N_K, lazy_depth=0, chol_refresh=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, transport, kind, n_local, T, m, N_K, q, lazy_depth, chol_refresh)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
@@ -66,11 +66,11 @@ def _run(world, backend, transport, kind, n_local, T, m, N_K, lazy_depth=0):
     return res
 
 
-def _single(rbpf, kind, N, T, m, N_K):
+def _single(rbpf, kind, N, T, m, N_K, **opts):
     c = _case(kind, N, T, m, N_K)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     out = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"],
-                                               x0, P0, c["Q"], R, N, N_K, c["dt"], rng=cases.device_rng(rbpf, c), extras=True)
+                                               x0, P0, c["Q"], R, N, N_K, c["dt"], rng=cases.device_rng(rbpf, c), extras=True, **opts)
     return c, out
 
 
@@ -112,6 +112,38 @@ def test_two_ranks_with_lazy_update_match_single_gpu_smoother(rbpf, kind, n_loca
     orc = cases.oracle_smoother(c, info_form=True)
     np.testing.assert_allclose(res[0][1], orc["XNK"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
+
+
+@pytest.mark.parametrize("kind,n_local,T,m,N_K,lazy_depth,K", [("mag", 24, 14, 130, 3, 0, 4), ("mag", 24, 14, 130, 3, 3, 5),
+                                                                ("radio", 40, 16, 128, 3, 3, 4), ("mag", 12, 9, 256, 2, 2, 3)])
+def test_two_ranks_with_carried_factors(rbpf, kind, n_local, T, m, N_K, lazy_depth, K):
+    """chol_refresh = K in the sharded smoother: the factors migrate inside the particle records, the refreshes fetch base
+    matrices from the other rank.  Same ancestor draws and trajectory as the single-GPU smoother with the same option (which
+    tests/test_gpu_chol_carry.py holds to the fresh factorisation), outputs to 1e-9, and the oracle to 1e-9."""
+    res = _run(2, "gloo", "host", kind, n_local, T, m, N_K, lazy_depth, K)
+    c, ref = _single(rbpf, kind, 2 * n_local, T, m, N_K, lazy_depth=lazy_depth, chol_refresh=K)
+    for rank, XNK, XLK, PK, aks, stats in res:
+        np.testing.assert_array_equal(np.asarray(aks), ref[3]["ak"])
+        np.testing.assert_allclose(XNK, ref[0], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(XLK, ref[1], rtol=1e-9, atol=1e-9 * np.max(np.abs(ref[1])))
+        np.testing.assert_allclose(PK, ref[2], rtol=1e-9, atol=1e-9 * np.max(np.abs(ref[2])))
+        assert stats["refreshes"] == (N_K - 1) * (1 + (T - 2) // K)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][5]["migrated"] > 0
+    assert res[0][5]["refresh_fetched"] + res[1][5]["refresh_fetched"] > 0     # base matrices did cross ranks
+    orc = cases.oracle_smoother(c, info_form=True)
+    np.testing.assert_allclose(res[0][1], orc["XNK"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(res[0][3], orc["PK"], rtol=1e-9, atol=1e-9 * np.max(np.abs(orc["PK"])))
+
+
+def test_world_size_one_carried_factors_equal_single_gpu(rbpf):
+    """World 1, RCCL device transport: the sharded code path with carried factors against the single-GPU entry point."""
+    kind, n_local, T, m, N_K, K = "mag", 32, 12, 130, 2, 4
+    res = _run(1, "nccl", "device", kind, n_local, T, m, N_K, 3, K)
+    _, ref = _single(rbpf, kind, n_local, T, m, N_K, lazy_depth=3, chol_refresh=K)
+    np.testing.assert_array_equal(np.asarray(res[0][4]), ref[3]["ak"])
+    np.testing.assert_allclose(res[0][1], ref[0], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(res[0][3], ref[2], rtol=1e-9, atol=1e-9 * np.max(np.abs(ref[2])))
 
 
 def test_two_ranks_above_8192_particles_equal_single_gpu(rbpf):

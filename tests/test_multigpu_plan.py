@@ -146,3 +146,35 @@ def test_exchange_over_gloo(world):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) == 1.0
+
+
+@pytest.mark.parametrize("world,nl,seed", [(1, 16, 0), (2, 8, 1), (3, 7, 2), (8, 32, 3)])
+def test_refresh_plan_fetches_every_remote_base_matrix_once(world, nl, seed):
+    """plan_refresh (carried factors in the sharded smoother): every rank derives its part of the same fetch plan from the two
+    replicated tables; a matrix goes to a rank once however many of its particles descend from it, and base_index resolves to
+    the right matrix in [own bank | received matrices]."""
+    mg = _mg()
+    rs = np.random.RandomState(seed)
+    N = world * nl
+    owner_now = rs.permutation(N)                                  # logical slot -> rank * nl + physical slot
+    w = rs.random_sample(N) ** 4
+    base_loc = rs.choice(N, size=N, p=w / w.sum())                 # few distinct ancestors: siblings share a base
+    bank = [np.arange(q * nl, (q + 1) * nl, dtype=np.int64) for q in range(world)]   # matrix id = its location
+    plans = [mg.plan_refresh(owner_now, base_loc, nl, world, r) for r in range(world)]
+    pairs = {(int(o) // nl, int(b)) for o, b in zip(owner_now, base_loc) if int(o) // nl != int(b) // nl}
+    assert sum(int(p.send_counts.sum()) for p in plans) == len(pairs)            # unique (destination, matrix) pairs
+    for r in range(world):
+        pr = plans[r]
+        assert pr.send_counts[r] == 0 and pr.recv_counts[r] == 0
+        for q in range(world):
+            assert pr.recv_counts[q] == plans[q].send_counts[r]
+            np.testing.assert_array_equal(pr.send_totals, plans[q].send_totals)  # replicated verdict about the capacity
+            np.testing.assert_array_equal(pr.recv_totals, plans[q].recv_totals)
+        assert pr.send_totals[r] == pr.send_counts.sum() and pr.recv_totals[r] == pr.recv_counts.sum()
+        recv = []
+        for q in range(world):                                     # all_to_all: chunks arrive in rank order
+            off = int(plans[q].send_counts[:r].sum())
+            recv.extend(bank[q][plans[q].send_slots[off:off + int(plans[q].send_counts[r])]])
+        space = np.concatenate((bank[r], np.array(recv, dtype=np.int64)))
+        mine = np.nonzero(owner_now // nl == r)[0]
+        np.testing.assert_array_equal(space[pr.base_index[owner_now[mine] % nl]], base_loc[mine])
