@@ -261,7 +261,7 @@ def smoother_radio_large(pkg, datagen):
             "seconds": min(runs), "runs": runs, "unit": "s", "finite": bool(np.all(np.isfinite(XNK)))}
 
 
-def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full, N_K, seed, rank, world, lazy_depth):
+def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full, N_K, seed, rank, world, lazy_depth, chol_refresh=0):
     """The metric's smoother as the N-GPU job runs it: particleSmootherInformationForm with world * N_local particles sharded over
     the ranks (ShardedSmootherSession: all_gather of the forward bank and of the ancestor log-weights, all_to_all of the migrating
     particle records), timed over the first T_s of the T_full time steps of both CPF-AS iterations; max over ranks.  The full-length
@@ -270,7 +270,7 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
     d = datagen.bean_6D(T_s, Q, THETA_MAG, 0.01, seed=seed)
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, d["LL"], THETA_MAG)
     sess = mg.ShardedSmootherSession(model, d["dx"], d["y"], d["initState"], x0_lin, P0, Q, R, N_local, N_K, 0.01,
-                                     rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth)
+                                     rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth, chol_refresh=chol_refresh)
     try:
         torch.cuda.synchronize()
         if dist is not None:
@@ -292,7 +292,8 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
         raise RuntimeError("non-finite smoother output")
     per_step = [v / T_s for v in tt[1:]]
     return {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_local * world} ({N_local} per GPU x {world}) m={m} N_K={N_K}, "
-                        f"first {T_s} of {T_full} time steps of every iteration, lazy_depth {lazy_depth}, fresh factorisation every step",
+                        f"first {T_s} of {T_full} time steps of every iteration, lazy_depth {lazy_depth}, "
+                        + (f"ancestor-weight factors carried, refreshed every {chol_refresh} steps" if chol_refresh > 1 else "fresh factorisation every step"),
             "seconds": tt[0], "seconds_per_iteration": tt[1:], "ms_per_time_step_per_iteration": [v * 1e3 for v in per_step],
             "extrapolated_full_T_seconds": sum(per_step) * T_full, "sharding": st}
 
@@ -519,16 +520,22 @@ def main():
         dog = threading.Timer(args.smoother_timeout, give_up)
         dog.daemon = True
         dog.start()
-        try:
-            res = smoother_sharded_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.m, min(args.smoother_steps, T), T, 2,
-                                       args.seed, rank, world, min(args.lazy_depth, 3))
-        except Exception as exc:
-            res = {"error": f"{type(exc).__name__}: {exc}"}
+        def leg(chol_refresh):
+            try:
+                return smoother_sharded_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.m, min(args.smoother_steps, T), T, 2,
+                                            args.seed, rank, world, min(args.lazy_depth, 3), chol_refresh)
+            except Exception as exc:
+                return {"error": f"{type(exc).__name__}: {exc}"}
+        res = leg(0)                       # the reference's arithmetic (a fresh factorisation per particle and step)
+        res_c = leg(32)                    # factors carried along the lineages (tolerance: DESIGN.md 4.3)
         dog.cancel()
         if rank == 0:
             line["smoother_sharded"] = res
+            line["smoother_sharded_carried_factors"] = res_c
             if "extrapolated_full_T_seconds" in res:
                 line["smoother_wall_clock_extrapolated_s"] = res["extrapolated_full_T_seconds"]
+            if "extrapolated_full_T_seconds" in res_c:
+                line["smoother_wall_clock_carried_factors_extrapolated_s"] = res_c["extrapolated_full_T_seconds"]
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
