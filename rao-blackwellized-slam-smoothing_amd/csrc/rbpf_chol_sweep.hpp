@@ -101,9 +101,13 @@ struct SweepV {
 //   r_a = sqrt(r_{a-1}^2 +- x_a(k)^2),  c_a = r_a / r_{a-1},  s_a = x_a(k) / r_{a-1}     (r_0 = L_kk)
 //   L_ik = (L_ik +- s_a x_a(i)) / c_a;  x_a(i) = c_a x_a(i) - s_a L_ik
 // A rotation changes only its own vector and the column, so the pivots x_a(k) of all 2 D vectors are read first and the
-// squared pivots t_a = L_kk^2 +- ... are accumulated directly: the 2 D reciprocal square roots are then independent of
-// each other (one exposed latency chain per column instead of 2 D), and only the column updates are sequential across a,
-// with the slots as independent work in between.  Returns false when a downdate loses definiteness.
+// squared pivots t_a = L_kk^2 +- ... are accumulated directly; the 2 D + 1 square roots are then independent of each other
+// and are taken in ONE pass, lane a working on t_a (v_rsq_f64 + Newton, 13 instructions instead of 13 (2 D + 1)), the results
+// broadcast with v_readlane.  The division by c_a is deferred: the column is kept unscaled, L = sigma_a * Lt with
+// sigma_a = r_0 / r_a (the product of the 1 / c so far), so that a rotation costs three operations per element
+//   Lt_i += (+- x_a(k) / r_0) x_a(i)         [the factor s_a / sigma_a]
+//   x_a(i) = c_a x_a(i) - (s_a sigma_{a+1}) Lt_i
+// and one multiplication by sigma_{2D} at the end.  Returns false when a downdate loses definiteness.
 template <int D, int NS, int B, bool VLDS>
 __device__ __forceinline__ bool sweep_rotate_all(double (&col)[NS], double (&u)[D][NS], SweepV<D, NS, VLDS>& v, int r_lane, int lane,
                                                  double& Lkk) {
@@ -117,30 +121,43 @@ __device__ __forceinline__ bool sweep_rotate_all(double (&col)[NS], double (&u)[
 #pragma unroll
   for (int a = 0; a <= 2 * D; ++a) ok = ok && (t[a] > 0.0);
   if (!ok) return false;
-  double rt[2 * D + 1], ri[2 * D + 1];                 // sqrt(t_a), 1 / sqrt(t_a)
+  double rt[2 * D + 1], ri[2 * D + 1];                 // sqrt(t_a), 1 / sqrt(t_a): lane a takes the roots of t_a
+  {
+    double tv = t[0];
 #pragma unroll
-  for (int a = 0; a <= 2 * D; ++a) sqrt_rsqrt(t[a], rt[a], ri[a]);
+    for (int a = 1; a <= 2 * D; ++a) tv = (lane == a) ? t[a] : tv;
+    double g, h;
+    sqrt_rsqrt(tv, g, h);
+#pragma unroll
+    for (int a = 0; a <= 2 * D; ++a) { rt[a] = readlane_f64(g, a); ri[a] = readlane_f64(h, a); }
+  }
 #pragma unroll
   for (int a = 0; a < 2 * D; ++a) {
-    const double c = rt[a + 1] * ri[a], s = xk[a] * ri[a], cinv = rt[a] * ri[a + 1];
-    const double ss = (a < D) ? s : -s;
+    // sigma_a = rt[0] ri[a]; s_a / sigma_a = xk ri[a] / (rt[0] ri[a]) = xk ri[0]; c_a = rt[a+1] ri[a];
+    // s_a sigma_{a+1} = xk ri[a] rt[0] ri[a+1]
+    const double c = rt[a + 1] * ri[a];
+    const double f = (a < D ? xk[a] : -xk[a]) * ri[0];
+    const double g = -(xk[a] * ri[a]) * (rt[0] * ri[a + 1]);
     if (a < D) {
 #pragma unroll
       for (int q = B; q < NS; ++q) {
-        const double lq = fma(ss, u[a][q], col[q]) * cinv;
-        u[a][q] = fma(c, u[a][q], -s * lq);
+        const double lq = fma(f, u[a][q], col[q]);
+        u[a][q] = fma(g, lq, c * u[a][q]);
         col[q] = lq;
       }
     } else {
 #pragma unroll
       for (int q = B; q < NS; ++q) {
         const double vq = v.get(a - D, q);
-        const double lq = fma(ss, vq, col[q]) * cinv;
-        v.set(a - D, q, fma(c, vq, -s * lq));
+        const double lq = fma(f, vq, col[q]);
+        v.set(a - D, q, fma(g, lq, c * vq));
         col[q] = lq;
       }
     }
   }
+  const double sig = rt[0] * ri[2 * D];
+#pragma unroll
+  for (int q = B; q < NS; ++q) col[q] *= sig;
   // rows above the pivot inside the diagonal slot are structurally zero
   col[B] = (lane >= r_lane) ? col[B] : 0.0;
   Lkk = rt[2 * D];
@@ -153,6 +170,9 @@ __device__ __forceinline__ bool sweep_block(const SweepArgs& a, const double* __
                                             double& sumlog, double& vv) {
   const int k0 = 64 * B, k1 = min(a.n, k0 + 64);
   if (k0 >= a.n) return true;
+  // sum of log L_kk (wave-uniform): the mantissas are multiplied up and one logarithm is taken per 16 columns
+  double mant = 1.0;
+  int expo = 0;
   double col[NS], nxt[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) { col[q] = 0.0; nxt[q] = 0.0; }
@@ -187,10 +207,13 @@ __device__ __forceinline__ bool sweep_block(const SweepArgs& a, const double* __
       if (q == NS - 1 && tailc) { if (lane < 8) __builtin_nontemporal_store(col[q], &cd[(size_t)(q - B) * 64 + lane]); }
       else __builtin_nontemporal_store(col[q], &cd[(size_t)(q - B) * 64 + lane]);
     }
-    if (lane == r_lane) sumlog += log(Lkk);
+    mant *= __builtin_amdgcn_frexp_mant(Lkk);
+    expo += __builtin_amdgcn_frexp_exp(Lkk);
+    if ((r_lane & 15) == 15) { sumlog += log(mant); mant = 1.0; }
     if (lane == (a.n & 63)) vv = fma(col[NS - 1], col[NS - 1], vv);    // z_k = L(n, k): the augmented row sits in the last slot
   }
 #undef RBPF_SW_LOAD
+  sumlog += log(mant) + 0.6931471805599453094 * (double)expo;
   return true;
 }
 
@@ -241,8 +264,7 @@ __global__ __launch_bounds__(256, VLDS ? 2 : 1) void chol_sweep_kernel(const Swe
   RBPF_SWEEP_BLOCK(0) RBPF_SWEEP_BLOCK(1) RBPF_SWEEP_BLOCK(2) RBPF_SWEEP_BLOCK(3) RBPF_SWEEP_BLOCK(4)
   RBPF_SWEEP_BLOCK(5) RBPF_SWEEP_BLOCK(6) RBPF_SWEEP_BLOCK(7) RBPF_SWEEP_BLOCK(8)
 #undef RBPF_SWEEP_BLOCK
-  sumlog = wave_sum(sumlog);
-  vv = wave_sum(vv);
+  vv = wave_sum(vv);                                     // (sumlog is wave-uniform)
   if (lane == 0) {
     if (ok) a.pant_log[p] += -0.5 * a.qf[p] - a.hld[p] - sumlog + 0.5 * vv;        // InformationForm.m:234-236
     else { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
