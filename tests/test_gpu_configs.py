@@ -5,12 +5,16 @@ two independent schedules of the same arithmetic (single bank in place vs ping-p
 (c) oracle parity at the full matrix size with few particles, and (d) the plain-C restatement (oracle/rbpf_oracle_c.c) of
 the filter and of both smoothers at N ~ 1000, T ~ 100."""
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
 
 import cases
 import oracle_c
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-9
@@ -224,3 +228,40 @@ def test_carried_factors_and_lazy_update_at_the_configuration_sizes(rbpf, kind, 
     assert np.max(np.abs(pa - pb)) <= 1e-9
     assert rel(b[3]["w"], a[3]["w"]) <= 1e-9
     assert rel(b[0], a[0]) <= RTOL and rel(b[1], a[1]) <= RTOL and rel(b[2], a[2]) <= RTOL
+
+
+def test_two_ranks_carried_factors_at_the_share_size_equal_one_gpu(rbpf):
+    """The N-GPU smoother's code path at a realistic per-rank size: two ranks of 4096 particles (m = 512, nLin = 515) sharing the
+    card, lazy covariance update + carried factors (records with factors and base matrices cross ranks), against the single-GPU
+    smoother with 8192 particles and the same options on the same Philox streams: the same trajectory draws, outputs to 1e-9."""
+    import socket
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sharded_rehearsal as sr
+    import bench
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    o = dict(world=2, n_local=4096, m=512, T=36, N_K=2, lazy_depth=3, chol_refresh=16, exchange_capacity=0)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=sr._worker, args=(r, 2, port, o, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert "error" not in res[0] and "error" not in res[1], (res[0].get("error"), res[1].get("error"))
+    Q = bench.q_mag()
+    d = dg.bean_6D(o["T"], Q, bench.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(o["m"], d["LL"], bench.THETA_MAG)
+    XNK, XLK, PK, ex = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
+                                                            x0, P0, Q, R, 8192, o["N_K"], 0.01, rng=rbpf.PhiloxRNG(1), extras=True,
+                                                            lazy_depth=3, chol_refresh=16)
+    for r in res:
+        assert r["finite"] and r["migrated"] > 0 and r["sent_records"] > 0
+        np.testing.assert_array_equal(np.asarray(r["aks"]), ex["ak"])
+        np.testing.assert_allclose(r["XNK"], XNK, rtol=1e-9, atol=1e-11)
+    assert res[0]["refreshes"] == 1 + (o["T"] - 2) // 16

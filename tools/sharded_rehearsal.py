@@ -41,6 +41,7 @@ def _worker(rank, world, port, o, q):
         st.update(rank=rank, seconds=dt, finite=bool(np.all(np.isfinite(XNK)) and np.all(np.isfinite(PK))), aks=list(s.aks),
                   refresh_capacity=s.refresh_capacity, send_capacity=int(s.v.send_capacity), recv_capacity=int(s.v.recv_capacity))
         s.close()
+        st["XNK"] = XNK                                       # for tests; main() drops it before printing
         q.put(st)
     except Exception as exc:                                   # report, so that the parent does not wait for the timeout
         q.put({"rank": rank, "error": f"{type(exc).__name__}: {exc}"})
@@ -66,6 +67,8 @@ def main():
     res = sorted((q.get(timeout=900) for _ in procs), key=lambda r: r["rank"])
     for p in procs:
         p.join(60)
+    for r in res:
+        r.pop("XNK", None)
     steps = max(1, res[0].get("steps", 1))
     out = {"options": o, "ranks": res}
     if "error" not in res[0]:
