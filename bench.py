@@ -347,7 +347,7 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--lazy-depth", type=int, default=3, help="rewrite the covariances every C-th step only (0/1: every step)")
+    ap.add_argument("--lazy-depth", type=int, default=4, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
     ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")

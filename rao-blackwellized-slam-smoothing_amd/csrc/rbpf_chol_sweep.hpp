@@ -304,7 +304,8 @@ static hipError_t launch_sweep_from_chol64(int n, int batch, const double* Lfrag
 // Between two refreshes nothing reads Imat, so it is not advanced at all: at a refresh step the information matrix of every
 // particle is rebuilt from the last materialised generation t0 ("base") and the measurement Jacobians along its ancestral
 // path,  Imat_i(t-1) = Imat_base(anc_{t0}(i)) + sum_{s = t0+1}^{t-1} H(x_{path_i(s), s})' R^-1 H(...),  the H recomputed from
-// the state history (basis evaluation is cheap) and the sum formed as G' G on the matrix cores, G = [W H_s] stacked.
+// the state history (basis evaluation is cheap) and the sum formed as G' G on the matrix cores, G = [W H_s] stacked (block-lower
+// tiles only, the base matrix added in the GEMM's epilogue).
 // Exactly the terms :334 adds step by step, in another summation order.
 
 // thread per particle: walk the ancestor table back from generation t_last to t0 + 1, collecting the states on the way
@@ -366,21 +367,6 @@ __global__ void sweep_whiten_kernel(size_t rows, int d, int n, const double* __r
   for (int b = 0; b < d; ++b) v[b] = h[(size_t)b * n];
   for (int a = 0; a < d; ++a) { double s = 0.0; for (int b = 0; b < d; ++b) s = fma(W[a + d * b], v[b], s); o[a] = s; }
   for (int a = 0; a < d; ++a) h[(size_t)a * n] = o[a];
-}
-
-// Imat_new[i] += base[base_slot[i]] over the block-lower part the factorisation kernels read
-// (sharded smoother: entries >= n_bank are matrices fetched from other ranks, rec [..][n*n])
-__global__ __launch_bounds__(256) void sweep_add_base_kernel(int n, const double* __restrict__ base, long base_stride,
-                                                             const int* __restrict__ base_slot, double* __restrict__ Imat,
-                                                             const double* __restrict__ rec, int n_bank) {
-  const int p = blockIdx.x;
-  const int bs = base_slot ? base_slot[p] : 0;
-  const double* src = (rec && bs >= n_bank) ? rec + (size_t)(bs - n_bank) * n * n : base + (size_t)bs * base_stride;
-  double* dst = Imat + (size_t)p * n * n;
-  for (int c = blockIdx.y; c < n; c += gridDim.y) {
-    const int r0 = (c >> 6) << 6;
-    for (int r = r0 + threadIdx.x; r < n; r += blockDim.x) dst[(size_t)r + (size_t)n * c] += src[(size_t)r + (size_t)n * c];
-  }
 }
 
 // Imat(:,:,i) of the new generation = ancestor's stored matrix + the particle's own last update (InformationForm.m:170,334),

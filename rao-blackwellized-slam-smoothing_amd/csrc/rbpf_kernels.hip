@@ -143,9 +143,12 @@ Layout make_layout_low_regs(int n, int d) {
 
 // The blocked variant is taken when the plain plan would leave one workgroup per CU (> 80 KB) and the wave decomposition
 // has no remainder chunk (every wave runs the same block loop: it contains workgroup barriers).
+#ifndef RBPF_KB_THRESHOLD_KB
+#define RBPF_KB_THRESHOLD_KB 80
+#endif
 bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
   if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;
-  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, 0).total * sizeof(double) > 80 * 1024;
+  return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, 0).total * sizeof(double) > (size_t)RBPF_KB_THRESHOLD_KB * 1024;
 }
 
 size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra, int n_sets) {

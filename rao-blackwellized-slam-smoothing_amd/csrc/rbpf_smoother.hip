@@ -144,6 +144,11 @@ struct GemmArgs {
   const double* A; long rsA, csA, bsA;
   const double* B; long rsB, csB, bsB;
   double* C; long rsC, csC, bsC;
+  // optional (zero: off).  lower: only the 64 x 64 tiles on and below the diagonal of C are computed (symmetric products whose
+  // reader takes the block-lower part).  add: C += add[add_idx[batch]] (same strides as C; entries >= add_nbank come from
+  // add_rec [..][M*N]; add_idx null: entry 0) -- the refresh of the carried factors adds the base matrix in the epilogue.
+  int lower;
+  const double* add; long add_stride; const int* add_idx; const double* add_rec; int add_nbank;
 };
 
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
@@ -158,6 +163,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   double* C = g.C + (size_t)bz * g.bsC;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int i0 = blockIdx.y * kGemmTile, j0 = blockIdx.x * kGemmTile;
+  if (g.lower == 1 && blockIdx.y < blockIdx.x) return;      // tile above the diagonal (rows along blockIdx.y)
+  if (g.lower == 2 && blockIdx.x < blockIdx.y) return;      // ... of the transposed problem launch_gemm set up
   const int wi = (wv >> 1) * 32, wj = (wv & 1) * 32;
   const bool a_kfast = (g.csA == 1), b_kfast = (g.rsB == 1);
   gemm_v4d acc[2][2];
@@ -202,6 +209,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     __syncthreads();
   }
   // result layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+  const double* addp = nullptr;
+  if (g.add) {
+    const int e = g.add_idx ? g.add_idx[bz] : 0;
+    addp = (g.add_rec && e >= g.add_nbank) ? g.add_rec + (size_t)(e - g.add_nbank) * g.M * g.N : g.add + (size_t)e * g.add_stride;
+  }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -209,7 +221,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = i0 + wi + 16 * x + (lane >> 4) + 4 * r, j = j0 + wj + 16 * y + (lane & 15);
-        if (i < g.M && j < g.N) C[(size_t)i * g.rsC + (size_t)j * g.csC] = acc[x][y][r];
+        if (i < g.M && j < g.N) {
+          const size_t o = (size_t)i * g.rsC + (size_t)j * g.csC;
+          C[o] = addp ? acc[x][y][r] + addp[o] : acc[x][y][r];
+        }
       }
 }
 
@@ -221,6 +236,7 @@ static hipError_t launch_gemm(const GemmArgs& g0, int batch, hipStream_t s) {
     g.A = g0.B; g.rsA = g0.csB; g.csA = g0.rsB; g.bsA = g0.bsB;
     g.B = g0.A; g.rsB = g0.csA; g.csB = g0.rsA; g.bsB = g0.bsA;
     g.rsC = g0.csC; g.csC = g0.rsC;
+    if (g0.lower) g.lower = 2;
   }
   dim3 grid((g.N + kGemmTile - 1) / kGemmTile, (g.M + kGemmTile - 1) / kGemmTile, batch);
   hipLaunchKernelGGL(gemm_kernel, grid, dim3(256), 0, s, g);
@@ -1064,10 +1080,11 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             HIPCHK(hipGetLastError());
             const long Kd = (long)Kp * d;
             GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
-            HIPCHK(launch_gemm(gg, N, st));                                   // G' G
-            hipLaunchKernelGGL(sweep_add_base_kernel, dim3(N, 4), dim3(256), 0, st, n, t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur],
-                               t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni], (const double*)nullptr, 0);
-            HIPCHK(hipGetLastError());
+            gg.lower = 1;                                                      // the factorisation reads the block-lower part
+            gg.add = t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur];             // + the base matrix, in the epilogue
+            gg.add_stride = t0 < 0 ? 0L : (long)((size_t)n * n);
+            gg.add_idx = t0 < 0 ? (const int*)nullptr : s->d_base_slot;
+            HIPCHK(launch_gemm(gg, N, st));                                   // Imat = base + G' G
             s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
             ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
             ca.Imat = s->d_Imat[ni]; ca.imat_stride = (long)((size_t)n * n); ca.imat_anc = nullptr; ca.ImatOut = nullptr;
@@ -1485,11 +1502,12 @@ int rbpf_shard_smoother_refresh_end(rbpf_ctx* c, const int32_t* base_index, int3
   HIPCHK(hipGetLastError());
   const long Kd = (long)Kp * d;
   GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
-  HIPCHK(launch_gemm(gg, N, st));                                   // G' G
-  hipLaunchKernelGGL(sweep_add_base_kernel, dim3(N, 4), dim3(256), 0, st, n, t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur],
-                     t0 < 0 ? 0L : (long)((size_t)n * n), t0 < 0 ? (const int*)nullptr : s->d_base_slot, s->d_Imat[ni],
-                     t0 < 0 ? (const double*)nullptr : s->d_rf_recv, N);
-  HIPCHK(hipGetLastError());
+  gg.lower = 1;
+  gg.add = t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur];               // base matrix: own bank entry or a fetched one
+  gg.add_stride = t0 < 0 ? 0L : (long)((size_t)n * n);
+  gg.add_idx = t0 < 0 ? (const int*)nullptr : s->d_base_slot;
+  gg.add_rec = t0 < 0 ? (const double*)nullptr : s->d_rf_recv; gg.add_nbank = N;
+  HIPCHK(launch_gemm(gg, N, st));                                      // Imat = base + G' G
   s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
   HIPCHK(hipMemcpyAsync(s->d_base_gid, s->d_owner_now, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToDevice, st));
   CholArgs ca;

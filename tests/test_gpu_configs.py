@@ -53,27 +53,30 @@ def check_filter_properties(out, N, steps, P0):
     assert np.all(np.diag(P) <= np.diag(P0) * (1 + 1e-12)) and np.trace(P) < np.trace(P0)   # information only shrinks it
 
 
-def test_configs2_filter_single_bank_in_place(rbpf):
-    """BASELINE.json configs[2], filter: N = 65 536, m = 512 (nLin = 515), fp64, lazy_depth 3 -- one 139 GB covariance bank
-    rewritten in place (chosen automatically: two banks do not fit).  Two runs are bit-identical; properties hold."""
-    N, steps = 65536, 8
+@pytest.mark.parametrize("lazy_depth", [3, 4])
+def test_configs2_filter_single_bank_in_place(rbpf, lazy_depth):
+    """BASELINE.json configs[2], filter: N = 65 536, m = 512 (nLin = 515), fp64, lazy_depth 3 / 4 (bench.py's default) -- one
+    139 GB covariance bank rewritten in place (chosen automatically: two banks do not fit).  Two runs are bit-identical;
+    properties hold."""
+    N, steps = 65536, 10
     d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
     want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean")
-    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=3, inplace=0)
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=0)
     check_filter_properties(a, N, steps, P0)
-    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=3, inplace=0)
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=0)
     for k in want:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
-def test_in_place_equals_ping_pong_at_the_largest_size_with_two_banks(rbpf):
+@pytest.mark.parametrize("lazy_depth", [3, 4])
+def test_in_place_equals_ping_pong_at_the_largest_size_with_two_banks(rbpf, lazy_depth):
     """N = 32 768, m = 512: two 69.5 GB banks still fit, so the in-place flush (children moved to dead entries, first
     children overwritten last) can be compared with the ping-pong schedule: every output bit for bit."""
-    N, steps = 32768, 8
+    N, steps = 32768, 10
     d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
     want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean", "trace_logw")
-    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=3, inplace=1)
-    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=3, inplace=-1)
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=1)
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=-1)
     check_filter_properties(a, N, steps, P0)
     for k in want:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)

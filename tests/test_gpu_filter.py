@@ -77,7 +77,7 @@ def test_multi_step_lazy_update_matches_oracle(rbpf, kind, N_P, N_T, m, lazy_dep
     check_filter(ref, out)
 
 
-@pytest.mark.parametrize("lazy_depth", [2, 3])
+@pytest.mark.parametrize("lazy_depth", [2, 3, 4])
 @pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 24, 14, 125), ("mag", 300, 9, 130), ("radio", 33, 13, 128)])
 def test_single_bank_inplace_flush_is_bit_identical(rbpf, kind, N_P, N_T, m, lazy_depth):
     """inplace=1: ONE covariance bank; at a flush the siblings of every stored matrix are written to dead entries

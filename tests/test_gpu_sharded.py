@@ -91,7 +91,7 @@ def test_two_ranks_on_one_gpu_equal_single_gpu(m, n_local, planner):
     assert stats["migrated"] >= 0 and stats["steps"] == T
 
 
-@pytest.mark.parametrize("lazy_depth", [2, 3])
+@pytest.mark.parametrize("lazy_depth", [2, 3, 4])
 @pytest.mark.parametrize("m,n_local", [(130, 24), (256, 16), (125, 160)])
 def test_two_ranks_with_lazy_update_match_single_gpu(m, n_local, lazy_depth):
     """Sharded filter + multi-step lazy update: migrating children get a record with the pending sets already
