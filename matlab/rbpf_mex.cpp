@@ -281,6 +281,16 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 
 }  // namespace
 
+// Options that change the schedule or the arithmetic, not the interface (include/rbpf.h `rbpf_options`): they cannot travel in
+// the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
+// matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
+struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0; double jitter = 0.0; };
+SessionOptions g_session;
+
+void session_field(const mxArray* s, const char* name, int& v) {
+  if (const mxArray* f = mxGetField(s, 0, name)) { if (!mxIsEmpty(f)) v = (int)mxGetScalar(f); }
+}
+
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("rbpf:usage", "first argument must be a command string");
   char cmdbuf[24] = {0};
@@ -293,7 +303,25 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   rbpf_options opt;
   std::memset(&opt, 0, sizeof(opt));
   opt.keep_history = 1;
-  if (cmd == "filter") {
+  opt.lazy_depth = g_session.lazy_depth; opt.chol_refresh = g_session.chol_refresh; opt.chol_variant = g_session.chol_variant;
+  opt.storage = g_session.storage; opt.inplace = g_session.inplace; opt.fix_p_mean = g_session.fix_p_mean; opt.jitter = g_session.jitter;
+  if (cmd == "options") {
+    if (nrhs > 2 || (nrhs == 2 && !mxIsStruct(prhs[1]))) mexErrMsgIdAndTxt("rbpf:usage", "options expects one struct (or nothing: query)");
+    if (nrhs == 2) {
+      SessionOptions o;                                       // fields that are absent go back to zero
+      session_field(prhs[1], "lazy_depth", o.lazy_depth); session_field(prhs[1], "chol_refresh", o.chol_refresh);
+      session_field(prhs[1], "chol_variant", o.chol_variant); session_field(prhs[1], "storage", o.storage);
+      session_field(prhs[1], "inplace", o.inplace); session_field(prhs[1], "fix_p_mean", o.fix_p_mean);
+      if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
+      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 1) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
+      g_session = o;
+    }
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 7, names);
+    const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
+                           (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter};
+    for (int q = 0; q < 7; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+  } else if (cmd == "filter") {
     if (nrhs != 12 && nrhs != 13) mexErrMsgIdAndTxt("rbpf:usage", "filter expects 11 or 12 arguments after the command");
     rbpf_model m = model_from(prhs[1], nn, g, cb);
     rbpf_problem p = problem_from(prhs[2], prhs[3], prhs[4], prhs[5], prhs[6], prhs[7], prhs[8], prhs[9], prhs[10]);

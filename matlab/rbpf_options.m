@@ -1,0 +1,26 @@
+function o = rbpf_options(varargin)
+% RBPF_OPTIONS - session options of the MI355X library behind particleFilter / particleSmoother /
+% particleSmootherInformationForm (include/rbpf.h `rbpf_options`).  They change the schedule or the arithmetic of the device
+% code, never the interface, so the example scripts keep calling the three functions unchanged:
+%
+%   rbpf_options('lazy_depth', 3, 'chol_refresh', 32);   % before run_dense3D_magfield / run_dense2D_withHeading
+%   o = rbpf_options();                                   % query
+%   rbpf_options('reset');                                % all zero again = the reference's behaviour
+%
+%   lazy_depth    C >= 2: rewrite the stored covariances every C-th step only (filter: <= 4, information form: <= 3);
+%                 same algebra, results to rounding
+%   chol_refresh  K > 1: carry the ancestor-weight Cholesky factors of particleSmootherInformationForm along the lineages
+%                 (rank-1 up/down-dates), refactorise every K-th step; ancestor probabilities within 1e-9 of the default
+%   chol_variant  which kernel factorises (0 automatic); same arithmetic
+%   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9)
+%   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
+%   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
+%   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)
+% UNTESTED under MATLAB here (no MATLAB in the build image); the gateway command is exercised by tests/test_gpu_mex_gateway.py.
+  if nargin == 0, o = rbpf_mex('options'); return; end
+  if nargin == 1 && ischar(varargin{1}) && strcmp(varargin{1}, 'reset'), o = rbpf_mex('options', struct()); return; end
+  if nargin == 1 && isstruct(varargin{1}), o = rbpf_mex('options', varargin{1}); return; end
+  cur = rbpf_mex('options');
+  for q = 1:2:numel(varargin), cur.(varargin{q}) = varargin{q+1}; end
+  o = rbpf_mex('options', cur);
+end

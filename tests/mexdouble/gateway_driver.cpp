@@ -300,6 +300,25 @@ int main(int argc, char** argv) {
       catch (const MatlabError& e) { report << "usage_error " << e.id << "\n"; }
       mxDestroyArray(cmd);
     }
+    {   // 7. session options (matlab/rbpf_options.m): set -> they apply to the next smoother call; an empty struct resets
+      const char* names[] = {"chol_refresh"};
+      mxArray* so = mxCreateStructMatrix(1, 1, 1, names);
+      mxSetField(so, 0, "chol_refresh", mxCreateDoubleScalar(3));
+      mxArray* cmd = mxCreateString("options");
+      mxArray* cur = gateway1({cmd, so});
+      report << "options_set " << mxGetScalar(mxGetField(cur, 0, "chol_refresh")) << " " << mxGetScalar(mxGetField(cur, 0, "lazy_depth")) << "\n";
+      mxDestroyArray(cur);
+      mxArray* desc = family_desc(); mxArray* rng = rng_block(true, true);
+      run_smoother("smoother_options_info", desc, rng, 1, nullptr);
+      mxDestroyArray(desc); mxDestroyArray(rng);
+      mxArray* none = mxCreateStructMatrix(1, 1, 0, nullptr);
+      cur = gateway1({cmd, none});
+      report << "options_reset " << mxGetScalar(mxGetField(cur, 0, "chol_refresh")) << "\n";
+      mxDestroyArray(cur);
+      cur = gateway1({cmd});
+      report << "options_query " << mxGetScalar(mxGetField(cur, 0, "chol_refresh")) << "\n";
+      mxDestroyArray(cur); mxDestroyArray(cmd); mxDestroyArray(so); mxDestroyArray(none);
+    }
   } catch (const std::exception& e) {
     report << "DRIVER_FAILED " << e.what() << "\n";
     fprintf(stderr, "gateway_driver: %s\n", e.what());

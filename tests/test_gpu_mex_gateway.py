@@ -115,3 +115,9 @@ def test_gateway_matches_the_ctypes_path(rbpf, tmp_path, kind):
     assert rep["leaked"] == "0"
     assert rep["callback_error"].startswith("rbpf:callback") and "Index exceeds matrix dimensions." in rep["callback_error"]
     assert rep["usage_error"] == "rbpf:usage"
+    # ---- session options (rbpf_options.m): the carried-factor option reaches the library through the unchanged signature
+    assert rep["options_set"] == "3 0" and rep["options_reset"] == "0" and rep["options_query"] == "0"
+    XNK, XLK, PK = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
+                                                        c["Q"], R, N, N_K, c["dt"], rng=rngs, chol_refresh=3)
+    for name, want in (("XNK", XNK), ("XLK", XLK), ("PK", PK)):
+        np.testing.assert_array_equal(read(tmp, "smoother_options_info", name).reshape(want.shape, order="F"), want, err_msg="options " + name)
