@@ -141,10 +141,13 @@ Layout make_layout_low_regs(int n, int d) {
   return L;
 }
 
-// The blocked variant is taken when the plain plan would leave one workgroup per CU (> 80 KB) and the wave decomposition
-// has no remainder chunk (every wave runs the same block loop: it contains workgroup barriers).
+// The blocked variant is taken when the plain plan would leave one workgroup per CU -- or two that fill the CU's 160 KB to the
+// last KB: measured at nLin = 515 (r02), plans of 80.2 KB (filter, three pending sets; information form, one set) are faster
+// through the blocked stage (28.5 vs 29.1 ms per filter step, 8.65 vs 8.93 ms per smoother step), plans of 68 KB are not
+// (29.8 vs 29.2 ms) -- and the wave decomposition has no remainder chunk (every wave runs the same block loop: it contains
+// workgroup barriers).
 #ifndef RBPF_KB_THRESHOLD_KB
-#define RBPF_KB_THRESHOLD_KB 80
+#define RBPF_KB_THRESHOLD_KB 72
 #endif
 bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
   if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;

@@ -168,7 +168,7 @@ int rbpf_shard_normalise_search(rbpf_ctx* c, const int32_t* perm_host, int32_t* 
 }  // extern "C"
 
 // ai_host == kDrawOnly: draw the ancestors but leave them on the device (device planner: nobody reads them on the host)
-static int32_t* const kDrawOnly = reinterpret_cast<int32_t*>(static_cast<intptr_t>(-1));
+static int32_t* const kDrawOnly = rbpf::draw_only_tag();
 
 int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host, int k_iter, int n_draw) {
   HIPCHK(hipSetDevice(c->device));

@@ -59,6 +59,8 @@ int shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, const r
 // (logical id Nglob - 1) and information-form buffers of the sharded smoother (null for the filter)
 int shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32_t* slot_ids_host, int k_iter,
                     const double* xref_t, const InfoStep* info);
+// ai_host value of shard_normalise_impl that draws the ancestors but leaves them on the device and does not synchronise
+inline int32_t* draw_only_tag() { return reinterpret_cast<int32_t*>(static_cast<intptr_t>(-1)); }
 // rbpf_shard_normalise_search with the draw count (N for the filter, N - 1 when slot N - 1 is the reference
 // trajectory) and the iteration whose RNG page is used
 int shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host, int k_iter, int n_draw);

@@ -59,7 +59,6 @@ struct SmootherState {
   double* d_Rinv = nullptr;     // [d*d]
   std::vector<double> h_ivec0;  // [ldx]
   double hld0 = 0.0;
-  std::vector<int> h_ai;        // [Nglob] D2H target of the global ancestor draw
   // sharded smoother with carried factors: where every logical slot's particle lives now / lived when the Imat bank was
   // materialised, and the base matrices fetched from (packed for) other ranks at a refresh
   int* d_owner_now = nullptr;   // [Nglob] rank * Nloc + physical slot
@@ -1299,7 +1298,6 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   info_initial_values(c, s->h_ivec0, Imat0, s->hld0);
   HIPCHK(hipMemcpy(s->d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
-  s->h_ai.assign((size_t)c->sh->Nglob, 0);
   if (s->refresh) {
     // carried ancestor-weight factors (rbpf_chol_sweep.hpp): factor banks, the buffers of the refresh from the state history,
     // and the exchange buffers for base matrices that sit on another rank
@@ -1370,7 +1368,8 @@ int rbpf_shard_smoother_normalise(rbpf_ctx* c, int32_t want_draw) {
   if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
   ShardState* sh = c->sh;
   const int n_draw = (sh->k_iter > 0) ? sh->Nglob - 1 : sh->Nglob;
-  return shard_normalise_impl(c, nullptr, want_draw ? c->sm->h_ai.data() : nullptr, sh->k_iter, n_draw);
+  // the ancestors stay on the device (the device planner reads them there); the next host synchronisation is the plan's
+  return shard_normalise_impl(c, nullptr, want_draw ? draw_only_tag() : nullptr, sh->k_iter, n_draw);
 }
 
 // k > 1, t > 1: ancestor log-weights of my particles against the reference state of the step about to run
