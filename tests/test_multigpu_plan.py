@@ -178,3 +178,53 @@ def test_refresh_plan_fetches_every_remote_base_matrix_once(world, nl, seed):
         space = np.concatenate((bank[r], np.array(recv, dtype=np.int64)))
         mine = np.nonzero(owner_now // nl == r)[0]
         np.testing.assert_array_equal(space[pr.base_index[owner_now[mine] % nl]], base_loc[mine])
+
+
+def _refresh_worker(rank, world, port, nl, seed, q):
+    """One rank of the refresh exchange over gloo: plan_refresh on replicated tables, all_to_all of the base matrices (rows
+    tagged with their location), base_index resolved against [own bank | received rows]."""
+    mg = _mg()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(seed)                           # same seed on every rank: replicated tables
+        N, width, ok = world * nl, 5, True
+        for rnd in range(4):
+            owner_now = rs.permutation(N)
+            w = rs.random_sample(N) ** (2 + rnd)
+            base_loc = rs.choice(N, size=N, p=w / w.sum())
+            rp = mg.plan_refresh(owner_now, base_loc, nl, world, rank)
+            bank = (torch.arange(rank * nl, (rank + 1) * nl, dtype=torch.float64)[:, None] * 10.0
+                    + torch.arange(width, dtype=torch.float64)[None, :])
+            ns, nr = int(rp.send_counts.sum()), int(rp.recv_counts.sum())
+            send = torch.empty((max(ns, 1), width), dtype=torch.float64)
+            if ns:
+                send[:ns] = bank[torch.from_numpy(rp.send_slots.astype(np.int64))]
+            recv = torch.full((max(nr, 1), width), -1.0, dtype=torch.float64)
+            mg.exchange_rows(send, recv, rp.send_counts, rp.recv_counts, dist)
+            space = torch.cat((bank, recv[:nr]))
+            mine = np.nonzero(owner_now // nl == rank)[0]
+            got = space[torch.from_numpy(rp.base_index[owner_now[mine] % nl].astype(np.int64))]
+            ok = ok and bool(torch.equal(got[:, 0] / 10.0, torch.from_numpy(base_loc[mine].astype(np.float64))))
+            ok = ok and bool(torch.equal(got[:, 4] - got[:, 0], torch.full((len(mine),), 4.0, dtype=torch.float64)))
+        flag = torch.tensor([1.0 if ok else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            q.put(float(flag.item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_refresh_exchange_over_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_refresh_worker, args=(r, world, port, 9, 77, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) == 1.0
