@@ -178,9 +178,10 @@ typedef struct {
                           * particleSmootherInformationForm.m:228 does (default).  K > 1: CARRY the factor along every lineage   *
                           * -- per step n_y rank-1 updates (the particle's own H' R^-1 H) and n_y rank-1 downdates (the reference *
                           * trajectory's term leaving ImatAddt) of the ancestor's factor, O(n^2) instead of n^3/3, the forward     *
-                          * solve carried as an augmented row -- and refactorise from the exactly carried Imat every K-th step.     *
-                          * Same algebra, different arithmetic: ancestor probabilities agree with the default to ~1e-10 (measured   *
-                          * bounds in tests/test_gpu_chol_carry.py and DESIGN.md), not bit-wise.  nLin <= 575, unsharded.           */
+                          * solve carried as an augmented row -- and refactorise every K-th step (Imat rebuilt from the state       *
+                          * history).  Same algebra, different arithmetic: ancestor probabilities within 2e-9 of the default's      *
+                          * (8.8e-10 measured over T = 3000 at nLin = 515; tests/test_gpu_chol_carry.py), not         *
+                          * bit-wise.  nLin <= 575; also in the sharded smoother (rbpf_shard_smoother_refresh_*).                    */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
                           * 0: min(N_local, max(1024, N_local / 4)).  A step that needs more fails on EVERY rank with         *

@@ -10,7 +10,7 @@ function o = rbpf_options(varargin)
 %   lazy_depth    C >= 2: rewrite the stored covariances every C-th step only (filter: <= 4, information form: <= 3);
 %                 same algebra, results to rounding
 %   chol_refresh  K > 1: carry the ancestor-weight Cholesky factors of particleSmootherInformationForm along the lineages
-%                 (rank-1 up/down-dates), refactorise every K-th step; ancestor probabilities within 1e-9 of the default
+%                 (rank-1 up/down-dates), refactorise every K-th step; ancestor probabilities within 2e-9 of the default
 %   chol_variant  which kernel factorises (0 automatic); same arithmetic
 %   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9)
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)

@@ -1,9 +1,9 @@
 """rbpf_options.chol_refresh = K > 1: the ancestor-weight factors of particleSmootherInformationForm.m:224-236 are carried
 along the lineages (ny rank-1 updates + ny rank-1 downdates per step, rbpf_chol_sweep.hpp) and recomputed from the exactly
 carried Imat every K-th step, instead of a fresh chol(Imat_i + ImatAddt) per particle and step.  Same algebra, different
-arithmetic.  Stated tolerance: ancestor probabilities paNt within 1e-9 (absolute, they are <= 1) of the numpy oracle's, which
-factorises from scratch as the reference does; every ancestor index and every output equal to the oracle's as in the default
-mode.  K = 1000 never refreshes after the first step: the drift over the whole run stays inside the same bound."""
+arithmetic.  Stated tolerance: ancestor probabilities paNt within 2e-9 (absolute, they are <= 1) of the fresh factorisation's;
+the cases against the numpy oracle (which factorises from scratch as the reference does) hold 1e-9; every ancestor index and
+every output equal to the oracle's as in the default mode.  K = 1000 never refreshes after the first step: the drift over the whole run stays inside the same bound."""
 import numpy as np
 import pytest
 
@@ -58,3 +58,32 @@ def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
     with pytest.raises(rbpf.RBPFError) as ei:
         run(rbpf, c, chol_refresh=8)
     assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+
+
+def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf):
+    """The options of bench.py's second smoother number (lazy_depth = 3, chol_refresh = 32) at the metric's matrix size
+    (slam-dense-mag m = 512, nLin = 515) over the metric's T = 3000 time steps -- 94 refresh cycles, device Philox, the product's own data
+    generator -- against the fresh factorisation on the same streams: ancestor probabilities within the stated 2e-9 at every
+    step (measured 8.8e-10; it does not grow with the refresh period, tools/drift_study.py), every ancestor index and trajectory
+    draw identical."""
+    import importlib
+    import bench
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T, N_K = 128, 3000, 2
+    Q = bench.q_mag()
+    d = dg.bean_6D(T, Q, bench.THETA_MAG, 0.01, seed=5)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(512, d["LL"], bench.THETA_MAG)
+
+    def go(**kw):
+        return rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R,
+                                                    N, N_K, 0.01, rng=rbpf.PhiloxRNG(17), extras=True, **kw)
+    a = go(lazy_depth=3)
+    b = go(lazy_depth=3, chol_refresh=32)
+    pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
+    assert np.all(np.isfinite(pb))
+    drift = np.max(np.abs(pa - pb), axis=1)                 # per time step
+    print("max |paNt difference| over 3000 steps:", float(drift.max()), "at step", int(drift.argmax()) + 1)
+    assert float(drift.max()) <= 2e-9, (float(drift.max()), int(drift.argmax()))
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
