@@ -324,6 +324,25 @@ def smoother_kernel_roofline(pkg):
             "finite": bool(np.all(np.isfinite(logw))) and status == 0}
 
 
+def smoother_sweep_roofline(pkg):
+    """The dominant kernel of the smoother WITH carried factors, on its own: one up/down-date sweep per particle over its
+    ancestor's factor (rbpf_chol_sweep.hpp), 8192 factors of nLin = 515, n_y = 3: HBM-bound, one read + one write of the stored
+    factor (1.21 MB in sweep layout)."""
+    import numpy as np
+    n, d, batch = 515, 3, 8192
+    rs = np.random.RandomState(7)
+    L = np.tril(0.02 * rs.randn(n + 1, n + 1)) + np.diag(1.0 + rs.random_sample(n + 1))
+    U = rs.randn(d, n) / np.sqrt(n)
+    V = 0.3 * rs.randn(d, n) / np.sqrt(n)
+    Lo, logw, status, ms = pkg.chol_sweep_probe(L, U, V, rs.randn(d), batch=batch, reps=10)
+    M = 8                                                     # slots below the compact tail: 64 * (64 (b M - b (b - 1) / 2) + r (M - b)) + 8 k
+    per = 8.0 * (sum(64 * (M - (k >> 6)) for k in range(64 * M)) + 8 * n)      # bytes of one stored factor (columns 0 .. n-1)
+    by = 2.0 * per * batch
+    return {"kernel": "chol_sweep_kernel<3,9>", "workload": f"{batch} factors, nLin={n}, n_y={d}, fp64", "bound": "hbm",
+            "achieved": by / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": by / (ms * 1e-3) / 1e9 / 8000.0,
+            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": by, "traffic": None, "finite": bool(np.isfinite(logw)) and status == 0}
+
+
 def guarded(f, *a):
     try:
         return f(*a)
@@ -481,7 +500,8 @@ def main():
                 line["roofline"]["traffic_note"] = why
         if solo and not args.no_smoother:
             sm = {"reference_size": guarded(smoother_reference_size, pkg, datagen),
-                  "kernel_roofline": guarded(smoother_kernel_roofline, pkg)}
+                  "kernel_roofline": guarded(smoother_kernel_roofline, pkg),
+                  "sweep_kernel_roofline": guarded(smoother_sweep_roofline, pkg)}
             if not args.no_smoother_full:
                 # the reference's arithmetic (a fresh factorisation per particle and step, :228), covariances rewritten every
                 # third step -- and the same run with the ancestor-weight factors carried along the lineages (option

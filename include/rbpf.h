@@ -452,6 +452,14 @@ int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
  * (its logw is NaN).                                                                               */
 int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e, double jitter,
                       int32_t variant, int32_t reps, double* logw, int32_t* status, double* ms);
+/* The sweep kernel of the carried factors (rbpf_options.chol_refresh) on its own, for the kernel-level parity test and the
+ * bench: ONE augmented factor L [(n+1) x (n+1)] column-major lower = [chol(A) 0; z' *], z = chol(A) \ b, replicated `batch`
+ * times; U, V [d x n] column-major (row a = update / downdate vector a), eta [d] = the entry both vectors carry in the augmented
+ * row.  Result (copy 0): L_out (same layout) = the factor of A + U'U - V'V with the row (L_out \ (b + U' eta - V' eta))', and
+ * *logw = -sum(log(diag(L_out))) + z_out' z_out / 2 (particleSmootherInformationForm.m:234-236 without the qf / halfLogDetP
+ * terms).  d = 1 or 3, n <= 575.  *status bit 1: a downdate lost definiteness.  reps / *ms as in rbpf_chol_weights.        */
+int rbpf_chol_sweep_probe(int32_t n, int32_t d, int32_t batch, const double* L, const double* U, const double* V,
+                          const double* eta, int32_t reps, double* L_out, double* logw, int32_t* status, double* ms);
 /* Quaternion helpers of tools/ on the device, batched over n columns, for the parity tests:
  *   op 0  expq, scalar branch   tools/expq.m:22-31  (flip when q0 < 0)          in [3 x n]      -> out [4 x n]
  *   op 1  expq, batched branch  tools/expq.m:33-37  (flip when q0 <= 0)         in [3 x n]      -> out [4 x n]

@@ -12,7 +12,7 @@ from ._ffi import (RBPFError, load_library, EXPORTS,                  # noqa: F4
                    RBPF_ERR_OUT_OF_MEMORY, RBPF_ERR_CHOL_FAILED, RBPF_ERR_STATE, RBPF_ERR_CALLBACK)
 from .host import (particleFilter, particleSmoother, particleSmootherInformationForm,   # noqa: F401
                    DenseMagModel, DenseRadioModel, SparseVisualModel, dense_mag_prior, dense_radio_prior,
-                   domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample, chol_weights, quat_helper,
+                   domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample, chol_weights, chol_sweep_probe, quat_helper,
                    GenericDenseModel, particle_filter_external)
 
 

@@ -1680,5 +1680,113 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   return RBPF_OK;
 }
 
+// The carried-factor sweep on its own (tests/test_gpu_chol.py, bench.py): ONE augmented factor, replicated `batch` times.
+//   L [(n+1) x (n+1)] column-major, lower: [L 0; z' *] with L = chol(A), z = L \ b;  U [d x n] the update vectors (rows), V [d x n]
+//   the downdate vectors, eta [d] the entry both carry in the augmented row  ->  L_out (same layout: the factor of
+//   A + U'U - V'V and the row (L_out \ (b + U' eta - V' eta))'), logw = -sum log diag(L_out) + z_out' z_out / 2.
+// reps > 1 repeats the launch; *ms is the mean kernel time (HIP events).  Every copy gives the same result; copy 0 is returned.
+__global__ void sweep_probe_fill_kernel(size_t len, int batch, const double* __restrict__ src, double* __restrict__ dst) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  const double v = src[i];
+  for (int p = blockIdx.y; p < batch; p += gridDim.y) dst[(size_t)p * len + i] = v;
+}
+
+int rbpf_chol_sweep_probe(int32_t n, int32_t d, int32_t batch, const double* L, const double* U, const double* V, const double* eta,
+                          int32_t reps, double* L_out, double* logw, int32_t* status, double* ms) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!L || !U || !V || !eta || n < 1 || sweep_slots(n) > kSweepMaxSlots || (d != 1 && d != 3) || batch < 1 || reps < 1) {
+    set_error("bad argument (n <= 575, d = 1 or 3)"); return RBPF_ERR_INVALID_ARG;
+  }
+  const int NS = sweep_slots(n), tailc = sweep_tail_compact(n), ldx = (n + 1) & ~1, n1 = n + 1;
+  const size_t fd = sweep_factor_doubles(n);
+  // dense lower factor -> sweep layout (rows 0..n of the columns 0..n-1; the rest of every stored slot is zero)
+  std::vector<double> hsw(fd, 0.0);
+  for (int k = 0; k < n; ++k) {
+    const int b = k >> 6;
+    double* col = hsw.data() + sweep_col_offset(k, NS, tailc);
+    for (int q = b; q < NS; ++q)
+      for (int ln = 0; ln < ((tailc && q == NS - 1) ? 8 : 64); ++ln) {
+        const int row = 64 * q + ln;
+        col[(size_t)(q - b) * 64 + ln] = (row >= k && row <= n) ? L[(size_t)row + (size_t)n1 * k] : 0.0;
+      }
+  }
+  std::vector<double> hH((size_t)d * ldx, 0.0), hHref((size_t)d * n), hW((size_t)d * d, 0.0);
+  for (int a = 0; a < d; ++a) {
+    for (int c = 0; c < n; ++c) { hH[(size_t)a * ldx + c] = U[a + (size_t)d * c]; hHref[(size_t)a * n + c] = V[a + (size_t)d * c]; }
+    hW[a + (size_t)d * a] = 1.0;
+  }
+  double *d1 = nullptr, *dold = nullptr, *dnew = nullptr, *dH1 = nullptr, *dH = nullptr, *dHref = nullptr, *dW = nullptr, *dy = nullptr, *dz = nullptr, *dlw = nullptr;
+  int* dst = nullptr;
+  auto cleanup = [&]() { hipFree(d1); hipFree(dold); hipFree(dnew); hipFree(dH1); hipFree(dH); hipFree(dHref); hipFree(dW); hipFree(dy); hipFree(dz); hipFree(dlw); hipFree(dst); };
+  int rc = dmalloc(&d1, fd);
+  if (rc == RBPF_OK) rc = dmalloc(&dold, (size_t)batch * fd);
+  if (rc == RBPF_OK) rc = dmalloc(&dnew, (size_t)batch * fd);
+  if (rc == RBPF_OK) rc = dmalloc(&dH1, (size_t)d * ldx);
+  if (rc == RBPF_OK) rc = dmalloc(&dH, (size_t)batch * d * ldx);
+  if (rc == RBPF_OK) rc = dmalloc(&dHref, (size_t)d * n);
+  if (rc == RBPF_OK) rc = dmalloc(&dW, (size_t)d * d);
+  if (rc == RBPF_OK) rc = dmalloc(&dy, (size_t)d);
+  if (rc == RBPF_OK) rc = dmalloc(&dz, (size_t)batch);
+  if (rc == RBPF_OK) rc = dmalloc(&dlw, (size_t)batch);
+  if (rc == RBPF_OK) rc = dmalloc(&dst, 4);
+  if (rc != RBPF_OK) { cleanup(); return rc; }
+  hipError_t err = hipMemcpy(d1, hsw.data(), fd * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dH1, hH.data(), hH.size() * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dHref, hHref.data(), hHref.size() * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dW, hW.data(), hW.size() * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dy, eta, (size_t)d * 8, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemset(dz, 0, (size_t)batch * 8);
+  if (err == hipSuccess) err = hipMemset(dst, 0, 16);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(sweep_probe_fill_kernel, dim3((unsigned)((fd + 255) / 256), 64), dim3(256), 0, nullptr, fd, batch, d1, dold);
+    hipLaunchKernelGGL(sweep_probe_fill_kernel, dim3((unsigned)(((size_t)d * ldx + 255) / 256), 64), dim3(256), 0, nullptr, (size_t)d * ldx, batch, dH1, dH);
+    err = hipGetLastError();
+  }
+  SweepArgs sw;
+  sw.n = n; sw.d = d; sw.ldx = ldx; sw.NS = NS; sw.tailc = tailc; sw.N = batch; sw.ref_slot = -1;
+  sw.Lold = dold; sw.Lnew = dnew; sw.stride = fd; sw.anc = nullptr; sw.order = nullptr;
+  sw.Hb = dH; sw.Href = dHref; sw.W = dW; sw.yt = dy; sw.qf = dz; sw.hld = dz; sw.pant_log = dlw; sw.status = dst;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (err == hipSuccess) err = hipEventCreate(&e0);
+  if (err == hipSuccess) err = hipEventCreate(&e1);
+  float total = 0.f;
+  for (int r = 0; r < reps && err == hipSuccess; ++r) {
+    err = hipMemsetAsync(dlw, 0, (size_t)batch * 8, nullptr);
+    if (err == hipSuccess) err = hipEventRecord(e0, nullptr);
+    if (err == hipSuccess) err = launch_chol_sweep(sw, nullptr);
+    if (err == hipSuccess) err = hipEventRecord(e1, nullptr);
+    if (err == hipSuccess) err = hipEventSynchronize(e1);
+    float t = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&t, e0, e1);
+    total += t;
+  }
+  if (err == hipSuccess) err = hipMemcpy(hsw.data(), dnew, fd * 8, hipMemcpyDeviceToHost);
+  double lw = 0.0;
+  if (err == hipSuccess) err = hipMemcpy(&lw, dlw, 8, hipMemcpyDeviceToHost);
+  int flags[4] = {0, 0, 0, 0};
+  if (err == hipSuccess) err = hipMemcpy(flags, dst, 16, hipMemcpyDeviceToHost);
+  if (e0) hipEventDestroy(e0);
+  if (e1) hipEventDestroy(e1);
+  cleanup();
+  if (err != hipSuccess) return hip_fail(err, "rbpf_chol_sweep_probe", __FILE__, __LINE__);
+  if (L_out) {
+    std::memset(L_out, 0, (size_t)n1 * n1 * 8);
+    for (int k = 0; k < n; ++k) {
+      const int b = k >> 6;
+      const double* col = hsw.data() + sweep_col_offset(k, NS, tailc);
+      for (int row = k; row <= n; ++row) {
+        const int q = row >> 6, ln = row & 63;
+        L_out[(size_t)row + (size_t)n1 * k] = col[(size_t)(q - b) * 64 + ln];
+      }
+    }
+  }
+  if (logw) *logw = lw;
+  if (status) *status = flags[0];
+  if (ms) *ms = (double)total / reps;
+  return RBPF_OK;
+}
+
 
 }  // extern "C"

@@ -774,6 +774,26 @@ def chol_weights(S, e, jitter=0.0, variant=0, reps=1, info_form=False):
     return logw, int(status[0]), float(ms[0])
 
 
+def chol_sweep_probe(L, U, V, eta, batch=1, reps=1):
+    """The sweep kernel of the carried ancestor-weight factors (rbpf_options.chol_refresh) on its own: L [(n+1) x (n+1)] lower,
+    the augmented factor [chol(A) 0; z' *]; U, V [d x n] update / downdate vectors (rows); eta [d] their entry in the augmented
+    row.  Returns (L_out, logw, status, mean kernel ms): the factor of A + U'U - V'V with the carried row, and
+    -sum(log(diag)) + z'z/2.  `batch` copies are swept (timing); copy 0 is returned."""
+    lib = load_library()
+    L = np.asfortranarray(np.asarray(L, dtype=np.float64))
+    U = np.asfortranarray(np.asarray(U, dtype=np.float64))
+    V = np.asfortranarray(np.asarray(V, dtype=np.float64))
+    eta = np.ascontiguousarray(np.asarray(eta, dtype=np.float64))
+    d, n = U.shape
+    assert L.shape == (n + 1, n + 1) and V.shape == (d, n) and eta.shape == (d,)
+    Lo = np.zeros((n + 1, n + 1), order="F")
+    logw = np.zeros(1)
+    status = np.zeros(1, dtype=np.int32)
+    ms = np.zeros(1)
+    check(lib.rbpf_chol_sweep_probe(n, d, int(batch), _dp(L), _dp(U), _dp(V), _dp(eta), int(reps), _dp(Lo), _dp(logw), _ip(status), _dp(ms)))
+    return Lo, float(logw[0]), int(status[0]), float(ms[0])
+
+
 # ------------------------------------------------------------------------------------------------
 # resident-state driver used by bench.py (inputs already in HBM when the timed region starts)
 # ------------------------------------------------------------------------------------------------

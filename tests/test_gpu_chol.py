@@ -183,3 +183,44 @@ def test_every_kernel_over_a_sweep_of_sizes(rbpf):
             got, status, _ = rbpf.chol_weights(S, e, variant=variant, info_form=True)
             assert status == 0, (M, variant)
             np.testing.assert_allclose(got, want1, rtol=1e-11, atol=1e-9, err_msg=f"M={M} variant={variant} info")
+
+
+@pytest.mark.parametrize("n,d", [(24, 1), (63, 3), (64, 3), (128, 1), (130, 3), (259, 3), (515, 3), (575, 3)])
+def test_sweep_kernel_equals_a_fresh_factorisation(rbpf, n, d):
+    """The carried-factor sweep (rbpf_chol_sweep.hpp) at kernel level against numpy: d rank-1 updates and d rank-1 downdates of
+    an augmented Cholesky factor [L 0; z' *] in one pass == chol(A + U'U - V'V) with the forward solve of the updated right-hand
+    side carried in the extra row, and the log-weight expression of particleSmootherInformationForm.m:234-236 out of the same
+    pass.  Sizes cover one slot, the slot boundaries, the compact tail (n = 128, 515), both vector storages, and the maximum."""
+    rs = np.random.RandomState(100 + n)
+    G = rs.randn(n, n + 40)
+    A = G @ G.T / (n + 40) + np.eye(n)                       # well-conditioned SPD
+    b = rs.randn(n)
+    V = 0.3 * rs.randn(d, n) / np.sqrt(n)                    # small enough that A - V'V stays positive definite
+    U = rs.randn(d, n) / np.sqrt(n)
+    eta = rs.randn(d)
+    L = np.linalg.cholesky(A)
+    Laug = np.zeros((n + 1, n + 1))
+    Laug[:n, :n] = L
+    Laug[n, :n] = np.linalg.solve(L, b)
+    Lo, logw, status, ms = rbpf.chol_sweep_probe(Laug, U, V, eta, batch=3)
+    assert status == 0
+    A2 = A + U.T @ U - V.T @ V
+    b2 = b + U.T @ eta - V.T @ eta
+    L2 = np.linalg.cholesky(A2)
+    z2 = np.linalg.solve(L2, b2)
+    scale = np.max(np.abs(L2))
+    np.testing.assert_allclose(Lo[:n, :n], L2, rtol=0, atol=1e-12 * scale * n)
+    np.testing.assert_allclose(Lo[n, :n], z2, rtol=0, atol=1e-11 * max(1.0, np.max(np.abs(z2))) * n)
+    want = -np.sum(np.log(np.diag(L2))) + 0.5 * z2 @ z2
+    assert abs(logw - want) <= 1e-10 * max(1.0, abs(want))
+    assert np.all(np.triu(Lo[:n, :n], 1) == 0.0)
+
+
+def test_sweep_kernel_reports_a_lost_downdate(rbpf):
+    """A downdate that makes the matrix indefinite: status bit 1, NaN weight (as the fresh factorisation reports a failed chol)."""
+    n, d = 40, 1
+    L = np.eye(n + 1)
+    L[n, :n] = 0.1
+    V = np.zeros((d, n)); V[0, 3] = 2.0                      # A - v v' has a negative pivot
+    Lo, logw, status, ms = rbpf.chol_sweep_probe(L, np.zeros((d, n)), V, np.zeros(d))
+    assert status & 2 and np.isnan(logw)
