@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Wall-clock of the particle-sharded information-form smoother (one process per GPU; launch with torchrun for more than
 one rank).  At world size 1 it shows the host-side overhead of the sharded session against the unsharded smoother.
-Usage: [torchrun --nproc-per-node W --master-addr 127.0.0.1] sharded_smoother_bench.py mag|radio N_local T m N_K"""
+Usage: [python -m torch.distributed.run --nproc-per-node W --master-addr 127.0.0.1] tools/sharded_smoother_bench.py
+           mag|radio N_local T m N_K [lazy_depth=3] [chol_refresh=32] [sync_phases=1] [exchange_capacity=..]
+sync_phases=1 synchronises the stream after every phase, so that sharding.phase_ms_per_step is device time per phase (gather /
+normalise / ancestor weights / plan / exchange / step) instead of host enqueue time."""
 import importlib
 import json
 import os
@@ -21,6 +24,7 @@ import bench  # noqa: E402
 
 kind = sys.argv[1]
 N_local, T, m, N_K = (int(v) for v in sys.argv[2:6])
+opts = {k: int(v) for k, v in (a.split("=") for a in sys.argv[6:])}
 rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -36,7 +40,8 @@ else:
     d = dg.planar_heading(T, Q, th, dt, seed=1, nLL=4, traj="square_3D")
     mdl, x0, P0, R = rbpf.dense_radio_prior(m, d["LL"], th)
 s = mg.ShardedSmootherSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, Q, R, N_local, N_K, dt, rng=rbpf.PhiloxRNG(3),
-                              rank=rank, world=world)
+                              rank=rank, world=world, lazy_depth=opts.get("lazy_depth", 0), chol_refresh=opts.get("chol_refresh", 0),
+                              sync_phases=bool(opts.get("sync_phases", 0)), exchange_capacity=opts.get("exchange_capacity", 0))
 torch.cuda.synchronize()
 dist.barrier()
 t0 = time.perf_counter()
@@ -50,6 +55,6 @@ if rank == 0:
     ph = st.pop("phase_s", {})
     st["phase_ms_per_step"] = {k: round(v / max(st.get("steps", 1), 1) * 1e3, 3) for k, v in ph.items()}
     print(json.dumps({"smoother": "info (sharded)", "model": "dense-" + kind, "world": world, "N_local": N_local,
-                      "N_global": N_local * world, "T": T, "m": m, "N_K": N_K, "seconds": round(secs, 3),
+                      "N_global": N_local * world, "T": T, "m": m, "N_K": N_K, "options": opts, "seconds": round(secs, 3),
                       "finite": bool(np.all(np.isfinite(XNK))), "sharding": st}), flush=True)
 dist.destroy_process_group()
