@@ -604,10 +604,12 @@ class ShardedSmootherSession(ShardedFilterSession):
                 if t == 0:
                     check(lib.rbpf_shard_smoother_step(self.ctx))
                     continue
+                diag = self.stream.synchronize if self.sync_phases else (lambda: None)     # device time per phase (diagnostic)
                 t0 = time.perf_counter()
                 self._gather()
                 t1 = time.perf_counter()
                 check(lib.rbpf_shard_smoother_normalise(self.ctx, 1))
+                diag()
                 t2 = time.perf_counter()
                 if k > 0:
                     K = self.chol_refresh
@@ -617,6 +619,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                         check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
                     self._gather_anc()
                     check(lib.rbpf_shard_smoother_anc_sample(self.ctx))
+                    diag()
                 t3 = time.perf_counter()
                 cnt = np.zeros(2 * W + 2, dtype=np.int64)
                 check(lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
@@ -625,6 +628,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                     self._exchange((cnt[:W], cnt[W:2 * W]), int(cnt[2 * W + 1]))
                 t5 = time.perf_counter()
                 check(lib.rbpf_shard_smoother_step(self.ctx))
+                diag()
                 t6 = time.perf_counter()
                 tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["anc"] += t3 - t2; tm["plan"] += t4 - t3
                 tm["exchange"] += t5 - t4; tm["step"] += t6 - t5
