@@ -277,7 +277,8 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
     d = datagen.bean_6D(T_s, Q, THETA_MAG, 0.01, seed=seed)
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, d["LL"], THETA_MAG)
     sess = mg.ShardedSmootherSession(model, d["dx"], d["y"], d["initState"], x0_lin, P0, Q, R, N_local, N_K, 0.01,
-                                     rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth, chol_refresh=chol_refresh)
+                                     rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth, chol_refresh=chol_refresh,
+                                     force_collectives=(world == 1))
     try:
         torch.cuda.synchronize()
         if dist is not None:
@@ -423,7 +424,7 @@ def main():
         mg = importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
         sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
                                        N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world,
-                                       lazy_depth=args.lazy_depth, storage=args.storage)
+                                       lazy_depth=args.lazy_depth, storage=args.storage, force_collectives=(world == 1))
         sess.advance(W)
         sess.sync()
         sess.timing(enable=True)
@@ -450,7 +451,7 @@ def main():
         try:
             sess = mg.ShardedFilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R,
                                            N_local, 0.01, rng=pkg.PhiloxRNG(args.seed), rank=rank, world=world,
-                                           lazy_depth=args.lazy_depth, storage=args.storage, sync_phases=True)
+                                           lazy_depth=args.lazy_depth, storage=args.storage, sync_phases=True, force_collectives=(world == 1))
             sess.advance(6)
             sess.sync()
             sess.stats["phase_s"] = dict(gather=0.0, normalise=0.0, plan=0.0, exchange=0.0, step=0.0)

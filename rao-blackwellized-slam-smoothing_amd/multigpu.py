@@ -168,11 +168,14 @@ class ShardedFilterSession:
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
                  transport="device", planner="device", lazy_depth=0, storage="fp64", keep_history=False, exchange_capacity=0,
-                 sync_phases=False):
+                 sync_phases=False, force_collectives=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.sync_phases = bool(sync_phases)   # diagnostic: synchronise after every phase so that stats["phase_s"] is GPU time
+        # world 1 normally short-cuts the collectives (a device copy, no exchange); force_collectives issues the real calls --
+        # all_gather_into_tensor / all_to_all_single on the library's buffers and stream -- so that a one-GPU box exercises them
+        self.force_collectives = bool(force_collectives)
         self.lib = load_library()
         for name, argt in (("rbpf_shard_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
                                                   C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
@@ -227,10 +230,11 @@ class ShardedFilterSession:
         fwd = (model.nNonLin + 1) * self.N_local
         self.t_fwd_local = _view(torch, v.fwd_local, (fwd,), self.device)
         self.t_fwd_gather = _view(torch, v.fwd_gather, (self.world * fwd,), self.device)
-        self.t_send = _view(torch, v.send_rec, (max(int(v.send_capacity), 1), int(v.record_doubles)), self.device) \
-            if self.world > 1 else None
-        self.t_recv = _view(torch, v.recv_rec, (max(int(v.recv_capacity), 1), int(v.record_doubles)), self.device) \
-            if self.world > 1 else None
+        coll = self.world > 1 or self.force_collectives
+        self.t_send = _view(torch, v.send_rec if v.send_capacity else None, (max(int(v.send_capacity), 1), int(v.record_doubles)),
+                            self.device) if coll else None
+        self.t_recv = _view(torch, v.recv_rec if v.recv_capacity else None, (max(int(v.recv_capacity), 1), int(v.record_doubles)),
+                            self.device) if coll else None
 
     def _n_iter(self):
         return 1
@@ -247,7 +251,7 @@ class ShardedFilterSession:
     def _gather(self):
         torch, dist = self.torch, self.dist
         with torch.cuda.stream(self.stream):
-            if self.world == 1:
+            if self.world == 1 and not self.force_collectives:
                 self.t_fwd_gather.copy_(self.t_fwd_local)
             elif self.transport == "device":
                 dist.all_gather_into_tensor(self.t_fwd_gather, self.t_fwd_local)
@@ -319,7 +323,7 @@ class ShardedFilterSession:
                     check(self.lib.rbpf_shard_normalise_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
                     self.t_norm += 1
                     t2 = t3 = time.perf_counter()
-                    if self.world > 1:
+                    if self.world > 1 or self.force_collectives:
                         self._exchange((cnt[:self.world], cnt[self.world:2 * self.world]), int(cnt[2 * self.world + 1]))
                     t4 = time.perf_counter()
                     check(self.lib.rbpf_shard_step(self.ctx, None, None))
@@ -493,7 +497,7 @@ class ShardedSmootherSession(ShardedFilterSession):
     particles bit for bit."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
-                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0):
+                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0, force_collectives=False):
         self.N_K = int(N_K)
         self.chol_refresh = int(chol_refresh)
         lib = load_library()
@@ -514,7 +518,7 @@ class ShardedSmootherSession(ShardedFilterSession):
             getattr(lib, name).argtypes = argt
         super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
                          transport=transport, planner="device", lazy_depth=lazy_depth, exchange_capacity=exchange_capacity,
-                         sync_phases=sync_phases)
+                         sync_phases=sync_phases, force_collectives=force_collectives)
         sv = rbpf_shard_smoother_views()
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
         self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)
@@ -538,7 +542,7 @@ class ShardedSmootherSession(ShardedFilterSession):
     def _gather_anc(self):
         torch, dist = self.torch, self.dist
         with torch.cuda.stream(self.stream):
-            if self.world == 1:
+            if self.world == 1 and not self.force_collectives:
                 self.t_anc_gather.copy_(self.t_anc_local)
             elif self.transport == "device":
                 dist.all_gather_into_tensor(self.t_anc_gather, self.t_anc_local)
@@ -571,7 +575,7 @@ class ShardedSmootherSession(ShardedFilterSession):
         ns, nr = int(rp.send_counts.sum()), int(rp.recv_counts.sum())
         slots = np.ascontiguousarray(rp.send_slots)
         check(lib.rbpf_shard_smoother_refresh_pack(self.ctx, _ip(slots) if ns else None, ns))
-        if W > 1:
+        if W > 1 or self.force_collectives:
             plan = RankPlan(None, None, None, rp.send_counts, rp.recv_counts)
             with torch.cuda.stream(self.stream):
                 if self.transport == "device":
@@ -624,7 +628,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                 cnt = np.zeros(2 * W + 2, dtype=np.int64)
                 check(lib.rbpf_shard_plan(self.ctx, cnt.ctypes.data_as(C.POINTER(C.c_int64))))
                 t4 = time.perf_counter()
-                if W > 1:
+                if W > 1 or self.force_collectives:
                     self._exchange((cnt[:W], cnt[W:2 * W]), int(cnt[2 * W + 1]))
                 t5 = time.perf_counter()
                 check(lib.rbpf_shard_smoother_step(self.ctx))

@@ -42,7 +42,7 @@ def _worker(rank, world, port, backend, transport, kind, n_local, T, m, N_K, q, 
         mdl, x0, P0, R = cases.device_model(rbpf, c)
         s = mg.ShardedSmootherSession(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, n_local, N_K, c["dt"],
                                       rng=cases.device_rng(rbpf, c), rank=rank, world=world, transport=transport,
-                                      lazy_depth=lazy_depth, chol_refresh=chol_refresh)
+                                      lazy_depth=lazy_depth, chol_refresh=chol_refresh, force_collectives=(world == 1))
         XNK, XLK, PK = s.run()
         stats = dict(s.stats)
         aks = list(s.aks)
