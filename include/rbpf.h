@@ -184,7 +184,7 @@ typedef struct {
                           * bit-wise.  nLin <= 575; also in the sharded smoother (rbpf_shard_smoother_refresh_*).                    */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
-                          * 0: min(N_local, max(1024, N_local / 4)).  A step that needs more fails on EVERY rank with         *
+                          * 0: min(N_local, max(1024, N_local / 8)).  A step that needs more fails on EVERY rank with         *
                           * RBPF_ERR_OUT_OF_MEMORY before any collective is issued (the plan is replicated).                 */
   rbpf_on_step_fn on_step; /* NULL: no hook                                                       */
   void* on_step_user;

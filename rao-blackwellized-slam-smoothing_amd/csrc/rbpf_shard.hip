@@ -95,8 +95,9 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     // of the free memory, so that every rank reaches the same verdict about a step's exchange): `step_cap` records may
     // leave / enter a rank per time step; received records stay alive until the next flush of the lazy update.  With
     // owner-computes placement a step moves the load imbalance only -- and one record per (destination, ancestor) pair,
-    // however many children it has -- so the default is a quarter of the local particles.
-    const size_t dflt = std::min(Nloc, std::max<size_t>(1024, Nloc / 4));
+    // however many children it has -- so the default is an eighth of the local particles (measured need at N_local = 4096: 1 %,
+    // tools/sharded_rehearsal.py; at N_local = 32 768, nLin = 515, lazy_depth 4 the buffers then take 44 GB next to 139 GB of banks).
+    const size_t dflt = std::min(Nloc, std::max<size_t>(1024, Nloc / 8));
     s->step_cap = o.exchange_capacity > 0 ? std::min<size_t>((size_t)o.exchange_capacity, Nloc * (size_t)(world - 1)) : dflt;
     s->send_cap = s->step_cap;
     s->recv_cap = std::min(s->step_cap, Nloc) * (size_t)std::max(c->lazy_depth, 1);
