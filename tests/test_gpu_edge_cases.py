@@ -175,6 +175,18 @@ def test_device_kalman_recursion_equals_batch_gp_posterior(rbpf, oracle, lazy_de
     for i in range(N):
         np.testing.assert_allclose(ex["xl"][:, i], mean, rtol=1e-7, atol=1e-8 * np.max(np.abs(mean)))
         np.testing.assert_allclose(ex["P"][:, :, i], cov, rtol=1e-6, atol=1e-9 * np.max(np.abs(cov)))
+    # ... and the importance weights (particleFilter.m:139-150, constants included): along a fixed path the unnormalised
+    # log-weights are the one-step predictive log-densities, so their sum is the log marginal likelihood of all 3 T
+    # measurements under the prior,  log N(y; Phi x0, Phi P0 Phi' + kron(I, R))
+    yv = d["y"].reshape(-1)
+    C = Phi @ P0 @ Phi.T + np.kron(np.eye(T), R)
+    Lm = np.linalg.cholesky(C)
+    v = np.linalg.solve(Lm, yv - Phi @ np.asarray(x0).reshape(-1))
+    loglik = -0.5 * v @ v - np.sum(np.log(np.diag(Lm))) - 0.5 * yv.size * np.log(2.0 * np.pi)
+    logw = np.asarray(ex["logw"])
+    logw = logw if logw.shape[0] == N else logw.T
+    for i in range(N):
+        assert abs(float(np.sum(logw[i])) - loglik) <= 1e-8 * abs(loglik), (float(np.sum(logw[i])), loglik)
 
 
 @pytest.mark.gpu

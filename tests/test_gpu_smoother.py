@@ -189,3 +189,26 @@ def test_information_form_smoother_with_the_lazy_covariance_update(rbpf, kind, N
                                                c["Q"], R, N_P, 3, c["dt"], rng=cases.device_rng(rbpf, c), extras=True,
                                                lazy_depth=lazy_depth)
     check(ref, out, 3)
+
+
+@pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 8, 7, 16), ("mag", 12, 9, 130), ("radio", 9, 8, 24), ("radio", 14, 10, 128)])
+def test_device_covariance_and_information_form_agree(rbpf, kind, N_P, N_T, m):
+    """Known answer that needs no restatement of the reference: particleSmootherInformationForm.m:35-37 says the two smoothers
+    are identical up to the form the weights are computed in.  On the DEVICE, with the same random numbers, the covariance form
+    (stacked future innovations: MFMA GEMMs + a (n_y (T - t)) x (n_y (T - t)) Cholesky) and the information form (suffix sums of
+    H' R^-1 H + an n x n Cholesky, other kernels altogether) must give the same normalised weights, ancestor probabilities,
+    ancestor indices and outputs (quirk Q6: the unnormalised weights differ by a constant)."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=83, N_K=3)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    outs = []
+    for f in (rbpf.particleSmoother, rbpf.particleSmootherInformationForm):
+        outs.append(f(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                      c["N_P"], c["N_K"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True))
+    (X1, L1, P1, e1), (X2, L2, P2, e2) = outs
+    np.testing.assert_array_equal(e1["ai"][:, 1:], e2["ai"][:, 1:])
+    np.testing.assert_array_equal(e1["ak"], e2["ak"])
+    np.testing.assert_allclose(e1["w"], e2["w"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(e1["paNt"][1:, 1:], e2["paNt"][1:, 1:], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(X1, X2, rtol=0, atol=1e-12)
+    assert rel(L1, L2) <= 1e-9 and rel(P1, P2) <= 1e-9
