@@ -994,7 +994,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
   HIPCHK(hipSetDevice(c->device));
   if (c->t < 1) { set_error("finish before any step"); return RBPF_ERR_STATE; }
   RB_TRY(ctx_check_flags(c));
-  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d;
+  const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n;
   const int Tdone = c->t;
   const Layout& L = c->lay;
   const int cur = c->xcur;          // bank of the means (== covariance bank unless the lazy update is on)
