@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 5
+#define RBPF_ABI_VERSION 6
 
 typedef enum {
   RBPF_OK = 0,
@@ -305,10 +305,12 @@ typedef struct {
   size_t record_doubles;       /* doubles per exchanged particle record [Pt | Pb | F | xl]            */
   size_t recv_capacity;        /* records the receive buffer can hold                                */
   size_t send_capacity;        /* records the send buffer can hold                                   */
-  double* fwd_local;           /* [(n_nonlin+1)][N_local]: rows xn, last row logw (step kernel output) */
-  double* fwd_gather;          /* [world][(n_nonlin+1)][N_local] all_gather target                    */
+  double* fwd_local;           /* [fwd_rows][N_local]: rows xn, then logw (step kernel output); the sharded smoother
+                                * appends one row, the measurement part of my particles' ancestor log-weights        */
+  double* fwd_gather;          /* [world][fwd_rows][N_local] all_gather target                        */
   double* send_rec;            /* [send_capacity][record_doubles]                                     */
   double* recv_rec;            /* [recv_capacity][record_doubles]                                     */
+  int32_t fwd_rows;            /* n_nonlin + 1 (filter) / n_nonlin + 2 (smoother)                     */
 } rbpf_shard_views;
 
 int rbpf_shard_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
@@ -363,19 +365,24 @@ int rbpf_shard_set_ancestors(rbpf_ctx* ctx, const int32_t* ai);
 /* ---- particle-sharded information-form smoother ---------------------------------
  * particleSmootherInformationForm.m with the N = world * N_P particles of every CPF-AS iteration sharded like the
  * filter above.  The extra information-form state (ivec, Imat, halfLogDetP) travels in the particle records.
- * The ancestor weights of the reference trajectory (:205-240) are computed on the rank that holds each particle,
- * all-gathered (N doubles) and normalised / sampled identically on every rank.  Results equal the single-GPU
- * rbpf_particle_smoother(info_form = 1) with N particles bit for bit.  Per iteration k the host side does
+ * The measurement part of the ancestor weights of the reference trajectory (:205-236: one n x n factorisation per particle, or
+ * one sweep over its carried factor) is computed on the rank that holds each particle, BEFORE the all_gather of the forward
+ * bank, whose extra row carries it along (one collective per step instead of two); log w and the dynResNorm part are added
+ * for all N particles from the gathered bank, identically on every rank, then normalised and sampled.  Results equal the
+ * single-GPU rbpf_particle_smoother(info_form = 1) with N particles bit for bit.  Per iteration k the host side does
  *   rbpf_shard_smoother_begin(ctx, k)
  *   t = 0: rbpf_shard_smoother_step(ctx)
- *   t > 0: all_gather(fwd_local -> fwd_gather); rbpf_shard_smoother_normalise(ctx, 1)
- *          k > 0: rbpf_shard_smoother_anc_weights(ctx); all_gather(anc_local -> anc_gather);
- *                 rbpf_shard_smoother_anc_sample(ctx)
+ *   t > 0: k > 0 (no refresh due): rbpf_shard_smoother_anc_weights(ctx)
+ *          all_gather(fwd_local -> fwd_gather); rbpf_shard_smoother_normalise(ctx, 1)
+ *          k > 0: rbpf_shard_smoother_anc_sample(ctx, 0)
+ *                 (refresh steps of the carried factors: the refresh sequence below, all_gather(anc_local -> anc_gather),
+ *                  rbpf_shard_smoother_anc_sample(ctx, 1))
  *          rbpf_shard_plan; rbpf_shard_pack; all_to_all_single(send_rec -> recv_rec); rbpf_shard_smoother_step(ctx)
  *   all_gather; rbpf_shard_smoother_normalise(ctx, 0); rbpf_shard_smoother_end(ctx, ...)                       */
 typedef struct {
-  double* anc_local;           /* [N_local] ancestor log-weights of my particles (physical order)          */
-  double* anc_gather;          /* [world][N_local] all_gather target                                      */
+  double* anc_local;           /* [N_local] measurement part of my particles' ancestor log-weights (physical order): the
+                                * last row of fwd_local                                                    */
+  double* anc_gather;          /* [world][N_local] all_gather target of anc_local on its own (refresh steps) */
   /* carried factors (chol_refresh > 1): base matrices exchanged at a refresh, [refresh_capacity][matrix_doubles]; NULL / 0
    * otherwise                                                                                                */
   double* refresh_send;
@@ -391,10 +398,11 @@ int rbpf_shard_smoother_views_get(rbpf_ctx* ctx, rbpf_shard_smoother_views* out)
 int rbpf_shard_smoother_begin(rbpf_ctx* ctx, int32_t k);
 /* Global weights of the finished step; want_draw: ancestors of the ordinary slots of the next one (:160-166).   */
 int rbpf_shard_smoother_normalise(rbpf_ctx* ctx, int32_t want_draw);
-/* k > 0, t > 0: ancestor log-weights of my particles -> anc_local (:205-240).  Synchronises.                     */
+/* k > 0, t > 0, before the gather: measurement part of my particles' ancestor log-weights -> anc_local (:205-236). */
 int rbpf_shard_smoother_anc_weights(rbpf_ctx* ctx);
-/* After the all_gather of anc_local: normalise (:243-245) and draw ai(N_P) (:248).                                */
-int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx);
+/* After gather + normalise: add log w and the dynResNorm part (:175-182,232) for all N particles, normalise (:243-245) and
+ * draw ai(N_P) (:248).  separate_gather: 0 = the measurement parts came with the forward bank, 1 = they are in anc_gather. */
+int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx, int32_t separate_gather);
 /* Carried ancestor-weight factors in the sharded smoother (rbpf_options.chol_refresh = K > 1, lazy_depth as usual): between
  * refreshes rbpf_shard_smoother_anc_weights runs one up/down-date sweep per particle over its ancestor's factor, which migrates
  * inside the particle records in place of Imat.  At the steps t = 1 and (t - 1) % K == 0 of an iteration k > 0 the factors are
@@ -406,7 +414,8 @@ int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx);
  *   rbpf_shard_smoother_refresh_pack(ctx, slots, count); all_to_all_single(refresh_send -> refresh_recv);
  *   rbpf_shard_smoother_refresh_end(ctx, base_index, n_recv)      base_index [N_local]: bank slot or N_local + position in
  *        refresh_recv
- * then all_gather(anc_local) and rbpf_shard_smoother_anc_sample as usual.                                            */
+ * (after the gather and normalise of the finished step: the walk reads the state history), then all_gather(anc_local ->
+ * anc_gather) and rbpf_shard_smoother_anc_sample(ctx, 1).                                           */
 int rbpf_shard_smoother_refresh_begin(rbpf_ctx* ctx, int32_t* owner_now, int32_t* base_loc);
 int rbpf_shard_smoother_refresh_pack(rbpf_ctx* ctx, const int32_t* slots, int32_t count);
 int rbpf_shard_smoother_refresh_end(rbpf_ctx* ctx, const int32_t* base_index, int32_t n_recv);

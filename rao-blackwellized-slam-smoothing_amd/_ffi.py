@@ -187,8 +187,8 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_chol_sweep_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
                                           c_double_p, c_double_p, c_int32_p, c_double_p]
     lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
-    if lib.rbpf_abi_version() != 5:
-        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 5 (rebuild)")
+    if lib.rbpf_abi_version() != 6:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 6 (rebuild)")
     _lib = lib
     return lib
 

@@ -208,7 +208,7 @@ hipError_t launch_pack_records_flushed(const Layout& lay, int d, const int* idx,
                                        const int* base, int n_bank_local, const double* rec, size_t rec_stride,
                                        const double* xl, double* out, hipStream_t s, int fp32 = 0);
 hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
-                              double* logw, double* xn_soa, hipStream_t s);
+                              double* logw, double* xn_soa, hipStream_t s, int rows = 0, double* extra = nullptr);
 hipError_t launch_gather_xl(int N, int n, int ldx, const double* xl, double* out_colmajor, hipStream_t s);
 
 }  // namespace rbpf

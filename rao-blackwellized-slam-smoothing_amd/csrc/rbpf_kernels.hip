@@ -1902,25 +1902,27 @@ hipError_t launch_pack_records(const Layout& lay, int d, const int* idx, int cou
   return hipGetLastError();
 }
 
-// all_gather layout [world][nN+1][Nloc] in PHYSICAL slot order (rows 0..nN-1: xn, row nN: logw) ->
-// logical order: logw[i], SoA xn[c][i], with i = logical slot id and phys_of_logical[i] = rank*Nloc + idx
-__global__ void permute_fwd_kernel(int N, int nN, int world, int Nloc, const int* __restrict__ phys_of_logical,
+// all_gather layout [world][rows][Nloc] in PHYSICAL slot order (rows 0..nN-1: xn, row nN: logw; rows = nN + 2 in the sharded
+// smoother, whose extra row carries the measurement part of the ancestor log-weights) ->
+// logical order: logw[i], SoA xn[c][i], extra[i], with i = logical slot id and phys_of_logical[i] = rank*Nloc + idx
+__global__ void permute_fwd_kernel(int N, int nN, int rows, int Nloc, const int* __restrict__ phys_of_logical,
                                    const double* __restrict__ fwd_gather, double* __restrict__ logw,
-                                   double* __restrict__ xn_soa) {
+                                   double* __restrict__ xn_soa, double* __restrict__ extra) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int ph = phys_of_logical ? phys_of_logical[i] : i;
   const int r = ph / Nloc, j = ph % Nloc;
-  const double* blk = fwd_gather + (size_t)r * (nN + 1) * Nloc;
+  const double* blk = fwd_gather + (size_t)r * rows * Nloc;
   for (int c = 0; c < nN; ++c) xn_soa[(size_t)c * N + i] = blk[(size_t)c * Nloc + j];
-  logw[i] = blk[(size_t)nN * Nloc + j];
-  (void)world;
+  if (logw) logw[i] = blk[(size_t)nN * Nloc + j];
+  if (extra) extra[i] = blk[(size_t)(nN + 1) * Nloc + j];
 }
 
 hipError_t launch_permute_fwd(int N, int nN, int world, int Nloc, const int* phys_of_logical, const double* fwd_gather,
-                              double* logw, double* xn_soa, hipStream_t s) {
-  hipLaunchKernelGGL(permute_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nN, world, Nloc, phys_of_logical,
-                     fwd_gather, logw, xn_soa);
+                              double* logw, double* xn_soa, hipStream_t s, int rows, double* extra) {
+  (void)world;
+  hipLaunchKernelGGL(permute_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, nN, rows > 0 ? rows : nN + 1, Nloc, phys_of_logical,
+                     fwd_gather, logw, xn_soa, extra);
   return hipGetLastError();
 }
 

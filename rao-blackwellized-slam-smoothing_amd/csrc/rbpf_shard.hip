@@ -28,7 +28,7 @@ void shard_free(rbpf_ctx* c) {
   hipFree(s->pb.order); hipFree(s->pb.mv_child); hipFree(s->pb.mv_src); hipFree(s->pb.mv_q); hipFree(s->pb.pref);
   hipFree(s->pb.slot_ids); hipFree(s->pb.anc_bank); hipFree(s->pb.send_idx); hipFree(s->pb.scalars); hipFree(s->pb.counts_dev);
   hipFree(s->gid_buf[0]); hipFree(s->gid_buf[1]);
-  hipFree(s->Xhist); hipFree(s->Ahist); hipFree(s->anc_local); hipFree(s->anc_gather); hipFree(s->anc_glob);
+  hipFree(s->Xhist); hipFree(s->Ahist); hipFree(s->anc_gather); hipFree(s->anc_glob);      // anc_local is a row of fwd_local
   hipFree(s->anc_w); hipFree(s->anc_wc); hipFree(s->w_local); hipFree(s->ident_bank);
   if (s->counts_pin) hipHostFree(s->counts_pin);
   delete s;
@@ -105,8 +105,9 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   s->rec_used_all.assign((size_t)world, 0);
   int st = RBPF_OK;
   auto A = [&](int r) { if (st == RBPF_OK) st = r; };
-  A(dmalloc(&s->fwd_local, Nloc * (nN + 1)));
-  A(dmalloc(&s->fwd_gather, (size_t)s->Nglob * (nN + 1)));
+  s->fwd_rows = nN + 1 + (smoother ? 1 : 0);
+  A(dmalloc(&s->fwd_local, Nloc * (size_t)s->fwd_rows));
+  A(dmalloc(&s->fwd_gather, (size_t)s->Nglob * s->fwd_rows));
   A(dmalloc(&s->logw_glob, (size_t)s->Nglob));
   A(dmalloc(&s->xn_glob, (size_t)s->Nglob * nN));
   A(dmalloc(&s->w_glob, (size_t)s->Nglob));
@@ -136,7 +137,11 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
   }
   if (smoother) {
     const size_t Ng = (size_t)s->Nglob;
-    A(dmalloc(&s->anc_local, Nloc)); A(dmalloc(&s->anc_gather, Ng)); A(dmalloc(&s->anc_glob, Ng));
+    if (st == RBPF_OK) {
+      s->anc_local = s->fwd_local + (size_t)(nN + 1) * Nloc;          // alias: the extra row of the forward bank
+      if (hipMemset(s->anc_local, 0, Nloc * sizeof(double)) != hipSuccess) st = RBPF_ERR_HIP;
+    }
+    A(dmalloc(&s->anc_gather, Ng)); A(dmalloc(&s->anc_glob, Ng));
     A(dmalloc(&s->anc_w, Ng)); A(dmalloc(&s->anc_wc, Ng)); A(dmalloc(&s->ident_bank, Nloc));
   }
   A(dmalloc(&s->w_local, Nloc));
@@ -158,6 +163,7 @@ int rbpf_shard_views_get(rbpf_ctx* c, rbpf_shard_views* v) {
   v->rank = s->rank; v->world = s->world; v->N_local = s->Nloc; v->N_global = s->Nglob; v->n_nonlin = c->mdl.nN;
   v->record_doubles = s->recsz; v->recv_capacity = s->recv_cap; v->send_capacity = s->send_cap;
   v->fwd_local = s->fwd_local; v->fwd_gather = s->fwd_gather; v->send_rec = s->send_rec; v->recv_rec = s->recv_rec;
+  v->fwd_rows = s->fwd_rows;
   return RBPF_OK;
 }
 
@@ -182,7 +188,9 @@ int rbpf::shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* a
     HIPCHK(hipMemcpyAsync(s->perm, perm_host, (size_t)N * sizeof(int), hipMemcpyHostToDevice, c->stream));
     perm = s->perm;
   }
-  HIPCHK(launch_permute_fwd(N, nN, s->world, s->Nloc, perm, s->fwd_gather, s->logw_glob, s->xn_glob, c->stream));
+  // (smoother: the extra row -- the measurement part of the ancestor log-weights -- comes along into anc_glob)
+  HIPCHK(launch_permute_fwd(N, nN, s->world, s->Nloc, perm, s->fwd_gather, s->logw_glob, s->xn_glob, c->stream, s->fwd_rows,
+                            s->smoother ? s->anc_glob : nullptr));
   NormArgs nm;
   nm.N = N; nm.nN = nN; nm.t = t_done; nm.logw = s->logw_glob; nm.w = s->w_glob; nm.wc = s->wc_glob; nm.xn = s->xn_glob;
   nm.traj_max = c->traj_max + (size_t)t_done * nN; nm.traj_mean = c->traj_mean + (size_t)t_done * nN;

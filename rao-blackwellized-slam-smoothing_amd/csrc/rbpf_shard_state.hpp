@@ -8,8 +8,9 @@ namespace rbpf {
 struct ShardState {
   int rank = 0, world = 1, Nloc = 0, Nglob = 0;
   size_t recsz = 0, recv_cap = 0, send_cap = 0;
-  double* fwd_local = nullptr;     // [(nN+1)][Nloc]
-  double* fwd_gather = nullptr;    // [world][(nN+1)][Nloc]
+  int fwd_rows = 0;                // rows of the forward bank: nN + 1 (states, log-weight); + 1 in the smoother (anc_local)
+  double* fwd_local = nullptr;     // [fwd_rows][Nloc]
+  double* fwd_gather = nullptr;    // [world][fwd_rows][Nloc]
   double* logw_glob = nullptr;     // [Nglob] logical order
   double* xn_glob = nullptr;       // SoA [nN][Nglob] logical order
   double* w_glob = nullptr;        // [Nglob]
@@ -44,7 +45,8 @@ struct ShardState {
   size_t rec_off_I = 0, rec_off_hld = 0, rec_off_Hb = 0, rec_off_Imat = 0;   // information part of a record
   double* Xhist = nullptr;         // [T][nN][Nglob] states of every step, logical order (replicated)
   int* Ahist = nullptr;            // [T][Nglob] ancestors of every step, logical ids (replicated)
-  double* anc_local = nullptr;     // [Nloc] ancestor log-weights of my particles, physical order
+  double* anc_local = nullptr;     // [Nloc] measurement part of the ancestor log-weights of my particles, physical order:
+                                   // the LAST ROW of fwd_local, so that one all_gather moves it with the forward bank
   double* anc_gather = nullptr;    // [world][Nloc] all_gather target
   double* anc_glob = nullptr;      // [Nglob] logical order
   double* anc_w = nullptr;         // [Nglob] normalised ancestor probabilities (paNt)

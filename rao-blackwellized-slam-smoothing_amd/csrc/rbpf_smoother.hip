@@ -731,13 +731,6 @@ __global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, c
   }
 }
 
-// w_local[p] = w_glob[logical id of physical slot p]
-__global__ void gather_w_local_kernel(int Nloc, int slot0, const int* __restrict__ slot_ids, const double* __restrict__ w_glob,
-                                      double* __restrict__ w_local) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < Nloc) w_local[p] = w_glob[slot_ids ? slot_ids[p] : slot0 + p];
-}
-
 }  // namespace rbpf
 
 using namespace rbpf;
@@ -1372,22 +1365,19 @@ int rbpf_shard_smoother_normalise(rbpf_ctx* c, int32_t want_draw) {
   return shard_normalise_impl(c, nullptr, want_draw ? draw_only_tag() : nullptr, sh->k_iter, n_draw);
 }
 
-// k > 1, t > 1: ancestor log-weights of my particles against the reference state of the step about to run
-// (:205-240) -> anc_local [N_local] (physical order).  Synchronises: the all_gather follows.
-// dynResNorm part of the weights into anc_local and the (t-1) term out of the suffix sums: common to the fresh factorisation,
-// the sweep and the refresh
-static int shard_anc_head(rbpf_ctx* c) {
+// k > 1, t > 1: the measurement part of my particles' ancestor log-weights for the step about to run (:205-236) -> anc_local
+// [N_local] (physical order), BEFORE the all_gather of the forward bank, which carries it along.  Synchronises unless async.
+// Start of the MEASUREMENT part of my particles' ancestor log-weights (logwMeas, :205-236) in anc_local -- the extra row of the
+// forward bank, so that one all_gather carries it with the states and log-weights -- and the (t-1) term out of the suffix
+// sums.  It needs nothing from other ranks; the dynResNorm part and log w are added for all N particles after the gather
+// (rbpf_shard_smoother_anc_sample), in the reference's order of summation.
+static int shard_anc_meas_begin(rbpf_ctx* c) {
   SmootherState* s = c->sm;
   ShardState* sh = c->sh;
-  const int t = c->t, k = sh->k_iter, N = sh->Nloc, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
-  if (k < 1 || t < 1 || t >= c->T || sh->t_norm < t) { set_error("ancestor weights need k > 0, t > 0 and the normalised weights of step t-1"); return RBPF_ERR_STATE; }
+  const int t = c->t, k = sh->k_iter, n = c->mdl.n, d = c->mdl.d;
+  if (k < 1 || t < 1 || t >= c->T) { set_error("ancestor weights need k > 0 and 0 < t < N_T"); return RBPF_ERR_STATE; }
   hipStream_t st = c->stream;
-  const double* xref = s->d_xnk + (size_t)t * nN;
-  hipLaunchKernelGGL(gather_w_local_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, sh->rank * N,
-                     sh->placed ? sh->pb.slot_ids : nullptr, sh->w_glob, sh->w_local);
-  const double* Lq = c->d_cholQfull + (size_t)((c->chol_pages > 1) ? t - 1 : 0) * nw * nw;
-  hipLaunchKernelGGL(anc_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, c->mdl, N, sh->fwd_local, xref,
-                     c->d_odo + (size_t)(t - 1) * c->mdl.nodo, Lq, sh->w_local, sh->anc_local);
+  HIPCHK(hipMemsetAsync(sh->anc_local, 0, (size_t)sh->Nloc * sizeof(double), st));
   // the (t-1) term leaves the suffix sums (:194-201)
   hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, t - 1, t, -1.0,
                      s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
@@ -1405,7 +1395,7 @@ int rbpf_shard_smoother_anc_weights(rbpf_ctx* c) {
   const int t = c->t, N = sh->Nloc, n = c->mdl.n, d = c->mdl.d;
   hipStream_t st = c->stream;
   if (shard_refresh_due(s, t)) { set_error("carried factors: this step refreshes them (rbpf_shard_smoother_refresh_begin / _pack / _end)"); return RBPF_ERR_STATE; }
-  RB_TRY(shard_anc_head(c));
+  RB_TRY(shard_anc_meas_begin(c));
   if (s->refresh > 1) {
     // carried factors: one sweep turns the ancestor's factor -- bank entry or received record -- into this particle's
     if (!s->sw_valid || !sh->placed) { set_error("carried factors: no factor bank for the previous generation"); return RBPF_ERR_STATE; }
@@ -1447,7 +1437,8 @@ int rbpf_shard_smoother_refresh_begin(rbpf_ctx* c, int32_t* owner_now, int32_t* 
   ShardState* sh = c->sh;
   const int t = c->t, nN = c->mdl.nN;
   if (!shard_refresh_due(s, t)) { set_error("no refresh is due at this step"); return RBPF_ERR_STATE; }
-  RB_TRY(shard_anc_head(c));
+  if (sh->t_norm < t) { set_error("a refresh walks the state history: gather + normalise the finished step first"); return RBPF_ERR_STATE; }
+  RB_TRY(shard_anc_meas_begin(c));
   const int t0 = s->base_gen, Kp = t - 1 - t0;
   if (Kp < 1 || Kp > s->refresh) { set_error("internal: refresh window"); return RBPF_ERR_STATE; }
   hipStream_t st = c->stream;
@@ -1525,14 +1516,33 @@ int rbpf_shard_smoother_refresh_end(rbpf_ctx* c, const int32_t* base_index, int3
   return RBPF_OK;
 }
 
-// After the all_gather of anc_local: normalise the global ancestor probabilities (:243-245) and draw ai(N_P) (:248).
-int rbpf_shard_smoother_anc_sample(rbpf_ctx* c) {
+// anc[j] = (log w_j + logwDyn_j) + meas[j] in place over all N logical slots
+__global__ void anc_combine_kernel(int N, const double* __restrict__ dyn, double* __restrict__ anc) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < N) anc[j] = dyn[j] + anc[j];
+}
+
+// After the gather and rbpf_shard_smoother_normalise: the complete ancestor log-weights of all N particles against the
+// reference state of the step about to run (:175-182,232: log w + logwDyn, evaluated replicated from the gathered bank; +
+// the gathered measurement parts), normalised (:243-245), and ai(N_P) drawn (:248).  separate_gather = 0: the measurement parts
+// came with the forward bank (its extra row, already in logical order); 1: they sit in anc_gather (refresh steps: they are
+// computed after the gather of the forward bank and all-gathered on their own).
+int rbpf_shard_smoother_anc_sample(rbpf_ctx* c, int32_t separate_gather) {
   if (!c || !c->sh || !c->sm) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
   ShardState* sh = c->sh;
-  const int t = c->t, k = sh->k_iter, N = sh->Nglob;
+  const int t = c->t, k = sh->k_iter, N = sh->Nglob, nN = c->mdl.nN, nw = c->mdl.nw;
+  if (k < 1 || t < 1 || t >= c->T || sh->t_norm < t) { set_error("ancestor sampling needs k > 0, t > 0 and the normalised weights of step t-1"); return RBPF_ERR_STATE; }
   hipStream_t st = c->stream;
-  HIPCHK(launch_permute_fwd(N, 0, sh->world, sh->Nloc, sh->placed ? sh->cur_gid : nullptr, sh->anc_gather, sh->anc_glob, nullptr, st));
+  if (separate_gather)
+    HIPCHK(launch_permute_fwd(N, 0, sh->world, sh->Nloc, sh->placed ? sh->cur_gid : nullptr, sh->anc_gather, sh->anc_glob, nullptr, st));
+  const double* xref = s->d_xnk + (size_t)t * nN;
+  const double* Lq = c->d_cholQfull + (size_t)((c->chol_pages > 1) ? t - 1 : 0) * nw * nw;
+  hipLaunchKernelGGL(anc_dyn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, c->mdl, N, sh->xn_glob, xref,
+                     c->d_odo + (size_t)(t - 1) * c->mdl.nodo, Lq, sh->w_glob, sh->anc_w);      // anc_w: scratch until the normalisation
+  hipLaunchKernelGGL(anc_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, sh->anc_w, sh->anc_glob);
+  HIPCHK(hipGetLastError());
   RB_TRY(normalise_draw_one(c, N, t, k, sh->anc_glob, sh->anc_w, sh->anc_wc, N - 1,
                             c->d_U ? c->d_U + ((size_t)k * (c->T - 1) + (t - 1)) * N : nullptr, sh->ai_glob, st));
   HIPCHK(hipMemcpyAsync(sh->Ahist + (size_t)t * N + (N - 1), sh->ai_glob + (N - 1), sizeof(int), hipMemcpyDeviceToDevice, st));

@@ -157,7 +157,7 @@ class rbpf_shard_views(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("N_local", C.c_int32), ("N_global", C.c_int32),
                 ("n_nonlin", C.c_int32), ("record_doubles", C.c_size_t), ("recv_capacity", C.c_size_t),
                 ("send_capacity", C.c_size_t), ("fwd_local", _ffi.c_double_p), ("fwd_gather", _ffi.c_double_p),
-                ("send_rec", _ffi.c_double_p), ("recv_rec", _ffi.c_double_p)]
+                ("send_rec", _ffi.c_double_p), ("recv_rec", _ffi.c_double_p), ("fwd_rows", C.c_int32)]
 
 
 class ShardedFilterSession:
@@ -227,7 +227,7 @@ class ShardedFilterSession:
         v = rbpf_shard_views()
         check(self.lib.rbpf_shard_views_get(self.ctx, C.byref(v)))
         self.v = v
-        fwd = (model.nNonLin + 1) * self.N_local
+        fwd = int(v.fwd_rows) * self.N_local          # states, log-weights (+ the smoother's ancestor-weight row)
         self.t_fwd_local = _view(torch, v.fwd_local, (fwd,), self.device)
         self.t_fwd_gather = _view(torch, v.fwd_gather, (self.world * fwd,), self.device)
         coll = self.world > 1 or self.force_collectives
@@ -508,7 +508,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                            ("rbpf_shard_smoother_begin", [C.c_void_p, C.c_int32]),
                            ("rbpf_shard_smoother_normalise", [C.c_void_p, C.c_int32]),
                            ("rbpf_shard_smoother_anc_weights", [C.c_void_p]),
-                           ("rbpf_shard_smoother_anc_sample", [C.c_void_p]),
+                           ("rbpf_shard_smoother_anc_sample", [C.c_void_p, C.c_int32]),
                            ("rbpf_shard_smoother_refresh_begin", [C.c_void_p, _ffi.c_int32_p, _ffi.c_int32_p]),
                            ("rbpf_shard_smoother_refresh_pack", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
                            ("rbpf_shard_smoother_refresh_end", [C.c_void_p, _ffi.c_int32_p, C.c_int32]),
@@ -609,6 +609,14 @@ class ShardedSmootherSession(ShardedFilterSession):
                     check(lib.rbpf_shard_smoother_step(self.ctx))
                     continue
                 diag = self.stream.synchronize if self.sync_phases else (lambda: None)     # device time per phase (diagnostic)
+                K = self.chol_refresh
+                refresh = k > 0 and K > 1 and (t == 1 or (t - 1) % K == 0)
+                ta = time.perf_counter()
+                if k > 0 and not refresh:
+                    # measurement part of the ancestor weights (one factorisation or sweep per particle): local data only, so it
+                    # runs BEFORE the gather, whose extra row carries it along -- one collective per step instead of two
+                    check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
+                    diag()
                 t0 = time.perf_counter()
                 self._gather()
                 t1 = time.perf_counter()
@@ -616,13 +624,10 @@ class ShardedSmootherSession(ShardedFilterSession):
                 diag()
                 t2 = time.perf_counter()
                 if k > 0:
-                    K = self.chol_refresh
-                    if K > 1 and (t == 1 or (t - 1) % K == 0):
+                    if refresh:                      # the refresh walks the state history: after gather + normalise, own all_gather
                         self._refresh()
-                    else:
-                        check(lib.rbpf_shard_smoother_anc_weights(self.ctx))
-                    self._gather_anc()
-                    check(lib.rbpf_shard_smoother_anc_sample(self.ctx))
+                        self._gather_anc()
+                    check(lib.rbpf_shard_smoother_anc_sample(self.ctx, 1 if refresh else 0))
                     diag()
                 t3 = time.perf_counter()
                 cnt = np.zeros(2 * W + 2, dtype=np.int64)
@@ -634,7 +639,7 @@ class ShardedSmootherSession(ShardedFilterSession):
                 check(lib.rbpf_shard_smoother_step(self.ctx))
                 diag()
                 t6 = time.perf_counter()
-                tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["anc"] += t3 - t2; tm["plan"] += t4 - t3
+                tm["gather"] += t1 - t0; tm["normalise"] += t2 - t1; tm["anc"] += (t3 - t2) + (t0 - ta); tm["plan"] += t4 - t3
                 tm["exchange"] += t5 - t4; tm["step"] += t6 - t5
                 self.stats["migrated"] += int(cnt[2 * W])
                 self.stats["steps"] += 1
