@@ -306,6 +306,35 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
             "extrapolated_full_T_seconds": sum(per_step) * T_full, "sharding": st}
 
 
+def smoother_sharded_radio_leg(pkg, mg, datagen, torch, dist, N_local, seed, rank, world, **opts):
+    """BASELINE.json configs[3] as written: slam-dense-radio (m = 128, T = 48, N_K = 3), information-form smoother sharded over the
+    ranks, 8192 particles per GPU (N = 65 536 at 8 GPUs), complete run; max over ranks."""
+    import numpy as np
+    T, N_K, th = 48, 3, [0.25, 2.0, 0.01]
+    Qr = datagen.radio_Q(T, "square_3D")
+    d = datagen.planar_heading(T, Qr, th, 1.0, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = pkg.dense_radio_prior(128, d["LL"], th)
+    sess = mg.ShardedSmootherSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, Qr, R, N_local, N_K, 1.0, rng=pkg.PhiloxRNG(seed),
+                                     rank=rank, world=world, force_collectives=(world == 1), **opts)
+    try:
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        XNK, XLK, PK = sess.run()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        st = {k: v for k, v in sess.stats.items() if k not in ("phase_s", "iter_s")}
+    finally:
+        sess.close()
+    tt = torch.tensor([dt_s], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return {"workload": f"slam-dense-radio particleSmootherInformationForm N_P={N_local * world} ({N_local} per GPU x {world}) m=128 T={T} "
+                        f"N_K={N_K}, complete run" + (f", options {opts}" if opts else ""),
+            "seconds": float(tt.item()), "finite": bool(np.all(np.isfinite(XNK)) and np.all(np.isfinite(PK))), "sharding": st}
+
+
 def smoother_kernel_roofline(pkg):
     """The smoothers' dominant kernel on its own: the batched ancestor-weight factorisation (particleSmoother.m:221-229,
     particleSmootherInformationForm.m:224-236) of 2048 matrices of the m=512 size (n=515), timed with HIP events inside
@@ -556,10 +585,20 @@ def main():
                 return {"error": f"{type(exc).__name__}: {exc}"}
         res = leg(0)                       # the reference's arithmetic (a fresh factorisation per particle and step)
         res_c = leg(32)                    # factors carried along the lineages (tolerance: DESIGN.md 4.3)
+
+        def radio(**o):
+            try:
+                return smoother_sharded_radio_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.seed, rank, world, **o)
+            except Exception as exc:
+                return {"error": f"{type(exc).__name__}: {exc}"}
+        res_r = radio()                    # BASELINE.json configs[3]: dense-radio, 8192 particles per GPU
+        res_rc = radio(lazy_depth=3, chol_refresh=16)
         dog.cancel()
         if rank == 0:
             line["smoother_sharded"] = res
             line["smoother_sharded_carried_factors"] = res_c
+            line["smoother_sharded_radio"] = res_r
+            line["smoother_sharded_radio_carried_factors"] = res_rc
             if "extrapolated_full_T_seconds" in res:
                 line["smoother_wall_clock_extrapolated_s"] = res["extrapolated_full_T_seconds"]
             if "extrapolated_full_T_seconds" in res_c:
