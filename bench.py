@@ -108,14 +108,16 @@ def roofline_of(tm):
                     "roofline fraction: the lazy update elides writes)"}
 
 
-def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage):
-    """One single-GPU filter run: W warm-up steps, K timed steps."""
+def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True):
+    """One single-GPU filter run: W warm-up steps, K timed steps.  keep_history: the state history and the ancestor table
+    (particleFilter.m:117-118,233: xn_traj / traj_sample_iwmax) are written inside the timed steps, so the run could return the
+    reference's full output set."""
     import numpy as np
     Q = q_mag()
     data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=seed)
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, data["LL"], THETA_MAG)
     with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N, 0.01,
-                           rng=pkg.PhiloxRNG(seed), keep_history=False, lazy_depth=lazy_depth, inplace=inplace,
+                           rng=pkg.PhiloxRNG(seed), keep_history=keep_history, lazy_depth=lazy_depth, inplace=inplace,
                            storage=storage) as sess:
         sess.advance(W)
         sess.sync()
@@ -125,9 +127,11 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage):
         sess.sync()
         dt_s = time.perf_counter() - t0
         tm = sess.timing(reset=True)
-        chk = sess.finish(want=("traj_mean",))
+        chk = sess.finish(want=("traj_mean", "traj_sample_iwmax") if keep_history else ("traj_mean",))
     if not np.all(np.isfinite(chk["traj_mean"][:, :W + K])):
         raise RuntimeError("non-finite filter output")
+    if keep_history and not np.all(np.isfinite(chk["traj_sample_iwmax"][:, :W + K])):
+        raise RuntimeError("non-finite back-traced trajectory")
     return {"value": N * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
             "roofline": roofline_of(tm)}, data, model, x0_lin, P0, R
 
@@ -402,7 +406,7 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
-    ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of the sharded smoother leg, seconds")
+    ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of EACH sharded smoother leg, seconds (a leg that does not return ends every rank with exit code 3)")
     args = ap.parse_args()
 
     if args.traffic_child:
@@ -514,7 +518,7 @@ def main():
             "config": {"workload": workload_string(N_total, T, args.m, n, args.storage, args.lazy_depth, world, single_bank),
                        "baseline_config": "BASELINE.json configs[2] (filter part)" if (N_total, T, args.m, args.storage) == (65536, 3000, 512, "fp64") else "custom",
                        "particles_total": N_total, "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
-                       "lazy_depth": args.lazy_depth, "inplace": args.inplace, "storage": args.storage, "filter_seed": args.seed},
+                       "lazy_depth": args.lazy_depth, "inplace": args.inplace, "storage": args.storage, "filter_seed": args.seed, "keep_history": True},
             "roofline": head["roofline"],
         }
         if shard_stats:
@@ -567,33 +571,49 @@ def main():
         # The smoother as the N-GPU job runs it.  Every rank takes part (collectives), so the leg runs under a watchdog: if it
         # does not come back in time, rank 0 prints the line it already has (the filter measurement) and every rank leaves.
         import threading
+        done = {}                          # legs that came back, in order
 
-        def give_up():
+        def give_up(name):
+            # A leg that does not return (a hung collective, or ranks deadlocked because one rank's leg failed while the others
+            # wait in RCCL) must not look like success: rank 0 prints what it has, names the leg, and every rank exits NON-ZERO.
             if rank == 0:
-                line["smoother_sharded"] = {"error": f"no result within {args.smoother_timeout} s"}
+                line.update(done)
+                line["smoother_sharded_timeout"] = {"leg": name, "error": f"no result within {args.smoother_timeout} s"}
                 print(json.dumps(line), flush=True)
             sys.stdout.flush()
-            os._exit(0)
-        dog = threading.Timer(args.smoother_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        def leg(chol_refresh):
+            os._exit(3)
+
+        def timed(name, fn):
+            # one watchdog per leg (four legs share no budget: a slow but healthy run is not cut off by its predecessors)
+            dog = threading.Timer(args.smoother_timeout, give_up, args=(name,))
+            dog.daemon = True
+            dog.start()
             try:
-                return smoother_sharded_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.m, min(args.smoother_steps, T), T, 2,
-                                            args.seed, rank, world, min(args.lazy_depth, 3), chol_refresh)
+                r = fn()
             except Exception as exc:
-                return {"error": f"{type(exc).__name__}: {exc}"}
-        res = leg(0)                       # the reference's arithmetic (a fresh factorisation per particle and step)
-        res_c = leg(32)                    # factors carried along the lineages (tolerance: DESIGN.md 4.3)
+                r = {"error": f"{type(exc).__name__}: {exc}"}
+            dog.cancel()
+            # a leg that failed on one rank only would leave the others waiting in the next collective: agree on it
+            bad = torch.tensor([1 if "error" in r else 0], device=f"cuda:{local_rank}")
+            if dist is not None:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            if int(bad.item()) and "error" not in r:
+                r = {"error": "another rank failed in this leg", "partial": r}
+            done[name] = r
+            return r
+
+        def leg(chol_refresh):
+            return smoother_sharded_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.m, min(args.smoother_steps, T), T, 2,
+                                        args.seed, rank, world, min(args.lazy_depth, 3), chol_refresh)
 
         def radio(**o):
-            try:
-                return smoother_sharded_radio_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.seed, rank, world, **o)
-            except Exception as exc:
-                return {"error": f"{type(exc).__name__}: {exc}"}
-        res_r = radio()                    # BASELINE.json configs[3]: dense-radio, 8192 particles per GPU
-        res_rc = radio(lazy_depth=3, chol_refresh=16)
-        dog.cancel()
+            return smoother_sharded_radio_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.seed, rank, world, **o)
+        # the reference's arithmetic (a fresh factorisation per particle and step), then factors carried along the lineages
+        # (tolerance: DESIGN.md 4.3); BASELINE.json configs[3]: dense-radio, 8192 particles per GPU, both ways
+        res = timed("smoother_sharded", lambda: leg(0))
+        res_c = timed("smoother_sharded_carried_factors", lambda: leg(32))
+        res_r = timed("smoother_sharded_radio", lambda: radio())
+        res_rc = timed("smoother_sharded_radio_carried_factors", lambda: radio(lazy_depth=3, chol_refresh=16))
         if rank == 0:
             line["smoother_sharded"] = res
             line["smoother_sharded_carried_factors"] = res_c

@@ -160,7 +160,7 @@ typedef struct {
   int32_t lazy_depth;    /* filter and information-form smoother: C >= 2 keeps up to C pending rank-n_y downdates on the    *
                           * fly and rewrites the stored covariances every C-th step only (C-1 read-only steps in         *
                           * between); 0/1: rewrite every step.  Results agree to rounding (same algebra).  max 4 (filter) *
-                          * / 3 (information form); ignored by the covariance-form and the sharded smoother             */
+                          * / 3 (information form, also in the sharded smoother); ignored by the covariance-form smoother */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
   int32_t inplace;       /* filter with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
                           * every flush (the first child of a stored matrix overwrites it after its siblings    *
@@ -181,7 +181,12 @@ typedef struct {
                           * solve carried as an augmented row -- and refactorise every K-th step (Imat rebuilt from the state       *
                           * history).  Same algebra, different arithmetic: ancestor probabilities within 2e-9 of the default's      *
                           * (8.8e-10 measured over T = 3000 at nLin = 515; tests/test_gpu_chol_carry.py), not         *
-                          * bit-wise.  nLin <= 575; also in the sharded smoother (rbpf_shard_smoother_refresh_*).                    */
+                          * bit-wise.  nLin <= 575; also in the sharded smoother (rbpf_shard_smoother_refresh_*).                    *
+                          * Failure behaviour differs from the default: the reference retries a failed chol with the jitter       *
+                          * (:228-231); a carried DOWNDATE that loses definiteness cannot be retried in place -- it sets status      *
+                          * bit 2, the particle's ancestor log-weight becomes NaN and the run ends with RBPF_ERR_CHOL_FAILED when   *
+                          * the iteration's flags are checked; a factor obtained at a refresh WITH the jitter retry is carried for    *
+                          * up to K steps.  Use chol_refresh = 0 where near-singular Imat + ImatAddt are expected.                   */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
                           * 0: min(N_local, max(1024, N_local / 8)).  A step that needs more fails on EVERY rank with         *

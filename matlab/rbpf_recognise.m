@@ -98,7 +98,8 @@ function ok = verify(desc, dynModel, measModel, dynResNorm)
       ok = true; return                       % sparse-visual: nLand is fixed by size(y,2) in the wrapper; text + constants suffice
     end
     if desc.kind == 1, nN = 7; nw = 6; nodo = 7; else, nN = 3; nw = 1; nodo = 3; end
-    s0 = rng;                                 % leave the caller's random stream untouched
+    s0 = rng;                                 % leave the caller's random stream untouched -- also when a handle throws on
+    restore = onCleanup(@() rng(s0));         % the probe input (the catch below is reached after randn advanced the stream)
     x = 0.3 * desc.L(1) * randn(nN, 2);
     if desc.kind == 1
       for j = 1:2, x(4:7, j) = x(4:7, j) / norm(x(4:7, j)); end
@@ -120,7 +121,6 @@ function ok = verify(desc, dynModel, measModel, dynResNorm)
       eb = rbpf_mex('dynResNorm', desc, x(:, 1), x(:, 2), dx, dt, Q);
       ok = numel(ea) == numel(eb) && max(abs(ea(:) - eb(:))) <= 1e-10 * max(1, max(abs(ea(:))));
     end
-    rng(s0);
   catch
     ok = false;
   end

@@ -258,7 +258,9 @@ int rbpf_shard_pack(rbpf_ctx* c, const int32_t* idx_host, int32_t count) {
                                c->stream, s->recsz, c->fp32 ? 1 : 0));
   }
   if (s->smoother) RB_TRY(shard_smoother_pack_info(c, idx, count));
-  if (!s->async) HIPCHK(hipStreamSynchronize(c->stream));     // the collective runs on another stream / library
+  // the collective runs on another stream / library; and `idx_host` is caller memory read by an asynchronous copy: a host
+  // plan always synchronises, whatever rbpf_shard_set_async says (only the device-plan path is sync-free)
+  if (!s->async || idx_host) HIPCHK(hipStreamSynchronize(c->stream));
   return RBPF_OK;
 }
 
@@ -362,7 +364,9 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
   HIPCHK(launch_step(a, c->stream));
   if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); ctx_account_launch(c, a); }
-  if (!s->async) HIPCHK(hipStreamSynchronize(c->stream));     // fwd_local feeds the next collective
+  // fwd_local feeds the next collective; host arrays (anc_bank / slot_ids) are caller memory behind asynchronous copies
+  if (!s->async || anc_bank_host || slot_ids_host) HIPCHK(hipStreamSynchronize(c->stream));
+  if (t > 0 && !dev_plan) s->host_planned = true;           // placement unknown to the library from here on (rbpf_shard_finish)
   if (dev_plan) {                                           // commit the placement of the new generation
     s->cur_gid = s->pb.new_gid;
     s->gid_cur ^= 1;
@@ -508,6 +512,13 @@ int rbpf_shard_finish(rbpf_ctx* c, int32_t phase, double* xl_max, double* P_max,
   ShardState* s = c->sh;
   if (s->smoother) { set_error("smoother context: use rbpf_shard_smoother_end"); return RBPF_ERR_STATE; }
   if (c->t < 1 || s->t_norm != c->t) { set_error("finish needs the last finished step gathered and normalised"); return RBPF_ERR_STATE; }
+  if (s->host_planned) {
+    // owner / slot / weight of a logical particle come from the device planner's tables; after a step placed by a HOST plan
+    // (rbpf_shard_step with anc_bank / slot_ids) they are unknown here and an identity guess would silently return the wrong
+    // particles' xl_max / P_max / xl_mean / P_mean
+    set_error("rbpf_shard_finish needs every step placed by the device planner (rbpf_shard_plan); this session took a host plan");
+    return RBPF_ERR_STATE;
+  }
   RB_TRY(ctx_check_flags(c));
   const int n = c->mdl.n, nN = c->mdl.nN, N = s->Nglob, Nloc = s->Nloc, Td = c->t;
   const Layout& L = c->lay;

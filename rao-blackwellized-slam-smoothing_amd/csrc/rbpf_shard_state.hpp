@@ -30,6 +30,7 @@ struct ShardState {
   int gid_cur = 0;
   bool placed = false;             // false until the first planned generation (identity placement)
   bool plan_ready = false;         // a device plan for the next step exists
+  bool host_planned = false;       // some step was placed by a host plan: the device tables no longer locate the particles
   long long* counts_pin = nullptr; // pinned host copy of [send counts | recv counts | migrated]
   int last_send_total = 0;
   // multi-step lazy update: received records persist until the next flush (imported lineages use them as base)

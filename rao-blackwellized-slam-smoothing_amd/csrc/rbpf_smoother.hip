@@ -1339,7 +1339,7 @@ int rbpf_shard_smoother_begin(rbpf_ctx* c, int32_t k) {
   if (k < 0 || k >= c->N_K) { set_error("iteration out of range"); return RBPF_ERR_INVALID_ARG; }
   const int T = c->T, n = c->mdl.n, d = c->mdl.d;
   RB_TRY(ctx_reset(c));
-  sh->t_norm = 0; sh->placed = false; sh->plan_ready = false; sh->gid_cur = 0; sh->cur_gid = nullptr;
+  sh->t_norm = 0; sh->placed = false; sh->plan_ready = false; sh->host_planned = false; sh->gid_cur = 0; sh->cur_gid = nullptr;
   sh->rec_used = 0; sh->plan_recv = 0; sh->k_iter = k;
   std::fill(sh->rec_used_all.begin(), sh->rec_used_all.end(), 0);
   RB_TRY(info_begin_iteration(c, s->h_ivec0.data(), s->hld0, 0.0, 0.0, s->d_Rinv));

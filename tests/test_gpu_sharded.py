@@ -50,6 +50,14 @@ def _worker(rank, world, port, backend, transport, T, m, n_local, q, planner="de
         s.advance(T)
         out = s.finish()
         stats = dict(s.stats)
+        if planner == "host":
+            # the library cannot locate particles placed by a host plan: asking for their maps is an error, never a silent
+            # identity guess
+            try:
+                s.finish(want=("traj_max", "traj_mean", "xl_max", "P_max", "xl_mean"))
+                stats["host_plan_finish"] = "returned"
+            except rbpf.RBPFError as exc:
+                stats["host_plan_finish"] = int(exc.status)
         s.close()
         if rank == 0:
             q.put((out["traj_mean"], out["traj_max"], stats))
@@ -85,6 +93,10 @@ def _run(world, backend, transport, T, m, n_local, planner="device", lazy_depth=
 def test_two_ranks_on_one_gpu_equal_single_gpu(m, n_local, planner):
     T = 9
     tm, tx, stats = _run(2, "gloo", "host", T, m, n_local, planner)
+    if planner == "host":
+        import importlib
+        ffi = importlib.import_module("rao-blackwellized-slam-smoothing_amd._ffi")
+        assert stats["host_plan_finish"] == ffi.RBPF_ERR_STATE
     ref = _single(T, m, 2 * n_local)
     np.testing.assert_array_equal(tm, ref["traj_mean"])          # bit for bit
     np.testing.assert_array_equal(tx, ref["traj_max"])

@@ -209,3 +209,28 @@ def test_ekf_measurement_jacobian_matches_finite_differences(oracle):
         J[:, j] = (oracle.measModel_ekf(m, c["LL"], x + d, q)[0] - oracle.measModel_ekf(m, c["LL"], x - d, q)[0]) / 2e-6
     np.testing.assert_allclose(dy[:, 0:3], J, rtol=1e-6, atol=1e-8 * np.abs(J).max())
     np.testing.assert_allclose(dy[:, 6:] @ x[6:], yh, rtol=1e-12)              # linear in the map states
+
+
+@pytest.mark.parametrize("info_form", [False, True])
+def test_oracle_cpf_as_reproduces_rts_smoother_moments(info_form):
+    """A known answer that pins the restatement of CPF-AS itself (particleSmoother.m:88-366, ...InformationForm.m:98-362), not
+    just its agreement with a second restatement: on the jointly linear-Gaussian toy model of tests/kat_rts.py the oracle's
+    trajectory draws and map posteriors reproduce the Rauch-Tung-Striebel moments (300 iterations, 60 discarded, fixed seeds;
+    means within 4 standard errors at an effective sample size of a quarter of the draws, variances within [0.7, 1.45])."""
+    import kat_rts
+    p = kat_rts.problem()
+
+    class Toy:
+        nNonLin, ny, nw, nLin = 1, 1, 1, 2
+
+        def dynModel(self, xn, dx, dt, Qt, z):
+            return np.asarray(xn).ravel() + np.asarray(dx).ravel() + np.sqrt(dt * Qt[0, 0]) * np.asarray(z).ravel(), None
+
+        def measModel(self, xn):
+            return kat_rts.measModel(xn)
+
+    N_P, N_K = 32, 300
+    f = O.particleSmootherInformationForm if info_form else O.particleSmoother
+    out = f(Toy(), p["odometry"], p["y"], p["x0_nonLin"], p["x0_lin"], p["P0_lin"], p["Q"], p["R"], N_P, N_K, p["dt"],
+            O.ReplayRNG.draw(7, N_K, p["T"], N_P, 1), trace=False, use_dynResNorm=False)
+    kat_rts.check_moments(p, out["XNK"], out["XLK"], out["PK"], burn=60, n_se=4.0, var_lo=0.7, var_hi=1.45)
