@@ -402,7 +402,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=4, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
-    ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
+    ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32", "fp64sym"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")

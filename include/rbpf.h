@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 6
+#define RBPF_ABI_VERSION 7
 
 typedef enum {
   RBPF_OK = 0,
@@ -170,7 +170,14 @@ typedef struct {
   int32_t storage;       /* dense-mag filter (also sharded): 0 = the covariance banks hold fp64 (the reference's precision); 1 = fp32     *
                           * STORAGE of the banks (BASELINE.json configs[4]): half the HBM traffic and memory, all     *
                           * arithmetic and every other state stay fp64.  Results then agree with the fp64 run to     *
-                          * ~1e-6 relative per step (not to 1e-9) and resampling indices may differ.                 */
+                          * ~1e-6 relative per step (not to 1e-9) and resampling indices may differ.                 *
+                          * 2 = fp64, SYMMETRIC storage: particleFilter.m:198 keeps P_i symmetric up to rounding, so only the   *
+                          * lower block triangle (64 x 64 tiles) + the border rows are kept -- 0.5625 n^2 elements at nLin =   *
+                          * 515, i.e. 0.56 x the HBM traffic and memory of storage 0; read-only steps of lazy_depth apply the  *
+                          * pending sets as P H' - KS (K' H') instead of element-wise.  Same algebra: results within 1e-9 of  *
+                          * storage 0 (P(r,c) and P(c,r), which differ by rounding in the reference's plain form, are one     *
+                          * stored value).  Unsharded dense filter with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json        *
+                          * configs[2]); RBPF_ERR_UNSUPPORTED elsewhere.                                                        */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
                           * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 as  *
                           * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
@@ -486,6 +493,10 @@ int rbpf_chol_sweep_probe(int32_t n, int32_t d, int32_t batch, const double* L, 
  *   op 8  mcross                tools/mcross.m:33-42                             in [3 x n]      -> out [3 x 3 x n]
  * q0 > 1 by rounding is clamped before acos (quirk Q7).                                                             */
 int rbpf_quat_helpers(int32_t op, int32_t n, const double* in, double* out);
+/* The wave-level reduction of the symmetric-storage step kernel (rbpf_step_sym.hip: v_permlane32_swap / v_permlane16_swap
+ * folds + DPP row rotations) on its own, for the kernel-level test: in [4][64] (four values per lane of one wave64) -> out [4],
+ * out[v] = sum over the 64 lanes of in[v][.] in the kernel's fixed association order.                                    */
+int rbpf_probe_wave_reduce(const double* in, double* out);
 
 #ifdef __cplusplus
 }

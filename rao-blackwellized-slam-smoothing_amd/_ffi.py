@@ -100,7 +100,7 @@ EXPORTS = [
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
     "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
-    "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_chol_sweep_probe", "rbpf_quat_helpers",
+    "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_chol_sweep_probe", "rbpf_quat_helpers", "rbpf_probe_wave_reduce",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
     "rbpf_shard_trajectories", "rbpf_shard_plan", "rbpf_shard_plan_read", "rbpf_shard_normalise_plan",
     "rbpf_stream_get", "rbpf_shard_set_async", "rbpf_shard_finish", "rbpf_shard_set_ancestors",
@@ -187,8 +187,8 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_chol_sweep_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
                                           c_double_p, c_double_p, c_int32_p, c_double_p]
     lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
-    if lib.rbpf_abi_version() != 6:
-        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 6 (rebuild)")
+    if lib.rbpf_abi_version() != 7:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 7 (rebuild)")
     _lib = lib
     return lib
 

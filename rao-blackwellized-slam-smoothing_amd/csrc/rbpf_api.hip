@@ -224,7 +224,16 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->lay_low = make_layout_low_regs(prob->n_lin, prob->n_y);
   const bool sparse = model->kind == RBPF_MODEL_SPARSE_VISUAL_2D;
   c->fp32 = c->opt.storage == 1;
-  if (c->opt.storage != 0 && c->opt.storage != 1) { set_error("options.storage must be 0 (fp64) or 1 (fp32)"); return RBPF_ERR_INVALID_ARG; }
+  if (c->opt.storage < 0 || c->opt.storage > 2) { set_error("options.storage must be 0 (fp64), 1 (fp32) or 2 (fp64, symmetric)"); return RBPF_ERR_INVALID_ARG; }
+  if (c->opt.storage == 2) {
+    // symmetric storage (lower block triangle, rbpf_step_sym.hip): the unsharded filter of the ny = 3 dense families at the
+    // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
+    if (smoother || sparse || ex || !sym_supported(prob->n_lin, prob->n_y)) {
+      set_error("symmetric storage (options.storage = 2): unsharded dense filter with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
+    }
+    c->lay = make_layout_sym(prob->n_lin, prob->n_y);
+    c->lay_low = c->lay;
+  }
   if (c->fp32 && (smoother || sparse || prob->n_y != 3)) {
     set_error("fp32 storage of the covariance banks: dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
   }
@@ -357,7 +366,8 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
-    if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    if (L.sym && step_sym_lds_bytes(c->mdl, c->lay, c->lazy_depth, 1) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
     for (int b = 0; b <= c->lazy_depth; ++b) {            // entry N of every bank stays zero (fresh lineages)
       RB_TRY(dmalloc(&c->Fb[b], (size_t)(N + 1) * 2 * d * L.ldx));
       HIPCHK(hipMemsetAsync(c->Fb[b], 0, (size_t)(N + 1) * 2 * d * L.ldx * sizeof(double), c->stream));
@@ -511,7 +521,9 @@ int generic_finish_inputs(rbpf_ctx* c, const double* xref_host) {
 // and out (+ ivec in / out and H out for the information form).
 void ctx_account_launch(rbpf_ctx* c, const StepArgs& a) {
   const double sP = c->fp32 ? 4.0 : 8.0, nn = (double)c->mdl.n, d = (double)c->mdl.d, nN = (double)c->mdl.nN;
-  const double per = nn * nn * sP * ((a.t > 0 ? 1.0 : 0.0) + (a.write_base ? 1.0 : 0.0))
+  // stored elements of one covariance: n^2, or the lower block triangle + border rows of the symmetric layout
+  const double stored = c->lay.sym ? (double)(c->lay.szT + c->lay.szB) : nn * nn;
+  const double per = stored * sP * ((a.t > 0 ? 1.0 : 0.0) + (a.write_base ? 1.0 : 0.0))
                    + 8.0 * (2.0 * nn * d * (a.n_sets + 1) + 2.0 * nn + 2.0 * nN + (a.info ? 2.0 * nn + d * nn : 0.0));
   c->sched_bytes += per * (double)a.N;
 }
@@ -860,7 +872,7 @@ int rbpf_device_count(void) {
 
 int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, const rbpf_options* opt, size_t* bytes) {
   if (!model || !p || !bytes) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
-  const Layout L = make_layout(p->n_lin, p->n_y);
+  const Layout L = (opt && opt->storage == 2 && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y) : make_layout(p->n_lin, p->n_y);
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;
   size_t b = 2 * bank_bytes(L, p->n_y, p->N_P);
@@ -1296,6 +1308,18 @@ int rbpf_quat_helpers(int32_t op, int32_t n, const double* in, double* out) {
   HIPCHK(launch_quat_helpers(op, n, di.as<double>(), dout.as<double>(), 0));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, dout.p, (size_t)n * nout_of[op] * 8, hipMemcpyDeviceToHost));
+  return RBPF_OK;
+}
+
+int rbpf_probe_wave_reduce(const double* in, double* out) {
+  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
+  if (!in || !out) { set_error("bad argument"); return RBPF_ERR_INVALID_ARG; }
+  DevBuf di, dout;
+  RB_TRY(di.alloc(256 * 8)); RB_TRY(dout.alloc(4 * 8));
+  HIPCHK(hipMemcpy(di.p, in, 256 * 8, hipMemcpyHostToDevice));
+  HIPCHK(launch_probe_wave_reduce(di.as<double>(), dout.as<double>(), 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, dout.p, 4 * 8, hipMemcpyDeviceToHost));
   return RBPF_OK;
 }
 

@@ -46,12 +46,30 @@ struct ModelDev {
 //   border rows  r in [0, nb)  -> block B, row-major  B[r*ldb + c],          c in [0,n)
 //   core rows    r in [nb, n)  -> block T, column-major T[c*mc + (r - nb)],  c in [0,n)
 // with mc = 128*floor(n/128), nb = n - mc, ldb = n rounded up to even.
+//
+// Symmetric storage (rbpf_options.storage = 2, `sym` != 0): the covariance is symmetric (particleFilter.m:198 keeps it so up to
+// rounding), so block T holds only the lower block triangle of the core x core part, in 64 x 64 tiles (I >= J) of 32 column pairs:
+//   element (r, c), core coordinates, tile (I, J) = (r / 64, c / 64):  T[(I (I + 1) / 2 + J) * 4096 + ((c % 64) / 2) * 128 + (r % 64) * 2 + c % 2]
+// i.e. one wave-wide 16-byte-per-lane load brings rows 64 I .. 64 I + 63 of the two columns of a pair.  Diagonal tiles are stored
+// in full (both triangles).  The border rows stay in block B as above (they hold the border columns too, by symmetry), so the
+// core rows x border columns part of T disappears.  0.5625 n^2 elements at nLin = 515 instead of n^2.
+constexpr int kSymChunk = 64;                         // rows / columns of a tile
+constexpr int kSymTile = kSymChunk * kSymChunk;       // elements of a tile
 struct Layout {
   int n, nb, mc, ldb, ldx;   // ldx: padded length of per-particle vectors (xl, K, KS)
   int CH;                    // mc / 128
   int RS, CS, CPL;           // wave decomposition of the core stream (rows x column phases)
+  int sym, CH64;             // symmetric storage: mc / 64 tile rows
   size_t szT, szB;           // elements per particle
 };
+
+// offset of core element (r, c) (core coordinates, r, c in [0, mc)) inside block T of the symmetric layout; (r, c) above the
+// block diagonal is read from its mirror image
+__host__ __device__ inline size_t sym_t_index(int r, int c) {
+  int I = r / kSymChunk, J = c / kSymChunk;
+  if (J > I) { const int t = r; r = c; c = t; I = r / kSymChunk; J = c / kSymChunk; }
+  return ((size_t)I * (I + 1) / 2 + J) * kSymTile + (size_t)((c % kSymChunk) / 2) * (2 * kSymChunk) + (size_t)(r % kSymChunk) * 2 + (c & 1);
+}
 
 struct StepArgs {
   ModelDev mdl;
@@ -149,6 +167,12 @@ size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0, int n
 bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets);
 Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
+Layout make_layout_sym(int n, int d);            // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
+bool sym_supported(int n, int d);
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base);
+hipError_t launch_step_sym(const StepArgs& a, hipStream_t s);
+// wave-level reduction primitives of the symmetric step kernel on their own (tests): in [4][64] -> out [4] lane sums
+hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s);
 
 // dynModel for all slots (must run before launch_step of the same StepArgs)
 hipError_t launch_propagate(const StepArgs& a, hipStream_t s);

@@ -16,6 +16,7 @@
 // SURVEY 8(d).  The kernel is HBM-bound (12 flop per 16 B).
 #include "rbpf_internal.hpp"
 #include "rbpf_device.hpp"
+#include "rbpf_model_dev.hpp"
 
 #include <cstdlib>
 
@@ -179,67 +180,11 @@ Layout make_layout(int n, int d) {
     if (rs >= 1 && cs >= 1 && rs * cs <= kWaves && L.CH > 0) { L.RS = rs; L.CS = cs; }
   }
   L.CPL = L.CH / L.RS;      // full rounds; the remaining CH % RS chunks go to the first waves
+  L.sym = 0; L.CH64 = L.mc / kSymChunk;
   L.szT = (size_t)n * L.mc;
   L.szB = (size_t)L.nb * L.ldb;
   (void)d;
   return L;
-}
-
-// ---------------------------------------------------------------------------------------------
-// basis / measurement model pieces shared by the step kernel and the standalone test kernels
-// ---------------------------------------------------------------------------------------------
-// sin / cos of pi*k*(x_a+L_a)/(2 L_a) for k = 1..kmax[a]  (tools/domain_cartesian_dx.m:91,154)
-__device__ inline void basis_table_entry(const ModelDev& M, int q, const double* pos, double* tabS, double* tabC) {
-  int a = 0, k = q;
-  if (k >= M.kmax[0]) { k -= M.kmax[0]; a = 1; if (k >= M.kmax[1]) { k -= M.kmax[1]; a = 2; } }
-  const double La = M.L[a];
-  const double arg = RBPF_PI * (double)(k + 1) * (pos[a] + La) / (2.0 * La);
-  double s, c;
-  sincos(arg, &s, &c);
-  tabS[q] = s;
-  tabC[q] = c;
-}
-
-// Column c of H_i (ny x nLin).
-//   dense-mag   : Rnb' * [e_c] for c<3, Rnb' * [dphi_x; dphi_y; dphi_z](j=c-3) otherwise
-//                 (examples/slam-dense-mag/run_dense3D_magfield.m:267-277,
-//                  tools/domain_cartesian_dx.m:146-170 evaluation order kept)
-//   dense-radio : phi_c(x,y) (run_dense2D_withHeading.m:168, domain_cartesian_dx.m:88-93)
-template <int D>
-__device__ inline void H_column(const ModelDev& M, int c, const double* tabS, const double* tabC, const double* Rm,
-                                double* h) {
-  if (M.kind == 1) {
-    double g[3];
-    if (c < 3) {
-      g[0] = (c == 0); g[1] = (c == 1); g[2] = (c == 2);
-    } else {
-      const int j = c - 3;
-      int base[3] = {0, M.kmax[0], M.kmax[0] + M.kmax[1]};
-      int nn[3];
-      for (int a = 0; a < 3; ++a) nn[a] = M.NN[a * M.m + j];
-      for (int di = 0; di < 3; ++di) {
-        double v = 1.0;
-        for (int a = 0; a < 3; ++a) {
-          const double La = M.L[a];
-          const int q = base[a] + nn[a] - 1;
-          if (a == di) v = v * RBPF_PI * (double)nn[a] / (2.0 * La * sqrt(La)) * tabC[q];
-          else v = v * 1.0 / sqrt(La) * tabS[q];
-        }
-        g[di] = v;
-      }
-    }
-    // (Rnb' * g)_k = sum_a Rnb(a,k) g_a
-    for (int k = 0; k < D; ++k) h[k] = Rm[0 * 3 + k] * g[0] + Rm[1 * 3 + k] * g[1] + Rm[2 * 3 + k] * g[2];
-  } else {
-    double v = 1.0;
-    int base[2] = {0, M.kmax[0]};
-    for (int a = 0; a < 2; ++a) {
-      const int nn = M.NN[a * M.m + c];
-      v = v * 1.0 / sqrt(M.L[a]) * tabS[base[a] + nn - 1];
-    }
-    h[0] = v;
-    for (int k = 1; k < D; ++k) h[k] = 0.0;
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -980,6 +925,7 @@ static hipError_t launch_step_lazy(const StepArgs& a, hipStream_t s) {
 hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   const int D = a.mdl.d;
   if (a.n_sets < 0 || a.n_sets > kMaxSets) return hipErrorInvalidValue;
+  if (a.lay.sym) return launch_step_sym(a, s);             // symmetric storage: rbpf_step_sym.hip
   const bool legacy = a.write_base && a.n_sets <= 1;       // one pending set, rewritten every step
   if (a.fp32) {
     // fp32 storage of the covariance banks: filter only (E = 0), dense-mag outputs (D = 3)
@@ -1498,7 +1444,8 @@ __global__ void pack_P_kernel(Layout L, const double* __restrict__ P, size_t src
     const int r = (int)(q % L.n), c = (int)(q / L.n);
     const double v = src[q];
     if (r < L.nb) b[(size_t)r * L.ldb + c] = (TS)v;
-    else t[(size_t)c * L.mc + (r - L.nb)] = (TS)v;
+    else if (!L.sym) t[(size_t)c * L.mc + (r - L.nb)] = (TS)v;
+    else if (c >= L.nb && (r - L.nb) / kSymChunk >= (c - L.nb) / kSymChunk) t[sym_t_index(r - L.nb, c - L.nb)] = (TS)v;   // lower block triangle
   }
   // zero the pad column of the border block
   if (L.ldb > L.n)
@@ -1539,7 +1486,10 @@ __global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const TS
     F[sset] = sset < us.n_sets ? us.fset[sset] + (size_t)(us.fidx[sset] ? us.fidx[sset][src] : src) * 2 * d * L.ldx : nullptr;
   for (int r = threadIdx.x; r < L.n; r += 256) {
     for (int c = c0; c < c1; ++c) {
-      double v = (r < L.nb) ? (double)b[(size_t)r * L.ldb + c] : (double)t[(size_t)c * L.mc + (r - L.nb)];
+      double v;
+      if (r < L.nb) v = (double)b[(size_t)r * L.ldb + c];
+      else if (!L.sym) v = (double)t[(size_t)c * L.mc + (r - L.nb)];
+      else v = (c < L.nb) ? (double)b[(size_t)c * L.ldb + r] : (double)t[sym_t_index(r - L.nb, c - L.nb)];   // mirror image where not stored
       for (int sset = 0; sset < us.n_sets; ++sset)
         for (int k = 0; k < d; ++k) v = fma(-F[sset][(size_t)k * L.ldx + r], F[sset][(size_t)(d + k) * L.ldx + c], v);
       dst[(size_t)c * L.n + r] = v;

@@ -1,0 +1,565 @@
+// The filter's step kernel on SYMMETRIC covariance storage (rbpf_options.storage = 2), gfx950.
+//
+// particleFilter.m:198 `P = P - K*SS*K'` keeps every P_i symmetric up to rounding, and the step kernel of rbpf_kernels.hip sits
+// on the HBM roofline, so the only lever left on a particle-step is the number of bytes: here the stored matrix is the lower
+// block triangle in 64 x 64 tiles (Layout::sym, 0.5625 n^2 elements at nLin = 515).  The same fused chain as step_kernel
+// (resample-gather -> measModel -> importance weight -> Kalman update, particleFilter.m:100-204) with two differences:
+//
+// * Every stored off-diagonal tile T(I,J), I > J, contributes twice to P*H':  rows of block I get T*H_J' (lanes own rows, no
+//   reduction, as before) and rows of block J get T'*H_I' -- a sum over the tile's ROWS, i.e. over lanes.  A wave owns the tile
+//   rows {w, 7-w} (9 tiles each: balanced), accumulates per lane the products of its (up to two) rows for a pair of columns,
+//   and reduces the six sums of a column pair across the wave in registers: v_permlane32_swap / v_permlane16_swap fold four
+//   values into one register (two adds each halve the lanes), DPP row rotations finish the 16-lane rows.  Each wave keeps its
+//   column contributions in its own LDS strip (fixed summation order -> bit-reproducible), combined after the stream by the
+//   lane that owns the row.
+// * Read-only steps of the multi-step lazy update do not touch the pending factor sets per element:
+//   (P - sum_s KS_s K_s') H' = P H' - sum_s KS_s (K_s' H'), and K_s' H' is d x d -- an O(n d^2) epilogue instead of n^2 d
+//   multiply-adds in the stream (same algebra, agreement to rounding as for lazy_depth itself).  A flush applies the sets
+//   element-wise as before (it has to write P+), with the column factors of the current 64 columns in a wave-private LDS stage.
+//
+// Supported: dense families with ny = 3, fp64, 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]), filter.
+#include "rbpf_internal.hpp"
+#include "rbpf_device.hpp"
+#include "rbpf_model_dev.hpp"
+
+namespace rbpf {
+
+typedef double dbl2s __attribute__((ext_vector_type(2)));
+
+constexpr int kSymRows = 2;            // tile rows per wave (CH64 = 8: rows w and 7 - w)
+constexpr int kSymCH = 8;              // tile rows of the supported layout
+
+bool sym_supported(int n, int d) {
+  const int mc = (n / kChunkRows) * kChunkRows;
+  return d == 3 && mc / kSymChunk == kSymCH;
+}
+
+Layout make_layout_sym(int n, int d) {
+  Layout L = make_layout(n, d);
+  L.sym = 1;
+  L.CH64 = L.mc / kSymChunk;
+  L.szT = (size_t)L.CH64 * (L.CH64 + 1) / 2 * kSymTile;
+  return L;
+}
+
+// LDS plan (doubles).  Column strips: wave w > 0 keeps its column contributions for core columns [0, 64 (7 - w)); wave 0's
+// go straight into PHt.
+struct SymPlan { int off_H, off_xl, off_PHt, off_col1, off_tab, off_misc, off_red, off_kst, total; };
+// strip of wave w (w >= 1): D x ld_col(w) doubles at off_col1 + D * 64 * sum_{v=1}^{w-1} (7 - v)   (closed forms: no indexed
+// arrays, which would live in scratch memory)
+__host__ __device__ inline int sym_ld_col(int w) { return kSymChunk * (kSymCH - 1 - w); }
+__host__ __device__ inline int sym_off_col(int off_col1, int D, int w) { return off_col1 + D * kSymChunk * ((w - 1) * (kSymCH - 1) - (w - 1) * w / 2); }
+
+__host__ __device__ inline int sym_even(int x) { return (x + 1) & ~1; }
+
+__host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage) {
+  SymPlan p;
+  int o = 0;
+  p.off_H = o;   o += sym_even(n * D + 2);           // + pad so that the first core column pair is 16-byte aligned
+  p.off_xl = o;  o += ldx;
+  p.off_PHt = o; o += D * ldx;
+  p.off_col1 = o;
+  for (int w = 1; w < kWaves; ++w) o += D * sym_ld_col(w);
+  p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
+  p.off_misc = o; o += 64;
+  p.off_red = o;  o += kWaves * 48;
+  p.off_kst = o;  o += kWaves * kSymChunk * nd_stage;
+  p.total = o;
+  return p;
+}
+
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base) {
+  return (size_t)sym_plan(lay.n, m.d, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0).total * sizeof(double);
+}
+
+// ---- wave-level reduction primitives ---------------------------------------------------------------------------------------
+// lanes 0..31: a[l] + a[l + 32]; lanes 32..63: b[l - 32] + b[l]   (v_permlane32_swap: upper half of the first operand <-> lower
+// half of the second)
+__device__ __forceinline__ double fold32(double a, double b) {
+  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// rows of 16 lanes: [a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3]   (v_permlane16_swap: odd rows of the first operand <->
+// even rows of the second)
+__device__ __forceinline__ double fold16(double a, double b) {
+  const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// every lane of a 16-lane row gets the row's sum (rotations by 8, 4, 2, 1: a fixed order)
+__device__ __forceinline__ double row16_sum(double x) {
+  x += dpp_mov<0x128>(x);      // row_ror:8
+  x += dpp_mov<0x124>(x);      // row_ror:4
+  x += dpp_mov<0x122>(x);      // row_ror:2
+  x += dpp_mov<0x121>(x);      // row_ror:1
+  return x;
+}
+// Sums of four per-lane values over the 64 lanes.  Afterwards every lane of row rho (= lane / 16) holds the total of
+// x[(rho & 1) * 2 + (rho >> 1)]:  rows 0..3 <-> x0, x2, x1, x3.
+__device__ __forceinline__ double wave_sum4(double x0, double x1, double x2, double x3) {
+  return row16_sum(fold16(fold32(x0, x1), fold32(x2, x3)));
+}
+
+__global__ void probe_wave_reduce_kernel(const double* __restrict__ in, double* __restrict__ out) {
+  const int lane = threadIdx.x;
+  const double r = wave_sum4(in[lane], in[64 + lane], in[128 + lane], in[192 + lane]);
+  if ((lane & 15) == 0) { const int rho = lane >> 4; out[(rho & 1) * 2 + (rho >> 1)] = r; }
+}
+
+hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(probe_wave_reduce_kernel, dim3(1), dim3(64), 0, s, in, out);
+  return hipGetLastError();
+}
+
+// ---- one block column (64 columns = 32 pairs) of a wave's tiles ---------------------------------------------------------------
+// NACT active tile rows (the last NACT of the wave's rows); DIAG: the first active row's tile is the diagonal tile (row
+// contribution only).  src / dst: the tiles' base + 2 * lane.  Hc: H of the block's first column ([col][D], 16-byte aligned),
+// kst: the wave's stage of column factors [pair][ND][2] (flush only), colp: the wave's strip at the block's first column.
+template <int D, int NS, bool WR, int NACT, bool DIAG>
+__device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], double* const (&dst)[kSymRows],
+                                          const double* __restrict__ Hc, const double* __restrict__ kst,
+                                          const double (&ks)[kSymRows][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][D],
+                                          double (&accr)[kSymRows][D], double* __restrict__ colp, int ldc, int lane) {
+  constexpr int ND = NS * D, Q0 = kSymRows - NACT;
+  constexpr int UP = 8 / NACT;                          // column pairs per round: 8 wave-wide 1 KB loads in flight
+  constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
+  constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
+  for (int p0 = 0; p0 < kSymChunk / 2; p0 += UP) {
+    dbl2s v[UP][NACT];
+#pragma unroll
+    for (int u = 0; u < UP; ++u)
+#pragma unroll
+      for (int q = 0; q < NACT; ++q) v[u][q] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(p0 + u) * (2 * kSymChunk));
+#pragma unroll
+    for (int hh = 0; hh < UP / PB; ++hh) {
+      double pc[PB][2][D];
+#pragma unroll
+      for (int uu = 0; uu < PB; ++uu) {
+        const int u = hh * PB + uu, p = p0 + u;
+        double h0[D], h1[D];
+        {
+          // the pair's 2 * D values of H sit contiguously
+          double hb[2 * D + 2];
+#pragma unroll
+          for (int k2 = 0; k2 < (2 * D + 1) / 2; ++k2) {
+            const dbl2s t = *reinterpret_cast<const dbl2s*>(Hc + (size_t)p * 2 * D + 2 * k2);
+            hb[2 * k2] = t.x; hb[2 * k2 + 1] = t.y;
+          }
+#pragma unroll
+          for (int k = 0; k < D; ++k) { h0[k] = hb[k]; h1[k] = hb[D + k]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int k = 0; k < D; ++k) pc[uu][e][k] = 0.0;
+        double kc0[ND > 0 ? ND : 1], kc1[ND > 0 ? ND : 1];
+        if (WR) {
+#pragma unroll
+          for (int k = 0; k < ND; ++k) {
+            const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)p * ND + k) * 2);
+            kc0[k] = t.x; kc1[k] = t.y;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) {
+          double p0v = v[u][q].x, p1v = v[u][q].y;
+          if (WR) {
+#pragma unroll
+            for (int k = 0; k < ND; ++k) { p0v = fma(-ks[Q0 + q][k], kc0[k], p0v); p1v = fma(-ks[Q0 + q][k], kc1[k], p1v); }
+            dbl2s o; o.x = p0v; o.y = p1v;
+            __builtin_nontemporal_store(o, reinterpret_cast<dbl2s*>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk)));
+          }
+#pragma unroll
+          for (int k = 0; k < D; ++k) accr[Q0 + q][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][k]));
+          if (!(DIAG && q == 0)) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) { pc[uu][0][k] = fma(p0v, hown[Q0 + q][k], pc[uu][0][k]); pc[uu][1][k] = fma(p1v, hown[Q0 + q][k], pc[uu][1][k]); }
+          }
+        }
+      }
+      if (kCol) {
+        // four values per register: columns 2p, 2p+1, 2p+2, 2p+3 of one output k; row rho of the wave ends up with column
+        // offset (rho & 1) * 2 + (rho >> 1)
+        const int rho = lane >> 4, coff = (rho & 1) * 2 + (rho >> 1);
+#pragma unroll
+        for (int g = 0; g < PB / 2; ++g)
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            const double r = wave_sum4(pc[2 * g][0][k], pc[2 * g][1][k], pc[2 * g + 1][0][k], pc[2 * g + 1][1][k]);
+            if ((lane & 15) == 0) colp[(size_t)k * ldc + 2 * (p0 + hh * PB + 2 * g) + coff] = r;
+          }
+      }
+    }
+  }
+}
+
+template <int D, int NS, bool WR>
+__global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a) {
+  extern __shared__ double smem[];
+  constexpr int ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
+  const ModelDev& M = a.mdl;
+  const Layout& Ly = a.lay;
+  const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
+  const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
+  if (WR && a.phase >= 0 && pre_i[9] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
+  const int i = pre_i[0];
+  const int dslot = WR ? pre_i[8] : i;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const SymPlan lp = sym_plan(n, D, ldx, M.ktot, WR ? ND : 0);
+  double* Hs = smem + lp.off_H + ((nb * D) & 1);              // H column c at Hs[c * D ..): core pairs 16-byte aligned
+  double* xls = smem + lp.off_xl;
+  double* PHt = smem + lp.off_PHt;                            // [D][ldx]
+  double* tabS = smem + lp.off_tab;
+  double* tabC = tabS + (M.ktot > 0 ? M.ktot : 1);
+  double* misc = smem + lp.off_misc;
+  double* red = smem + lp.off_red;
+  const int ancb = pre_i[2], baseb = pre_i[3];
+  const double* srcT = a.Pt_old + (size_t)baseb * a.Pt_old_stride;
+  const double* srcB = a.Pb_old + (size_t)baseb * a.Pb_old_stride;
+  const double* srcX = a.xl_old + (size_t)ancb * a.xl_old_stride;
+  const double* Fs[NSA];
+#pragma unroll
+  for (int s = 0; s < NSA; ++s) Fs[s] = nullptr;
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    Fs[s] = a.fset[s] ? a.fset[s] + (size_t)pre_i[4 + s] * 2 * D * ldx : a.F_old + (size_t)ancb * 2 * D * ldx;
+
+  // ---- A: propagated state (propagate_kernel ran first), prior mean ----
+  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];
+  for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
+  __syncthreads();
+  // ---- B: per-axis sin / cos tables ----
+  for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
+  __syncthreads();
+  // ---- C: measurement Jacobian, one column per thread ----
+  for (int c = tid; c < n; c += kThreads) {
+    double h[D];
+    if (a.H_ext != nullptr) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) h[k] = a.H_ext[((size_t)i * D + k) * ldx + c];
+    } else {
+      H_column<D>(M, c, tabS, tabC, &misc[8], h);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) Hs[c * D + k] = h[k];
+  }
+  __syncthreads();
+
+  // ---- D: stream the stored tiles once ----
+  const int rows[kSymRows] = {wave, kSymCH - 1 - wave};       // ascending
+  double accr[kSymRows][D], hown[kSymRows][D], ks[kSymRows][NDA];
+#pragma unroll
+  for (int q = 0; q < kSymRows; ++q) {
+    const int r = nb + rows[q] * kSymChunk + lane;
+#pragma unroll
+    for (int k = 0; k < D; ++k) { accr[q][k] = 0.0; hown[q][k] = Hs[r * D + k]; }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) ks[q][s * D + k] = WR ? Fs[s][(size_t)k * ldx + r] : 0.0;
+  }
+  {
+    double* dT = a.Pt_new + (size_t)dslot * Ly.szT;
+    double* kst = smem + lp.off_kst + (size_t)wave * kSymChunk * ND;
+    double* colw = (wave == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, D, wave);
+    const int ldc = (wave == 0) ? ldx : sym_ld_col(wave);
+    const double* Hcore = Hs + (size_t)nb * D;
+    // column factors of block column J for the flush: lane = column, stage entry [pair][k][e]
+    double kpre[NDA];
+    auto fetch = [&](int J) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < D; ++k) kpre[s * D + k] = Fs[s][(size_t)(D + k) * ldx + nb + J * kSymChunk + lane];
+    };
+    auto park = [&]() {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) kst[((size_t)(lane >> 1) * ND + k) * 2 + (lane & 1)] = kpre[k];
+    };
+    const int last = rows[kSymRows - 1];
+    for (int J = 0; J <= last; ++J) {
+      // (a register prefetch of block J + 1 during block J costs 2 * ND registers across the whole stream loop and pushes the
+      // four-set flush into scratch; the fetch latency is paid once per 64 columns and hidden by the other seven waves of the CU)
+      if (WR && ND > 0) { fetch(J); park(); }
+      const double* src[kSymRows]; double* dst[kSymRows];
+#pragma unroll
+      for (int q = 0; q < kSymRows; ++q) {
+        const size_t off = ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * lane;
+        src[q] = srcT + off; dst[q] = dT + off;
+      }
+      const double* Hc = Hcore + (size_t)J * kSymChunk * D;
+      double* colp = colw + (size_t)J * kSymChunk;
+      if (J < rows[0]) sym_block<D, NS, WR, 2, false>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
+      else if (J == rows[0]) sym_block<D, NS, WR, 2, true>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
+      else if (J < last) sym_block<D, NS, WR, 1, false>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
+      else sym_block<D, NS, WR, 1, true>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
+    }
+  }
+  // border rows (row-major block B, all n columns): lanes walk columns, wave-reduce per row (as in step_kernel)
+  for (int b = wave; b < nb; b += kWaves) {
+    const double* src = srcB + (size_t)b * ldb;
+    double* dstb = a.Pb_new + (size_t)dslot * Ly.szB + (size_t)b * ldb;
+    double ksb[NDA];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int k = 0; k < D; ++k) ksb[s * D + k] = WR ? Fs[s][(size_t)k * ldx + b] : 0.0;
+    double accb[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) accb[k] = 0.0;
+    for (int c = 2 * lane; c < ldb; c += 128) {
+      const dbl2s vv = *reinterpret_cast<const dbl2s*>(src + c);
+      double p[2] = {vv.x, vv.y};
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int cc = c + e;
+        if (cc < n) {
+          if (WR) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+              for (int k = 0; k < D; ++k) p[e] = fma(-ksb[s * D + k], Fs[s][(size_t)(D + k) * ldx + cc], p[e]);
+          }
+#pragma unroll
+          for (int k = 0; k < D; ++k) accb[k] = fma(p[e], Hs[cc * D + k], accb[k]);
+        }
+      }
+      if (WR) { dbl2s o; o.x = p[0]; o.y = p[1]; *reinterpret_cast<dbl2s*>(dstb + c) = o; }
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double s = wave_sum(accb[k]);
+      if (lane == 0) PHt[(size_t)k * ldx + b] = s;
+    }
+  }
+  __syncthreads();
+  // combine, by the lane that owns the row: row part (registers) + the waves' column parts in wave order + the border columns
+  // P(r, b) = B(b, r) (downdated like the border phase did when this is a flush)
+#pragma unroll
+  for (int q = 0; q < kSymRows; ++q) {
+    const int rc = rows[q] * kSymChunk + lane;                // core coordinate
+    double s[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k] = accr[q][k];
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      if (rows[q] < kSymCH - 1 - w) {                         // wave w holds off-diagonal tiles in this block column
+        const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, D, w);
+        const int ldw = (w == 0) ? ldx : sym_ld_col(w);
+#pragma unroll
+        for (int k = 0; k < D; ++k) s[k] += cw[(size_t)k * ldw + rc];
+      }
+    }
+    for (int b = 0; b < nb; ++b) {
+      double pv = srcB[(size_t)b * ldb + nb + rc];
+      if (WR) {
+#pragma unroll
+        for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+          for (int k = 0; k < D; ++k) pv = fma(-Fs[sset][(size_t)k * ldx + b], Fs[sset][(size_t)(D + k) * ldx + nb + rc], pv);
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) s[k] = fma(pv, Hs[b * D + k], s[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
+  }
+  __syncthreads();
+  if (!WR && NS > 0) {
+    // read-only step: PHt holds P_base * H'; subtract sum_s KS_s * (K_s' * H')
+    constexpr int NG = NS * D * D > 0 ? NS * D * D : 1;
+    double g[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) g[q] = 0.0;
+    for (int c = tid; c < n; c += kThreads) {
+      double h[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) h[k] = Hs[c * D + k];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double kv = Fs[s][(size_t)(D + k) * ldx + c];
+#pragma unroll
+          for (int j = 0; j < D; ++j) g[(s * D + k) * D + j] = fma(kv, h[j], g[(s * D + k) * D + j]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      const double s = wave_sum(g[q]);
+      if (lane == 0) red[wave * 48 + q] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      double s = red[q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + q];
+      g[q] = s;
+    }
+    for (int r = tid; r < n; r += kThreads) {
+      double ph[D];
+#pragma unroll
+      for (int j = 0; j < D; ++j) ph[j] = PHt[(size_t)j * ldx + r];
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const double ksv = Fs[s][(size_t)k * ldx + r];
+#pragma unroll
+          for (int j = 0; j < D; ++j) ph[j] = fma(-ksv, g[(s * D + k) * D + j], ph[j]);
+        }
+#pragma unroll
+      for (int j = 0; j < D; ++j) PHt[(size_t)j * ldx + r] = ph[j];
+    }
+    __syncthreads();
+  }
+
+  // ---- E: S = H (P H') + R, e = y - H xl   (particleFilter.m:139-150) ----
+  constexpr int NRED = D * D + D;
+  {
+    double part[NRED];
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) part[q] = 0.0;
+    for (int r = tid; r < n; r += kThreads) {
+      double h[D], ph[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) { h[k] = Hs[r * D + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
+      const double x = xls[r];
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb)
+#pragma unroll
+        for (int aa = 0; aa < D; ++aa) part[aa + D * bb] = fma(h[aa], ph[bb], part[aa + D * bb]);
+#pragma unroll
+      for (int aa = 0; aa < D; ++aa) part[D * D + aa] = fma(h[aa], x, part[D * D + aa]);
+    }
+#pragma unroll
+    for (int q = 0; q < NRED; ++q) {
+      const double s = wave_sum(part[q]);
+      if (lane == 0) red[wave * 48 + q] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double SS[D * D], e[D], cS[D * D], v[D];
+    for (int q = 0; q < D * D; ++q) {
+      double s = red[q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + q];
+      SS[q] = s + M.R[q];                                                   // particleFilter.m:141
+    }
+    for (int q = 0; q < D; ++q) {
+      double s = red[D * D + q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + D * D + q];
+      e[q] = a.y[q] - s;                                                    // :140
+    }
+    bool ok = chol_lower_small<D>(SS, cS);                                  // :145
+    if (!ok) {
+      double SJ[D * D];
+      for (int q = 0; q < D * D; ++q) SJ[q] = SS[q];
+      for (int q = 0; q < D; ++q) SJ[q + D * q] += M.jitter;                // :147
+      ok = chol_lower_small<D>(SJ, cS);
+    }
+    double lw = 0.0;
+    if (ok) {
+      fwd_subst<D>(cS, e, v);                                               // :149
+      double vv = 0.0, sl = 0.0;
+      for (int q = 0; q < D; ++q) { sl += log(cS[q + D * q]); vv += v[q] * v[q]; }
+      lw = -sl - 0.5 * vv + M.logconst;                                     // :150
+    } else {
+      atomicOr(a.status, 1);
+      lw = nan("");
+      for (int q = 0; q < D * D; ++q) cS[q] = 0.0;
+      for (int q = 0; q < D; ++q) cS[q + D * q] = 1.0;
+    }
+    a.logw[i] = lw;
+    for (int q = 0; q < D * D; ++q) { misc[20 + q] = cS[q]; misc[30 + q] = SS[q]; }
+    for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
+  }
+  __syncthreads();
+
+  // ---- F: Kalman gain rows, mean update, new pending factors (particleFilter.m:194-198) ----
+  {
+    double cS[D * D], SS[D * D], e[D];
+#pragma unroll
+    for (int q = 0; q < D * D; ++q) { cS[q] = misc[20 + q]; SS[q] = misc[30 + q]; }
+#pragma unroll
+    for (int q = 0; q < D; ++q) e[q] = misc[40 + q];
+    double* KSn = a.F_new + ((size_t)i * 2 + 0) * D * ldx;
+    double* Kn = a.F_new + ((size_t)i * 2 + 1) * D * ldx;
+    if (tid == 0) {
+      if (a.base_new) a.base_new[i] = WR ? dslot : baseb;
+      if (!WR) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          if (a.fset_idx_new[s]) a.fset_idx_new[s][i] = pre_i[4 + s];
+      }
+      if (a.fself_idx_new) a.fself_idx_new[i] = i;
+    }
+    double* xln = a.xl_new + (size_t)i * ldx;
+    for (int r = tid; r < n; r += kThreads) {
+      double ph[D], u[D], kk[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) ph[k] = PHt[(size_t)k * ldx + r];
+      fwd_subst<D>(cS, ph, u);
+      bwd_subst_T<D>(cS, u, kk);
+      double xn_ = xls[r];
+#pragma unroll
+      for (int k = 0; k < D; ++k) xn_ = fma(kk[k], e[k], xn_);              // :197
+      xln[r] = xn_;
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s = fma(kk[k], SS[k + D * j], s);
+        KSn[(size_t)j * ldx + r] = s;
+        Kn[(size_t)j * ldx + r] = kk[j];
+      }
+    }
+  }
+}
+
+template <int D, int NS, bool WR>
+static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0);
+  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
+  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32 || a.info || a.rec != nullptr) return hipErrorInvalidValue;
+  if (a.write_base) {
+    switch (a.n_sets) {
+      case 0: return launch_sym_k<3, 0, true>(a, s);
+      case 1: return launch_sym_k<3, 1, true>(a, s);
+      case 2: return launch_sym_k<3, 2, true>(a, s);
+      case 3: return launch_sym_k<3, 3, true>(a, s);
+      case 4: return launch_sym_k<3, 4, true>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (a.n_sets) {
+    case 1: return launch_sym_k<3, 1, false>(a, s);
+    case 2: return launch_sym_k<3, 2, false>(a, s);
+    case 3: return launch_sym_k<3, 3, false>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace rbpf

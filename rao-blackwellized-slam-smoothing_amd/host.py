@@ -441,12 +441,15 @@ class _Problem:
 
 
 def _storage_code(storage):
-    """rbpf_options.storage: "fp64" (default, the reference's precision) or "fp32" storage of the covariance banks."""
+    """rbpf_options.storage: "fp64" (default, the reference's precision), "fp32" storage of the covariance banks, or
+    "fp64sym" (fp64, lower block triangle only: particleFilter.m:198 keeps the covariances symmetric)."""
     if storage in ("fp64", 0, None):
         return 0
     if storage in ("fp32", 1):
         return 1
-    raise ValueError("storage must be 'fp64' or 'fp32'")
+    if storage in ("fp64sym", "sym", 2):
+        return 2
+    raise ValueError("storage must be 'fp64', 'fp32' or 'fp64sym'")
 
 
 def _check_sparse_flag(model, sparseFeatures):

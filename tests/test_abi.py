@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(rbpf):
     lib = rbpf.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rbpf_abi_version() == 6
+    assert lib.rbpf_abi_version() == 7
     assert lib.rbpf_status_string(0) == b"ok"
     assert b"positive definite" in lib.rbpf_status_string(rbpf.RBPF_ERR_CHOL_FAILED)
 

@@ -1,0 +1,124 @@
+"""GPU: symmetric covariance storage (rbpf_options.storage = 2, rbpf_step_sym.hip) -- the lower block triangle of every P_i only
+(particleFilter.m:198 keeps P symmetric up to rounding), 0.5625 n^2 stored elements at nLin = 515.
+
+Parity bar as everywhere: resampling indices bit-exact, fp64 quantities within 1e-9 relative of the numpy oracle / the plain-C
+restatement (particleFilter.m:100-218), and of the full-square storage on the same Philox streams."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_c
+from test_gpu_filter import check_filter, rel
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def test_wave_reduction_primitive(rbpf):
+    """v_permlane32_swap / v_permlane16_swap folds + DPP row rotations: four values per lane -> four lane sums."""
+    lib = rbpf.load_library()
+    lib.rbpf_probe_wave_reduce.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    rs = np.random.RandomState(3)
+    for trial in range(4):
+        x = np.ascontiguousarray(rs.standard_normal((4, 64)) * 10.0 ** rs.randint(-3, 4, size=(4, 1)))
+        if trial == 0:
+            x = np.ascontiguousarray(np.arange(256, dtype=np.float64).reshape(4, 64))      # exact in any order
+        out = np.zeros(4)
+        st = lib.rbpf_probe_wave_reduce(x.ctypes.data_as(C.POINTER(C.c_double)), out.ctypes.data_as(C.POINTER(C.c_double)))
+        assert st == 0
+        want = x.sum(axis=1)
+        if trial == 0:
+            np.testing.assert_array_equal(out, want)
+        np.testing.assert_allclose(out, want, rtol=0, atol=1e-13 * np.abs(x).sum(axis=1).max())
+
+
+def run_sym(rbpf, c, lazy_depth, inplace, storage="fp64sym"):
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    return rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                               rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth, inplace=inplace, storage=storage)
+
+
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, -1), (3, 1), (4, -1), (4, 1)])
+def test_symmetric_storage_filter_matches_oracle(rbpf, lazy_depth, inplace):
+    """slam-dense-mag m = 512 (nLin = 515), 13 steps: every variant of step_sym_kernel -- t = 0 (no pending set), rewrite every
+    step (lazy 0), read-only steps with 1..3 sets (epilogue correction P H' - KS (K' H')) and flushes with 2..4 sets, ping-pong
+    banks and the single bank rewritten in place -- against the numpy oracle."""
+    c = cases.mag_case(8, 13, 512, seed=61)
+    ref = cases.oracle_filter(c)
+    out = run_sym(rbpf, c, lazy_depth, inplace)
+    check_filter(ref, out)
+
+
+def test_symmetric_storage_against_the_c_restatement(rbpf, tmp_path_factory):
+    """N = 512, T = 60, m = 512 on replayed random numbers: symmetric storage, lazy_depth 4, in place (the bench configuration
+    at small N) against the plain-C restatement -- all indices, weights, final maps and covariances of all particles."""
+    import bench
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T, m = 512, 60, 512
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    rs = np.random.RandomState(91)
+    rng = rbpf.ReplayRNG(rs.random_sample((1, T - 1, N)), rs.standard_normal((1, T - 1, N, 6)))
+    lib = oracle_c.build(native_dir=str(tmp_path_factory.mktemp("oracle_native_sym")))
+    ref, _ = oracle_c.particle_filter(rbpf, mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng,
+                                      n_threads=bench.usable_cores(), want_full=True, lib_path=lib)
+    for lazy_depth, inplace in ((4, 1), (4, -1)):
+        out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                                  extras=True, lazy_depth=lazy_depth, inplace=inplace, storage="fp64sym")
+        ex = out[8]
+        np.testing.assert_array_equal(ex["ai"][1:], ref["trace_ai"].T[1:])
+        assert rel(ex["w"], ref["trace_w"].T) <= RTOL
+        assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
+        assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
+        assert rel(out[4], ref["P_max"]) <= RTOL and rel(out[5], ref["P_mean"]) <= RTOL
+        assert rel(ex["xl"], ref["final_xl"]) <= RTOL and rel(ex["P"], ref["final_P"]) <= RTOL
+        assert np.array_equal(out[4], out[4].T)                                 # one stored value per (r, c) / (c, r) pair
+
+
+@pytest.mark.parametrize("lazy_depth", [3, 4])
+def test_symmetric_storage_equals_full_storage_on_philox_streams(rbpf, lazy_depth):
+    """N = 4096, m = 512, 21 steps on the device generator: same resampling indices as the full-square storage, outputs to
+    1e-9; the in-place schedule equals the ping-pong schedule bit for bit; two runs are bit-identical."""
+    from test_gpu_configs import check_filter_properties, mag_inputs, run_session
+    N, steps = 4096, 21
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
+    want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean")
+    full = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=-1)
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=-1, storage="fp64sym")
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=1, storage="fp64sym")
+    a2 = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=lazy_depth, inplace=-1, storage="fp64sym")
+    check_filter_properties(a, N, steps, P0)
+    np.testing.assert_array_equal(a["trace_ai"], full["trace_ai"])
+    for k in ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "xl_mean"):
+        assert rel(a[k], full[k]) <= RTOL, k
+    for k in want:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
+
+
+def test_symmetric_storage_at_configs2_size(rbpf):
+    """BASELINE.json configs[2], filter: N = 65 536, m = 512, symmetric storage (78 GB per bank), lazy_depth 4: properties hold
+    and two runs are bit-identical."""
+    from test_gpu_configs import check_filter_properties, mag_inputs, run_session
+    N, steps = 65536, 10
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
+    want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean")
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=1, storage="fp64sym")
+    check_filter_properties(a, N, steps, P0)
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=1, storage="fp64sym")
+    for k in want:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_symmetric_storage_is_rejected_where_it_is_not_implemented(rbpf):
+    c = cases.mag_case(6, 5, 256, seed=1)                                       # nLin = 259: four tile rows
+    with pytest.raises(rbpf.RBPFError):
+        run_sym(rbpf, c, 3, -1)
+    c = cases.radio_case(6, 5, 128, seed=1, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError):
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 1.0,
+                            rng=cases.device_rng(rbpf, c), storage="fp64sym")
