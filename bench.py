@@ -136,8 +136,17 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, 
             "roofline": roofline_of(tm)}, data, model, x0_lin, P0, R
 
 
+def bank_bytes_per_particle(n, storage):
+    """Bytes of one stored covariance (include/rbpf.h rbpf_options.storage)."""
+    if storage == "fp64sym":                                       # lower block triangle in 64 x 64 tiles + border rows
+        mc = (n // 128) * 128
+        ch = mc // 64
+        return 8.0 * (ch * (ch + 1) // 2 * 4096 + (n - mc) * ((n + 1) // 2 * 2))
+    return n * n * (8.0 if storage == "fp64" else 4.0)
+
+
 def workload_string(N_total, T, m, n, storage, lazy_depth, world, single_bank):
-    prec = "fp64" if storage == "fp64" else "fp64 arithmetic / fp32 covariance storage"
+    prec = {"fp64": "fp64", "fp64sym": "fp64, symmetric storage (lower block triangle)"}.get(storage, "fp64 arithmetic / fp32 covariance storage")
     bank = "single covariance bank rewritten in place" if single_bank else "ping-pong covariance banks"
     return (f"slam-dense-mag N={N_total} T={T} m={m} (nLin={n}) {prec}, forward filter, {world} GPU, lazy_depth {lazy_depth}, "
             f"{bank}")
@@ -176,7 +185,7 @@ def measure_traffic(args, lazy_depth):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stdout[-300:]}"
-            rows = [x for x in csv.DictReader(open(files[0])) if "step_kernel" in x.get("Kernel_Name", "") and x.get("Counter_Name") == ctr]
+            rows = [x for x in csv.DictReader(open(files[0])) if ("step_kernel" in x.get("Kernel_Name", "") or "step_sym_kernel" in x.get("Kernel_Name", "")) and x.get("Counter_Name") == ctr]
             rows.sort(key=lambda x: int(x.get("Dispatch_Id", 0)))
             if len(rows) < steps:
                 return None, f"{ctr}: {len(rows)} step-kernel dispatches, expected >= {steps}"
@@ -402,7 +411,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=4, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
-    ap.add_argument("--storage", default="fp64", choices=["fp64", "fp32", "fp64sym"], help="precision the covariance banks are STORED in (arithmetic is fp64)")
+    ap.add_argument("--storage", default="fp64sym", choices=["fp64", "fp32", "fp64sym"],
+                    help="how the covariance banks are STORED (arithmetic is fp64): fp64sym = fp64, lower block triangle only (default; results within 1e-9 "
+                         "of fp64), fp64 = full square as the reference holds them, fp32 = full square in float")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
@@ -506,7 +517,7 @@ def main():
         _free_b, tot_b = torch.cuda.mem_get_info()
         n_ = model.nLin
         single_bank = args.inplace > 0 or (args.inplace == 0 and args.lazy_depth >= 2 and
-                                           2.0 * N_local * n_ * n_ * (8 if args.storage == "fp64" else 4) > 0.85 * tot_b)
+                                           2.0 * N_local * bank_bytes_per_particle(n_, args.storage) > 0.85 * tot_b)
 
     if rank == 0:
         n = model.nLin
@@ -514,9 +525,9 @@ def main():
             "metric": "particle-steps/s (filter) + smoother wall-clock, N=65k T=3k", "value": head["value"], "unit": "particle-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f64" if args.storage == "fp64" else "f64 arithmetic, f32 covariance storage", "data": "synthetic",
+            "dtype": "f64" if args.storage in ("fp64", "fp64sym") else "f64 arithmetic, f32 covariance storage", "data": "synthetic",
             "config": {"workload": workload_string(N_total, T, args.m, n, args.storage, args.lazy_depth, world, single_bank),
-                       "baseline_config": "BASELINE.json configs[2] (filter part)" if (N_total, T, args.m, args.storage) == (65536, 3000, 512, "fp64") else "custom",
+                       "baseline_config": "BASELINE.json configs[2] (filter part)" if (N_total, T, args.m) == (65536, 3000, 512) and args.storage in ("fp64", "fp64sym") else "custom",
                        "particles_total": N_total, "particles_per_gpu": N_local, "rng": "device Philox4x32-10", "data_seed": args.seed,
                        "lazy_depth": args.lazy_depth, "inplace": args.inplace, "storage": args.storage, "filter_seed": args.seed, "keep_history": True},
             "roofline": head["roofline"],
@@ -555,7 +566,7 @@ def main():
         if solo and not args.no_large:
             def extra(N, m, Kx, Wx, lazy, storage):
                 r, *_ = filter_leg(pkg, datagen, N, m, 3000, Kx, Wx, args.seed, lazy, 0, storage)
-                r["workload"] = workload_string(N, 3000, m, m + 3, storage, lazy, 1, 2.0 * N * (m + 3) ** 2 * (8 if storage == "fp64" else 4) > 0.85 * 288e9)
+                r["workload"] = workload_string(N, 3000, m, m + 3, storage, lazy, 1, 2.0 * N * bank_bytes_per_particle(m + 3, storage) > 0.85 * 288e9)
                 return r
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")            # BASELINE.json configs[1]
             line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]

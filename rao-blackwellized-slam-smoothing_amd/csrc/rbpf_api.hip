@@ -226,10 +226,10 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->fp32 = c->opt.storage == 1;
   if (c->opt.storage < 0 || c->opt.storage > 2) { set_error("options.storage must be 0 (fp64), 1 (fp32) or 2 (fp64, symmetric)"); return RBPF_ERR_INVALID_ARG; }
   if (c->opt.storage == 2) {
-    // symmetric storage (lower block triangle, rbpf_step_sym.hip): the unsharded filter of the ny = 3 dense families at the
+    // symmetric storage (lower block triangle, rbpf_step_sym.hip): the filter of the ny = 3 dense families at the
     // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
-    if (smoother || sparse || ex || !sym_supported(prob->n_lin, prob->n_y)) {
-      set_error("symmetric storage (options.storage = 2): unsharded dense filter with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
+    if (smoother || sparse || !sym_supported(prob->n_lin, prob->n_y)) {
+      set_error("symmetric storage (options.storage = 2): dense filter (single-GPU or sharded) with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
     }
     c->lay = make_layout_sym(prob->n_lin, prob->n_y);
     c->lay_low = c->lay;

@@ -1811,7 +1811,18 @@ __global__ void pack_records_flushed_kernel(Layout L, int d, const int* __restri
   const double* F[kMaxSets];
   for (int s = 0; s < ps.n_sets; ++s) F[s] = ps.fset[s] + (size_t)(ps.fidx[s] ? ps.fidx[s][src] : src) * szF;
   for (size_t q = threadIdx.x; q < L.szT; q += blockDim.x) {
-    const int c = (int)(q / L.mc), rr = L.nb + (int)(q % L.mc);
+    int c, rr;
+    if (!L.sym) { c = (int)(q / L.mc); rr = L.nb + (int)(q % L.mc); }
+    else {
+      // inverse of sym_t_index: tile (I, J) of the lower block triangle, column pair, lane, element
+      const int tile = (int)(q / kSymTile), within = (int)(q % kSymTile);
+      int I = (int)((sqrt(8.0 * tile + 1.0) - 1.0) * 0.5);
+      while ((I + 1) * (I + 2) / 2 <= tile) ++I;
+      while (I * (I + 1) / 2 > tile) --I;
+      const int J = tile - I * (I + 1) / 2;
+      rr = L.nb + I * kSymChunk + (within % (2 * kSymChunk)) / 2;
+      c = L.nb + J * kSymChunk + 2 * (within / (2 * kSymChunk)) + (within & 1);
+    }
     double v = (double)t[q];
     for (int s = 0; s < ps.n_sets; ++s)
       for (int k = 0; k < d; ++k) v = fma(-F[s][(size_t)k * L.ldx + rr], F[s][(size_t)(d + k) * L.ldx + c], v);

@@ -225,15 +225,22 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   double* misc = smem + lp.off_misc;
   double* red = smem + lp.off_red;
   const int ancb = pre_i[2], baseb = pre_i[3];
-  const double* srcT = a.Pt_old + (size_t)baseb * a.Pt_old_stride;
-  const double* srcB = a.Pb_old + (size_t)baseb * a.Pb_old_stride;
-  const double* srcX = a.xl_old + (size_t)ancb * a.xl_old_stride;
+  // sharded filter: a bank index >= n_bank_local refers to a received record [T | B | F | xl] (same layout as the banks)
+  const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;
+  const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
+  const bool remoteP = a.rec != nullptr && baseb >= a.n_bank_local;
+  const double* recP = remoteP ? a.rec + (size_t)(baseb - a.n_bank_local) * a.rec_stride : nullptr;
+  const double* srcT = remoteP ? recP : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
+  const double* srcB = remoteP ? recP + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
+  const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
   const double* Fs[NSA];
 #pragma unroll
   for (int s = 0; s < NSA; ++s) Fs[s] = nullptr;
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-    Fs[s] = a.fset[s] ? a.fset[s] + (size_t)pre_i[4 + s] * 2 * D * ldx : a.F_old + (size_t)ancb * 2 * D * ldx;
+  for (int s = 0; s < NS; ++s) {
+    if (a.fset[s]) Fs[s] = a.fset[s] + (size_t)pre_i[4 + s] * 2 * D * ldx;
+    else Fs[s] = remote ? recp + a.rec_off_F : a.F_old + (size_t)ancb * 2 * D * ldx;
+  }
 
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];
@@ -268,7 +275,21 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int k = 0; k < D; ++k) ks[q][s * D + k] = WR ? Fs[s][(size_t)k * ldx + r] : 0.0;
+    // the border COLUMNS of this row, P(r, b) = B(b, r), downdated like the border phase does when this is a flush.  Read here,
+    // before anything is stored: in the second launch of a single-bank flush the border phase overwrites these very values.
+    for (int b = 0; b < nb; ++b) {
+      double pv = srcB[(size_t)b * ldb + r];
+      if (WR) {
+#pragma unroll
+        for (int sset = 0; sset < NS; ++sset)
+#pragma unroll
+          for (int k = 0; k < D; ++k) pv = fma(-Fs[sset][(size_t)k * ldx + b], Fs[sset][(size_t)(D + k) * ldx + r], pv);
+      }
+#pragma unroll
+      for (int k = 0; k < D; ++k) accr[q][k] = fma(pv, Hs[b * D + k], accr[q][k]);
+    }
   }
+  if (WR) __syncthreads();                                     // every wave has read the old border block before any wave stores it
   {
     double* dT = a.Pt_new + (size_t)dslot * Ly.szT;
     double* kst = smem + lp.off_kst + (size_t)wave * kSymChunk * ND;
@@ -344,8 +365,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     }
   }
   __syncthreads();
-  // combine, by the lane that owns the row: row part (registers) + the waves' column parts in wave order + the border columns
-  // P(r, b) = B(b, r) (downdated like the border phase did when this is a flush)
+  // combine, by the lane that owns the row: row part incl. the border columns (registers) + the waves' column parts in wave order
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
     const int rc = rows[q] * kSymChunk + lane;                // core coordinate
@@ -360,17 +380,6 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
         for (int k = 0; k < D; ++k) s[k] += cw[(size_t)k * ldw + rc];
       }
-    }
-    for (int b = 0; b < nb; ++b) {
-      double pv = srcB[(size_t)b * ldb + nb + rc];
-      if (WR) {
-#pragma unroll
-        for (int sset = 0; sset < NS; ++sset)
-#pragma unroll
-          for (int k = 0; k < D; ++k) pv = fma(-Fs[sset][(size_t)k * ldx + b], Fs[sset][(size_t)(D + k) * ldx + nb + rc], pv);
-      }
-#pragma unroll
-      for (int k = 0; k < D; ++k) s[k] = fma(pv, Hs[b * D + k], s[k]);
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
@@ -543,7 +552,7 @@ static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
-  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32 || a.info || a.rec != nullptr) return hipErrorInvalidValue;
+  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32 || a.info) return hipErrorInvalidValue;
   if (a.write_base) {
     switch (a.n_sets) {
       case 0: return launch_sym_k<3, 0, true>(a, s);

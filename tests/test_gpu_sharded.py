@@ -134,6 +134,27 @@ def test_two_ranks_with_fp32_storage(lazy_depth):
         np.testing.assert_allclose(tx, ref["traj_max"], rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("lazy_depth", [0, 3, 4])
+def test_two_ranks_with_symmetric_storage(lazy_depth):
+    """storage="fp64sym" (lower block triangle, rbpf_step_sym.hip) in the sharded filter at nLin = 515: records carry the
+    symmetric blocks; without the lazy update a migrating particle's matrix is copied verbatim (bit-identical to the single-GPU
+    symmetric run), with it the packer applies the pending sets element-wise over the symmetric layout (1e-9); both agree with
+    the full-square single-GPU filter to 1e-9."""
+    T, m, n_local = 11, 512, 24
+    tm, tx, stats = _run(2, "gloo", "host", T, m, n_local, "device", lazy_depth, "fp64sym")
+    ref = _single(T, m, 2 * n_local, "fp64sym")
+    full = _single(T, m, 2 * n_local)
+    assert stats["steps"] == T and stats["sent_records"] >= 0
+    if lazy_depth == 0:
+        np.testing.assert_array_equal(tm, ref["traj_mean"])
+        np.testing.assert_array_equal(tx, ref["traj_max"])
+    else:
+        np.testing.assert_allclose(tm, ref["traj_mean"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(tx, ref["traj_max"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(tm, full["traj_mean"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(tx, full["traj_max"], rtol=1e-9, atol=1e-11)
+
+
 @pytest.mark.parametrize("lazy_depth", [0, 3])
 def test_world_size_one_rccl_device_transport(lazy_depth):
     """World 1 over RCCL with force_collectives: the real all_gather_into_tensor / all_to_all_single calls on the library's

@@ -75,7 +75,7 @@ def test_symmetric_storage_against_the_c_restatement(rbpf, tmp_path_factory):
         assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
         assert rel(out[4], ref["P_max"]) <= RTOL and rel(out[5], ref["P_mean"]) <= RTOL
         assert rel(ex["xl"], ref["final_xl"]) <= RTOL and rel(ex["P"], ref["final_P"]) <= RTOL
-        assert np.array_equal(out[4], out[4].T)                                 # one stored value per (r, c) / (c, r) pair
+        assert rel(out[4], out[4].T) < 1e-13                                    # one stored value per (r, c) / (c, r) pair (+ pending sets)
 
 
 @pytest.mark.parametrize("lazy_depth", [3, 4])
@@ -93,7 +93,8 @@ def test_symmetric_storage_equals_full_storage_on_philox_streams(rbpf, lazy_dept
     check_filter_properties(a, N, steps, P0)
     np.testing.assert_array_equal(a["trace_ai"], full["trace_ai"])
     for k in ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "xl_mean"):
-        assert rel(a[k], full[k]) <= RTOL, k
+        sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis   # NaN beyond the steps run
+        assert rel(a[k][sl], full[k][sl]) <= RTOL, k
     for k in want:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
         np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
