@@ -200,6 +200,17 @@ typedef struct {
                           * RBPF_ERR_OUT_OF_MEMORY before any collective is issued (the plan is replicated).                 */
   rbpf_on_step_fn on_step; /* NULL: no hook                                                       */
   void* on_step_user;
+  int32_t n_devices;     /* rbpf_particle_filter / rbpf_particle_smoother(info_form = 1) only.  0 / 1 with device_ids == NULL: one  *
+                          * GPU (the current device).  W > 1: the N_P particles are sharded over W GPUs of this node INSIDE the   *
+                          * library -- one host thread per device runs the sharded step loop (rbpf_shard_* below) and the library  *
+                          * issues the collectives itself over RCCL (ncclCommInitAll; all-gather of the forward bank + grouped     *
+                          * send / recv of the migrating particle records, on each context's stream), so a single host process   *
+                          * (a MATLAB session behind the MEX gateway: particleSmootherInformationForm.m is one call) reaches all  *
+                          * GPUs.  N_P must be a multiple of W; recognised dense model families; results equal the single-GPU run *
+                          * (bit for bit without lazy_depth, 1e-9 with it), outputs without xn_traj / traces / final banks.       */
+  const int32_t* device_ids; /* [n_devices] HIP device of every rank, NULL = 0 .. n_devices-1.  A device named more than once makes *
+                          * its ranks share that GPU over a host-staged transport (no RCCL) -- how a one-GPU machine exercises the  *
+                          * multi-rank loop; n_devices = 1 with device_ids set runs the loop with a world of one.                  */
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */

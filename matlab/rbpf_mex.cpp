@@ -284,7 +284,7 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 // Options that change the schedule or the arithmetic, not the interface (include/rbpf.h `rbpf_options`): they cannot travel in
 // the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
 // matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
-struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0; double jitter = 0.0; };
+struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0; double jitter = 0.0; };
 SessionOptions g_session;
 
 void session_field(const mxArray* s, const char* name, int& v) {
@@ -305,6 +305,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   opt.keep_history = 1;
   opt.lazy_depth = g_session.lazy_depth; opt.chol_refresh = g_session.chol_refresh; opt.chol_variant = g_session.chol_variant;
   opt.storage = g_session.storage; opt.inplace = g_session.inplace; opt.fix_p_mean = g_session.fix_p_mean; opt.jitter = g_session.jitter;
+  opt.n_devices = g_session.n_devices;                       // > 1: the library shards the particles over that many GPUs itself (RCCL)
   if (cmd == "options") {
     if (nrhs > 2 || (nrhs == 2 && !mxIsStruct(prhs[1]))) mexErrMsgIdAndTxt("rbpf:usage", "options expects one struct (or nothing: query)");
     if (nrhs == 2) {
@@ -312,15 +313,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       session_field(prhs[1], "lazy_depth", o.lazy_depth); session_field(prhs[1], "chol_refresh", o.chol_refresh);
       session_field(prhs[1], "chol_variant", o.chol_variant); session_field(prhs[1], "storage", o.storage);
       session_field(prhs[1], "inplace", o.inplace); session_field(prhs[1], "fix_p_mean", o.fix_p_mean);
+      session_field(prhs[1], "n_devices", o.n_devices);
       if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
-      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 1) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
+      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
       g_session = o;
     }
-    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 7, names);
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 8, names);
     const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
-                           (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter};
-    for (int q = 0; q < 7; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+                           (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter,
+                           (double)g_session.n_devices};
+    for (int q = 0; q < 8; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
   } else if (cmd == "filter") {
     if (nrhs != 12 && nrhs != 13) mexErrMsgIdAndTxt("rbpf:usage", "filter expects 11 or 12 arguments after the command");
     rbpf_model m = model_from(prhs[1], nn, g, cb);

@@ -12,7 +12,12 @@ function o = rbpf_options(varargin)
 %   chol_refresh  K > 1: carry the ancestor-weight Cholesky factors of particleSmootherInformationForm along the lineages
 %                 (rank-1 up/down-dates), refactorise every K-th step; ancestor probabilities within 2e-9 of the default
 %   chol_variant  which kernel factorises (0 automatic); same arithmetic
-%   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9)
+%   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9);
+%                 2: double precision, lower block triangle only (particleFilter keeps P symmetric: 0.56 x the memory and
+%                 traffic, results within 1e-9; dense-mag filter with 512 basis functions)
+%   n_devices     W > 1: particleFilter / particleSmootherInformationForm shard their N_P particles over W GPUs of this
+%                 machine inside the library (one thread per GPU, RCCL collectives); N_P must be a multiple of W; the
+%                 reference's outputs, without xn_traj
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
 %   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
 %   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)

@@ -71,7 +71,7 @@ class rbpf_options(C.Structure):
     _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
                 ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
                 ("chol_variant", C.c_int32), ("chol_refresh", C.c_int32), ("exchange_capacity", C.c_int32), ("on_step", ON_STEP_FN),
-                ("on_step_user", C.c_void_p)]
+                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
 
 
 class rbpf_filter_out(C.Structure):

@@ -1138,6 +1138,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
 
 int rbpf_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
                          rbpf_filter_out* out) {
+  if (wants_multi(opt)) return multi_particle_filter(model, prob, rng, opt, out);      // sharded over several GPUs in this process
   rbpf_ctx* c = nullptr;
   int s = rbpf_filter_create(model, prob, rng, opt, &c);
   if (s != RBPF_OK) return s;

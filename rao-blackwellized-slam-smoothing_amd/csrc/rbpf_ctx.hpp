@@ -133,6 +133,12 @@ int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother);
 void ctx_account_launch(rbpf_ctx* c, const StepArgs& a);
 int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
+// in-library multi-device driver (rbpf_multi.hip): rbpf_options.n_devices
+inline bool wants_multi(const rbpf_options* o) { return o && (o->n_devices > 1 || (o->n_devices == 1 && o->device_ids)); }
+int multi_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                          rbpf_filter_out* out);
+int multi_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                            int32_t N_K, int32_t info_form, rbpf_smoother_out* out);
 void shard_free(rbpf_ctx* c);
 
 }  // namespace rbpf

@@ -1,0 +1,333 @@
+// In-library multi-device driver: ONE host process (e.g. a MATLAB session behind the MEX gateway) runs the particle-sharded
+// filter / information-form smoother over several GPUs of a node (BASELINE.json north_star "host code stays MATLAB ...
+// partitioned across the 8 GPUs of one node").
+//
+// The sharded algorithm itself is unchanged (rbpf_shard.hip, rbpf_smoother.hip: owner-computes placement, one all-gather of the
+// forward bank + one all-to-all of the migrating particle records per step); what moves into the library is the step loop that
+// multigpu.py drives from Python under torchrun: one C++ thread per device runs gather -> normalise + draw + plan -> pack ->
+// exchange -> step on that device's context and stream, and the collectives are issued by the library itself --
+//
+//   * RCCL (ncclCommInitAll: one communicator per device of this process, ncclAllGather and grouped ncclSend / ncclRecv on
+//     each context's own stream, so a step needs one host synchronisation: the plan's count read-back), loaded with dlopen at
+//     the first multi-device call (the single-GPU path has no RCCL dependency), or
+//   * a host-staged transport (pinned-free plain host buffers + a thread barrier) when the device list names a device more than
+//     once -- several ranks sharing one GPU, which is how a one-GPU box exercises the world-2 loop (RCCL refuses duplicates).
+//
+// Selected by rbpf_options.n_devices (> 1, or == 1 with device_ids set: the loop with a world of one) in the ordinary one-shot
+// entry points rbpf_particle_filter / rbpf_particle_smoother, so the MATLAB wrappers shard with an option and nothing else.
+#include "rbpf_ctx.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace rbpf {
+
+namespace {
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string& why) {
+    if (h) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) { why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return false; }
+#define RB_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(h, sym)); if (!field) { why = std::string("RCCL lacks ") + sym; return false; }
+    RB_SYM(CommInitAll, "ncclCommInitAll") RB_SYM(CommDestroy, "ncclCommDestroy") RB_SYM(AllGather, "ncclAllGather")
+    RB_SYM(Send, "ncclSend") RB_SYM(Recv, "ncclRecv") RB_SYM(GroupStart, "ncclGroupStart") RB_SYM(GroupEnd, "ncclGroupEnd")
+    RB_SYM(GetErrorString, "ncclGetErrorString")
+#undef RB_SYM
+    return true;
+  }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
+
+// reusable barrier for the host-staged transport; abort() releases everybody (a rank failed)
+struct HostBarrier {
+  std::mutex m; std::condition_variable cv; int n = 1, waiting = 0; unsigned gen = 0; bool aborted = false;
+  bool wait() {
+    std::unique_lock<std::mutex> lk(m);
+    if (aborted) return false;
+    const unsigned g = gen;
+    if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); return true; }
+    cv.wait(lk, [&] { return gen != g || aborted; });
+    return !aborted;
+  }
+  void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }
+};
+
+struct Multi {
+  int W = 1;
+  std::vector<int> devs;
+  bool host_staged = false, smoother = false;
+  int N_K = 1, Nloc = 0, Nglob = 0, T = 0, nN = 0, n = 0;
+  std::vector<rbpf_ctx*> ctx;
+  std::vector<rbpf_shard_views> v;
+  std::vector<hipStream_t> stream;
+  std::vector<ncclComm_t> comm;
+  // host staging (host_staged only)
+  std::vector<double> h_fwd;                       // [W][fwd_rows * Nloc]
+  std::vector<std::vector<double>> h_send;         // per rank: its send records of this step
+  std::vector<std::vector<long long>> h_cnt;       // per rank: counts_host of this step
+  HostBarrier bar;
+  // per-rank status of the last parallel section
+  std::vector<int> status; std::vector<std::string> msg;
+  long long migrated = 0, sent_records = 0;
+  ~Multi() {
+    for (size_t r = 0; r < ctx.size(); ++r) {
+      if (!ctx[r]) continue;
+      hipSetDevice(devs[r]);
+      rbpf_destroy(ctx[r]);
+    }
+    for (auto c : comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+  }
+};
+
+#define MT_TRY(expr) do { int _s = (expr); if (_s != RBPF_OK) return _s; } while (0)
+#define MT_NCCL(expr) do { ncclResult_t _r = (expr); if (_r != ncclSuccess) { set_error(std::string(#expr " failed: ") + g_rccl.GetErrorString(_r)); return RBPF_ERR_HIP; } } while (0)
+
+// every rank runs fn(rank) on its own thread with its device current; the first failing rank's status / message is returned
+template <typename F>
+int run_ranks(Multi& M, F fn) {
+  M.status.assign(M.W, RBPF_OK); M.msg.assign(M.W, std::string());
+  auto body = [&](int r) {
+    int s = (hipSetDevice(M.devs[r]) == hipSuccess) ? RBPF_OK : RBPF_ERR_HIP;
+    if (s == RBPF_OK) s = fn(r);
+    M.status[r] = s;
+    if (s != RBPF_OK) { const char* e = rbpf_last_error(); M.msg[r] = e ? e : ""; M.bar.abort(); }
+  };
+  if (M.W == 1) body(0);
+  else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < M.W; ++r) th.emplace_back(body, r);
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < M.W; ++r)
+    if (M.status[r] != RBPF_OK) { set_error("device " + std::to_string(M.devs[r]) + " (rank " + std::to_string(r) + "): " + M.msg[r]); return M.status[r]; }
+  return RBPF_OK;
+}
+
+int gather_rows(Multi& M, int r, const double* local, double* gathered, size_t count) {
+  if (!M.host_staged) { MT_NCCL(g_rccl.AllGather(local, gathered, count, ncclDouble, M.comm[r], M.stream[r])); return RBPF_OK; }
+  HIPCHK(hipStreamSynchronize(M.stream[r]));
+  if (M.h_fwd.size() < (size_t)M.W * count) { set_error("host staging buffer too small"); return RBPF_ERR_STATE; }
+  HIPCHK(hipMemcpy(M.h_fwd.data() + (size_t)r * count, local, count * sizeof(double), hipMemcpyDeviceToHost));
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  HIPCHK(hipMemcpy(gathered, M.h_fwd.data(), (size_t)M.W * count * sizeof(double), hipMemcpyHostToDevice));
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  return RBPF_OK;
+}
+
+int gather_fwd(Multi& M, int r) {
+  return gather_rows(M, r, M.v[r].fwd_local, M.v[r].fwd_gather, (size_t)M.v[r].fwd_rows * M.Nloc);
+}
+
+// all-to-all of the migrating particle records; cnt = counts_host of rbpf_shard_plan: [send to q | receive from q | migrated | first
+// record of recv_rec to write]
+int exchange(Multi& M, int r, const long long* cnt) {
+  const int W = M.W;
+  const size_t rs = M.v[r].record_doubles;
+  long long ns = 0;
+  for (int q = 0; q < W; ++q) ns += cnt[q];
+  const long long recv_off = cnt[2 * W + 1];
+  MT_TRY(rbpf_shard_pack(M.ctx[r], nullptr, (int32_t)ns));
+  if (r == 0) { M.migrated += cnt[2 * W]; }
+  if (!M.host_staged) {
+    MT_NCCL(g_rccl.GroupStart());
+    size_t so = 0, ro = (size_t)recv_off;
+    for (int q = 0; q < W; ++q) {
+      if (cnt[q] > 0) MT_NCCL(g_rccl.Send(M.v[r].send_rec + so * rs, (size_t)cnt[q] * rs, ncclDouble, q, M.comm[r], M.stream[r]));
+      if (cnt[W + q] > 0) MT_NCCL(g_rccl.Recv(M.v[r].recv_rec + ro * rs, (size_t)cnt[W + q] * rs, ncclDouble, q, M.comm[r], M.stream[r]));
+      so += (size_t)cnt[q]; ro += (size_t)cnt[W + q];
+    }
+    MT_NCCL(g_rccl.GroupEnd());
+    return RBPF_OK;
+  }
+  M.h_cnt[r].assign(cnt, cnt + 2 * W + 2);
+  M.h_send[r].resize((size_t)ns * rs);
+  if (ns) HIPCHK(hipMemcpy(M.h_send[r].data(), M.v[r].send_rec, (size_t)ns * rs * sizeof(double), hipMemcpyDeviceToHost));
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  size_t ro = (size_t)recv_off;
+  for (int q = 0; q < W; ++q) {
+    const long long want = cnt[W + q];
+    if (want <= 0) continue;
+    size_t so = 0;
+    for (int p = 0; p < r; ++p) so += (size_t)M.h_cnt[q][p];            // records rank q sends to ranks before me
+    if (M.h_cnt[q][r] != want) { set_error("exchange plan mismatch between ranks"); return RBPF_ERR_STATE; }
+    HIPCHK(hipMemcpy(M.v[r].recv_rec + ro * rs, M.h_send[q].data() + so * rs, (size_t)want * rs * sizeof(double), hipMemcpyHostToDevice));
+    ro += (size_t)want;
+  }
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  return RBPF_OK;
+}
+
+int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt, bool smoother,
+           int N_K) {
+  const int W = opt->n_devices;
+  if (W < 1 || W > 64) { set_error("options.n_devices must be in 1..64"); return RBPF_ERR_INVALID_ARG; }
+  if (prob->N_P % W) { set_error("N_P must be a multiple of options.n_devices"); return RBPF_ERR_INVALID_ARG; }
+  if (model->kind == RBPF_MODEL_GENERIC_DENSE || model->kind == RBPF_MODEL_SPARSE_VISUAL_2D) {
+    set_error("options.n_devices: the recognised dense model families only (host callbacks are not sharded)"); return RBPF_ERR_UNSUPPORTED;
+  }
+  if (opt->on_step && !smoother) { set_error("options.n_devices: the per-step hook (makePlots) is not available in the sharded filter"); return RBPF_ERR_UNSUPPORTED; }
+  if (smoother && opt->chol_refresh > 1) { set_error("options.n_devices: chol_refresh > 1 is available through multigpu.py only"); return RBPF_ERR_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device visible"); return RBPF_ERR_NO_DEVICE; }
+  M.W = W; M.smoother = smoother; M.N_K = N_K;
+  M.devs.resize(W);
+  for (int r = 0; r < W; ++r) {
+    M.devs[r] = opt->device_ids ? opt->device_ids[r] : r;
+    if (M.devs[r] < 0 || M.devs[r] >= ndev) { set_error("options.device_ids names a device that does not exist (" + std::to_string(ndev) + " visible)"); return RBPF_ERR_INVALID_ARG; }
+    for (int q = 0; q < r; ++q) if (M.devs[q] == M.devs[r]) M.host_staged = true;     // ranks sharing a GPU: RCCL refuses that
+  }
+  M.Nloc = prob->N_P / W; M.Nglob = prob->N_P; M.T = prob->N_T; M.nN = prob->n_nonlin; M.n = prob->n_lin;
+  M.ctx.assign(W, nullptr); M.v.resize(W); M.stream.assign(W, nullptr); M.comm.assign(W, nullptr);
+  M.h_send.resize(W); M.h_cnt.resize(W); M.bar.n = W;
+  if (!M.host_staged) {
+    std::lock_guard<std::mutex> lk(g_rccl_mutex);
+    std::string why;
+    if (!g_rccl.load(why)) { set_error(why); return RBPF_ERR_UNSUPPORTED; }
+    MT_NCCL(g_rccl.CommInitAll(M.comm.data(), W, M.devs.data()));
+  }
+  rbpf_options o = *opt;
+  o.n_devices = 0; o.device_ids = nullptr; o.on_step = nullptr; o.on_step_user = nullptr;
+  MT_TRY(run_ranks(M, [&](int r) -> int {
+    rbpf_problem p = *prob;
+    p.N_P = M.Nloc;
+    if (prob->x0_lin_cols > 1) p.x0_lin = prob->x0_lin + (size_t)r * M.Nloc * prob->n_lin;      // this rank's columns of x0_lin
+    if (smoother) MT_TRY(rbpf_shard_smoother_create(model, &p, rng, &o, N_K, r, W, &M.ctx[r]));
+    else MT_TRY(rbpf_shard_create(model, &p, rng, &o, r, W, &M.ctx[r]));
+    MT_TRY(rbpf_shard_views_get(M.ctx[r], &M.v[r]));
+    void* sp = nullptr;
+    MT_TRY(rbpf_stream_get(M.ctx[r], &sp));
+    M.stream[r] = reinterpret_cast<hipStream_t>(sp);
+    return rbpf_shard_set_async(M.ctx[r], M.host_staged ? 0 : 1);
+  }));
+  if (M.host_staged) M.h_fwd.assign((size_t)W * std::max<size_t>((size_t)M.v[0].fwd_rows * M.Nloc, (size_t)M.Nloc), 0.0);
+  return RBPF_OK;
+}
+
+// n_steps time steps of the sharded filter on rank r (multigpu.ShardedFilterSession.advance, device planner)
+int filter_steps(Multi& M, int r, int n_steps) {
+  const int W = M.W;
+  std::vector<long long> cnt(2 * W + 2, 0);
+  for (int sidx = 0; sidx < n_steps; ++sidx) {
+    int32_t t = 0;
+    MT_TRY(rbpf_filter_tell(M.ctx[r], &t));
+    if (t > 0) {
+      MT_TRY(gather_fwd(M, r));
+      MT_TRY(rbpf_shard_normalise_plan(M.ctx[r], reinterpret_cast<int64_t*>(cnt.data())));
+      MT_TRY(exchange(M, r, cnt.data()));
+    }
+    MT_TRY(rbpf_shard_step(M.ctx[r], nullptr, nullptr));
+  }
+  return RBPF_OK;
+}
+
+}  // namespace
+
+int multi_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                          rbpf_filter_out* out) {
+  if (!model || !prob || !rng || !opt || !out) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  if (out->xn_traj || out->trace_logw || out->trace_w || out->trace_ai || out->final_xn || out->final_xl || out->final_P) {
+    set_error("options.n_devices: xn_traj, the traces and the final particle banks are not gathered from the sharded filter"); return RBPF_ERR_UNSUPPORTED;
+  }
+  Multi M;
+  MT_TRY(create(M, model, prob, rng, opt, false, 1));
+  MT_TRY(run_ranks(M, [&](int r) { return filter_steps(M, r, M.T); }));
+  const int n = M.n, nN = M.nN, T = M.T, W = M.W;
+  // last step: gather + normalise (no draw), then the extraction of particleFilter.m:220-233 -- every rank fills what it holds
+  std::vector<std::vector<double>> xl_max(W, std::vector<double>(n, 0.0)), xl_mean(W, std::vector<double>(n, 0.0)),
+      P_max(W), P_mean(W);
+  std::vector<int32_t> iw(W, 0);
+  const bool need_mean = out->xl_mean || out->P_mean;
+  MT_TRY(run_ranks(M, [&](int r) -> int {
+    MT_TRY(gather_fwd(M, r));
+    MT_TRY(rbpf_shard_normalise_search(M.ctx[r], nullptr, nullptr));
+    if (out->P_max) P_max[r].assign((size_t)n * n, 0.0);
+    MT_TRY(rbpf_shard_finish(M.ctx[r], 0, out->xl_max ? xl_max[r].data() : nullptr, out->P_max ? P_max[r].data() : nullptr,
+                             need_mean ? xl_mean[r].data() : nullptr, nullptr, (r == 0) ? out->traj_sample_iwmax : nullptr, &iw[r]));
+    if (r == 0) MT_TRY(rbpf_shard_trajectories(M.ctx[r], out->traj_max, out->traj_mean));
+    return RBPF_OK;
+  }));
+  // the owner's rows (zeros elsewhere) / the ranks' shares of the weighted mean, summed in rank order
+  std::vector<double> mean(n, 0.0);
+  for (int r = 0; r < W; ++r) for (int q = 0; q < n; ++q) mean[q] += xl_mean[r][q];
+  if (out->xl_max) { std::memset(out->xl_max, 0, (size_t)n * sizeof(double)); for (int r = 0; r < W; ++r) for (int q = 0; q < n; ++q) out->xl_max[q] += xl_max[r][q]; }
+  if (out->P_max) { std::memset(out->P_max, 0, (size_t)n * n * sizeof(double)); for (int r = 0; r < W; ++r) for (size_t q = 0; q < (size_t)n * n; ++q) out->P_max[q] += P_max[r][q]; }
+  if (out->xl_mean) std::memcpy(out->xl_mean, mean.data(), (size_t)n * sizeof(double));
+  if (out->iw_max) *out->iw_max = iw[0];
+  if (out->P_mean) {
+    MT_TRY(run_ranks(M, [&](int r) -> int {
+      P_mean[r].assign((size_t)n * n, 0.0);
+      std::vector<double> xm(mean);
+      return rbpf_shard_finish(M.ctx[r], 1, nullptr, nullptr, xm.data(), P_mean[r].data(), nullptr, nullptr);
+    }));
+    std::memset(out->P_mean, 0, (size_t)n * n * sizeof(double));
+    for (int r = 0; r < W; ++r) for (size_t q = 0; q < (size_t)n * n; ++q) out->P_mean[q] += P_mean[r][q];
+  }
+  (void)nN; (void)T;
+  return RBPF_OK;
+}
+
+int multi_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
+                            int32_t N_K, int32_t info_form, rbpf_smoother_out* out) {
+  if (!model || !prob || !rng || !opt || !out) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  if (!info_form) { set_error("options.n_devices: the covariance-form smoother is not sharded (particleSmootherInformationForm is)"); return RBPF_ERR_UNSUPPORTED; }
+  if (out->trace_logw || out->trace_w || out->trace_ai || out->trace_paNt) { set_error("options.n_devices: traces are not gathered from the sharded smoother"); return RBPF_ERR_UNSUPPORTED; }
+  Multi M;
+  MT_TRY(create(M, model, prob, rng, opt, true, N_K));
+  const int n = M.n, nN = M.nN, T = M.T, W = M.W;
+  for (int k = 0; k < N_K; ++k) {
+    std::vector<std::vector<double>> xlk(W, std::vector<double>(n, 0.0)), pk(W, std::vector<double>((size_t)n * n, 0.0));
+    std::vector<int32_t> ak(W, 0), owner(W, 0);
+    double* XNK_k = out->XNK ? out->XNK + (size_t)k * nN * T : nullptr;
+    std::vector<double> xnk_scratch((size_t)nN * T, 0.0);
+    MT_TRY(run_ranks(M, [&](int r) -> int {
+      // multigpu.ShardedSmootherSession.run, one CPF-AS iteration (particleSmootherInformationForm.m:98-362)
+      std::vector<long long> cnt(2 * W + 2, 0);
+      MT_TRY(rbpf_shard_smoother_begin(M.ctx[r], k));
+      for (int t = 0; t < T; ++t) {
+        if (t == 0) { MT_TRY(rbpf_shard_smoother_step(M.ctx[r])); continue; }
+        if (k > 0) MT_TRY(rbpf_shard_smoother_anc_weights(M.ctx[r]));     // local factorisations, before the gather that carries them
+        MT_TRY(gather_fwd(M, r));
+        MT_TRY(rbpf_shard_smoother_normalise(M.ctx[r], 1));
+        if (k > 0) MT_TRY(rbpf_shard_smoother_anc_sample(M.ctx[r], 0));
+        MT_TRY(rbpf_shard_plan(M.ctx[r], reinterpret_cast<int64_t*>(cnt.data())));
+        MT_TRY(exchange(M, r, cnt.data()));
+        MT_TRY(rbpf_shard_smoother_step(M.ctx[r]));
+      }
+      MT_TRY(gather_fwd(M, r));
+      MT_TRY(rbpf_shard_smoother_normalise(M.ctx[r], 0));
+      std::vector<double> xnk_r((size_t)nN * T, 0.0);
+      MT_TRY(rbpf_shard_smoother_end(M.ctx[r], (r == 0) ? xnk_scratch.data() : xnk_r.data(), xlk[r].data(), pk[r].data(), &ak[r], &owner[r]));
+      return RBPF_OK;
+    }));
+    if (XNK_k) std::memcpy(XNK_k, xnk_scratch.data(), (size_t)nN * T * sizeof(double));
+    if (out->XLK) { double* d = out->XLK + (size_t)k * n; std::memset(d, 0, (size_t)n * sizeof(double)); for (int r = 0; r < W; ++r) for (int q = 0; q < n; ++q) d[q] += xlk[r][q]; }
+    if (out->PK) { double* d = out->PK + (size_t)k * n * n; std::memset(d, 0, (size_t)n * n * sizeof(double)); for (int r = 0; r < W; ++r) for (size_t q = 0; q < (size_t)n * n; ++q) d[q] += pk[r][q]; }
+    if (out->trace_ak) out->trace_ak[k] = ak[0];
+    if (opt->on_step) {                                                     // makePlots(xnk,xlk,k,XNK,XLK,PK), particleSmoother.m:360-362
+      rbpf_view vw; vw.ctx = nullptr; vw.t = k; vw.is_smoother = 1;
+      if (opt->on_step(&vw, opt->on_step_user) != 0) { set_error("the on_step hook returned non-zero"); return RBPF_ERR_CALLBACK; }
+    }
+  }
+  return RBPF_OK;
+}
+
+}  // namespace rbpf

@@ -1207,6 +1207,7 @@ static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, 
 extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
                                       const rbpf_options* opt, int32_t N_K, int32_t info_form, rbpf_smoother_out* out) {
   if (!out || N_K < 1) { set_error("bad smoother arguments"); return RBPF_ERR_INVALID_ARG; }
+  if (wants_multi(opt)) return multi_particle_smoother(model, prob, rng, opt, N_K, info_form, out);   // sharded over several GPUs
   rbpf_ctx* c = nullptr;
   int st = ctx_create(model, prob, rng, opt, true, N_K, &c);
   if (st != RBPF_OK) return st;

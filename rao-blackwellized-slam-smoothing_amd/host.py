@@ -508,7 +508,8 @@ def _raise_callback_error(model, exc):
 # ------------------------------------------------------------------------------------------------
 def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, *, rng=None, trace=False,
-                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64", fix_p_mean=False):
+                   want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64", fix_p_mean=False, n_devices=0,
+                   device_ids=None):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended.
@@ -520,7 +521,10 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     evaluated on the host through `rbpf_callbacks`; resampling uniforms still come from `rng` (the normals of a ReplayRNG
     are not used: dynModel owns its randomness, as in the reference).
     makePlots is called after every step with the reference's nine arguments (particleFilter.m:215-217) through the
-    library's on_step hook."""
+    library's on_step hook.
+    n_devices = W > 1 (rbpf_options.n_devices): the library shards the N_P particles over W GPUs itself -- one host thread per
+    device, RCCL collectives -- and returns the reference's outputs without xn_traj (None); device_ids names the HIP devices
+    (a device named twice makes its ranks share it over a host-staged transport: tests on one GPU)."""
     model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
     generic = model is None
     if generic:
@@ -538,6 +542,23 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
                             lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
                             storage=_storage_code(storage))
     mdesc = model.descriptor()
+    multi = int(n_devices) > 1 or (int(n_devices) == 1 and device_ids is not None)
+    if multi:
+        if extras or makePlots is not None:
+            raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "n_devices: traces / final banks / makePlots are not available in the sharded filter")
+        ids = None
+        if device_ids is not None:
+            ids = (C.c_int32 * int(n_devices))(*[int(v) for v in device_ids])
+            opt.device_ids = C.cast(ids, C.POINTER(C.c_int32))
+        opt.n_devices = int(n_devices)
+        o = _ffi.rbpf_filter_out()
+        b = dict(traj_max=np.full((nN, T), np.nan, order="F"), traj_mean=np.full((nN, T), np.nan, order="F"), xl_max=np.empty(n),
+                 P_max=np.empty((n, n), order="F"), xl_mean=np.empty(n), P_mean=np.empty((n, n), order="F"),
+                 traj_sample_iwmax=np.empty((nN, T), order="F"), iw_max=np.zeros(1, dtype=np.int32))
+        for k, v in b.items():
+            setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
+        check(lib.rbpf_particle_filter(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(o)))
+        return (b["traj_max"], b["traj_mean"], b["xl_max"], b["xl_mean"], b["P_max"], b["P_mean"], b["traj_sample_iwmax"], None)
 
     def alloc_out(Tdone, full):
         o = _ffi.rbpf_filter_out()
@@ -653,7 +674,7 @@ def model_dyn_res_norm(dynModel):
 
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0):
+              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -674,6 +695,13 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
                             chol_variant=int(chol_variant), chol_refresh=int(chol_refresh))
+    if int(n_devices) > 1 or (int(n_devices) == 1 and device_ids is not None):
+        if extras:
+            raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "n_devices: traces are not gathered from the sharded smoother")
+        opt.n_devices = int(n_devices)
+        if device_ids is not None:
+            _ids = (C.c_int32 * int(n_devices))(*[int(v) for v in device_ids])
+            opt.device_ids = C.cast(_ids, C.POINTER(C.c_int32))
     mdesc = model.descriptor(use_dyn_res_norm=use_drn)
     o = _ffi.rbpf_smoother_out()
     b = dict(XNK=np.full((nN, T, N_K), np.nan, order="F"), XLK=np.full((n, N_K), np.nan, order="F"),
@@ -721,13 +749,14 @@ def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
-                                    chol_variant=0, lazy_depth=0, chol_refresh=0):
+                                    chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
     covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
     chol_refresh = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1 up/down-dates and
-    recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default)."""
+    recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default).
+    n_devices = W > 1: the particles of every iteration are sharded over W GPUs inside the library (rbpf_options.n_devices)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids)
 
 
 def sample(w, u):
