@@ -9,26 +9,15 @@ function [traj_max,traj_mean,xl_max,xl_mean,P_max,P_mean,traj_sample_iwmax,xn_tr
 % Random numbers.  Recognised families: drawn HERE with MATLAB's own rand / randn in the reference's interleaved order
 % (particleFilter.m:106-108: per slot one rand, then the randn's of dynModel), so rng(s,'twister') reproduces the reference
 % run.  Generic family: the resampling rand's of a step are drawn before that step's dynModel calls (the handle draws its
-% own randn's), i.e. the same distribution but not the reference's exact interleaving.
+% own randn's), i.e. the same distribution but not the reference's exact interleaving.  rbpf_options('rng_mode', 1) draws
+% vectorised, rbpf_options('rng_mode', 2, 'rng_seed', s) uses the device generator (rbpf_rngblock.m): no O(N_P*T) host loop.
 % UNTESTED under MATLAB here: no MATLAB in the build image (the MEX gateway is executed against a mex.h test double).
   if nargin < 12 || isempty(sparseFeatures), sparseFeatures = false; end     % quirk Q1 of the reference's nargin tests
   if nargin < 13, makePlots = []; end
   desc = rbpf_recognise(dynModel, measModel, [], logical(sparseFeatures));
   if desc.kind == 3, desc.nLand = size(y, 2); end
   N_T = size(y,1); nw = size(Q,1);
-  U = zeros(N_P, max(N_T-1,0));
-  if desc.kind == 4
-    U(:) = rand(size(U));
-    rngblk = struct('mode','replay','U',U);
-  else
-    Z = zeros(nw, N_P, max(N_T-1,0));
-    for t = 1:N_T-1
-      for i = 1:N_P
-        U(i,t) = rand; Z(:,i,t) = randn(nw,1);
-      end
-    end
-    rngblk = struct('mode','replay','U',U,'Z',Z);
-  end
+  rngblk = rbpf_rngblock(desc.kind, nw, N_P, N_T, 1, false);   % rbpf_options rng_mode: exact (default) / vectorised / device Philox
   [traj_max,traj_mean,xl_max,xl_mean,P_max,P_mean,traj_sample_iwmax,xn_traj] = ...
       rbpf_mex('filter', desc, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rngblk, makePlots);
 end

@@ -284,7 +284,7 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 // Options that change the schedule or the arithmetic, not the interface (include/rbpf.h `rbpf_options`): they cannot travel in
 // the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
 // matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
-struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0; double jitter = 0.0; };
+struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0; double jitter = 0.0, rng_seed = 0.0; };
 SessionOptions g_session;
 
 void session_field(const mxArray* s, const char* name, int& v) {
@@ -313,17 +313,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       session_field(prhs[1], "lazy_depth", o.lazy_depth); session_field(prhs[1], "chol_refresh", o.chol_refresh);
       session_field(prhs[1], "chol_variant", o.chol_variant); session_field(prhs[1], "storage", o.storage);
       session_field(prhs[1], "inplace", o.inplace); session_field(prhs[1], "fix_p_mean", o.fix_p_mean);
-      session_field(prhs[1], "n_devices", o.n_devices);
+      session_field(prhs[1], "n_devices", o.n_devices); session_field(prhs[1], "rng_mode", o.rng_mode);
+      if (const mxArray* f = mxGetField(prhs[1], 0, "rng_seed")) { if (!mxIsEmpty(f)) o.rng_seed = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
-      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
+      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
       g_session = o;
     }
-    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 8, names);
+    // rng_mode / rng_seed are consumed by the .m wrappers (matlab/rbpf_rngblock.m): 0 = MATLAB's stream in the reference's
+    // interleaved order (seed-exact), 1 = MATLAB's stream, vectorised draws, 2 = the device Philox generator keyed by rng_seed
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 10, names);
     const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
                            (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter,
-                           (double)g_session.n_devices};
-    for (int q = 0; q < 8; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+                           (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed};
+    for (int q = 0; q < 10; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
   } else if (cmd == "filter") {
     if (nrhs != 12 && nrhs != 13) mexErrMsgIdAndTxt("rbpf:usage", "filter expects 11 or 12 arguments after the command");
     rbpf_model m = model_from(prhs[1], nn, g, cb);

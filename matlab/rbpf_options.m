@@ -21,6 +21,9 @@ function o = rbpf_options(varargin)
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
 %   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
 %   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)
+%   rng_mode      0: MATLAB's rand / randn in the reference's interleaved order (seed-exact, interpreted loop); 1: MATLAB's
+%                 stream, vectorised draws; 2: the device Philox generator keyed by rng_seed (rbpf_rngblock.m)
+%   rng_seed      seed of the device generator (rng_mode 2)
 % UNTESTED under MATLAB here (no MATLAB in the build image); the gateway command is exercised by tests/test_gpu_mex_gateway.py.
   if nargin == 0, o = rbpf_mex('options'); return; end
   if nargin == 1 && ischar(varargin{1}) && strcmp(varargin{1}, 'reset'), o = rbpf_mex('options', struct()); return; end

@@ -6,21 +6,6 @@ function [XNK,XLK,PK] = rbpf_smoother_common(info_form, dynModel,measModel,dynRe
   desc = rbpf_recognise(dynModel, measModel, dynResNorm, logical(sparse));
   if desc.kind == 3, desc.nLand = size(y, 2); end
   N_T = size(y,1); nw = size(Q,1);
-  U = zeros(N_P, max(N_T-1,0), N_K); Ufin = zeros(N_K,1);
-  if desc.kind == 4
-    U(:) = rand(size(U)); Ufin(:) = rand(N_K,1);
-    rngblk = struct('mode','replay','U',U,'Ufin',Ufin);
-  else
-    Z = zeros(nw, N_P, max(N_T-1,0), N_K);
-    for k = 1:N_K
-      for t = 1:N_T-1
-        for i = 1:N_P-1, U(i,t,k) = rand; Z(:,i,t,k) = randn(nw,1); end
-        U(N_P,t,k) = rand;                              % particleSmoother.m:149 (k==1) / :241 (k>1)
-        if k == 1, Z(:,N_P,t,k) = randn(nw,1); end
-      end
-      Ufin(k) = rand;                                   % :346
-    end
-    rngblk = struct('mode','replay','U',U,'Z',Z,'Ufin',Ufin);
-  end
+  rngblk = rbpf_rngblock(desc.kind, nw, N_P, N_T, N_K, true);   % rbpf_options rng_mode: exact (default) / vectorised / device Philox
   [XNK,XLK,PK] = rbpf_mex('smoother', desc, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt, rngblk, info_form, makePlots);
 end

@@ -319,6 +319,23 @@ int main(int argc, char** argv) {
       report << "options_query " << mxGetScalar(mxGetField(cur, 0, "chol_refresh")) << "\n";
       mxDestroyArray(cur); mxDestroyArray(cmd); mxDestroyArray(so); mxDestroyArray(none);
     }
+    {   // 8. n_devices routes the next call to the in-library multi-device driver (rbpf_options.n_devices): on a one-GPU machine
+        //    the second device does not exist, which surfaces as a MATLAB error; on a multi-GPU machine the smoother runs sharded
+      const char* names[] = {"n_devices"};
+      mxArray* so = mxCreateStructMatrix(1, 1, 1, names);
+      mxSetField(so, 0, "n_devices", mxCreateDoubleScalar(2));
+      mxArray* cmd = mxCreateString("options");
+      mxArray* cur = gateway1({cmd, so});
+      report << "options_n_devices " << mxGetScalar(mxGetField(cur, 0, "n_devices")) << "\n";
+      mxDestroyArray(cur);
+      mxArray* desc = family_desc(); mxArray* rng = rng_block(true, true);
+      try { run_smoother("smoother_multi", desc, rng, 1, nullptr); report << "multi_route ran\n"; }
+      catch (const MatlabError& e) { report << "multi_route " << e.id << "\n"; }
+      mxDestroyArray(desc); mxDestroyArray(rng);
+      mxArray* none = mxCreateStructMatrix(1, 1, 0, nullptr);
+      cur = gateway1({cmd, none});
+      mxDestroyArray(cur); mxDestroyArray(cmd); mxDestroyArray(so); mxDestroyArray(none);
+    }
   } catch (const std::exception& e) {
     report << "DRIVER_FAILED " << e.what() << "\n";
     fprintf(stderr, "gateway_driver: %s\n", e.what());

@@ -72,7 +72,7 @@ def test_gateway_compiles_and_fails_loudly_without_a_device(rbpf, tmp_path):
     r = subprocess.run([exe, tmp, "--no-device"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     rep = report(tmp)
-    assert float(rep["version"]) == 6
+    assert float(rep["version"]) == 7
     assert rep["nodevice_error"].startswith("rbpf:status") and "no HIP device" in rep["nodevice_error"]
 
 
@@ -117,6 +117,9 @@ def test_gateway_matches_the_ctypes_path(rbpf, tmp_path, kind):
     assert rep["usage_error"] == "rbpf:usage"
     # ---- session options (rbpf_options.m): the carried-factor option reaches the library through the unchanged signature
     assert rep["options_set"] == "3 0" and rep["options_reset"] == "0" and rep["options_query"] == "0"
+    # rbpf_options('n_devices', 2): the call reaches the in-library multi-device driver (an error about the missing second GPU on
+    # a one-GPU box, a sharded run where two GPUs exist)
+    assert rep["options_n_devices"] == "2" and (rep["multi_route"] == "ran" or rep["multi_route"].startswith("rbpf:"))
     XNK, XLK, PK = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
                                                         c["Q"], R, N, N_K, c["dt"], rng=rngs, chol_refresh=3)
     for name, want in (("XNK", XNK), ("XLK", XLK), ("PK", PK)):
