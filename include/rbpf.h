@@ -196,8 +196,12 @@ typedef struct {
                           * up to K steps.  Use chol_refresh = 0 where near-singular Imat + ImatAddt are expected.                   */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
-                          * 0: min(N_local, max(1024, N_local / 8)).  A step that needs more fails on EVERY rank with         *
-                          * RBPF_ERR_OUT_OF_MEMORY before any collective is issued (the plan is replicated).                 */
+                          * > 0: a hard limit -- a step that needs more fails on EVERY rank with RBPF_ERR_OUT_OF_MEMORY before   *
+                          * any collective is issued (the plan is replicated).  0: start at min(N_local, max(256, N_local /    *
+                          * 16)) and GROW on demand: every rank reaches the same verdict from the replicated plan and enlarges *
+                          * its buffers by the same rule without communicating (rbpf_shard_views_get then returns the new      *
+                          * pointers / capacities; received records of the running lazy cycle are kept).  < 0: start at        *
+                          * |exchange_capacity| and grow likewise.                                                              */
   rbpf_on_step_fn on_step; /* NULL: no hook                                                       */
   void* on_step_user;
   int32_t n_devices;     /* rbpf_particle_filter / rbpf_particle_smoother(info_form = 1) only.  0 / 1 with device_ids == NULL: one  *

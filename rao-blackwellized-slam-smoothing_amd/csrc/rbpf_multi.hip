@@ -145,6 +145,7 @@ int exchange(Multi& M, int r, const long long* cnt) {
   long long ns = 0;
   for (int q = 0; q < W; ++q) ns += cnt[q];
   const long long recv_off = cnt[2 * W + 1];
+  MT_TRY(rbpf_shard_views_get(M.ctx[r], &M.v[r]));             // the plan may have grown the record buffers (exchange_capacity <= 0)
   MT_TRY(rbpf_shard_pack(M.ctx[r], nullptr, (int32_t)ns));
   if (r == 0) { M.migrated += cnt[2 * W]; }
   if (!M.host_staged) {

@@ -97,8 +97,10 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     // owner-computes placement a step moves the load imbalance only -- and one record per (destination, ancestor) pair,
     // however many children it has -- so the default is an eighth of the local particles (measured need at N_local = 4096: 1 %,
     // tools/sharded_rehearsal.py; at N_local = 32 768, nLin = 515, lazy_depth 4 the buffers then take 44 GB next to 139 GB of banks).
-    const size_t dflt = std::min(Nloc, std::max<size_t>(1024, Nloc / 8));
-    s->step_cap = o.exchange_capacity > 0 ? std::min<size_t>((size_t)o.exchange_capacity, Nloc * (size_t)(world - 1)) : dflt;
+    // (r03: the buffers grow on demand -- rbpf_shard_plan -- so the default starts at a sixteenth: four times the measured need.)
+    const size_t dflt = std::min(Nloc, std::max<size_t>(256, Nloc / 16));
+    const size_t asked = (size_t)(o.exchange_capacity > 0 ? o.exchange_capacity : -(long long)o.exchange_capacity);
+    s->step_cap = asked > 0 ? std::min<size_t>(asked, Nloc * (size_t)(world - 1)) : dflt;
     s->send_cap = s->step_cap;
     s->recv_cap = std::min(s->step_cap, Nloc) * (size_t)std::max(c->lazy_depth, 1);
   }
@@ -407,18 +409,52 @@ int rbpf_shard_plan(rbpf_ctx* c, int64_t* counts_host) {
   s->plan_recv = 0;
   for (int q = 0; q < s->world; ++q) s->plan_recv += (int)s->counts_pin[s->world + q];
   // Capacity verdict, identical on every rank: the plan and the buffer sizes are replicated, so every rank checks every
-  // rank's exchange BEFORE a collective is issued -- a step that does not fit is an error everywhere, not a hang.
+  // rank's exchange BEFORE a collective is issued -- a step that does not fit is an error everywhere, not a hang.  With an
+  // explicit exchange_capacity > 0 that is final (RBPF_ERR_OUT_OF_MEMORY on every rank); with the default (0) or a starting
+  // capacity (< 0) every rank GROWS its buffers by the same deterministic rule (the verdict and the old sizes are replicated, so
+  // no communication is needed) and the step goes on: a 3000-step run is not lost to one unusually skewed generation.
   if (s->world > 1) {
+    long long need_send = 0, need_hold = 0; int worst = -1;
     for (int q = 0; q < s->world; ++q) {
       const long long rcv = s->counts_pin[2 * s->world + 1 + q], snd = s->counts_pin[3 * s->world + 1 + q];
       const long long alive = (c->lazy_depth >= 2) ? s->rec_used_all[q] : 0;
-      if ((size_t)(alive + rcv) > s->recv_cap || (size_t)snd > s->send_cap) {
+      if ((size_t)(alive + rcv) > s->recv_cap || (size_t)snd > s->send_cap) worst = q;
+      need_send = std::max(need_send, snd); need_hold = std::max(need_hold, alive + rcv);
+    }
+    if (worst >= 0) {
+      if (c->opt.exchange_capacity > 0) {
+        const long long rcv = s->counts_pin[2 * s->world + 1 + worst], snd = s->counts_pin[3 * s->world + 1 + worst];
+        const long long alive = (c->lazy_depth >= 2) ? s->rec_used_all[worst] : 0;
         char buf[256];
         snprintf(buf, sizeof(buf), "exchange of step %d does not fit: rank %d would send %lld and hold %lld received records "
-                 "(capacity %zu / %zu); raise rbpf_options.exchange_capacity", c->t, q, snd, alive + rcv, s->send_cap, s->recv_cap);
+                 "(capacity %zu / %zu); raise rbpf_options.exchange_capacity", c->t, worst, snd, alive + rcv, s->send_cap, s->recv_cap);
         set_error(buf);
         return RBPF_ERR_OUT_OF_MEMORY;
       }
+      const size_t lz = (size_t)std::max(c->lazy_depth, 1);
+      size_t cap = std::max<size_t>(s->step_cap, 1);
+      while (cap < (size_t)need_send || std::min(cap, (size_t)s->Nloc) * lz < (size_t)need_hold) {
+        if (cap >= (size_t)s->Nloc * (size_t)(s->world - 1)) break;
+        cap *= 2;
+      }
+      cap = std::min(cap, (size_t)s->Nloc * (size_t)(s->world - 1));
+      const size_t new_send = cap, new_recv = std::max(std::min(cap, (size_t)s->Nloc) * lz, (size_t)need_hold);
+      double *ns = nullptr, *nr = nullptr; int* ni = nullptr;
+      int st = dmalloc(&ns, new_send * s->recsz);
+      if (st == RBPF_OK) st = dmalloc(&nr, new_recv * s->recsz);
+      if (st == RBPF_OK) st = dmalloc(&ni, new_send);
+      if (st != RBPF_OK) {
+        hipFree(ns); hipFree(nr); hipFree(ni);
+        set_error("exchange buffers could not be grown to " + std::to_string(new_send) + " / " + std::to_string(new_recv) + " records");
+        return RBPF_ERR_OUT_OF_MEMORY;
+      }
+      // records received earlier in this lazy cycle stay alive: they move to the new buffer
+      if (s->rec_used > 0) HIPCHK(hipMemcpyAsync(nr, s->recv_rec, (size_t)s->rec_used * s->recsz * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      hipFree(s->send_rec); hipFree(s->recv_rec); hipFree(s->pack_idx);
+      s->send_rec = ns; s->recv_rec = nr; s->pack_idx = ni;
+      s->step_cap = cap; s->send_cap = new_send; s->recv_cap = new_recv;
+      ++s->regrown;
     }
   }
   s->plan_ready = true;

@@ -239,6 +239,22 @@ class ShardedFilterSession:
     def _n_iter(self):
         return 1
 
+    def _refresh_views(self):
+        """rbpf_shard_plan may have grown the record buffers (rbpf_options.exchange_capacity <= 0): new pointers / capacities."""
+        v = rbpf_shard_views()
+        check(self.lib.rbpf_shard_views_get(self.ctx, C.byref(v)))
+        same = (C.cast(v.send_rec, C.c_void_p).value == C.cast(self.v.send_rec, C.c_void_p).value and
+                C.cast(v.recv_rec, C.c_void_p).value == C.cast(self.v.recv_rec, C.c_void_p).value and
+                int(v.recv_capacity) == int(self.v.recv_capacity))
+        if same:
+            return
+        self.v = v
+        self.stats["regrown"] = self.stats.get("regrown", 0) + 1
+        if self.world > 1 or self.force_collectives:
+            torch = self.torch
+            self.t_send = _view(torch, v.send_rec if v.send_capacity else None, (max(int(v.send_capacity), 1), int(v.record_doubles)), self.device)
+            self.t_recv = _view(torch, v.recv_rec if v.recv_capacity else None, (max(int(v.recv_capacity), 1), int(v.record_doubles)), self.device)
+
     def _create(self):
         check(self.lib.rbpf_shard_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),
                                          C.byref(self.opt), self.rank, self.world, C.byref(self.ctx)))
@@ -268,6 +284,8 @@ class ShardedFilterSession:
         for every rank from the replicated plan."""
         torch, dist = self.torch, self.dist
         send_counts, recv_counts = (rp.send_counts, rp.recv_counts) if isinstance(rp, RankPlan) else rp
+        if not isinstance(rp, RankPlan):
+            self._refresh_views()
         ns, nr = int(send_counts.sum()), int(recv_counts.sum())
         if recv_off + nr > self.v.recv_capacity or ns > self.v.send_capacity:
             raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"exchange of {ns}/{nr} records exceeds the buffer "

@@ -323,13 +323,14 @@ def _worker_skew(rank, world, port, n_local, cap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cap,fits", [(0, True), (8, False)])
+@pytest.mark.parametrize("cap,fits", [(0, True), (8, False), (-8, True)])
 def test_skewed_exchange_is_agreed_on_by_every_rank(cap, fits):
     """an exchange that does not fit a rank's record buffers must fail on EVERY rank before any collective is
     issued (the plan is replicated), never hang the peers in all_to_all.  All 64 children of a step descend from the 32
     particles of rank 0 (two each); the 32 children of the last 16 of them migrate, so 16 distinct records have to reach
     rank 1: fine with the default capacity, an error on both ranks -- also on rank 1, which only receives -- with
-    exchange_capacity = 8."""
+    exchange_capacity = 8 (a hard limit); with exchange_capacity = -8 (start at 8, grow on demand) both ranks enlarge their buffers
+    by the same rule from the replicated plan, the exchange goes through and the run continues."""
     n_local = 32
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
