@@ -89,27 +89,30 @@ __device__ inline v4d cs_elems(const CholArgs& a, int p, int i, int jb, int M, c
 // waves (owner = index % 4, register slot = index / 4: at most 12 tiles = 96 registers per wave), so every block
 // column's solves and every trailing update are spread over all waves whatever the column.
 __host__ __device__ constexpr int cs_tile_idx(int rt, int ct) { return ct * kCsMaxRT - ct * (ct - 1) / 2 + (rt - ct); }
+constexpr int kCsTiles = cs_tile_idx(kCsMaxRT - 1, kCsMaxRT - 1) + 1;        // 45
 constexpr int kCsSlots = (cs_tile_idx(kCsMaxRT - 1, kCsMaxRT - 1) + 4) / 4;
 
 // The whole factorisation as seen by wave WV (compile-time: its tile set is static, so every tile is a named register
 // set).  Returns through sl / vv this wave's share of sum(log(diag)) and v'v (per lane, to be reduced by the caller).
-template <int MODE, int WV>
+// NW: waves that share one particle (4: the workgroup kernel above; 1: one wave owns all 45 tiles -- 180 fp64 registers, no
+// other wave to wait for: the barriers below then involve this wave only).
+template <int MODE, int WV, int NW = 4>
 __device__ inline void cs_wave(const CholArgs& a, int p, int M, int RT, const double* rhs_s, const double* Hs, const double* RH,
                                double jit, int lane, double* NIs, double* Xs, int* sfail, double& sl, double& vv) {
   const int r = lane & 15, g = lane >> 4;
-  v4d T[kCsSlots];
+  v4d T[(kCsTiles + NW - 1) / NW];
 #pragma unroll
   for (int ct = 0; ct < kCsMaxRT; ++ct)
 #pragma unroll
     for (int rt = ct; rt < kCsMaxRT; ++rt)
-      if (cs_tile_idx(rt, ct) % 4 == WV && rt < RT)
-        T[cs_tile_idx(rt, ct) / 4] = cs_elems<MODE>(a, p, 16 * rt + r, 16 * ct + g, M, rhs_s, Hs, RH, jit);
+      if (cs_tile_idx(rt, ct) % NW == WV && rt < RT)
+        T[cs_tile_idx(rt, ct) / NW] = cs_elems<MODE>(a, p, 16 * rt + r, 16 * ct + g, M, rhs_s, Hs, RH, jit);
   const int rM = M & 15, tM = M >> 4;                                        // the right-hand-side row: row rM of row tile tM
 #pragma unroll
   for (int j = 0; j < kCsMaxRT; ++j) {
     if (j < RT) {                                                            // wave-uniform; barriers are reached by all waves
-      if (cs_tile_idx(j, j) % 4 == WV) {                                     // 1. diagonal tile (owner)
-        v4d V = -T[cs_tile_idx(j, j) / 4], NI;
+      if (cs_tile_idx(j, j) % NW == WV) {                                     // 1. diagonal tile (owner)
+        v4d V = -T[cs_tile_idx(j, j) / NW], NI;
         const bool bad = chol_diag_tile_frag(V, NI, M - 16 * j, lane);
         if (bad && lane == 0) *sfail = 1;
 #pragma unroll
@@ -126,8 +129,8 @@ __device__ inline void cs_wave(const CholArgs& a, int p, int M, int RT, const do
       for (int q = 0; q < 4; ++q) ni[q] = NIs[q * 64 + lane];
 #pragma unroll
       for (int rt = j + 1; rt < kCsMaxRT; ++rt) {
-        if (cs_tile_idx(rt, j) % 4 == WV && rt < RT) {
-          const v4d x = mfma4(ni, T[cs_tile_idx(rt, j) / 4], (v4d){0.0, 0.0, 0.0, 0.0});   // X' = inv(Ld) V' (ni = -inv, T = -V')
+        if (cs_tile_idx(rt, j) % NW == WV && rt < RT) {
+          const v4d x = mfma4(ni, T[cs_tile_idx(rt, j) / NW], (v4d){0.0, 0.0, 0.0, 0.0});   // X' = inv(Ld) V' (ni = -inv, T = -V')
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             Xs[(rt * 4 + q) * 64 + lane] = x[q];
@@ -140,11 +143,11 @@ __device__ inline void cs_wave(const CholArgs& a, int p, int M, int RT, const do
       for (int ct = j + 1; ct < kCsMaxRT; ++ct) {                            // 3. trailing update of the columns right of j
 #pragma unroll
         for (int rt = ct; rt < kCsMaxRT; ++rt) {
-          if (cs_tile_idx(rt, ct) % 4 == WV && rt < RT) {
+          if (cs_tile_idx(rt, ct) % NW == WV && rt < RT) {
             double xa[4], xb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { xa[q] = Xs[(ct * 4 + q) * 64 + lane]; xb[q] = Xs[(rt * 4 + q) * 64 + lane]; }
-            v4d& Z = T[cs_tile_idx(rt, ct) / 4];
+            v4d& Z = T[cs_tile_idx(rt, ct) / NW];
 #pragma unroll
             for (int q = 0; q < 4; ++q) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], xb[q], Z, 0, 0, 0);   // Z(rt,ct) += X(ct) X(rt)'
           }
@@ -212,16 +215,71 @@ __global__ __launch_bounds__(kCsThreads, 3) void chol_small_kernel(CholArgs a_in
   }
 }
 
+// Fewer waves per particle (VERDICT r02 item 5 asked for one): with NW = 1 the whole lower block triangle (45 tiles = 180 fp64
+// registers per lane, VGPRs + AGPRs at one wave per SIMD) belongs to one wave -- no workgroup barrier, four particles per CU
+// working independently -- but the loader keeps every element of the particle and of ImatAddt in flight on top of it and the
+// kernel spills (measured slower, see RBPF_CS_WAVES); NW = 2 fits 249 registers at two waves per SIMD (four particles per CU
+// instead of three, half the barrier participants) and is the default.  The same operations on every tile as chol_small_kernel (the tile
+// ownership changes, not the arithmetic; only the final sums of log(diag) and v'v are associated differently).
+template <int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 1 ? 1 : 2)) void chol_smallw_kernel(CholArgs a_in) {
+  extern __shared__ double csm[];
+  CholArgs a = a_in;
+  const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
+  if (MODE == 1) {
+    const int src = a.imat_anc ? a.imat_anc[p] : p;
+    const bool remote = a.rec != nullptr && src >= a.n_bank_local;
+    a.Imat = remote ? a.rec + (size_t)(src - a.n_bank_local) * a.rec_stride + a.rec_off_Imat
+                    : a.Imat + (size_t)src * a.imat_stride;
+    a.imat_stride = 0;
+  }
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int RT = (M + 1 + 15) >> 4;
+  double* NIs = csm;
+  double* Xs = NIs + 256;
+  double* red = Xs + kCsMaxRT * 256;
+  double* rhs_s = red + 16;
+  int* sfail = reinterpret_cast<int*>(rhs_s + M);
+  const bool pend = (MODE == 1 && a.Hb != nullptr);
+  double* Hs = (pend || MODE == 0) ? rhs_s + M + 2 : nullptr;
+  double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
+  chol_prologue(a, p, tid, 64 * NW, M, rhs_s, Hs, RH, pend);
+  if (tid == 0) *sfail = 0;
+  __syncthreads();
+  double sl = 0.0, vv = 0.0;
+  if (NW == 1 || wv == 0) cs_wave<MODE, 0, NW>(a, p, M, RT, rhs_s, Hs, RH, 0.0, lane, NIs, Xs, sfail, sl, vv);
+  else cs_wave<MODE, (NW > 1 ? 1 : 0), NW>(a, p, M, RT, rhs_s, Hs, RH, 0.0, lane, NIs, Xs, sfail, sl, vv);
+  __syncthreads();
+  const int failed = *sfail;
+  sl = wave_sum(sl); vv = wave_sum(vv);
+  if (lane == 0) { red[wv] = sl; red[8 + wv] = vv; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NW; ++w) { sl += red[w]; vv += red[8 + w]; }
+    if (!failed) a.pant_log[p] += -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
+    else { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
+  }
+}
+
 static size_t chol_small_lds_bytes(int M, int d) {
   return ((size_t)256 + kCsMaxRT * 256 + 16 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
 }
 
-static hipError_t launch_chol_small(const CholArgs& ca, int batch, int d_lds, hipStream_t st) {
+#ifndef RBPF_CS_WAVES
+#define RBPF_CS_WAVES 2         // waves per particle.  Measured r03 (16 384 matrices, n = 128; dense-radio smoother step at N_P = 65 536):
+                                // 4 waves 1.35 ms / 8.85 ms, 2 waves 1.24 ms / 8.52 ms, 1 wave 1.78 ms / 11.75 ms (180 fp64 tile
+                                // registers + every load of a particle in flight do not fit 512 registers: 274 spilled)
+#endif
+
+static hipError_t launch_chol_small(const CholArgs& ca, int batch, int d_lds, hipStream_t st, int waves = 0) {
   size_t lds = chol_small_lds_bytes(ca.Msz, d_lds);
   if (const char* pad = tuning_env("RBPF_CS_LDS_PAD")) lds += (size_t)atoi(pad) * 1024;   // tuning: fewer workgroups per CU
   // information form only: inlined fifteen times per wave, the covariance form's kron(I, R) / jitter variant of the loader
   // does not fit the registers (449 spilled), and its matrices are small problems anyway (they keep the 16-column kernel)
   if (ca.mode != 1) return hipErrorInvalidValue;
-  hipLaunchKernelGGL((chol_small_kernel<1>), dim3(batch), dim3(kCsThreads), lds, st, ca);
+  const int nw = waves ? waves : RBPF_CS_WAVES;
+  if (nw == 1) hipLaunchKernelGGL((chol_smallw_kernel<1, 1>), dim3(batch), dim3(64), lds, st, ca);
+  else if (nw == 2) hipLaunchKernelGGL((chol_smallw_kernel<1, 2>), dim3(batch), dim3(128), lds, st, ca);
+  else hipLaunchKernelGGL((chol_small_kernel<1>), dim3(batch), dim3(kCsThreads), lds, st, ca);
   return hipGetLastError();
 }

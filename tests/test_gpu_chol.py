@@ -144,10 +144,11 @@ def numpy_logw_info(S, e):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 16, 644])
+@pytest.mark.parametrize("variant", [1, 11, 12, 14, 16, 644])
 @pytest.mark.parametrize("M", [64, 65, 79, 80, 100, 127, 128, 129, 143])
 def test_information_form_factorisation_of_small_matrices(rbpf, M, variant):
-    """5..9 row tiles: the register-resident kernel (variant 1) against numpy and the two other kernels."""
+    """5..9 row tiles: the register-resident kernel (variant 1; 11 / 12 / 14 = one / two / four waves per matrix) against numpy
+    and the two other kernels."""
     S, e = spd_batch(33, M, seed=100 + M, scale_spread=1.0)
     got, status, _ = rbpf.chol_weights(S, e, variant=variant, info_form=True)
     assert status == 0
