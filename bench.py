@@ -249,7 +249,8 @@ def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed, **opts):
                                                     rng=pkg.PhiloxRNG(3), **opts)
     secs = time.perf_counter() - t0
     its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
-    return {"workload": f"slam-dense-mag N_P={N_share} (1/8 of N=65536) T={T} m={m} N_K={N_K} fp64, information form, complete run",
+    share = "1/8 of N=65536" if N_share == 8192 else f"{N_share / 65536:g} of N=65536: the largest power-of-two particle count whose smoother state fits one 288 GB GPU"
+    return {"workload": f"slam-dense-mag N_P={N_share} ({share}) T={T} m={m} N_K={N_K} fp64, information form, complete run",
             "options": opts, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
             "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
             "finite": bool(np.all(np.isfinite(XNK))),
@@ -405,6 +406,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother", action="store_true", help="skip every smoother leg")
     ap.add_argument("--no-smoother-full", action="store_true", help="skip the complete T=3000 smoother run of the per-GPU share (about a minute)")
+    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 16384, about 75 s)")
     ap.add_argument("--no-large", action="store_true", help="skip the extra filter configurations (configs[1], configs[4] share) and the N=65536 radio smoother")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
@@ -560,6 +562,16 @@ def main():
                     line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3, fresh factorisation every step"
                 if "seconds" in sm["share_full_carried_factors"]:
                     line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
+                if not args.no_smoother_largest:
+                    # the largest smoother one GPU holds: per particle 2 x 2.12 MB covariance banks + 2 x 2.12 MB Imat + 1.2 MB
+                    # factor workspace (+ 2 x 1.21 MB carried factors) = 10.3 (12.9) MB at nLin = 515 -> N_P = 16 384 needs
+                    # 169 (212) GB of the 288 GB; 32 768 would need 338 GB.  Complete run with the carried factors.
+                    sm["largest_single_gpu_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
+                                                                                                   lazy_depth=3, chol_refresh=32))
+                    if "seconds" in sm["largest_single_gpu_carried_factors"]:
+                        line["smoother_wall_clock_largest_single_gpu_s"] = sm["largest_single_gpu_carried_factors"]["seconds"]
+                        line["smoother_wall_clock_largest_single_gpu_workload"] = (sm["largest_single_gpu_carried_factors"]["workload"] +
+                                                                                   ", lazy_depth 3, chol_refresh 32")
             if not args.no_large:
                 sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
             line["smoother"] = sm
