@@ -168,7 +168,7 @@ __device__ inline void c64_strip_fast(const CholArgs& a, int p, int rt_s, int J,
   const size_t t0 = (size_t)16 * rt_s + (size_t)ld * (64 * J);               // wave-uniform
   const double* src = ((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
   const double* add = (MODE == 1) ? a.ImatAdd + t0 : nullptr;
-  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)blockIdx.x * a.n * a.n + t0 : nullptr;
+  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)p * a.n * a.n + t0 : nullptr;
   const double* hrow = Hs ? Hs + 16 * rt_s + r : nullptr;                    // Hs[aa * M + i]
   const double* rcol = RH ? RH + 64 * J + g : nullptr;                       // RH[aa * M + j]
 #pragma unroll
@@ -411,8 +411,17 @@ template <int MODE, int W>
 __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(CholArgs a_in) {
   constexpr int kThreads = W * 64, kNTMax = (W == 8) ? 4 : 2, kTilesPerPass = kNTMax * (W - 1);
   extern __shared__ double csm[];
+  // l_slots > 0 (r03 experiment, off in the product: see chol64_workspace_slots): PERSISTENT workgroups -- the grid has l_slots
+  // workgroups, each walks the particles blockIdx.x, blockIdx.x + gridDim.x, ... and keeps its factor in ONE workspace slot.
+  const int nslots = a_in.l_slots;
+  const int p_end = nslots > 0 ? a_in.batch : (int)blockIdx.x + 1, p_step = nslots > 0 ? (int)gridDim.x : 1;
+  for (int p = blockIdx.x; p < p_end; p += p_step) {
+  // a reused slot: the previous particle's factor may still sit in this CU's vector L1 (stores write through to the L2 but do not
+  // update lines other waves cached) -- drop it before the new factor is read back
+  if (nslots > 0 && p != (int)blockIdx.x) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  {
   CholArgs a = a_in;
-  const int p = blockIdx.x, tid = threadIdx.x, M = a.Msz;
+  const int tid = threadIdx.x, M = a.Msz;
   if (MODE == 1) {
     const int src = a.imat_anc ? a.imat_anc[p] : p;
     const bool remote = a.rec != nullptr && src >= a.n_bank_local;
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
   }
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices and operand bases in SGPRs
   const int RT = (M + 1 + 15) >> 4, KGS = 4 * RT;
-  double* Lt = a.Lbuf + (size_t)p * a.ldL;
+  double* Lt = a.Lbuf + (size_t)(nslots > 0 ? (int)blockIdx.x : p) * a.ldL;
   double* NLs = csm;                              // [4][4][64]  -inv(Ld_cc) as MFMA A fragments
   double* Lds = NLs + 1024;                       // [6][4][64]  Ld(c',c), c' > c, as MFMA A fragments
   double* Zd = csm;                               // [10][4][64] the diagonal block's tiles on their way to wave 0 — the same
@@ -539,13 +548,18 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
         else lw = -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
         a.pant_log[p] += lw;
       }
-      return;
+      goto next_particle;
     }
     if (MODE == 1 || attempt == 1) {
       if (tid == 0) { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
-      return;
+      goto next_particle;
     }
     jit = a.jitter;                                                         // particleSmoother.m:223
+  }
+  }
+next_particle:
+  if (nslots > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();                                 // the slot and the LDS state are free for the workgroup's next particle
   }
 }
 
@@ -562,7 +576,10 @@ static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, 
     if (e != hipSuccess) return e;
     attr = true;
   }
-  hipLaunchKernelGGL((chol_solve64_kernel<MODE, W>), dim3(batch), dim3(W * 64), lds, st, ca);
+  CholArgs cb = ca;
+  cb.batch = batch;
+  const int grid = (cb.l_slots > 0) ? std::min(batch, cb.l_slots) : batch;
+  hipLaunchKernelGGL((chol_solve64_kernel<MODE, W>), dim3(grid), dim3(W * 64), lds, st, cb);
   return hipGetLastError();
 }
 

@@ -266,6 +266,7 @@ struct CholArgs {
   double* pant_log;                 // += logwMeas
   int* status;
   int variant;                      // host side only: rbpf_options.chol_variant (0: kernel by matrix size)
+  int batch, l_slots;               // 64-column kernel: l_slots > 0 = persistent workgroups, Lbuf holds l_slots factor workspaces
 };
 
 // Blocked left-looking Cholesky on the fp64 matrix cores, one workgroup (16 waves) per particle.
@@ -387,7 +388,7 @@ __device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, i
       for (int q = 0; q < 4; ++q) v[q] += sacc[q];
     }
     if (a.ImatOut && i < M) {                                                // Imat(:,:,i) of the new generation
-      double* dst = a.ImatOut + (size_t)blockIdx.x * a.n * a.n;
+      double* dst = a.ImatOut + (size_t)p * a.n * a.n;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (j[q] < M) __builtin_nontemporal_store(v[q], &dst[(size_t)i + (size_t)a.n * j[q]]);
@@ -668,6 +669,26 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
   const char* vsm = tuning_env("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
   if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
   return launch_chol16(ca, batch, d_lds, st, w_env);
+}
+
+// Persistent mode of the 64-column kernel (rbpf_chol64.hpp, l_slots): one factor workspace per resident workgroup instead of one
+// per particle.  MEASURED AND NOT KEPT (r03): the idea was that 256 reused workspaces (294 MB at n = 515) would stay in the 256 MB
+// Infinity Cache, so that the factor's write + re-reads (4.1 of the 9.8 MB a particle moves) stop reaching HBM; in the smoother
+// (N_P = 8192, n = 515) the launch got SLOWER, 16.1 -> 19.8 ms (the cache does not keep them, and the persistent loop loses the
+// dispatcher's overlap of one workgroup's tail with the next one's prologue).  Compiled in only with -DRBPF_C64_PERSIST=1.
+#ifndef RBPF_C64_PERSIST
+#define RBPF_C64_PERSIST 0
+#endif
+static int chol64_workspace_slots(int M) {
+#if RBPF_C64_PERSIST
+  static int cus = 0;
+  if (!cus) { int dev = 0; hipGetDevice(&dev); if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256; }
+  const int RT = (M + 1 + 15) >> 4;
+  return cus * ((RT > 27) ? 1 : 2);
+#else
+  (void)M;
+  return 0;
+#endif
 }
 
 static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 1 + 15) / 16); return mp * mp; }
@@ -1185,6 +1206,9 @@ static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv, 
   ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
   s->imat_cur = ni;                 // after the launch the new bank is the current one
   s->imat_valid = true;
+  // nothing reads the factors of this launch afterwards unless they are carried on (chol_refresh): let the 64-column kernel
+  // run persistent workgroups over one workspace slot each (rbpf_chol64.hpp)
+  ca.l_slots = (s->refresh > 1) ? 0 : chol64_workspace_slots(n);
   return RBPF_OK;
 }
 
