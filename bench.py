@@ -292,7 +292,7 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, d["LL"], THETA_MAG)
     sess = mg.ShardedSmootherSession(model, d["dx"], d["y"], d["initState"], x0_lin, P0, Q, R, N_local, N_K, 0.01,
                                      rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth, chol_refresh=chol_refresh,
-                                     force_collectives=(world == 1))
+                                     force_collectives=(world == 1), storage="fp64sym" if m == 512 else "fp64")
     try:
         torch.cuda.synchronize()
         if dist is not None:
@@ -549,25 +549,28 @@ def main():
             sm = {"reference_size": guarded(smoother_reference_size, pkg, datagen),
                   "kernel_roofline": guarded(smoother_kernel_roofline, pkg),
                   "sweep_kernel_roofline": guarded(smoother_sweep_roofline, pkg)}
+            # the smoothers take the filter's storage option where it applies to them (symmetric covariance storage: nLin = 515)
+            sm_storage = args.storage if args.storage in ("fp64", "fp64sym") and args.m == 512 else "fp64"
             if not args.no_smoother_full:
                 # the reference's arithmetic (a fresh factorisation per particle and step, :228), covariances rewritten every
                 # third step -- and the same run with the ancestor-weight factors carried along the lineages (option
                 # chol_refresh: rank-1 up/down-dates, refactorised every 32nd step; ancestor probabilities within 1e-9 of the
                 # fresh factorisation's, tests/test_gpu_chol_carry.py)
-                sm["share_full"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3))
+                sm["share_full"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage))
                 sm["share_full_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3,
-                                                                                       chol_refresh=32))
+                                                                                       chol_refresh=32, storage=sm_storage))
                 if "seconds" in sm["share_full"]:
                     line["smoother_wall_clock_s"] = sm["share_full"]["seconds"]
                     line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3, fresh factorisation every step"
                 if "seconds" in sm["share_full_carried_factors"]:
                     line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
                 if not args.no_smoother_largest:
-                    # the largest smoother one GPU holds: per particle 2 x 2.12 MB covariance banks + 2 x 2.12 MB Imat + 1.2 MB
-                    # factor workspace (+ 2 x 1.21 MB carried factors) = 10.3 (12.9) MB at nLin = 515 -> N_P = 16 384 needs
-                    # 169 (212) GB of the 288 GB; 32 768 would need 338 GB.  Complete run with the carried factors.
+                    # the largest smoother one GPU holds: per particle 2 x 1.19 MB covariance banks (symmetric storage; 2 x 2.12
+                    # MB full), 2 x 2.12 MB Imat, 2.23 MB factorisation workspace (+ 2 x 1.21 MB carried factors + 0.4 MB refresh
+                    # scratch) = 8.9 (11.7) MB at nLin = 515 -> N_P = 16 384 needs 145 (191) GB of the 288 GB; 32 768 would need
+                    # 290 (383) GB.  Complete run with the carried factors.
                     sm["largest_single_gpu_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
-                                                                                                   lazy_depth=3, chol_refresh=32))
+                                                                                                   lazy_depth=3, chol_refresh=32, storage=sm_storage))
                     if "seconds" in sm["largest_single_gpu_carried_factors"]:
                         line["smoother_wall_clock_largest_single_gpu_s"] = sm["largest_single_gpu_carried_factors"]["seconds"]
                         line["smoother_wall_clock_largest_single_gpu_workload"] = (sm["largest_single_gpu_carried_factors"]["workload"] +

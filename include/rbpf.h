@@ -176,8 +176,8 @@ typedef struct {
                           * 515, i.e. 0.56 x the HBM traffic and memory of storage 0; read-only steps of lazy_depth apply the  *
                           * pending sets as P H' - KS (K' H') instead of element-wise.  Same algebra: results within 1e-9 of  *
                           * storage 0 (P(r,c) and P(c,r), which differ by rounding in the reference's plain form, are one     *
-                          * stored value).  Unsharded dense filter with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json        *
-                          * configs[2]); RBPF_ERR_UNSUPPORTED elsewhere.                                                        */
+                          * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]): filter *
+                          * and both smoothers, single-GPU and sharded; RBPF_ERR_UNSUPPORTED elsewhere.                         */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
                           * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 / 14 as *
                           * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */

@@ -228,8 +228,8 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->opt.storage == 2) {
     // symmetric storage (lower block triangle, rbpf_step_sym.hip): the filter of the ny = 3 dense families at the
     // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
-    if (smoother || sparse || !sym_supported(prob->n_lin, prob->n_y)) {
-      set_error("symmetric storage (options.storage = 2): dense filter (single-GPU or sharded) with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
+    if (sparse || !sym_supported(prob->n_lin, prob->n_y)) {
+      set_error("symmetric storage (options.storage = 2): dense filter / smoothers (single-GPU or sharded) with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
     }
     c->lay = make_layout_sym(prob->n_lin, prob->n_y);
     c->lay_low = c->lay;
@@ -367,7 +367,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
     if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
-    if (L.sym && step_sym_lds_bytes(c->mdl, c->lay, c->lazy_depth, 1) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    if (L.sym && step_sym_lds_bytes(c->mdl, c->lay, c->lazy_depth, 1, smoother ? 1 : 0) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
     for (int b = 0; b <= c->lazy_depth; ++b) {            // entry N of every bank stays zero (fresh lineages)
       RB_TRY(dmalloc(&c->Fb[b], (size_t)(N + 1) * 2 * d * L.ldx));
       HIPCHK(hipMemsetAsync(c->Fb[b], 0, (size_t)(N + 1) * 2 * d * L.ldx * sizeof(double), c->stream));

@@ -169,7 +169,7 @@ Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
 Layout make_layout_sym(int n, int d);            // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
 bool sym_supported(int n, int d);
-size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base);
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra = 0);   // extra = 1: information form
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s);
 // wave-level reduction primitives of the symmetric step kernel on their own (tests): in [4][64] -> out [4] lane sums
 hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s);

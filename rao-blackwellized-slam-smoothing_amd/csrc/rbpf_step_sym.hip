@@ -28,6 +28,7 @@ typedef double dbl2s __attribute__((ext_vector_type(2)));
 
 constexpr int kSymRows = 2;            // tile rows per wave (CH64 = 8: rows w and 7 - w)
 constexpr int kSymCH = 8;              // tile rows of the supported layout
+constexpr int kSymStage = 32;          // columns of pending column factors a wave keeps in LDS at a time (flush)
 
 bool sym_supported(int n, int d) {
   const int mc = (n / kChunkRows) * kChunkRows;
@@ -63,13 +64,13 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
   p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o; o += 64;
   p.off_red = o;  o += kWaves * 48;
-  p.off_kst = o;  o += kWaves * kSymChunk * nd_stage;
+  p.off_kst = o;  o += kWaves * kSymStage * nd_stage;
   p.total = o;
   return p;
 }
 
-size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base) {
-  return (size_t)sym_plan(lay.n, m.d, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0).total * sizeof(double);
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra) {
+  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0).total * sizeof(double);
 }
 
 // ---- wave-level reduction primitives ---------------------------------------------------------------------------------------
@@ -126,16 +127,16 @@ hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s
 // NACT active tile rows (the last NACT of the wave's rows); DIAG: the first active row's tile is the diagonal tile (row
 // contribution only).  src / dst: the tiles' base + 2 * lane.  Hc: H of the block's first column ([col][D], 16-byte aligned),
 // kst: the wave's stage of column factors [pair][ND][2] (flush only), colp: the wave's strip at the block's first column.
-template <int D, int NS, bool WR, int NACT, bool DIAG>
+template <int D, int DE, int NS, bool WR, int NACT, bool DIAG>
 __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], double* const (&dst)[kSymRows],
-                                          const double* __restrict__ Hc, const double* __restrict__ kst,
-                                          const double (&ks)[kSymRows][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][D],
-                                          double (&accr)[kSymRows][D], double* __restrict__ colp, int ldc, int lane) {
+                                          const double* __restrict__ Hc, const double* __restrict__ kst, int pbeg,
+                                          const double (&ks)[kSymRows][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
+                                          double (&accr)[kSymRows][DE], double* __restrict__ colp, int ldc, int lane) {
   constexpr int ND = NS * D, Q0 = kSymRows - NACT;
   constexpr int UP = 8 / NACT;                          // column pairs per round: 8 wave-wide 1 KB loads in flight
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
-  for (int p0 = 0; p0 < kSymChunk / 2; p0 += UP) {
+  for (int p0 = pbeg; p0 < pbeg + kSymStage / 2; p0 += UP) {       // the kSymStage columns whose pending factors are staged
     dbl2s v[UP][NACT];
 #pragma unroll
     for (int u = 0; u < UP; ++u)
@@ -143,31 +144,31 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
       for (int q = 0; q < NACT; ++q) v[u][q] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(p0 + u) * (2 * kSymChunk));
 #pragma unroll
     for (int hh = 0; hh < UP / PB; ++hh) {
-      double pc[PB][2][D];
+      double pc[PB][2][DE];
 #pragma unroll
       for (int uu = 0; uu < PB; ++uu) {
         const int u = hh * PB + uu, p = p0 + u;
-        double h0[D], h1[D];
+        double h0[DE], h1[DE];
         {
-          // the pair's 2 * D values of H sit contiguously
-          double hb[2 * D + 2];
+          // the pair's 2 * DE values of [H | ivec] sit contiguously
+          double hb[2 * DE + 2];
 #pragma unroll
-          for (int k2 = 0; k2 < (2 * D + 1) / 2; ++k2) {
-            const dbl2s t = *reinterpret_cast<const dbl2s*>(Hc + (size_t)p * 2 * D + 2 * k2);
+          for (int k2 = 0; k2 < (2 * DE + 1) / 2; ++k2) {
+            const dbl2s t = *reinterpret_cast<const dbl2s*>(Hc + (size_t)p * 2 * DE + 2 * k2);
             hb[2 * k2] = t.x; hb[2 * k2 + 1] = t.y;
           }
 #pragma unroll
-          for (int k = 0; k < D; ++k) { h0[k] = hb[k]; h1[k] = hb[D + k]; }
+          for (int k = 0; k < DE; ++k) { h0[k] = hb[k]; h1[k] = hb[DE + k]; }
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int k = 0; k < D; ++k) pc[uu][e][k] = 0.0;
+          for (int k = 0; k < DE; ++k) pc[uu][e][k] = 0.0;
         double kc0[ND > 0 ? ND : 1], kc1[ND > 0 ? ND : 1];
         if (WR) {
 #pragma unroll
           for (int k = 0; k < ND; ++k) {
-            const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)p * ND + k) * 2);
+            const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)(p % (kSymStage / 2)) * ND + k) * 2);
             kc0[k] = t.x; kc1[k] = t.y;
           }
         }
@@ -181,10 +182,10 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
             __builtin_nontemporal_store(o, reinterpret_cast<dbl2s*>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk)));
           }
 #pragma unroll
-          for (int k = 0; k < D; ++k) accr[Q0 + q][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][k]));
+          for (int k = 0; k < DE; ++k) accr[Q0 + q][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][k]));
           if (!(DIAG && q == 0)) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) { pc[uu][0][k] = fma(p0v, hown[Q0 + q][k], pc[uu][0][k]); pc[uu][1][k] = fma(p1v, hown[Q0 + q][k], pc[uu][1][k]); }
+            for (int k = 0; k < DE; ++k) { pc[uu][0][k] = fma(p0v, hown[Q0 + q][k], pc[uu][0][k]); pc[uu][1][k] = fma(p1v, hown[Q0 + q][k], pc[uu][1][k]); }
           }
         }
       }
@@ -195,7 +196,7 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #pragma unroll
         for (int g = 0; g < PB / 2; ++g)
 #pragma unroll
-          for (int k = 0; k < D; ++k) {
+          for (int k = 0; k < DE; ++k) {
             const double r = wave_sum4(pc[2 * g][0][k], pc[2 * g][1][k], pc[2 * g + 1][0][k], pc[2 * g + 1][1][k]);
             if ((lane & 15) == 0) colp[(size_t)k * ldc + 2 * (p0 + hh * PB + 2 * g) + coff] = r;
           }
@@ -204,10 +205,13 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
   }
 }
 
-template <int D, int NS, bool WR>
+// E = 1: information form (particleSmootherInformationForm.m:274-335): one more streamed right-hand side, P * ivec.  The
+// reference also needs P * ivecPlus with ivecPlus = ivec + H' R^-1 y (:292) -- that is P * ivec + (P H') (R^-1 y), formed from
+// the accumulated columns instead of streamed (same algebra; step_kernel<.., E = 2> streams both).
+template <int D, int NS, bool WR, int E>
 __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a) {
   extern __shared__ double smem[];
-  constexpr int ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
+  constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
@@ -216,10 +220,10 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[8] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SymPlan lp = sym_plan(n, D, ldx, M.ktot, WR ? ND : 0);
-  double* Hs = smem + lp.off_H + ((nb * D) & 1);              // H column c at Hs[c * D ..): core pairs 16-byte aligned
+  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0);
+  double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
   double* xls = smem + lp.off_xl;
-  double* PHt = smem + lp.off_PHt;                            // [D][ldx]
+  double* PHt = smem + lp.off_PHt;                            // [DE][ldx]
   double* tabS = smem + lp.off_tab;
   double* tabC = tabS + (M.ktot > 0 ? M.ktot : 1);
   double* misc = smem + lp.off_misc;
@@ -245,6 +249,18 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];
   for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
+  double Riy[D];                                               // R^-1 y (:292)
+  if (E > 0) {
+    const double* iv = remote ? recp + a.rec_off_I : a.ivec_old + (size_t)ancb * a.ivec_old_stride;
+    for (int c = tid; c < n; c += kThreads) Hs[c * DE + D] = iv[c];
+#pragma unroll
+    for (int aa = 0; aa < D; ++aa) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < D; ++bb) sacc = fma(M.Rinv[aa + D * bb], a.y[bb], sacc);
+      Riy[aa] = sacc;
+    }
+  }
   __syncthreads();
   // ---- B: per-axis sin / cos tables ----
   for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
@@ -259,18 +275,26 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       H_column<D>(M, c, tabS, tabC, &misc[8], h);
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) Hs[c * D + k] = h[k];
+    for (int k = 0; k < D; ++k) Hs[c * DE + k] = h[k];
+    if (E > 0) {
+      double sp = Hs[c * DE + D];                               // ivecPlus = ivec + dyi'/R*yt' (:292), the new information vector (:333)
+#pragma unroll
+      for (int k = 0; k < D; ++k) sp = fma(h[k], Riy[k], sp);
+#pragma unroll
+      for (int k = 0; k < D; ++k) a.Hb_new[((size_t)i * D + k) * ldx + c] = h[k];
+      a.ivec_new[(size_t)i * ldx + c] = sp;
+    }
   }
   __syncthreads();
 
   // ---- D: stream the stored tiles once ----
   const int rows[kSymRows] = {wave, kSymCH - 1 - wave};       // ascending
-  double accr[kSymRows][D], hown[kSymRows][D], ks[kSymRows][NDA];
+  double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSymRows][NDA];
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
     const int r = nb + rows[q] * kSymChunk + lane;
 #pragma unroll
-    for (int k = 0; k < D; ++k) { accr[q][k] = 0.0; hown[q][k] = Hs[r * D + k]; }
+    for (int k = 0; k < DE; ++k) { accr[q][k] = 0.0; hown[q][k] = Hs[r * DE + k]; }
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -286,45 +310,49 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
           for (int k = 0; k < D; ++k) pv = fma(-Fs[sset][(size_t)k * ldx + b], Fs[sset][(size_t)(D + k) * ldx + r], pv);
       }
 #pragma unroll
-      for (int k = 0; k < D; ++k) accr[q][k] = fma(pv, Hs[b * D + k], accr[q][k]);
+      for (int k = 0; k < DE; ++k) accr[q][k] = fma(pv, Hs[b * DE + k], accr[q][k]);
     }
   }
   if (WR) __syncthreads();                                     // every wave has read the old border block before any wave stores it
   {
     double* dT = a.Pt_new + (size_t)dslot * Ly.szT;
-    double* kst = smem + lp.off_kst + (size_t)wave * kSymChunk * ND;
-    double* colw = (wave == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, D, wave);
+    double* kst = smem + lp.off_kst + (size_t)wave * kSymStage * ND;
+    double* colw = (wave == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, wave);
     const int ldc = (wave == 0) ? ldx : sym_ld_col(wave);
-    const double* Hcore = Hs + (size_t)nb * D;
-    // column factors of block column J for the flush: lane = column, stage entry [pair][k][e]
+    const double* Hcore = Hs + (size_t)nb * DE;
+    // column factors K(c, .) of kSymStage columns of every pending set -> the wave's LDS stage [pair][k][e] (lane = column;
+    // wave-private: program order is the only synchronisation; the fetch latency is paid once per 32 columns and hidden by the
+    // other seven waves of the CU -- a register prefetch would cost 2 * ND registers across the whole stream loop)
     double kpre[NDA];
-    auto fetch = [&](int J) {
+    auto fetch = [&](int col0) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int k = 0; k < D; ++k) kpre[s * D + k] = Fs[s][(size_t)(D + k) * ldx + nb + J * kSymChunk + lane];
+        for (int k = 0; k < D; ++k) kpre[s * D + k] = Fs[s][(size_t)(D + k) * ldx + col0 + (lane & (kSymStage - 1))];
     };
     auto park = [&]() {
+      if (lane < kSymStage) {
 #pragma unroll
-      for (int k = 0; k < ND; ++k) kst[((size_t)(lane >> 1) * ND + k) * 2 + (lane & 1)] = kpre[k];
+        for (int k = 0; k < ND; ++k) kst[((size_t)(lane >> 1) * ND + k) * 2 + (lane & 1)] = kpre[k];
+      }
     };
     const int last = rows[kSymRows - 1];
     for (int J = 0; J <= last; ++J) {
-      // (a register prefetch of block J + 1 during block J costs 2 * ND registers across the whole stream loop and pushes the
-      // four-set flush into scratch; the fetch latency is paid once per 64 columns and hidden by the other seven waves of the CU)
-      if (WR && ND > 0) { fetch(J); park(); }
       const double* src[kSymRows]; double* dst[kSymRows];
 #pragma unroll
       for (int q = 0; q < kSymRows; ++q) {
         const size_t off = ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * lane;
         src[q] = srcT + off; dst[q] = dT + off;
       }
-      const double* Hc = Hcore + (size_t)J * kSymChunk * D;
+      const double* Hc = Hcore + (size_t)J * kSymChunk * DE;
       double* colp = colw + (size_t)J * kSymChunk;
-      if (J < rows[0]) sym_block<D, NS, WR, 2, false>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
-      else if (J == rows[0]) sym_block<D, NS, WR, 2, true>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
-      else if (J < last) sym_block<D, NS, WR, 1, false>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
-      else sym_block<D, NS, WR, 1, true>(src, dst, Hc, kst, ks, hown, accr, colp, ldc, lane);
+      for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
+        if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
+        if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+        else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+        else if (J < last) sym_block<D, DE, NS, WR, 1, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+        else sym_block<D, DE, NS, WR, 1, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+      }
     }
   }
   // border rows (row-major block B, all n columns): lanes walk columns, wave-reduce per row (as in step_kernel)
@@ -336,9 +364,9 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int k = 0; k < D; ++k) ksb[s * D + k] = WR ? Fs[s][(size_t)k * ldx + b] : 0.0;
-    double accb[D];
+    double accb[DE];
 #pragma unroll
-    for (int k = 0; k < D; ++k) accb[k] = 0.0;
+    for (int k = 0; k < DE; ++k) accb[k] = 0.0;
     for (int c = 2 * lane; c < ldb; c += 128) {
       const dbl2s vv = *reinterpret_cast<const dbl2s*>(src + c);
       double p[2] = {vv.x, vv.y};
@@ -353,13 +381,13 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
               for (int k = 0; k < D; ++k) p[e] = fma(-ksb[s * D + k], Fs[s][(size_t)(D + k) * ldx + cc], p[e]);
           }
 #pragma unroll
-          for (int k = 0; k < D; ++k) accb[k] = fma(p[e], Hs[cc * D + k], accb[k]);
+          for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], Hs[cc * DE + k], accb[k]);
         }
       }
       if (WR) { dbl2s o; o.x = p[0]; o.y = p[1]; *reinterpret_cast<dbl2s*>(dstb + c) = o; }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
+    for (int k = 0; k < DE; ++k) {
       const double s = wave_sum(accb[k]);
       if (lane == 0) PHt[(size_t)k * ldx + b] = s;
     }
@@ -369,39 +397,39 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
     const int rc = rows[q] * kSymChunk + lane;                // core coordinate
-    double s[D];
+    double s[DE];
 #pragma unroll
-    for (int k = 0; k < D; ++k) s[k] = accr[q][k];
+    for (int k = 0; k < DE; ++k) s[k] = accr[q][k];
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
       if (rows[q] < kSymCH - 1 - w) {                         // wave w holds off-diagonal tiles in this block column
-        const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, D, w);
+        const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, w);
         const int ldw = (w == 0) ? ldx : sym_ld_col(w);
 #pragma unroll
-        for (int k = 0; k < D; ++k) s[k] += cw[(size_t)k * ldw + rc];
+        for (int k = 0; k < DE; ++k) s[k] += cw[(size_t)k * ldw + rc];
       }
     }
 #pragma unroll
-    for (int k = 0; k < D; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
+    for (int k = 0; k < DE; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
   }
   __syncthreads();
   if (!WR && NS > 0) {
     // read-only step: PHt holds P_base * H'; subtract sum_s KS_s * (K_s' * H')
-    constexpr int NG = NS * D * D > 0 ? NS * D * D : 1;
+    constexpr int NG = NS * D * DE > 0 ? NS * D * DE : 1;
     double g[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) g[q] = 0.0;
     for (int c = tid; c < n; c += kThreads) {
-      double h[D];
+      double h[DE];
 #pragma unroll
-      for (int k = 0; k < D; ++k) h[k] = Hs[c * D + k];
+      for (int k = 0; k < DE; ++k) h[k] = Hs[c * DE + k];
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int k = 0; k < D; ++k) {
           const double kv = Fs[s][(size_t)(D + k) * ldx + c];
 #pragma unroll
-          for (int j = 0; j < D; ++j) g[(s * D + k) * D + j] = fma(kv, h[j], g[(s * D + k) * D + j]);
+          for (int j = 0; j < DE; ++j) g[(s * D + k) * DE + j] = fma(kv, h[j], g[(s * D + k) * DE + j]);
         }
     }
 #pragma unroll
@@ -417,25 +445,25 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       g[q] = s;
     }
     for (int r = tid; r < n; r += kThreads) {
-      double ph[D];
+      double ph[DE];
 #pragma unroll
-      for (int j = 0; j < D; ++j) ph[j] = PHt[(size_t)j * ldx + r];
+      for (int j = 0; j < DE; ++j) ph[j] = PHt[(size_t)j * ldx + r];
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
         for (int k = 0; k < D; ++k) {
           const double ksv = Fs[s][(size_t)k * ldx + r];
 #pragma unroll
-          for (int j = 0; j < D; ++j) ph[j] = fma(-ksv, g[(s * D + k) * D + j], ph[j]);
+          for (int j = 0; j < DE; ++j) ph[j] = fma(-ksv, g[(s * D + k) * DE + j], ph[j]);
         }
 #pragma unroll
-      for (int j = 0; j < D; ++j) PHt[(size_t)j * ldx + r] = ph[j];
+      for (int j = 0; j < DE; ++j) PHt[(size_t)j * ldx + r] = ph[j];
     }
     __syncthreads();
   }
 
   // ---- E: S = H (P H') + R, e = y - H xl   (particleFilter.m:139-150) ----
-  constexpr int NRED = D * D + D;
+  constexpr int NRED = D * D + D + 2 * E;
   {
     double part[NRED];
 #pragma unroll
@@ -443,7 +471,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     for (int r = tid; r < n; r += kThreads) {
       double h[D], ph[D];
 #pragma unroll
-      for (int k = 0; k < D; ++k) { h[k] = Hs[r * D + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
+      for (int k = 0; k < D; ++k) { h[k] = Hs[r * DE + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
       const double x = xls[r];
 #pragma unroll
       for (int bb = 0; bb < D; ++bb)
@@ -451,6 +479,15 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
         for (int aa = 0; aa < D; ++aa) part[aa + D * bb] = fma(h[aa], ph[bb], part[aa + D * bb]);
 #pragma unroll
       for (int aa = 0; aa < D; ++aa) part[D * D + aa] = fma(h[aa], x, part[D * D + aa]);
+      if (E > 0) {
+        // ivec' P ivec and ivecPlus' P ivecPlus (:301-303), P = the (downdated) prior covariance
+        const double iv = Hs[r * DE + D], piv = PHt[(size_t)D * ldx + r];
+        double ivp = iv, pivp = piv;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { ivp = fma(h[k], Riy[k], ivp); pivp = fma(ph[k], Riy[k], pivp); }
+        part[D * D + D] = fma(iv, piv, part[D * D + D]);
+        part[D * D + D + 1] = fma(ivp, pivp, part[D * D + D + 1]);
+      }
     }
 #pragma unroll
     for (int q = 0; q < NRED; ++q) {
@@ -490,9 +527,16 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       for (int q = 0; q < D * D; ++q) cS[q] = 0.0;
       for (int q = 0; q < D; ++q) cS[q + D * q] = 1.0;
     }
-    a.logw[i] = lw;
+    if (E == 0) a.logw[i] = lw;
     for (int q = 0; q < D * D; ++q) { misc[20 + q] = cS[q]; misc[30 + q] = SS[q]; }
     for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
+    if (E > 0) {
+      double qa = red[D * D + D], qb = red[D * D + D + 1];
+      for (int w = 1; w < kWaves; ++w) { qa += red[w * 48 + D * D + D]; qb += red[w * 48 + D * D + D + 1]; }
+      double sl2 = 0.0;
+      for (int q = 0; q < D; ++q) sl2 += log(cS[q + D * q]);
+      misc[44] = qa; misc[45] = qb; misc[46] = ok ? sl2 : nan("");
+    }
   }
   __syncthreads();
 
@@ -515,6 +559,9 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       if (a.fself_idx_new) a.fself_idx_new[i] = i;
     }
     double* xln = a.xl_new + (size_t)i * ldx;
+    double uK[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) uK[k] = 0.0;
     for (int r = tid; r < n; r += kThreads) {
       double ph[D], u[D], kk[D];
 #pragma unroll
@@ -533,40 +580,95 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
         KSn[(size_t)j * ldx + r] = s;
         Kn[(size_t)j * ldx + r] = kk[j];
       }
+      if (E > 0) {
+        double ivp = Hs[r * DE + D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) ivp = fma(Hs[r * DE + k], Riy[k], ivp);
+#pragma unroll
+        for (int k = 0; k < D; ++k) uK[k] = fma(ivp, kk[k], uK[k]);            // ivecPlus' * K
+      }
+    }
+    if (E > 0) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        const double s = wave_sum(uK[k]);
+        if (lane == 0) red[wave * 48 + k] = s;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double u[D];
+        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < kWaves; ++w) s += red[w * 48 + k]; u[k] = s; }
+        double corr = 0.0;                                                  // ivecPlus' * (K*SS*K') * ivecPlus
+        for (int bb = 0; bb < D; ++bb) {
+          double t = 0.0;
+          for (int aa = 0; aa < D; ++aa) t = fma(u[aa], SS[aa + D * bb], t);
+          corr = fma(t, u[bb], corr);
+        }
+        const double qa = misc[44], qbp = misc[45] - corr, sl = misc[46];
+        const double hld = remote ? recp[a.rec_off_hld] : a.hld_old[(size_t)ancb * a.hld_old_stride];
+        const double hldp = -sl + M.halfLogDetR + hld;                       // :298
+        double yRy = 0.0;
+        for (int bb = 0; bb < D; ++bb) {
+          double t = 0.0;
+          for (int aa = 0; aa < D; ++aa) t = fma(a.y[aa], M.Rinv[aa + D * bb], t);
+          yRy = fma(t, a.y[bb], yRy);
+        }
+        // :301-304   (1/2*log((2*pi)^ny*det(R)) = -logconst + halfLogDetR)
+        a.logw[i] = -0.5 * qa - hld + hldp + 0.5 * qbp - 0.5 * yRy - (-M.logconst + M.halfLogDetR);
+        a.hld_new[i] = hldp;
+        a.qf_new[i] = qbp;
+      }
     }
   }
 }
 
-template <int D, int NS, bool WR>
+template <int D, int NS, bool WR, int E>
 static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0);
-  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR>), dim3(a.N), dim3(kThreads), lds, s, a);
+  const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E);
+  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
-  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32 || a.info) return hipErrorInvalidValue;
+  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32) return hipErrorInvalidValue;
+  if (a.info) {                                            // information form: lazy_depth <= 3
+    if (a.write_base) {
+      switch (a.n_sets) {
+        case 0: return launch_sym_k<3, 0, true, 1>(a, s);
+        case 1: return launch_sym_k<3, 1, true, 1>(a, s);
+        case 2: return launch_sym_k<3, 2, true, 1>(a, s);
+        case 3: return launch_sym_k<3, 3, true, 1>(a, s);
+        default: return hipErrorInvalidValue;
+      }
+    }
+    switch (a.n_sets) {
+      case 1: return launch_sym_k<3, 1, false, 1>(a, s);
+      case 2: return launch_sym_k<3, 2, false, 1>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
   if (a.write_base) {
     switch (a.n_sets) {
-      case 0: return launch_sym_k<3, 0, true>(a, s);
-      case 1: return launch_sym_k<3, 1, true>(a, s);
-      case 2: return launch_sym_k<3, 2, true>(a, s);
-      case 3: return launch_sym_k<3, 3, true>(a, s);
-      case 4: return launch_sym_k<3, 4, true>(a, s);
+      case 0: return launch_sym_k<3, 0, true, 0>(a, s);
+      case 1: return launch_sym_k<3, 1, true, 0>(a, s);
+      case 2: return launch_sym_k<3, 2, true, 0>(a, s);
+      case 3: return launch_sym_k<3, 3, true, 0>(a, s);
+      case 4: return launch_sym_k<3, 4, true, 0>(a, s);
       default: return hipErrorInvalidValue;
     }
   }
   switch (a.n_sets) {
-    case 1: return launch_sym_k<3, 1, false>(a, s);
-    case 2: return launch_sym_k<3, 2, false>(a, s);
-    case 3: return launch_sym_k<3, 3, false>(a, s);
+    case 1: return launch_sym_k<3, 1, false, 0>(a, s);
+    case 2: return launch_sym_k<3, 2, false, 0>(a, s);
+    case 3: return launch_sym_k<3, 3, false, 0>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -674,7 +674,8 @@ def model_dyn_res_norm(dynModel):
 
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None):
+              sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None,
+              storage="fp64"):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -694,7 +695,7 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
         rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
-                            chol_variant=int(chol_variant), chol_refresh=int(chol_refresh))
+                            chol_variant=int(chol_variant), chol_refresh=int(chol_refresh), storage=_storage_code(storage))
     if int(n_devices) > 1 or (int(n_devices) == 1 and device_ids is not None):
         if extras:
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "n_devices: traces are not gathered from the sharded smoother")
@@ -741,22 +742,22 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
 
 
 def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
-                     sparseFeatures=False, makePlots=None, *, rng=None, extras=False, chol_variant=0):
+                     sparseFeatures=False, makePlots=None, *, rng=None, extras=False, chol_variant=0, storage="fp64"):
     """Mirror of src/particleSmoother.m:1-2 (covariance-form ancestor weights) -> (XNK, XLK, PK)."""
     return _smoother(False, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, storage=storage)
 
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
-                                    chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None):
+                                    chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None, storage="fp64"):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
     covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
     chol_refresh = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1 up/down-dates and
     recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default).
     n_devices = W > 1: the particles of every iteration are sharded over W GPUs inside the library (rbpf_options.n_devices)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids, storage)
 
 
 def sample(w, u):

@@ -515,7 +515,8 @@ class ShardedSmootherSession(ShardedFilterSession):
     particles bit for bit."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, N_K, dt, rng=None, rank=0, world=1,
-                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0, force_collectives=False):
+                 transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0, force_collectives=False,
+                 storage="fp64"):
         self.N_K = int(N_K)
         self.chol_refresh = int(chol_refresh)
         lib = load_library()
@@ -536,7 +537,7 @@ class ShardedSmootherSession(ShardedFilterSession):
             getattr(lib, name).argtypes = argt
         super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
                          transport=transport, planner="device", lazy_depth=lazy_depth, exchange_capacity=exchange_capacity,
-                         sync_phases=sync_phases, force_collectives=force_collectives)
+                         sync_phases=sync_phases, force_collectives=force_collectives, storage=storage)
         sv = rbpf_shard_smoother_views()
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
         self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)

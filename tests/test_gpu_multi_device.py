@@ -85,3 +85,17 @@ def test_multi_device_argument_errors(rbpf):
     with pytest.raises(rbpf.RBPFError):                                   # the covariance form is not sharded
         rbpf.host._smoother(False, mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, 8, 2,
                             0.01, False, None, rbpf.PhiloxRNG(1), False, n_devices=2, device_ids=[0, 0])
+
+
+@pytest.mark.parametrize("lazy_depth", [0, 3])
+def test_multi_device_smoother_on_symmetric_storage(rbpf, lazy_depth):
+    """The sharded information-form smoother with symmetric covariance storage (records carry the lower block triangle; the packer
+    applies pending sets over it) at nLin = 515, two ranks sharing the GPU, against the single-GPU smoother on full storage."""
+    d, mdl, x0, P0, R = _mag(rbpf, 8, 512)
+    N, N_K = 24, 2
+    args = (mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, N_K, 0.01)
+    ref = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(7))
+    out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(7), n_devices=2, device_ids=[0, 0], storage="fp64sym",
+                                               lazy_depth=lazy_depth)
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)

@@ -123,3 +123,48 @@ def test_symmetric_storage_is_rejected_where_it_is_not_implemented(rbpf):
     with pytest.raises(rbpf.RBPFError):
         rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 1.0,
                             rng=cases.device_rng(rbpf, c), storage="fp64sym")
+
+
+# ---- smoothers on symmetric storage (step_sym_kernel<.., E = 1>: P * ivec streamed, P * ivecPlus formed from the columns) ----------
+def _smooth(rbpf, c, info_form, **kw):
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    f = rbpf.particleSmootherInformationForm if info_form else rbpf.particleSmoother
+    return f(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["N_K"],
+             c["dt"], rng=cases.device_rng(rbpf, c), extras=True, **kw)
+
+
+@pytest.mark.parametrize("lazy_depth", [0, 2, 3])
+def test_information_form_smoother_on_symmetric_storage_matches_oracle(rbpf, lazy_depth):
+    """particleSmootherInformationForm.m:98-362 at nLin = 515 with the covariances in symmetric storage, N_K = 3, 8 steps (two lazy
+    cycles of depth 3): ancestors and trajectory draws bit-exact, weights / ancestor probabilities / XNK / XLK / PK to 1e-9."""
+    import test_gpu_smoother as ts
+    c = cases.mag_case(6, 8, 512, seed=37, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    out = _smooth(rbpf, c, True, storage="fp64sym", lazy_depth=lazy_depth)
+    ts.check(ref, out, 3)
+
+
+def test_covariance_form_smoother_on_symmetric_storage_matches_oracle(rbpf):
+    import test_gpu_smoother as ts
+    c = cases.mag_case(6, 5, 512, seed=39, N_K=2)
+    ref = cases.oracle_smoother(c, False)
+    out = _smooth(rbpf, c, False, storage="fp64sym")
+    ts.check(ref, out, 2)
+
+
+def test_carried_factors_on_symmetric_storage(rbpf):
+    """The bench's second smoother configuration (lazy_depth 3, chol_refresh) on symmetric storage at N_P = 2048, m = 512 against
+    the default arithmetic on full storage, same Philox streams: same ancestors and draws, paNt within 1e-9, outputs 1e-9."""
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T = 2048, 10
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(512, d["LL"], cases.THETA_MAG)
+    run = lambda **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
+                                                            x0, P0, cases.Q_MAG, R, N, 2, 0.01, rng=rbpf.PhiloxRNG(9), extras=True, **kw)
+    a = run()
+    b = run(lazy_depth=3, chol_refresh=4, storage="fp64sym")
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert np.max(np.abs(a[3]["paNt"][1, 1:] - b[3]["paNt"][1, 1:])) <= 1e-9
+    assert rel(b[3]["w"], a[3]["w"]) <= 1e-9
+    assert rel(b[0], a[0]) <= RTOL and rel(b[1], a[1]) <= RTOL and rel(b[2], a[2]) <= RTOL
