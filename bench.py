@@ -438,6 +438,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
+    # RCCL prints a version banner to STDOUT when its first communicator comes up; the contract is ONE JSON line on stdout, so the
+    # process's stdout (file descriptor 1) points at stderr until that line is printed
+    saved_stdout = None
+    if sharded:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(obj), flush=True)
     if sharded:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:
@@ -605,7 +618,7 @@ def main():
             if rank == 0:
                 line.update(done)
                 line["smoother_sharded_timeout"] = {"leg": name, "error": f"no result within {args.smoother_timeout} s"}
-                print(json.dumps(line), flush=True)
+                emit(line)
             sys.stdout.flush()
             os._exit(3)
 
@@ -650,7 +663,7 @@ def main():
             if "extrapolated_full_T_seconds" in res_c:
                 line["smoother_wall_clock_carried_factors_extrapolated_s"] = res_c["extrapolated_full_T_seconds"]
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -159,8 +159,9 @@ typedef struct {
                           * 1: accumulate it over the particles (the evident intent)            */
   int32_t lazy_depth;    /* filter and information-form smoother: C >= 2 keeps up to C pending rank-n_y downdates on the    *
                           * fly and rewrites the stored covariances every C-th step only (C-1 read-only steps in         *
-                          * between); 0/1: rewrite every step.  Results agree to rounding (same algebra).  max 4 (filter) *
-                          * / 3 (information form, also in the sharded smoother); ignored by the covariance-form smoother */
+                          * between); 0/1: rewrite every step.  Results agree to rounding (same algebra).  max 4 (filter; *
+                          * 8 on symmetric storage, storage = 2) / 3 (information form, also in the sharded smoother); ignored  *
+                          * by the covariance-form smoother                                                                  */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
   int32_t inplace;       /* filter with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
                           * every flush (the first child of a stored matrix overwrites it after its siblings    *

@@ -338,7 +338,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   // ---- particle banks ----
   // multi-step lazy update: the filter (up to kMaxSets pending sets) and the information-form smoother (up to 3: its step
   // kernel carries two more right-hand sides); the covariance-form smoother switches it off (smoother_run)
-  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (int)kMaxSets) : 1;
+  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (c->lay.sym ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     const bool can = !smoother && !ex && c->lazy_depth >= 2;

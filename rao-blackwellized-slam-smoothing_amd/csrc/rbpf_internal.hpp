@@ -18,10 +18,13 @@ inline const char* tuning_env(const char*) { return nullptr; }
 constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunkRows = 128;    // rows covered by one wave-wide 16-B-per-lane load
-constexpr int kPreInts = 12;        // per-workgroup descriptor written by propagate_kernel: slot, anc, ancb, base, set idx[4],
+constexpr int kPreInts = 16;        // per-workgroup descriptor written by propagate_kernel: slot, anc, ancb, base, destination slot
+                                    // of the stored matrix, flush phase, set idx[kMaxSets], 2 x pad   (r02 layout: set idx[4],
                                     // destination slot of the stored matrix, flush phase, 2 x pad
 constexpr int kPreDoubles = 17;    // ... and xn_new[8], Rnb[9]
-constexpr int kMaxSets = 4;        // pending rank-d factor sets the step kernel can apply on the fly
+constexpr int kPreSet0 = 6;        // first set index of the descriptor; [4] destination slot, [5] flush phase
+constexpr int kMaxSets = 8;        // pending rank-d factor sets a step kernel can carry (full storage: 4; symmetric storage: 8)
+constexpr int kMaxSetsFull = 4;    // ... of the full-square step kernel (rbpf_kernels.hip)
 
 // Model constants resident in kernel arguments (scalar registers).
 struct ModelDev {

@@ -455,10 +455,10 @@ __global__ void propagate_kernel(const StepArgs a) {
   for (int sset = 0; sset < kMaxSets; ++sset) {
     int v = ancb;
     if (sset < a.n_sets && a.fset[sset]) v = imported ? a.zero_set_idx : (a.fset_idx_old[sset] ? a.fset_idx_old[sset][tix] : ancb);
-    pi[4 + sset] = v;
+    pi[kPreSet0 + sset] = v;
   }
-  pi[8] = a.dst_slot ? a.dst_slot[i] : i;
-  pi[9] = a.phase_of ? a.phase_of[i] : 0;
+  pi[4] = a.dst_slot ? a.dst_slot[i] : i;
+  pi[5] = a.phase_of ? a.phase_of[i] : 0;
   double* pd = a.pre_d + (size_t)b * kPreDoubles;
 #pragma unroll
   for (int c = 0; c < 8; ++c) pd[c] = xp[c];
@@ -496,9 +496,9 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   // Infinity Cache; the order only permutes the schedule, slot i still reads / writes slot i's data.
   // propagate_kernel resolved the indirections of this workgroup into one descriptor.
   const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
-  if (WR && a.phase >= 0 && pre_i[9] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
+  if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
-  const int dslot = WR ? pre_i[8] : i;                         // bank entry the rewritten matrix goes to
+  const int dslot = WR ? pre_i[4] : i;                         // bank entry the rewritten matrix goes to
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const LdsPlan lp = lds_plan(n, D, E, NS, ldx, Ly.CS, mc, M.ktot, KB ? 1 : 0);
   double* HK = smem + lp.off_HK;        // per column c: H[0..D) | X[0..E) | Kcol of every pending set [NS][D] (not with KB)
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   for (int sset = 0; sset < NSA; ++sset) srcFs.p[sset] = nullptr;
 #pragma unroll
   for (int sset = 0; sset < NS; ++sset) {
-    if (a.fset[sset]) srcFs.p[sset] = a.fset[sset] + (size_t)pre_i[4 + sset] * 2 * D * ldx;
+    if (a.fset[sset]) srcFs.p[sset] = a.fset[sset] + (size_t)pre_i[kPreSet0 + sset] * 2 * D * ldx;
     else srcFs.p[sset] = remote ? recp + a.rec_off_F : a.F_old + (size_t)ancb * 2 * D * ldx;
   }
   const int nN = M.nN;
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
       if (!WR) {
 #pragma unroll
         for (int sset = 0; sset < NS; ++sset)
-          if (a.fset_idx_new[sset]) a.fset_idx_new[sset][i] = pre_i[4 + sset];
+          if (a.fset_idx_new[sset]) a.fset_idx_new[sset][i] = pre_i[kPreSet0 + sset];
       }
       if (a.fself_idx_new) a.fself_idx_new[i] = i;
     }

@@ -28,6 +28,7 @@ typedef double dbl2s __attribute__((ext_vector_type(2)));
 
 constexpr int kSymRows = 2;            // tile rows per wave (CH64 = 8: rows w and 7 - w)
 constexpr int kSymCH = 8;              // tile rows of the supported layout
+constexpr int kSymRed = 64;            // doubles per wave of the block-reduction scratch (up to 7 * 3 * 3 = 63 values)
 constexpr int kSymStage = 32;          // columns of pending column factors a wave keeps in LDS at a time (flush)
 
 bool sym_supported(int n, int d) {
@@ -63,7 +64,7 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
   for (int w = 1; w < kWaves; ++w) o += D * sym_ld_col(w);
   p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o; o += 64;
-  p.off_red = o;  o += kWaves * 48;
+  p.off_red = o;  o += kWaves * kSymRed;
   p.off_kst = o;  o += kWaves * kSymStage * nd_stage;
   p.total = o;
   return p;
@@ -127,12 +128,14 @@ hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s
 // NACT active tile rows (the last NACT of the wave's rows); DIAG: the first active row's tile is the diagonal tile (row
 // contribution only).  src / dst: the tiles' base + 2 * lane.  Hc: H of the block's first column ([col][D], 16-byte aligned),
 // kst: the wave's stage of column factors [pair][ND][2] (flush only), colp: the wave's strip at the block's first column.
-template <int D, int DE, int NS, bool WR, int NACT, bool DIAG>
+// Q0: index of the first active row in ks / hown / accr (default: the last NACT rows); ADD: the strip entries of these columns already
+// hold the other row's contribution of this block column (split flush) -- add to them.
+template <int D, int DE, int NS, bool WR, int NACT, bool DIAG, int Q0 = kSymRows - NACT, bool ADD = false, int KR = kSymRows>
 __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], double* const (&dst)[kSymRows],
                                           const double* __restrict__ Hc, const double* __restrict__ kst, int pbeg,
-                                          const double (&ks)[kSymRows][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
+                                          const double (&ks)[KR][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
                                           double (&accr)[kSymRows][DE], double* __restrict__ colp, int ldc, int lane) {
-  constexpr int ND = NS * D, Q0 = kSymRows - NACT;
+  constexpr int ND = NS * D;
   constexpr int UP = 8 / NACT;                          // column pairs per round: 8 wave-wide 1 KB loads in flight
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
@@ -164,8 +167,11 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int k = 0; k < DE; ++k) pc[uu][e][k] = 0.0;
-        double kc0[ND > 0 ? ND : 1], kc1[ND > 0 ? ND : 1];
-        if (WR) {
+        // pending column factors of the pair, at most kChunk values (four sets) live at a time: with more sets (split flush,
+        // NACT == 1) the next chunk is only read after the previous one was applied
+        constexpr int kChunk = 4 * D, NCH = (ND + kChunk - 1) / kChunk;
+        double kc0[kChunk], kc1[kChunk];
+        if (WR && NCH == 1) {
 #pragma unroll
           for (int k = 0; k < ND; ++k) {
             const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)(p % (kSymStage / 2)) * ND + k) * 2);
@@ -176,8 +182,27 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
         for (int q = 0; q < NACT; ++q) {
           double p0v = v[u][q].x, p1v = v[u][q].y;
           if (WR) {
+            if (NCH == 1) {
 #pragma unroll
-            for (int k = 0; k < ND; ++k) { p0v = fma(-ks[Q0 + q][k], kc0[k], p0v); p1v = fma(-ks[Q0 + q][k], kc1[k], p1v); }
+              for (int k = 0; k < ND; ++k) { p0v = fma(-ks[KR == 1 ? 0 : Q0 + q][k], kc0[k], p0v); p1v = fma(-ks[KR == 1 ? 0 : Q0 + q][k], kc1[k], p1v); }
+            } else {
+#pragma unroll
+              for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k) {
+                  if (ch * kChunk + k < ND) {
+                    const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)(p % (kSymStage / 2)) * ND + ch * kChunk + k) * 2);
+                    kc0[k] = t.x; kc1[k] = t.y;
+                  }
+                }
+#pragma unroll
+                for (int k = 0; k < kChunk; ++k)
+                  if (ch * kChunk + k < ND) {
+                    p0v = fma(-ks[KR == 1 ? 0 : Q0 + q][ch * kChunk + k], kc0[k], p0v); p1v = fma(-ks[KR == 1 ? 0 : Q0 + q][ch * kChunk + k], kc1[k], p1v);
+                  }
+                if (ch + 1 < NCH) __builtin_amdgcn_sched_barrier(0);
+              }
+            }
             dbl2s o; o.x = p0v; o.y = p1v;
             __builtin_nontemporal_store(o, reinterpret_cast<dbl2s*>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk)));
           }
@@ -198,7 +223,10 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #pragma unroll
           for (int k = 0; k < DE; ++k) {
             const double r = wave_sum4(pc[2 * g][0][k], pc[2 * g][1][k], pc[2 * g + 1][0][k], pc[2 * g + 1][1][k]);
-            if ((lane & 15) == 0) colp[(size_t)k * ldc + 2 * (p0 + hh * PB + 2 * g) + coff] = r;
+            if ((lane & 15) == 0) {
+              double* cp = &colp[(size_t)k * ldc + 2 * (p0 + hh * PB + 2 * g) + coff];
+              *cp = ADD ? *cp + r : r;
+            }
           }
       }
     }
@@ -212,13 +240,16 @@ template <int D, int NS, bool WR, int E>
 __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a) {
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
+  // more than four pending sets in a flush: the wave's two tile rows go through every block column one after the other, so that
+  // the row factors KS(r, .) of ONE row (NS * D registers) are live at a time
+  constexpr bool kSplit = WR && NS > 4;
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
   const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
-  if (WR && a.phase >= 0 && pre_i[9] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
+  if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
-  const int dslot = WR ? pre_i[8] : i;
+  const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0);
   double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   for (int s = 0; s < NSA; ++s) Fs[s] = nullptr;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    if (a.fset[s]) Fs[s] = a.fset[s] + (size_t)pre_i[4 + s] * 2 * D * ldx;
+    if (a.fset[s]) Fs[s] = a.fset[s] + (size_t)pre_i[kPreSet0 + s] * 2 * D * ldx;
     else Fs[s] = remote ? recp + a.rec_off_F : a.F_old + (size_t)ancb * 2 * D * ldx;
   }
 
@@ -289,7 +320,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 
   // ---- D: stream the stored tiles once ----
   const int rows[kSymRows] = {wave, kSymCH - 1 - wave};       // ascending
-  double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSymRows][NDA];
+  double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSplit ? 1 : kSymRows][NDA];
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
     const int r = nb + rows[q] * kSymChunk + lane;
@@ -298,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int k = 0; k < D; ++k) ks[q][s * D + k] = WR ? Fs[s][(size_t)k * ldx + r] : 0.0;
+      for (int k = 0; k < D; ++k) ks[kSplit ? 0 : q][s * D + k] = (WR && !kSplit) ? Fs[s][(size_t)k * ldx + r] : 0.0;
     // the border COLUMNS of this row, P(r, b) = B(b, r), downdated like the border phase does when this is a flush.  Read here,
     // before anything is stored: in the second launch of a single-bank flush the border phase overwrites these very values.
     for (int b = 0; b < nb; ++b) {
@@ -346,12 +377,36 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       }
       const double* Hc = Hcore + (size_t)J * kSymChunk * DE;
       double* colp = colw + (size_t)J * kSymChunk;
-      for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
-        if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
-        if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-        else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-        else if (J < last) sym_block<D, DE, NS, WR, 1, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-        else sym_block<D, DE, NS, WR, 1, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+      if constexpr (!kSplit) {
+        for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
+          if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
+          if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          else if (J < last) sym_block<D, DE, NS, WR, 1, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          else sym_block<D, DE, NS, WR, 1, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+        }
+      } else {
+        // row 1 (always active), then row 0 where it reaches this block column; row 0's column sums are added to row 1's
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[1] * kSymChunk + lane];
+        for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
+          fetch(nb + J * kSymChunk + 2 * pbeg); park();
+          if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          else sym_block<D, DE, NS, WR, 1, true, 1, false, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+        }
+        if (J <= rows[0]) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[0] * kSymChunk + lane];
+          for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
+            fetch(nb + J * kSymChunk + 2 * pbeg); park();
+            if (J < rows[0]) sym_block<D, DE, NS, WR, 1, false, 0, true, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+            else sym_block<D, DE, NS, WR, 1, true, 0, true, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          }
+        }
       }
     }
   }
@@ -435,13 +490,13 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       const double s = wave_sum(g[q]);
-      if (lane == 0) red[wave * 48 + q] = s;
+      if (lane == 0) red[wave * kSymRed + q] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       double s = red[q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + q];
       g[q] = s;
     }
     for (int r = tid; r < n; r += kThreads) {
@@ -492,7 +547,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
     for (int q = 0; q < NRED; ++q) {
       const double s = wave_sum(part[q]);
-      if (lane == 0) red[wave * 48 + q] = s;
+      if (lane == 0) red[wave * kSymRed + q] = s;
     }
   }
   __syncthreads();
@@ -500,12 +555,12 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     double SS[D * D], e[D], cS[D * D], v[D];
     for (int q = 0; q < D * D; ++q) {
       double s = red[q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + q];
       SS[q] = s + M.R[q];                                                   // particleFilter.m:141
     }
     for (int q = 0; q < D; ++q) {
       double s = red[D * D + q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * 48 + D * D + q];
+      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + D * D + q];
       e[q] = a.y[q] - s;                                                    // :140
     }
     bool ok = chol_lower_small<D>(SS, cS);                                  // :145
@@ -532,7 +587,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
     for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
     if (E > 0) {
       double qa = red[D * D + D], qb = red[D * D + D + 1];
-      for (int w = 1; w < kWaves; ++w) { qa += red[w * 48 + D * D + D]; qb += red[w * 48 + D * D + D + 1]; }
+      for (int w = 1; w < kWaves; ++w) { qa += red[w * kSymRed + D * D + D]; qb += red[w * kSymRed + D * D + D + 1]; }
       double sl2 = 0.0;
       for (int q = 0; q < D; ++q) sl2 += log(cS[q + D * q]);
       misc[44] = qa; misc[45] = qb; misc[46] = ok ? sl2 : nan("");
@@ -554,7 +609,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       if (!WR) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          if (a.fset_idx_new[s]) a.fset_idx_new[s][i] = pre_i[4 + s];
+          if (a.fset_idx_new[s]) a.fset_idx_new[s][i] = pre_i[kPreSet0 + s];
       }
       if (a.fself_idx_new) a.fself_idx_new[i] = i;
     }
@@ -593,12 +648,12 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 #pragma unroll
       for (int k = 0; k < D; ++k) {
         const double s = wave_sum(uK[k]);
-        if (lane == 0) red[wave * 48 + k] = s;
+        if (lane == 0) red[wave * kSymRed + k] = s;
       }
       __syncthreads();
       if (tid == 0) {
         double u[D];
-        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < kWaves; ++w) s += red[w * 48 + k]; u[k] = s; }
+        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + k]; u[k] = s; }
         double corr = 0.0;                                                  // ivecPlus' * (K*SS*K') * ivecPlus
         for (int bb = 0; bb < D; ++bb) {
           double t = 0.0;
@@ -662,6 +717,10 @@ hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
       case 2: return launch_sym_k<3, 2, true, 0>(a, s);
       case 3: return launch_sym_k<3, 3, true, 0>(a, s);
       case 4: return launch_sym_k<3, 4, true, 0>(a, s);
+      case 5: return launch_sym_k<3, 5, true, 0>(a, s);
+      case 6: return launch_sym_k<3, 6, true, 0>(a, s);
+      case 7: return launch_sym_k<3, 7, true, 0>(a, s);
+      case 8: return launch_sym_k<3, 8, true, 0>(a, s);
       default: return hipErrorInvalidValue;
     }
   }
@@ -669,6 +728,10 @@ hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
     case 1: return launch_sym_k<3, 1, false, 0>(a, s);
     case 2: return launch_sym_k<3, 2, false, 0>(a, s);
     case 3: return launch_sym_k<3, 3, false, 0>(a, s);
+    case 4: return launch_sym_k<3, 4, false, 0>(a, s);
+    case 5: return launch_sym_k<3, 5, false, 0>(a, s);
+    case 6: return launch_sym_k<3, 6, false, 0>(a, s);
+    case 7: return launch_sym_k<3, 7, false, 0>(a, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -41,12 +41,13 @@ def run_sym(rbpf, c, lazy_depth, inplace, storage="fp64sym"):
                                rng=cases.device_rng(rbpf, c), extras=True, lazy_depth=lazy_depth, inplace=inplace, storage=storage)
 
 
-@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, -1), (3, 1), (4, -1), (4, 1)])
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, -1), (3, 1), (4, -1), (4, 1), (5, -1), (6, 1), (8, -1), (8, 1)])
 def test_symmetric_storage_filter_matches_oracle(rbpf, lazy_depth, inplace):
     """slam-dense-mag m = 512 (nLin = 515), 13 steps: every variant of step_sym_kernel -- t = 0 (no pending set), rewrite every
     step (lazy 0), read-only steps with 1..3 sets (epilogue correction P H' - KS (K' H')) and flushes with 2..4 sets, ping-pong
-    banks and the single bank rewritten in place -- against the numpy oracle."""
-    c = cases.mag_case(8, 13, 512, seed=61)
+    banks and the single bank rewritten in place -- against the numpy oracle.  lazy_depth 5 .. 8 (symmetric storage only): read-only
+    steps with up to 7 pending sets, flushes with up to 8 (the two tile rows of a wave one after the other: split flush)."""
+    c = cases.mag_case(8, 19 if lazy_depth > 4 else 13, 512, seed=61)
     ref = cases.oracle_filter(c)
     out = run_sym(rbpf, c, lazy_depth, inplace)
     check_filter(ref, out)
@@ -65,7 +66,7 @@ def test_symmetric_storage_against_the_c_restatement(rbpf, tmp_path_factory):
     lib = oracle_c.build(native_dir=str(tmp_path_factory.mktemp("oracle_native_sym")))
     ref, _ = oracle_c.particle_filter(rbpf, mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng,
                                       n_threads=bench.usable_cores(), want_full=True, lib_path=lib)
-    for lazy_depth, inplace in ((4, 1), (4, -1)):
+    for lazy_depth, inplace in ((4, 1), (4, -1), (8, 1), (6, -1)):
         out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
                                   extras=True, lazy_depth=lazy_depth, inplace=inplace, storage="fp64sym")
         ex = out[8]
