@@ -229,7 +229,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     // symmetric storage (lower block triangle, rbpf_step_sym.hip): the filter of the ny = 3 dense families at the
     // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
     if (sparse || !sym_supported(prob->n_lin, prob->n_y)) {
-      set_error("symmetric storage (options.storage = 2): dense filter / smoothers (single-GPU or sharded) with ny = 3 and 515 <= nLin <= 639 only"); return RBPF_ERR_UNSUPPORTED;
+      set_error("symmetric storage (options.storage = 2): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639 only"); return RBPF_ERR_UNSUPPORTED;
     }
     c->lay = make_layout_sym(prob->n_lin, prob->n_y);
     c->lay_low = c->lay;
@@ -338,7 +338,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   // ---- particle banks ----
   // multi-step lazy update: the filter (up to kMaxSets pending sets) and the information-form smoother (up to 3: its step
   // kernel carries two more right-hand sides); the covariance-form smoother switches it off (smoother_run)
-  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : (c->lay.sym ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
+  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : ((c->lay.sym && c->lay.CH64 == 8) ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     const bool can = !smoother && !ex && c->lazy_depth >= 2;

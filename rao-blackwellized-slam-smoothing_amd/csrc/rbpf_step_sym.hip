@@ -26,14 +26,16 @@ namespace rbpf {
 
 typedef double dbl2s __attribute__((ext_vector_type(2)));
 
-constexpr int kSymRows = 2;            // tile rows per wave (CH64 = 8: rows w and 7 - w)
-constexpr int kSymCH = 8;              // tile rows of the supported layout
+constexpr int kSymRows = 2;            // tile rows per wave: rows rp and CH - 1 - rp (CH + 1 tiles whatever rp: balanced)
+// CH = 8 tile rows (nLin = 515): wave w owns the row pair rp = w and every column pair.  CH = 4 (nLin = 259): two waves share a row
+// pair (rp = w & 1) and split its column pairs by parity (column phase cp = w >> 1): their row sums are added after the stream, their
+// column sums go to disjoint columns of one strip.
 constexpr int kSymRed = 64;            // doubles per wave of the block-reduction scratch (up to 7 * 3 * 3 = 63 values)
 constexpr int kSymStage = 32;          // columns of pending column factors a wave keeps in LDS at a time (flush)
 
 bool sym_supported(int n, int d) {
   const int mc = (n / kChunkRows) * kChunkRows;
-  return d == 3 && mc / kSymChunk == kSymCH;
+  return d == 3 && (mc / kSymChunk == 8 || mc / kSymChunk == 4);
 }
 
 Layout make_layout_sym(int n, int d) {
@@ -44,24 +46,25 @@ Layout make_layout_sym(int n, int d) {
   return L;
 }
 
-// LDS plan (doubles).  Column strips: wave w > 0 keeps its column contributions for core columns [0, 64 (7 - w)); wave 0's
-// go straight into PHt.
-struct SymPlan { int off_H, off_xl, off_PHt, off_col1, off_tab, off_misc, off_red, off_kst, total; };
-// strip of wave w (w >= 1): D x ld_col(w) doubles at off_col1 + D * 64 * sum_{v=1}^{w-1} (7 - v)   (closed forms: no indexed
-// arrays, which would live in scratch memory)
-__host__ __device__ inline int sym_ld_col(int w) { return kSymChunk * (kSymCH - 1 - w); }
-__host__ __device__ inline int sym_off_col(int off_col1, int D, int w) { return off_col1 + D * kSymChunk * ((w - 1) * (kSymCH - 1) - (w - 1) * w / 2); }
+// LDS plan (doubles).  Column strips: row pair rp > 0 keeps its column contributions for core columns [0, 64 (CH - 1 - rp)); row
+// pair 0's go straight into PHt.  off_row: the row sums of the second column phase (CH = 4 only).
+struct SymPlan { int off_H, off_xl, off_PHt, off_col1, off_row, off_tab, off_misc, off_red, off_kst, total; };
+// strip of row pair rp (rp >= 1): D x ld_col(rp) doubles at off_col1 + D * 64 * sum_{v=1}^{rp-1} (CH - 1 - v)   (closed forms: no
+// indexed arrays, which would live in scratch memory)
+__host__ __device__ inline int sym_ld_col(int ch, int rp) { return kSymChunk * (ch - 1 - rp); }
+__host__ __device__ inline int sym_off_col(int off_col1, int D, int ch, int rp) { return off_col1 + D * kSymChunk * ((rp - 1) * (ch - 1) - (rp - 1) * rp / 2); }
 
 __host__ __device__ inline int sym_even(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage) {
+__host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage, int ch) {
   SymPlan p;
   int o = 0;
   p.off_H = o;   o += sym_even(n * D + 2);           // + pad so that the first core column pair is 16-byte aligned
   p.off_xl = o;  o += ldx;
   p.off_PHt = o; o += D * ldx;
   p.off_col1 = o;
-  for (int w = 1; w < kWaves; ++w) o += D * sym_ld_col(w);
+  for (int rp = 1; rp < ch / 2; ++rp) o += D * sym_ld_col(ch, rp);
+  p.off_row = o;  o += (ch == 4) ? D * ch * kSymChunk : 0;
   p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o; o += 64;
   p.off_red = o;  o += kWaves * kSymRed;
@@ -71,7 +74,7 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
 }
 
 size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra) {
-  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0).total * sizeof(double);
+  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, lay.CH64).total * sizeof(double);
 }
 
 // ---- wave-level reduction primitives ---------------------------------------------------------------------------------------
@@ -130,27 +133,28 @@ hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s
 // kst: the wave's stage of column factors [pair][ND][2] (flush only), colp: the wave's strip at the block's first column.
 // Q0: index of the first active row in ks / hown / accr (default: the last NACT rows); ADD: the strip entries of these columns already
 // hold the other row's contribution of this block column (split flush) -- add to them.
-template <int D, int DE, int NS, bool WR, int NACT, bool DIAG, int Q0 = kSymRows - NACT, bool ADD = false, int KR = kSymRows>
+// NPH column phases: this wave takes the pairs pbeg + cp, pbeg + cp + NPH, ... of the stage.
+template <int D, int DE, int NS, bool WR, int NACT, bool DIAG, int Q0 = kSymRows - NACT, bool ADD = false, int KR = kSymRows, int NPH = 1>
 __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], double* const (&dst)[kSymRows],
-                                          const double* __restrict__ Hc, const double* __restrict__ kst, int pbeg,
+                                          const double* __restrict__ Hc, const double* __restrict__ kst, int pbeg, int cp,
                                           const double (&ks)[KR][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
                                           double (&accr)[kSymRows][DE], double* __restrict__ colp, int ldc, int lane) {
   constexpr int ND = NS * D;
   constexpr int UP = 8 / NACT;                          // column pairs per round: 8 wave-wide 1 KB loads in flight
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
-  for (int p0 = pbeg; p0 < pbeg + kSymStage / 2; p0 += UP) {       // the kSymStage columns whose pending factors are staged
+  for (int p0 = pbeg + cp; p0 < pbeg + kSymStage / 2; p0 += UP * NPH) {   // the kSymStage columns whose pending factors are staged
     dbl2s v[UP][NACT];
 #pragma unroll
     for (int u = 0; u < UP; ++u)
 #pragma unroll
-      for (int q = 0; q < NACT; ++q) v[u][q] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(p0 + u) * (2 * kSymChunk));
+      for (int q = 0; q < NACT; ++q) v[u][q] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(p0 + u * NPH) * (2 * kSymChunk));
 #pragma unroll
     for (int hh = 0; hh < UP / PB; ++hh) {
       double pc[PB][2][DE];
 #pragma unroll
       for (int uu = 0; uu < PB; ++uu) {
-        const int u = hh * PB + uu, p = p0 + u;
+        const int u = hh * PB + uu, p = p0 + u * NPH;
         double h0[DE], h1[DE];
         {
           // the pair's 2 * DE values of [H | ivec] sit contiguously
@@ -215,17 +219,17 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
         }
       }
       if (kCol) {
-        // four values per register: columns 2p, 2p+1, 2p+2, 2p+3 of one output k; row rho of the wave ends up with column
-        // offset (rho & 1) * 2 + (rho >> 1)
-        const int rho = lane >> 4, coff = (rho & 1) * 2 + (rho >> 1);
+        // four values per register: the two columns of two pairs of one output k; row rho of the wave ends up with value
+        // (rho & 1) * 2 + (rho >> 1), i.e. pair (rho & 1), column rho >> 1 of it
+        const int rho = lane >> 4;
 #pragma unroll
         for (int g = 0; g < PB / 2; ++g)
 #pragma unroll
           for (int k = 0; k < DE; ++k) {
             const double r = wave_sum4(pc[2 * g][0][k], pc[2 * g][1][k], pc[2 * g + 1][0][k], pc[2 * g + 1][1][k]);
             if ((lane & 15) == 0) {
-              double* cp = &colp[(size_t)k * ldc + 2 * (p0 + hh * PB + 2 * g) + coff];
-              *cp = ADD ? *cp + r : r;
+              double* cq = &colp[(size_t)k * ldc + 2 * (p0 + (hh * PB + 2 * g + (rho & 1)) * NPH) + (rho >> 1)];
+              *cq = ADD ? *cq + r : r;
             }
           }
       }
@@ -236,8 +240,9 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 // E = 1: information form (particleSmootherInformationForm.m:274-335): one more streamed right-hand side, P * ivec.  The
 // reference also needs P * ivecPlus with ivecPlus = ivec + H' R^-1 y (:292) -- that is P * ivec + (P H') (R^-1 y), formed from
 // the accumulated columns instead of streamed (same algebra; step_kernel<.., E = 2> streams both).
-template <int D, int NS, bool WR, int E>
+template <int D, int NS, bool WR, int E, int CH>
 __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a) {
+  constexpr int NPH = (CH == 8) ? 1 : 2;                       // column phases (waves per row pair)
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
   // more than four pending sets in a flush: the wave's two tile rows go through every block column one after the other, so that
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0);
+  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH);
   double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;                            // [DE][ldx]
@@ -319,7 +324,8 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   __syncthreads();
 
   // ---- D: stream the stored tiles once ----
-  const int rows[kSymRows] = {wave, kSymCH - 1 - wave};       // ascending
+  const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
+  const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
   double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSplit ? 1 : kSymRows][NDA];
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       for (int k = 0; k < D; ++k) ks[kSplit ? 0 : q][s * D + k] = (WR && !kSplit) ? Fs[s][(size_t)k * ldx + r] : 0.0;
     // the border COLUMNS of this row, P(r, b) = B(b, r), downdated like the border phase does when this is a flush.  Read here,
     // before anything is stored: in the second launch of a single-bank flush the border phase overwrites these very values.
-    for (int b = 0; b < nb; ++b) {
+    for (int b = 0; b < nb && cp == 0; ++b) {                  // (once per row: the first column phase)
       double pv = srcB[(size_t)b * ldb + r];
       if (WR) {
 #pragma unroll
@@ -348,8 +354,8 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   {
     double* dT = a.Pt_new + (size_t)dslot * Ly.szT;
     double* kst = smem + lp.off_kst + (size_t)wave * kSymStage * ND;
-    double* colw = (wave == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, wave);
-    const int ldc = (wave == 0) ? ldx : sym_ld_col(wave);
+    double* colw = (rp == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, CH, rp);
+    const int ldc = (rp == 0) ? ldx : sym_ld_col(CH, rp);
     const double* Hcore = Hs + (size_t)nb * DE;
     // column factors K(c, .) of kSymStage columns of every pending set -> the wave's LDS stage [pair][k][e] (lane = column;
     // wave-private: program order is the only synchronisation; the fetch latency is paid once per 32 columns and hidden by the
@@ -380,10 +386,10 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       if constexpr (!kSplit) {
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
-          if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-          else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-          else if (J < last) sym_block<D, DE, NS, WR, 1, false>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-          else sym_block<D, DE, NS, WR, 1, true>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else sym_block<D, DE, NS, WR, 1, true, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
         }
       } else {
         // row 1 (always active), then row 0 where it reaches this block column; row 0's column sums are added to row 1's
@@ -393,8 +399,8 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
           for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[1] * kSymChunk + lane];
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           fetch(nb + J * kSymChunk + 2 * pbeg); park();
-          if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-          else sym_block<D, DE, NS, WR, 1, true, 1, false, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+          if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else sym_block<D, DE, NS, WR, 1, true, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
         }
         if (J <= rows[0]) {
 #pragma unroll
@@ -403,8 +409,8 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
             for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[0] * kSymChunk + lane];
           for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
             fetch(nb + J * kSymChunk + 2 * pbeg); park();
-            if (J < rows[0]) sym_block<D, DE, NS, WR, 1, false, 0, true, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
-            else sym_block<D, DE, NS, WR, 1, true, 0, true, 1>(src, dst, Hc, kst, pbeg, ks, hown, accr, colp, ldc, lane);
+            if (J < rows[0]) sym_block<D, DE, NS, WR, 1, false, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+            else sym_block<D, DE, NS, WR, 1, true, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
           }
         }
       }
@@ -447,25 +453,40 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       if (lane == 0) PHt[(size_t)k * ldx + b] = s;
     }
   }
+  if (NPH > 1 && cp > 0) {                                     // second column phase: its row sums go through LDS
+    double* rowp = smem + lp.off_row;
+#pragma unroll
+    for (int q = 0; q < kSymRows; ++q)
+#pragma unroll
+      for (int k = 0; k < DE; ++k) rowp[(size_t)k * (CH * kSymChunk) + rows[q] * kSymChunk + lane] = accr[q][k];
+  }
   __syncthreads();
-  // combine, by the lane that owns the row: row part incl. the border columns (registers) + the waves' column parts in wave order
+  // combine, by the lane (of the first column phase) that owns the row: row part incl. the border columns (registers) + the other
+  // phase's row part + the row pairs' column parts in order
+  if (cp == 0) {
 #pragma unroll
-  for (int q = 0; q < kSymRows; ++q) {
-    const int rc = rows[q] * kSymChunk + lane;                // core coordinate
-    double s[DE];
+    for (int q = 0; q < kSymRows; ++q) {
+      const int rc = rows[q] * kSymChunk + lane;              // core coordinate
+      double s[DE];
 #pragma unroll
-    for (int k = 0; k < DE; ++k) s[k] = accr[q][k];
+      for (int k = 0; k < DE; ++k) s[k] = accr[q][k];
+      if (NPH > 1) {
+        const double* rowp = smem + lp.off_row;
 #pragma unroll
-    for (int w = 0; w < kWaves; ++w) {
-      if (rows[q] < kSymCH - 1 - w) {                         // wave w holds off-diagonal tiles in this block column
-        const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, w);
-        const int ldw = (w == 0) ? ldx : sym_ld_col(w);
-#pragma unroll
-        for (int k = 0; k < DE; ++k) s[k] += cw[(size_t)k * ldw + rc];
+        for (int k = 0; k < DE; ++k) s[k] += rowp[(size_t)k * (CH * kSymChunk) + rc];
       }
-    }
 #pragma unroll
-    for (int k = 0; k < DE; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
+      for (int w = 0; w < CH / 2; ++w) {
+        if (rows[q] < CH - 1 - w) {                           // row pair w holds off-diagonal tiles in this block column
+          const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, CH, w);
+          const int ldw = (w == 0) ? ldx : sym_ld_col(CH, w);
+#pragma unroll
+          for (int k = 0; k < DE; ++k) s[k] += cw[(size_t)k * ldw + rc];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < DE; ++k) PHt[(size_t)k * ldx + nb + rc] = s[k];
+    }
   }
   __syncthreads();
   if (!WR && NS > 0) {
@@ -678,22 +699,29 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   }
 }
 
-template <int D, int NS, bool WR, int E>
-static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
+template <int D, int NS, bool WR, int E, int CH>
+static hipError_t launch_sym_kc(const StepArgs& a, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E);
-  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E>), dim3(a.N), dim3(kThreads), lds, s, a);
+  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E, CH>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }
 
+template <int D, int NS, bool WR, int E>
+static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
+  if (a.lay.CH64 == 8) return launch_sym_kc<D, NS, WR, E, 8>(a, s);
+  if constexpr (NS <= 4) { if (a.lay.CH64 == 4) return launch_sym_kc<D, NS, WR, E, 4>(a, s); }      // four tile rows: lazy_depth <= 4
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
-  if (!a.lay.sym || a.mdl.d != 3 || a.lay.CH64 != kSymCH || a.fp32) return hipErrorInvalidValue;
+  if (!a.lay.sym || a.mdl.d != 3 || (a.lay.CH64 != 8 && a.lay.CH64 != 4) || a.fp32) return hipErrorInvalidValue;
   if (a.info) {                                            // information form: lazy_depth <= 3
     if (a.write_base) {
       switch (a.n_sets) {

@@ -4,10 +4,10 @@ tools/boxplot_mag.py runs the protocol of examples/slam-dense-mag/main.m:37-57 o
 {0, 1, 5, 10} added to the measurements (run_dense3D_magfield.m:81), simulations of run_dense3D_magfield.m with N_P = 100, T = 192,
 m = 512, particleFilter, particleSmoother (covariance form, N_K = 10) and the EKF baseline, scored by the Procrustes-aligned
 position RMSE (:155-183,216-237,252-255).  The full protocol (20 simulations; 260 s of GPU time) is committed as
-profiles/r03_boxplot_mag.json; here 8 simulations per level (~100 s) must show what the PNG shows:
+profiles/r03_boxplot_mag.json; here 5 simulations per level (~65 s) must show what the PNG shows:
 
   * PS median < PF median at all four disturbances,
-  * the EKF median grows with the disturbance (neighbouring levels may differ by 10 % the wrong way with 8 runs; o = 10 > o = 0
+  * the EKF median grows with the disturbance (neighbouring levels may differ by 10 % the wrong way with 5 runs; o = 10 > o = 0
     strictly) and exceeds the PF median at o = 10,
   * the o = 0 medians lie in [0.08, 0.20] m (PNG, read by eye: EKF 0.125, PF 0.14, PS 0.115)."""
 import os
@@ -22,10 +22,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_boxplot_mag_ordering(rbpf):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import boxplot_mag
-    res = boxplot_mag.run_protocol(n_sim=8, N_K=10, N_P=100, m=512)
+    res = boxplot_mag.run_protocol(n_sim=5, N_K=10, N_P=100, m=512)
     problems = boxplot_mag.check_ordering(res, slack=0.9)
     assert not problems, (problems, [(r["disturbance"], r["ekf_q25_median_q75"][1], r["pf_q25_median_q75"][1], r["ps_q25_median_q75"][1])
                                      for r in res["table"]])
     # the smoother improves on its own first iteration (particleSmoother.m:88: iteration 1 is a plain particle filter draw)
     for r in res["table"]:
-        assert r["ps_median_by_iteration"][-1] < r["ps_median_by_iteration"][0] * 1.08
+        assert r["ps_median_by_iteration"][-1] < r["ps_median_by_iteration"][0] * 1.10

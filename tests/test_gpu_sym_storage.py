@@ -115,8 +115,44 @@ def test_symmetric_storage_at_configs2_size(rbpf):
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
 
 
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, 1), (4, -1), (4, 1)])
+def test_symmetric_storage_filter_at_m256_matches_oracle(rbpf, lazy_depth, inplace):
+    """nLin = 259 (BASELINE.json configs[1]): four tile rows -- two waves share a row pair and split its column pairs by parity, their
+    row sums meet in LDS -- against the numpy oracle."""
+    c = cases.mag_case(9, 13, 256, seed=67)
+    ref = cases.oracle_filter(c)
+    out = run_sym(rbpf, c, lazy_depth, inplace)
+    check_filter(ref, out)
+
+
+def test_symmetric_storage_reduced_c2_against_the_c_restatement(rbpf, tmp_path_factory):
+    """BASELINE.md "reduced C2" (N = 1024, T = 300, m = 256) on symmetric storage, lazy_depth 3, against the C restatement."""
+    import bench
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T, m = 1024, 300, 256
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    rs = np.random.RandomState(77)
+    rng = rbpf.ReplayRNG(rs.random_sample((1, T - 1, N)), rs.standard_normal((1, T - 1, N, 6)))
+    lib = oracle_c.build(native_dir=str(tmp_path_factory.mktemp("oracle_native_sym256")))
+    ref, _ = oracle_c.particle_filter(rbpf, mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng,
+                                      n_threads=bench.usable_cores(), want_full=False, lib_path=lib)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                              want_xn_traj=False, lazy_depth=3, storage="fp64sym")
+    assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
+    assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
+
+
+def test_information_form_smoother_on_symmetric_storage_at_m256(rbpf):
+    import test_gpu_smoother as ts
+    c = cases.mag_case(6, 8, 256, seed=71, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    out = _smooth(rbpf, c, True, storage="fp64sym", lazy_depth=3)
+    ts.check(ref, out, 3)
+
+
 def test_symmetric_storage_is_rejected_where_it_is_not_implemented(rbpf):
-    c = cases.mag_case(6, 5, 256, seed=1)                                       # nLin = 259: four tile rows
+    c = cases.mag_case(6, 5, 125, seed=1)                                       # nLin = 128: two tile rows
     with pytest.raises(rbpf.RBPFError):
         run_sym(rbpf, c, 3, -1)
     c = cases.radio_case(6, 5, 128, seed=1, N_K=2)
