@@ -140,7 +140,10 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
                                           const double (&ks)[KR][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
                                           double (&accr)[kSymRows][DE], double* __restrict__ colp, int ldc, int lane) {
   constexpr int ND = NS * D;
-  constexpr int UP = 8 / NACT;                          // column pairs per round: 8 wave-wide 1 KB loads in flight
+#ifndef RBPF_SYM_FLUSH_LOADS
+#define RBPF_SYM_FLUSH_LOADS 4
+#endif
+  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : 8) / NACT;   // column pairs per round: 8 wave-wide 1 KB loads in flight
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
   for (int p0 = pbeg + cp; p0 < pbeg + kSymStage / 2; p0 += UP * NPH) {   // the kSymStage columns whose pending factors are staged
