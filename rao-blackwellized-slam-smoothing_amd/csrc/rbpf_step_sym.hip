@@ -143,7 +143,13 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #ifndef RBPF_SYM_FLUSH_LOADS
 #define RBPF_SYM_FLUSH_LOADS 4
 #endif
-  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : 8) / NACT;   // column pairs per round: 8 wave-wide 1 KB loads in flight
+#ifndef RBPF_SYM_LIGHT_LOADS
+#define RBPF_SYM_LIGHT_LOADS 8
+#endif
+  // column pairs per round = wave-wide 1 KB loads in flight / active rows: 8 loads in the read-only steps, 4 in a flush (with 8 the
+  // three- and four-set flushes kept 28-85 registers in scratch inside the block-column loop: 10 % more HBM writes, flush 29.1 ->
+  // 26.1 ms at N = 65 536 with 4)
+  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : RBPF_SYM_LIGHT_LOADS) / NACT;
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
   for (int p0 = pbeg + cp; p0 < pbeg + kSymStage / 2; p0 += UP * NPH) {   // the kSymStage columns whose pending factors are staged
