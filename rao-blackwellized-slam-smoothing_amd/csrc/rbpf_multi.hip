@@ -20,6 +20,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -80,6 +81,8 @@ struct Multi {
   std::vector<rbpf_shard_views> v;
   std::vector<hipStream_t> stream;
   std::vector<ncclComm_t> comm;
+  std::vector<rbpf_shard_smoother_views> sv;       // smoother only
+  int chol_refresh = 0;
   // host staging (host_staged only)
   std::vector<double> h_fwd;                       // [W][fwd_rows * Nloc]
   std::vector<std::vector<double>> h_send;         // per rank: its send records of this step
@@ -137,6 +140,43 @@ int gather_fwd(Multi& M, int r) {
   return gather_rows(M, r, M.v[r].fwd_local, M.v[r].fwd_gather, (size_t)M.v[r].fwd_rows * M.Nloc);
 }
 
+// all-to-all of whole rows of `width` doubles: snd[q] rows go to rank q (concatenated in rank order in send), rcv[q] rows arrive
+// from rank q at recv + recv_off rows.  Identical plans on every rank (replicated), so the host-staged variant only needs barriers.
+int exchange_rows(Multi& M, int r, const double* send, double* recv, const long long* snd, const long long* rcv, size_t width,
+                  size_t recv_off) {
+  const int W = M.W;
+  long long ns = 0;
+  for (int q = 0; q < W; ++q) ns += snd[q];
+  if (!M.host_staged) {
+    MT_NCCL(g_rccl.GroupStart());
+    size_t so = 0, ro = recv_off;
+    for (int q = 0; q < W; ++q) {
+      if (snd[q] > 0) MT_NCCL(g_rccl.Send(send + so * width, (size_t)snd[q] * width, ncclDouble, q, M.comm[r], M.stream[r]));
+      if (rcv[q] > 0) MT_NCCL(g_rccl.Recv(recv + ro * width, (size_t)rcv[q] * width, ncclDouble, q, M.comm[r], M.stream[r]));
+      so += (size_t)snd[q]; ro += (size_t)rcv[q];
+    }
+    MT_NCCL(g_rccl.GroupEnd());
+    return RBPF_OK;
+  }
+  HIPCHK(hipStreamSynchronize(M.stream[r]));
+  M.h_cnt[r].assign(snd, snd + W);
+  M.h_send[r].resize((size_t)ns * width);
+  if (ns) HIPCHK(hipMemcpy(M.h_send[r].data(), send, (size_t)ns * width * sizeof(double), hipMemcpyDeviceToHost));
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  size_t ro = recv_off;
+  for (int q = 0; q < W; ++q) {
+    const long long want = rcv[q];
+    if (want <= 0) continue;
+    size_t so = 0;
+    for (int p = 0; p < r; ++p) so += (size_t)M.h_cnt[q][p];            // rows rank q sends to ranks before me
+    if (M.h_cnt[q][r] != want) { set_error("exchange plan mismatch between ranks"); return RBPF_ERR_STATE; }
+    HIPCHK(hipMemcpy(recv + ro * width, M.h_send[q].data() + so * width, (size_t)want * width * sizeof(double), hipMemcpyHostToDevice));
+    ro += (size_t)want;
+  }
+  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+  return RBPF_OK;
+}
+
 // all-to-all of the migrating particle records; cnt = counts_host of rbpf_shard_plan: [send to q | receive from q | migrated | first
 // record of recv_rec to write]
 int exchange(Multi& M, int r, const long long* cnt) {
@@ -148,33 +188,66 @@ int exchange(Multi& M, int r, const long long* cnt) {
   MT_TRY(rbpf_shard_views_get(M.ctx[r], &M.v[r]));             // the plan may have grown the record buffers (exchange_capacity <= 0)
   MT_TRY(rbpf_shard_pack(M.ctx[r], nullptr, (int32_t)ns));
   if (r == 0) { M.migrated += cnt[2 * W]; }
-  if (!M.host_staged) {
-    MT_NCCL(g_rccl.GroupStart());
-    size_t so = 0, ro = (size_t)recv_off;
-    for (int q = 0; q < W; ++q) {
-      if (cnt[q] > 0) MT_NCCL(g_rccl.Send(M.v[r].send_rec + so * rs, (size_t)cnt[q] * rs, ncclDouble, q, M.comm[r], M.stream[r]));
-      if (cnt[W + q] > 0) MT_NCCL(g_rccl.Recv(M.v[r].recv_rec + ro * rs, (size_t)cnt[W + q] * rs, ncclDouble, q, M.comm[r], M.stream[r]));
-      so += (size_t)cnt[q]; ro += (size_t)cnt[W + q];
+  return exchange_rows(M, r, M.v[r].send_rec, M.v[r].recv_rec, cnt, cnt + W, rs, (size_t)recv_off);
+}
+
+// Which base matrices cross ranks at a refresh of the carried factors (multigpu.plan_refresh, the numpy specification).  owner_now[j]
+// = rank * N_local + slot of logical slot j's particle, base_loc[j] = the same for the matrix its information matrix is rebuilt
+// from; both replicated, so every rank derives the same plan: rank q sends rank r each matrix some particle on r needs, once,
+// ordered by (destination, source, slot).
+struct RefreshPlan {
+  std::vector<int32_t> send_slots, base_index;
+  std::vector<long long> send_counts, recv_counts, send_totals, recv_totals;
+};
+RefreshPlan plan_refresh(const std::vector<int32_t>& owner_now, const std::vector<int32_t>& base_loc, int n_local, int world, int rank) {
+  RefreshPlan P;
+  const size_t N = owner_now.size();
+  std::vector<long long> keys;
+  keys.reserve(N);
+  for (size_t j = 0; j < N; ++j) {
+    const long long r = owner_now[j] / n_local, q = base_loc[j] / n_local, sl = base_loc[j] % n_local;
+    if (r != q) keys.push_back((r * world + q) * n_local + sl);
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  P.send_counts.assign(world, 0); P.recv_counts.assign(world, 0); P.send_totals.assign(world, 0); P.recv_totals.assign(world, 0);
+  std::vector<long long> recv_keys;
+  for (long long key : keys) {
+    const int ur = (int)(key / ((long long)world * n_local)), uq = (int)((key / n_local) % world), us = (int)(key % n_local);
+    P.send_totals[uq]++; P.recv_totals[ur]++;
+    if (uq == rank) { P.send_slots.push_back(us); P.send_counts[ur]++; }
+    if (ur == rank) { recv_keys.push_back(key); P.recv_counts[uq]++; }
+  }
+  P.base_index.assign(n_local, 0);
+  for (size_t j = 0; j < N; ++j) {
+    const long long r = owner_now[j] / n_local, p = owner_now[j] % n_local, q = base_loc[j] / n_local, sl = base_loc[j] % n_local;
+    if (r != rank) continue;
+    if (r == q) P.base_index[p] = (int32_t)sl;
+    else {
+      const long long key = (r * world + q) * n_local + sl;
+      P.base_index[p] = n_local + (int32_t)(std::lower_bound(recv_keys.begin(), recv_keys.end(), key) - recv_keys.begin());
     }
-    MT_NCCL(g_rccl.GroupEnd());
-    return RBPF_OK;
   }
-  M.h_cnt[r].assign(cnt, cnt + 2 * W + 2);
-  M.h_send[r].resize((size_t)ns * rs);
-  if (ns) HIPCHK(hipMemcpy(M.h_send[r].data(), M.v[r].send_rec, (size_t)ns * rs * sizeof(double), hipMemcpyDeviceToHost));
-  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
-  size_t ro = (size_t)recv_off;
-  for (int q = 0; q < W; ++q) {
-    const long long want = cnt[W + q];
-    if (want <= 0) continue;
-    size_t so = 0;
-    for (int p = 0; p < r; ++p) so += (size_t)M.h_cnt[q][p];            // records rank q sends to ranks before me
-    if (M.h_cnt[q][r] != want) { set_error("exchange plan mismatch between ranks"); return RBPF_ERR_STATE; }
-    HIPCHK(hipMemcpy(M.v[r].recv_rec + ro * rs, M.h_send[q].data() + so * rs, (size_t)want * rs * sizeof(double), hipMemcpyHostToDevice));
-    ro += (size_t)want;
+  return P;
+}
+
+// The refresh of the carried factors in place of rbpf_shard_smoother_anc_weights (multigpu.ShardedSmootherSession._refresh)
+int refresh(Multi& M, int r) {
+  std::vector<int32_t> own(M.Nglob), bl(M.Nglob);
+  MT_TRY(rbpf_shard_smoother_refresh_begin(M.ctx[r], own.data(), bl.data()));
+  if (bl[0] < 0) return rbpf_shard_smoother_refresh_end(M.ctx[r], nullptr, 0);     // first refresh of an iteration: the common initial matrix
+  RefreshPlan P = plan_refresh(own, bl, M.Nloc, M.W, r);
+  long long worst = 0, ns = 0, nr = 0;
+  for (int q = 0; q < M.W; ++q) { worst = std::max(worst, std::max(P.send_totals[q], P.recv_totals[q])); ns += P.send_counts[q]; nr += P.recv_counts[q]; }
+  if (worst > (long long)M.sv[r].refresh_capacity) {                                // replicated plan: every rank reaches this verdict
+    set_error("refresh of the carried factors moves up to " + std::to_string(worst) + " matrices per rank, above the capacity " +
+              std::to_string((long long)M.sv[r].refresh_capacity) + " (raise exchange_capacity)");
+    return RBPF_ERR_OUT_OF_MEMORY;
   }
-  if (!M.bar.wait()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
-  return RBPF_OK;
+  MT_TRY(rbpf_shard_smoother_refresh_pack(M.ctx[r], ns ? P.send_slots.data() : nullptr, (int32_t)ns));
+  MT_TRY(exchange_rows(M, r, M.sv[r].refresh_send, M.sv[r].refresh_recv, P.send_counts.data(), P.recv_counts.data(),
+                       (size_t)M.sv[r].matrix_doubles, 0));
+  return rbpf_shard_smoother_refresh_end(M.ctx[r], P.base_index.data(), (int32_t)nr);
 }
 
 int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt, bool smoother,
@@ -186,7 +259,6 @@ int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rb
     set_error("options.n_devices: the recognised dense model families only (host callbacks are not sharded)"); return RBPF_ERR_UNSUPPORTED;
   }
   if (opt->on_step && !smoother) { set_error("options.n_devices: the per-step hook (makePlots) is not available in the sharded filter"); return RBPF_ERR_UNSUPPORTED; }
-  if (smoother && opt->chol_refresh > 1) { set_error("options.n_devices: chol_refresh > 1 is available through multigpu.py only"); return RBPF_ERR_UNSUPPORTED; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { set_error("no HIP device visible"); return RBPF_ERR_NO_DEVICE; }
   M.W = W; M.smoother = smoother; M.N_K = N_K;
@@ -197,7 +269,8 @@ int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rb
     for (int q = 0; q < r; ++q) if (M.devs[q] == M.devs[r]) M.host_staged = true;     // ranks sharing a GPU: RCCL refuses that
   }
   M.Nloc = prob->N_P / W; M.Nglob = prob->N_P; M.T = prob->N_T; M.nN = prob->n_nonlin; M.n = prob->n_lin;
-  M.ctx.assign(W, nullptr); M.v.resize(W); M.stream.assign(W, nullptr); M.comm.assign(W, nullptr);
+  M.ctx.assign(W, nullptr); M.v.resize(W); M.stream.assign(W, nullptr); M.comm.assign(W, nullptr); M.sv.resize(W);
+  M.chol_refresh = smoother ? opt->chol_refresh : 0;
   M.h_send.resize(W); M.h_cnt.resize(W); M.bar.n = W;
   if (!M.host_staged) {
     std::lock_guard<std::mutex> lk(g_rccl_mutex);
@@ -214,6 +287,7 @@ int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rb
     if (smoother) MT_TRY(rbpf_shard_smoother_create(model, &p, rng, &o, N_K, r, W, &M.ctx[r]));
     else MT_TRY(rbpf_shard_create(model, &p, rng, &o, r, W, &M.ctx[r]));
     MT_TRY(rbpf_shard_views_get(M.ctx[r], &M.v[r]));
+    if (smoother) MT_TRY(rbpf_shard_smoother_views_get(M.ctx[r], &M.sv[r]));
     void* sp = nullptr;
     MT_TRY(rbpf_stream_get(M.ctx[r], &sp));
     M.stream[r] = reinterpret_cast<hipStream_t>(sp);
@@ -305,10 +379,18 @@ int multi_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, c
       MT_TRY(rbpf_shard_smoother_begin(M.ctx[r], k));
       for (int t = 0; t < T; ++t) {
         if (t == 0) { MT_TRY(rbpf_shard_smoother_step(M.ctx[r])); continue; }
-        if (k > 0) MT_TRY(rbpf_shard_smoother_anc_weights(M.ctx[r]));     // local factorisations, before the gather that carries them
+        const int K = M.chol_refresh;
+        const bool rf = k > 0 && K > 1 && (t == 1 || (t - 1) % K == 0);    // refresh of the carried factors due at this step
+        if (k > 0 && !rf) MT_TRY(rbpf_shard_smoother_anc_weights(M.ctx[r]));   // local factorisations / sweeps, before the gather that carries them
         MT_TRY(gather_fwd(M, r));
         MT_TRY(rbpf_shard_smoother_normalise(M.ctx[r], 1));
-        if (k > 0) MT_TRY(rbpf_shard_smoother_anc_sample(M.ctx[r], 0));
+        if (k > 0) {
+          if (rf) {                                                         // walks the state history: after gather + normalise, own all-gather
+            MT_TRY(refresh(M, r));
+            MT_TRY(gather_rows(M, r, M.sv[r].anc_local, M.sv[r].anc_gather, (size_t)M.Nloc));
+          }
+          MT_TRY(rbpf_shard_smoother_anc_sample(M.ctx[r], rf ? 1 : 0));
+        }
         MT_TRY(rbpf_shard_plan(M.ctx[r], reinterpret_cast<int64_t*>(cnt.data())));
         MT_TRY(exchange(M, r, cnt.data()));
         MT_TRY(rbpf_shard_smoother_step(M.ctx[r]));

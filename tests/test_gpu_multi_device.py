@@ -99,3 +99,22 @@ def test_multi_device_smoother_on_symmetric_storage(rbpf, lazy_depth):
                                                lazy_depth=lazy_depth)
     for a, b in zip(out, ref):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("kind,ids", [("radio", [0, 0]), ("mag", [0, 0, 0]), ("mag", [0])])
+def test_multi_device_smoother_with_carried_factors(rbpf, kind, ids):
+    """chol_refresh = K in the in-library driver: the factors migrate inside the particle records, the refreshes fetch base matrices
+    across ranks by the plan every rank derives from the replicated tables (rbpf_multi.hip plan_refresh == multigpu.plan_refresh).
+    Against the single-GPU smoother with the same options: same trajectory draws, outputs to 1e-9."""
+    if kind == "radio":
+        c = cases.radio_case(40, 14, 128, seed=5, N_K=3)
+        mdl, x0, P0, R = cases.device_model(rbpf, c)
+        args = (mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 40 // len(ids) * len(ids), 3, c["dt"])
+    else:
+        d, mdl, x0, P0, R = _mag(rbpf, 14, 130)
+        args = (mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, 36, 3, 0.01)
+    kw = dict(lazy_depth=3, chol_refresh=4)
+    ref = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), **kw)
+    out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), n_devices=len(ids), device_ids=ids, **kw)
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
