@@ -22,6 +22,10 @@
 #include "rbpf_device.hpp"
 #include "rbpf_model_dev.hpp"
 
+#ifndef RBPF_SYM_LIGHT_WGS
+#define RBPF_SYM_LIGHT_WGS 2       // workgroups per CU the read-only filter variant is compiled for (3: xl stays in global memory)
+#endif
+
 namespace rbpf {
 
 typedef double dbl2s __attribute__((ext_vector_type(2)));
@@ -56,11 +60,11 @@ __host__ __device__ inline int sym_off_col(int off_col1, int D, int ch, int rp) 
 
 __host__ __device__ inline int sym_even(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage, int ch) {
+__host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage, int ch, int xl_lds = 1) {
   SymPlan p;
   int o = 0;
   p.off_H = o;   o += sym_even(n * D + 2);           // + pad so that the first core column pair is 16-byte aligned
-  p.off_xl = o;  o += ldx;
+  p.off_xl = o;  o += xl_lds ? ldx : 0;
   p.off_PHt = o; o += D * ldx;
   p.off_col1 = o;
   for (int rp = 1; rp < ch / 2; ++rp) o += D * sym_ld_col(ch, rp);
@@ -74,7 +78,8 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
 }
 
 size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra) {
-  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, lay.CH64).total * sizeof(double);
+  const int xl_lds = (RBPF_SYM_LIGHT_WGS > 2 && !write_base && extra == 0) ? 0 : 1;
+  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, lay.CH64, xl_lds).total * sizeof(double);
 }
 
 // ---- wave-level reduction primitives ---------------------------------------------------------------------------------------
@@ -250,7 +255,7 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 // reference also needs P * ivecPlus with ivecPlus = ivec + H' R^-1 y (:292) -- that is P * ivec + (P H') (R^-1 y), formed from
 // the accumulated columns instead of streamed (same algebra; step_kernel<.., E = 2> streams both).
 template <int D, int NS, bool WR, int E, int CH>
-__global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2) void step_sym_kernel(const StepArgs a) {
   constexpr int NPH = (CH == 8) ? 1 : 2;                       // column phases (waves per row pair)
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH);
+  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH, (RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0) ? 0 : 1);
   double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;                            // [DE][ldx]
@@ -293,7 +298,8 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
 
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];
-  for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
+  constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
+  if (kXlLds) for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
   double Riy[D];                                               // R^-1 y (:292)
   if (E > 0) {
     const double* iv = remote ? recp + a.rec_off_I : a.ivec_old + (size_t)ancb * a.ivec_old_stride;
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       double h[D], ph[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) { h[k] = Hs[r * DE + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
-      const double x = xls[r];
+      const double x = kXlLds ? xls[r] : srcX[r];
 #pragma unroll
       for (int bb = 0; bb < D; ++bb)
 #pragma unroll
@@ -653,7 +659,7 @@ __global__ __launch_bounds__(kThreads, 2) void step_sym_kernel(const StepArgs a)
       for (int k = 0; k < D; ++k) ph[k] = PHt[(size_t)k * ldx + r];
       fwd_subst<D>(cS, ph, u);
       bwd_subst_T<D>(cS, u, kk);
-      double xn_ = xls[r];
+      double xn_ = kXlLds ? xls[r] : srcX[r];
 #pragma unroll
       for (int k = 0; k < D; ++k) xn_ = fma(kk[k], e[k], xn_);              // :197
       xln[r] = xn_;
