@@ -266,7 +266,14 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw, nodo = c->mdl.nodo;
   const Layout& L = c->lay;
   HIPCHK(hipGetDevice(&c->device));
-  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (const char* cuf = tuning_env("RBPF_CU_OF_32")) {   // diagnostic builds only: run on K of every 32 CUs (is a kernel bound inside the CU or by HBM?)
+    uint32_t mask[8];
+    const int k = atoi(cuf);
+    for (int w = 0; w < 8; ++w) mask[w] = (k >= 32) ? 0xffffffffu : ((1u << k) - 1u);
+    HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+  } else {
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
 
   // ---- model / problem constants ----
   RB_TRY(dmalloc(&c->d_NN, nn.size()));

@@ -44,6 +44,18 @@
 #ifndef RBPF_C64_LATE
 #define RBPF_C64_LATE 0
 #endif
+#ifndef RBPF_C64_LASTFAST
+#define RBPF_C64_LASTFAST 1                      // call-free loader for the last row tile (right-hand-side row)
+#endif
+#ifndef RBPF_C64_DIAGFAST
+#define RBPF_C64_DIAGFAST 1                      // call-free loader for the tiles of an interior diagonal block
+#endif
+#ifndef RBPF_C64_LARING
+#define RBPF_C64_LARING 8                        // operand ring depth of the look-ahead diagonal products
+#endif
+#ifndef RBPF_C64_INT1
+#define RBPF_C64_INT1 4                          // information form: first row tile below the diagonal block that takes the fast loader
+#endif
 #ifdef RBPF_C64_STAMPS                           // tuning aid: per-phase clocks of waves 0 / 1 of workgroup 0
 #define C64_STAMP(k) do { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } while (0)
 #define C64_STAMP_ARGS , long long (&cst)[8], long long& clast
@@ -159,25 +171,47 @@ __device__ __attribute__((noinline)) v4d c64_elems_general(const CholArgs* ka, c
 // order as chol_aug_elems; what goes is its per-element address and predicate arithmetic (the general loader is
 // VALU-bound: ~1.2 K clocks per four elements, 45 % of the information-form kernel at n = 515): one per-lane offset
 // r + ld g, everything else wave-uniform, so every load / store is scalar base + that one register.
-template <int MODE, bool ACC>
+// LAST: the last row tile (matrix rows up to M - 1, the right-hand-side row M, padding): the row index is clamped per lane for the
+// loads, nothing is stored for rows >= M, row M takes rhs_s.
+template <int MODE, bool ACC, bool LAST = false>
 __device__ inline void c64_strip_fast(const CholArgs& a, int p, int rt_s, int J, int M, const double* Hs, const double* RH,
-                                      int lane, v4d (&Zs)[4]) {
-  const int r = lane & 15, g = lane >> 4;
-  const int ld = (MODE == 0) ? M : a.n;
-  const unsigned lo = (unsigned)(r + ld * g);
-  const size_t t0 = (size_t)16 * rt_s + (size_t)ld * (64 * J);               // wave-uniform
+                                      int lane, v4d (&Zs)[4], const double* rhs_s = nullptr) {
+  const int g = lane >> 4, i = 16 * rt_s + (lane & 15);
+  const int r = LAST ? min(lane & 15, M - 1 - 16 * rt_s) : (lane & 15);   // (LAST needs M % 16 != 0: the tile holds a matrix row; otherwise
+  const int ld = (MODE == 0) ? M : a.n;                                   //  the general loader takes it)
+  const unsigned lo = (unsigned)(r + ld * g);                                     // unsigned: scalar base + 32-bit lane offset addressing
+  const bool pk = (MODE == 1) && a.imat_packed;   // packed storage (imat_packed_index): the strip is 8 KB of consecutive memory
+  const size_t t0 = pk ? imat_packed_row(rt_s) + (size_t)(16 * J) * 64 : (size_t)16 * rt_s + (size_t)ld * (64 * J);   // wave-uniform
   const double* src = ((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
   const double* add = (MODE == 1) ? a.ImatAdd + t0 : nullptr;
-  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)p * a.n * a.n + t0 : nullptr;
+  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)p * a.imat_out_stride + t0 : nullptr;
   const double* hrow = Hs ? Hs + 16 * rt_s + r : nullptr;                    // Hs[aa * M + i]
   const double* rcol = RH ? RH + 64 * J + g : nullptr;                       // RH[aa * M + j]
+  // all 32 loads of the strip in flight before the first use (one memory round trip per strip, not one per 16 columns:
+  // the element phase is latency-bound -- 40 % of a worker wave's clocks with the loads issued 16 columns at a time)
+  // (ACC: the accumulators are live -- half a strip at a time)
+  // The sixteen column offsets are kept as per-lane 32-bit registers, opaque to the compiler: as wave-uniform bases (its choice when
+  // it sees through them) three streams x sixteen columns are 48 scalar register pairs -- they overflow into vector lanes and from
+  // there into scratch.
+  constexpr int kB = ACC ? 2 : 4;
+  unsigned off[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { off[c][q] = pk ? (unsigned)(lane + 64 * (4 * c + q)) : lo + (unsigned)(ld * (16 * c + 4 * q)); asm volatile("" : "+v"(off[c][q])); }
+  double ad[4][4], v[4][4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    double ad[4], v[4];
+    if (c % kB == 0) {
+      C64_PIN();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      v[q] = (src + (size_t)ld * (16 * c + 4 * q))[lo];
-      ad[q] = (MODE == 1) ? (add + (size_t)ld * (16 * c + 4 * q))[lo] : 0.0;
+      for (int cc = c; cc < c + kB; ++cc)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[cc][q] = src[off[cc][q]];
+          ad[cc][q] = (MODE == 1) ? add[off[cc][q]] : 0.0;
+        }
+      C64_PIN();
     }
     if (MODE == 1) {
       if (Hs) {                                                              // + dyi'/R*dyi of the last update (:334)
@@ -188,17 +222,21 @@ __device__ inline void c64_strip_fast(const CholArgs& a, int p, int rt_s, int J,
           for (int q = 0; q < 4; ++q) sacc[q] = fma(h, rcol[aa * M + 16 * c + 4 * q], sacc[q]);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += sacc[q];
+        for (int q = 0; q < 4; ++q) v[c][q] += sacc[q];
       }
-      if (dst) {                                                             // Imat(:,:,i) of the new generation
+      if (dst && (!LAST || i < M)) {                                         // Imat(:,:,i) of the new generation
 #pragma unroll
-        for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(v[q], &(dst + (size_t)ld * (16 * c + 4 * q))[lo]);
+        for (int q = 0; q < 4; ++q) __builtin_nontemporal_store(v[c][q], &dst[off[c][q]]);
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += ad[q];                             // :225
+      for (int q = 0; q < 4; ++q) v[c][q] += ad[c][q];                       // :225
+    }
+    if (LAST) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[c][q] = (i < M) ? v[c][q] : ((i == M) ? rhs_s[64 * J + 16 * c + 4 * q + g] : 0.0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Zs[c][q] = ACC ? Zs[c][q] - v[q] : -v[q];
+    for (int q = 0; q < 4; ++q) Zs[c][q] = ACC ? Zs[c][q] - v[c][q] : -v[c][q];
   }
 }
 
@@ -206,43 +244,119 @@ __device__ inline int c64_pair(int cp, int c) { return cp * (cp - 1) / 2 + c; } 
 
 __device__ inline int c64_tri(int i, int c) { return i * (i + 1) / 2 + c; }         // (i >= c) -> 0..9
 
-// Row tile I of the diagonal block (one of waves 4..7): elements and panel product of its I + 1 lower tiles, handed to
-// wave 0 through LDS (Zd: [10][4][64]).
+// Elements of row tile I of an INTERIOR diagonal block (64 J + 64 <= M: no clamp, no right-hand-side row): the I + 1 lower
+// tiles, all loads in flight together.  Same operations in the same order as chol_aug_elems.
+template <int I, int MODE>
+__device__ inline void c64_diag_elems_fast(const CholArgs& a, int p, int J, int M, const double* Hs, const double* RH, double jit,
+                                           int lane, v4d (&Z)[I + 1]) {
+  const int r = lane & 15, g = lane >> 4;
+  const int ld = (MODE == 0) ? M : a.n;
+  const unsigned lo = (unsigned)(r + ld * g);
+  const int i0 = 16 * (4 * J + I);
+  const bool pk = (MODE == 1) && a.imat_packed;                               // packed storage (imat_packed_index)
+  const size_t t0 = pk ? imat_packed_row(4 * J + I) + (size_t)(16 * J) * 64 : (size_t)i0 + (size_t)ld * (64 * J);   // wave-uniform
+  const double* src = ((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
+  const double* add = (MODE == 1) ? a.ImatAdd + t0 : nullptr;
+  double* dst = (MODE == 1 && a.ImatOut) ? a.ImatOut + (size_t)p * a.imat_out_stride + t0 : nullptr;
+  unsigned off[I + 1][4];                                                     // (per-lane offsets, opaque: see c64_strip_fast)
+#pragma unroll
+  for (int c = 0; c <= I; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { off[c][q] = pk ? (unsigned)(lane + 64 * (4 * c + q)) : lo + (unsigned)(ld * (16 * c + 4 * q)); asm volatile("" : "+v"(off[c][q])); }
+  double v[I + 1][4], ad[I + 1][4];
+  C64_PIN();
+#pragma unroll
+  for (int c = 0; c <= I; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      v[c][q] = src[off[c][q]];
+      ad[c][q] = (MODE == 1) ? add[off[c][q]] : 0.0;
+    }
+  C64_PIN();
+#pragma unroll
+  for (int c = 0; c <= I; ++c) {
+    if (MODE == 0) {
+      if (a.R) {                                                             // kron(eye, R)
+        const int* dv = reinterpret_cast<const int*>(Hs);
+        const int di = dv[i0 + r];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int dj = dv[64 * J + 16 * c + 4 * q + g];
+          const double rr = a.R[(di & 7) + a.d * (dj & 7)];
+          v[c][q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
+        }
+      }
+    } else {
+      if (Hs) {                                                              // + dyi'/R*dyi of the last update (:334)
+        double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int aa = 0; aa < a.d; ++aa) {
+          const double h = Hs[aa * M + i0 + r];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) sacc[q] = fma(h, RH[aa * M + 64 * J + 16 * c + 4 * q + g], sacc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[c][q] += sacc[q];
+      }
+      if (dst) {                                                             // Imat(:,:,i) of the new generation
+#pragma unroll
+        for (int q = 0; q < 4; ++q)                                            // (packed storage: the lower triangle only)
+          if (!pk || 16 * I + r >= 16 * c + 4 * q + g) __builtin_nontemporal_store(v[c][q], &dst[off[c][q]]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[c][q] += ad[c][q];                       // :225
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = 16 * I + r, col = 16 * c + 4 * q + g;                  // inside the block
+      if (row == col) v[c][q] += jit;
+      Z[c][q] = (row >= col) ? -v[c][q] : 0.0;
+    }
+  }
+}
+
+// Row tile I of the diagonal block of block column J, formed ONE BLOCK COLUMN AHEAD by a worker wave: elements and the
+// panel product of its I + 1 lower tiles over the block columns < J - 1 (block column J - 1 is still being solved: wave 0
+// adds that part before it factorises), left in LDS (Zd: [10][4][64]).
 template <int I, int MODE, bool CALLS>
 __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* __restrict__ Lt, int KGS, int J, int M,
                                         const double* rhs_s, const double* Hs, const double* RH, double jit, int lane,
                                         double* Zd C64_STAMP_ARGS) {
   v4d Z[I + 1];
+  if (RBPF_C64_DIAGFAST && 64 * J + 64 <= M) {
+    c64_diag_elems_fast<I, MODE>(a, p, J, M, Hs, RH, jit, lane, Z);
+  } else {
 #pragma unroll
-  for (int c = 0; c <= I; ++c) {
-    if (CALLS) {
-      Z[c] = -c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
-    } else {
-      v4d e;
-      chol_aug_elems<MODE>(a, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
-      Z[c] = -e;
+    for (int c = 0; c <= I; ++c) {
+      if (CALLS) {
+        Z[c] = -c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+      } else {
+        v4d e;
+        chol_aug_elems<MODE>(a, p, 16 * (4 * J + I) + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+        Z[c] = -e;
+      }
     }
   }
   C64_STAMP(0);
-  if (J > 0) {
+  if (J > 1) {                                    // look-ahead: block column J - 1 is not final yet, wave 0 adds its part
     const double* pf[I + 1];
 #pragma unroll
     for (int c = 0; c <= I; ++c) pf[c] = Lt + (size_t)(4 * J + c) * KGS * 64;   // wave-uniform bases, + lane per load
-    const int nkg = 16 * J;
-    double F[4][I + 1];
+    const int nkg = 16 * (J - 1);
+    constexpr int kRing = RBPF_C64_LARING;                      // I + 1 products per column group cover little latency: a deep ring
+    double F[kRing][I + 1];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < kRing; ++b) {
       C64_PIN();
 #pragma unroll
-      for (int c = 0; c <= I; ++c) F[b][c] = (pf[c] + (size_t)b * 64)[lane];
+      for (int c = 0; c <= I; ++c) F[b][c] = (pf[c] + (size_t)min(b, nkg - 1) * 64)[lane];
       C64_PIN();
     }
-    for (int kg = 0; kg < nkg; kg += 4) {
+    for (int kg = 0; kg < nkg; kg += kRing) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < kRing; ++b) {
 #pragma unroll
         for (int c = 0; c <= I; ++c) Z[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][I], Z[c], 0, 0, 0);
-        const size_t kn = (size_t)min(kg + 4 + b, nkg - 1) * 64;
+        const size_t kn = (size_t)min(kg + kRing + b, nkg - 1) * 64;
         C64_PIN();
 #pragma unroll
         for (int c = 0; c <= I; ++c) F[b][c] = (pf[c] + kn)[lane];
@@ -270,6 +384,42 @@ __device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int
     for (int c = 0; c <= i; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q) Z[i][c][q] = (i < nd) ? Zd[(c64_tri(i, c) * 4 + q) * 64 + lane] : 0.0;
+  if (J > 0) {
+    // the part of the panel product the look-ahead could not have: block column J - 1, final since the last barrier
+    const int RTc = KGS >> 2;
+    const double* pf[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pf[c] = Lt + ((size_t)min(4 * J + c, RTc - 1) * KGS + 16 * (J - 1)) * 64;
+    double F[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      C64_PIN();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + (size_t)b * 64)[lane];
+      C64_PIN();
+    }
+    for (int kg = 0; kg < 16; kg += 4) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c <= i; ++c) Z[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][i], Z[i][c], 0, 0, 0);
+        const size_t kn = (size_t)min(kg + 4 + b, 15) * 64;
+        C64_PIN();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + kn)[lane];
+        C64_PIN();
+      }
+    }
+    if (nd < 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c)
+          if (i >= nd) Z[i][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+  }
   C64_STAMP(1);
   bool bad = false;
 #pragma unroll
@@ -318,30 +468,29 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
                                      double jit, int lane, const double* NLs, const double* Lds, bool barrier C64_STAMP_ARGS) {
   v4d Z[NT][4];
   const int RTl = (M + 1 + 15) >> 4;
-  auto elems = [&](auto acc) {
-    constexpr bool ACC = decltype(acc)::value;
+  // interior strip (wave-uniform): the fast loader; LATE defers exactly these (the general loader is a call: with the accumulators
+  // live around it they would all be saved and restored)
+  auto interior = [&](int s) { return rt[s] >= 4 * J + (MODE == 0 ? 5 : RBPF_C64_INT1) && rt[s] < RTl - 1 && 64 * J + 64 <= M; };   // (MODE 0: no kron(I, R) entry)
 #pragma unroll
-    for (int s = 0; s < NT; ++s) {
-      if (rt[s] >= 4 * J + 5 && rt[s] < RTl - 1 && 64 * J + 64 <= M) {      // interior strip (wave-uniform)
-        c64_strip_fast<MODE, ACC>(a, p, rt[s], J, M, Hs, RH, lane, Z[s]);
+  for (int s = 0; s < NT; ++s) {
+    if (interior(s)) {
+      if (LATE && J > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Z[s][c] = (v4d){0.0, 0.0, 0.0, 0.0};
       } else {
+        c64_strip_fast<MODE, false>(a, p, rt[s], J, M, Hs, RH, lane, Z[s]);
+      }
+    } else if (RBPF_C64_LASTFAST && (M & 15) != 0 && rt[s] == RTl - 1 && rt[s] >= 4 * J + (MODE == 0 ? 5 : 4) && 64 * J + 64 <= M) {
+      c64_strip_fast<MODE, false, true>(a, p, rt[s], J, M, Hs, RH, lane, Z[s], rhs_s);
+    } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v4d e;
-          if (CALLS) e = c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
-          else chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
-          Z[s][c] = ACC ? Z[s][c] - e : -e;
-        }
+      for (int c = 0; c < 4; ++c) {
+        v4d e;
+        if (CALLS) e = c64_elems_general<MODE>(c64_kernarg(), a.Imat, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit);
+        else chol_aug_elems<MODE>(a, p, 16 * rt[s] + (lane & 15), 64 * J + 16 * c + (lane >> 4), M, rhs_s, Hs, RH, jit, e);
+        Z[s][c] = -e;
       }
     }
-  };
-  if (LATE && J > 0) {
-#pragma unroll
-    for (int s = 0; s < NT; ++s)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Z[s][c] = (v4d){0.0, 0.0, 0.0, 0.0};
-  } else {
-    elems(std::false_type{});
   }
   C64_STAMP(0);
   if (J > 0) {
@@ -378,7 +527,11 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
       }
     }
   }
-  if (LATE && J > 0) elems(std::true_type{});
+  if (LATE && J > 0) {
+#pragma unroll
+    for (int s = 0; s < NT; ++s)
+      if (interior(s)) c64_strip_fast<MODE, true>(a, p, rt[s], J, M, Hs, RH, lane, Z[s]);
+  }
   C64_STAMP(1);
   if (barrier) __syncthreads();                                             // the diagonal block's LDS operands are ready
   C64_STAMP(3);
@@ -432,16 +585,15 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices and operand bases in SGPRs
   const int RT = (M + 1 + 15) >> 4, KGS = 4 * RT;
   double* Lt = a.Lbuf + (size_t)(nslots > 0 ? (int)blockIdx.x : p) * a.ldL;
-  double* NLs = csm;                              // [4][4][64]  -inv(Ld_cc) as MFMA A fragments
-  double* Lds = NLs + 1024;                       // [6][4][64]  Ld(c',c), c' > c, as MFMA A fragments
-  double* Zd = csm;                               // [10][4][64] the diagonal block's tiles on their way to wave 0 — the same
-                                                  // 20 KB: wave 0 has them in registers before it writes NLs / Lds, and the
-                                                  // next block column's tiles are written after the barrier that ends the solves
-  double* red = csm + 2560;                       // [32]
+  // two 20 KB buffers, block column J uses buffer J & 1:
+  //   Zd  [10][4][64]  the diagonal block's tiles (elements + panel product over the block columns < J - 1), formed by the worker
+  //                    waves ONE BLOCK COLUMN AHEAD (during the products of block column J - 1), so that they are off the serial chain
+  //   NLs [4][4][64]   -inv(Ld_cc) as MFMA A fragments          } written by wave 0 over Zd (which it holds in registers by then),
+  //   Lds [6][4][64]   Ld(c',c), c' > c, as MFMA A fragments    } read by the workers' solves of block column J
+  double* red = csm + 5120;                       // [32]
   double* rhs_s = red + 32;                       // [M]
   int* sfail = reinterpret_cast<int*>(rhs_s + M);   // [2]: block column J reports in slot J & 1 (sticky), so a fast wave 0 cannot
                                                     // overtake the check of the previous block column
-  int* ready = sfail + 2;                         // diagonal-block tiles handed over so far (monotonic within an attempt)
   const bool pend = (MODE == 1 && a.Hb != nullptr);
   double* Hs = (pend || MODE == 0) ? rhs_s + M + 2 : nullptr;
   double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
@@ -452,42 +604,40 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
 #endif
   double jit = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
-    if (tid == 0) { sfail[0] = 0; sfail[1] = 0; *ready = 0; }
-    int handed = 0;
+    if (tid == 0) { sfail[0] = 0; sfail[1] = 0; }
+    // row tile i of the diagonal block of block column JL is formed by wave W - 1 - i % (W - 1): waves 7, 6, 5, 4 (W = 8: the longest
+    // row on wave 4, which shares its SIMD with wave 0, idle half of the time) or 3, 2, 1, 3 (W = 4)
+    auto lookahead = [&](int JL) {
+      const int ndl = min(4, RT - 4 * JL);
+      double* Zd = csm + (size_t)(JL & 1) * 2560;
+      for (int di = W - 1 - wv; di < ndl; di += W - 1) {
+#define RBPF_C64D(I_) c64_diag_product<I_, MODE, true>(a, p, Lt, KGS, JL, M, rhs_s, Hs, RH, jit, lane, Zd C64_STAMP_PASS)
+        switch (di) {
+          case 0: RBPF_C64D(0); break;
+          case 1: RBPF_C64D(1); break;
+          case 2: RBPF_C64D(2); break;
+          default: RBPF_C64D(3); break;
+        }
+#undef RBPF_C64D
+      }
+    };
+    __syncthreads();
+    if (wv != 0) lookahead(0);
     __syncthreads();
     for (int J = 0; J < NJ; ++J) {
       const int nd = min(4, RT - 4 * J);
       const int first = 4 * J + nd, count = RT - first;
       const int npass = max(1, (count + kTilesPerPass - 1) / kTilesPerPass);
-      handed += nd;
+      double* NLs = csm + (size_t)(J & 1) * 2560;
+      double* Lds = NLs + 1024;
       if (wv == 0) {
-        // wait for the nd tiles of the diagonal block (only this wave waits; bounded, so a lost hand-off cannot hang the GPU)
-        int spins = 0;
-        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
-          __builtin_amdgcn_s_sleep(4);
-          ++spins;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         C64_STAMP(0);
-        bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, Zd, NLs, Lds C64_STAMP_PASS);
-        bad |= (spins >= (1 << 24));
+        const bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS);
         if (bad && lane == 0) sfail[J & 1] = 1;
         __syncthreads();
         C64_STAMP(3);
       } else {
-        // row tile i of the diagonal block is formed by wave W - 1 - i % (W - 1): waves 7, 6, 5, 4 (W = 8) or 3, 2, 1, 3 (W = 4)
-        for (int di = W - 1 - wv; di < nd; di += W - 1) {
-#define RBPF_C64D(I_) c64_diag_product<I_, MODE, true>(a, p, Lt, KGS, J, M, rhs_s, Hs, RH, jit, lane, Zd C64_STAMP_PASS)
-          switch (di) {
-            case 0: RBPF_C64D(0); break;
-            case 1: RBPF_C64D(1); break;
-            case 2: RBPF_C64D(2); break;
-            default: RBPF_C64D(3); break;
-          }
-#undef RBPF_C64D
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if (J + 1 < NJ) lookahead(J + 1);
         for (int pass = 0; pass < npass; ++pass) {
           int rt[4], nt = 0;
 #pragma unroll
@@ -522,7 +672,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
       if (sfail[J & 1]) break;
     }
 #ifdef RBPF_C64_STAMPS
-    if (p == 0 && lane == 0 && (wv <= 1 || wv == 7) && M >= 200)
+    if (p == 0 && lane == 0 && M >= 200)
       printf("chol64 M=%d wave %d clocks: elems(w0:spin) %lld product %lld diagtile %lld waitA %lld solve/update %lld waitB %lld\n", M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5]);
 #endif
     __syncthreads();
@@ -565,7 +715,7 @@ next_particle:
 
 constexpr size_t kC64MaxLds = 160 * 1024;         // the whole LDS of a CU
 static size_t chol64_lds_bytes(int M, int d) {
-  return ((size_t)2560 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
+  return ((size_t)5120 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
 }
 
 template <int MODE, int W>

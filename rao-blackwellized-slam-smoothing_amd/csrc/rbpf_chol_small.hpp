@@ -67,7 +67,7 @@ __device__ inline v4d cs_elems(const CholArgs& a, int p, int i, int jb, int M, c
       for (int q = 0; q < 4; ++q) v[q] += sacc[q];
     }
     if (a.ImatOut && i < M) {                                                // Imat(:,:,i) of the new generation
-      double* dst = a.ImatOut + (size_t)p * a.n * a.n;
+      double* dst = a.ImatOut + (size_t)p * a.imat_out_stride;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (j[q] < M) __builtin_nontemporal_store(v[q], &dst[off[q]]);

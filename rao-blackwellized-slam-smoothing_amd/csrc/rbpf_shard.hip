@@ -87,7 +87,7 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     s->rec_off_hld = s->rec_off_I + L.ldx;
     s->rec_off_Hb = s->rec_off_hld + 2;
     s->rec_off_Imat = s->rec_off_Hb + (size_t)d * L.ldx;
-    s->recsz = s->rec_off_Imat + smoother_record_matrix_doubles((int)n, o.chol_refresh);
+    s->recsz = s->rec_off_Imat + smoother_record_matrix_doubles((int)n, (int)d, o.chol_refresh);
     s->recsz += s->recsz & 1;
   }
   if (world > 1) {

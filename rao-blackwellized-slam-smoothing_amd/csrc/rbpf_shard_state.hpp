@@ -72,6 +72,6 @@ int shard_normalise_impl(rbpf_ctx* c, const int32_t* perm_host, int32_t* ai_host
 int shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count);
 int shard_unpack_particle(rbpf_ctx* c, int idx, double* dP);
 // doubles of the matrix part of a smoother record: Imat [n x n], or the carried factor in sweep layout (chol_refresh > 1)
-size_t smoother_record_matrix_doubles(int n, int chol_refresh);
+size_t smoother_record_matrix_doubles(int n, int d, int chol_refresh);
 
 }  // namespace rbpf

@@ -54,6 +54,8 @@ struct SmootherState {
   int icur = 0;                 // ping-pong index of ivec / hld / qf / Hb
   int imat_cur = 0;
   bool imat_valid = false;      // false until the first gather of an iteration (Imat = Imat0)
+  bool imat_packed = false;     // the banks, Imat0 and ImatAdd in packed block-lower storage (imat_packed_index)
+  size_t imat_len = 0;          // doubles per information matrix of the banks: n * n, or imat_packed_doubles(n)
   size_t Mmax = 0;
   // sharded information-form smoother
   double* d_Rinv = nullptr;     // [d*d]
@@ -267,7 +269,22 @@ struct CholArgs {
   int* status;
   int variant;                      // host side only: rbpf_options.chol_variant (0: kernel by matrix size)
   int batch, l_slots;               // 64-column kernel: l_slots > 0 = persistent workgroups, Lbuf holds l_slots factor workspaces
+  int imat_packed;                  // mode 1: Imat / ImatAdd / ImatOut / the records' matrices in packed storage (below)
+  long imat_out_stride;             // doubles between two matrices of ImatOut (n * n, or imat_packed_doubles(n))
 };
+
+// Packed storage of the information matrices (r03; the default-arithmetic information-form smoother at nLin >= 176).  They are
+// symmetric and only their block-lower half is ever read (the factorisation), so a matrix is stored as its row tiles of 16 rows,
+// row tile rt holding its 4 (rt + 1) column groups of 4 columns, 64 values each at kk * 16 + r -- the fragment order of the factor
+// storage, i.e. the lane order of an MFMA operand.  A 16 x 64 strip of the matrix is then 8 KB of consecutive memory (16 wave loads
+// of 512 B) instead of 64 segments of 128 B at a stride of 8 n bytes, and a bank entry takes 128 RT (RT + 1) doubles
+// (1.15 MB at nLin = 515) instead of n * n (2.12 MB).  Inside the diagonal tiles the positions above the diagonal exist but are
+// never written and never read unmasked.
+__host__ __device__ inline size_t imat_packed_row(int rt) { return (size_t)128 * rt * (rt + 1); }
+__host__ __device__ inline size_t imat_packed_doubles(int n) { return imat_packed_row((n + 15) >> 4); }
+__host__ __device__ inline size_t imat_packed_index(int i, int j) {                // i >= j
+  return imat_packed_row(i >> 4) + (size_t)(j >> 2) * 64 + (size_t)((j & 3) * 16 + (i & 15));
+}
 
 // Blocked left-looking Cholesky on the fp64 matrix cores, one workgroup (16 waves) per particle.
 //
@@ -372,10 +389,13 @@ __device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, i
   } else {
     double ad[4];
     const double* src = a.Imat + (size_t)p * a.imat_stride;                  // p: the ancestor's entry (resolved by the caller)
+    size_t idx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      v[q] = src[(size_t)ic + (size_t)a.n * jc[q]];
-      ad[q] = a.ImatAdd[(size_t)ic + (size_t)a.n * jc[q]];
+      // packed storage: the block-lower half only -- an element above the diagonal (masked out below) reads its mirror image
+      idx[q] = a.imat_packed ? imat_packed_index(max(ic, jc[q]), min(ic, jc[q])) : (size_t)ic + (size_t)a.n * jc[q];
+      v[q] = src[idx[q]];
+      ad[q] = a.ImatAdd[idx[q]];
     }
     if (Hs) {                                                                // + dyi'/R*dyi of the last update (:334)
       double sacc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -388,10 +408,10 @@ __device__ inline void chol_aug_elems(const CholArgs& a, int p, int i, int jb, i
       for (int q = 0; q < 4; ++q) v[q] += sacc[q];
     }
     if (a.ImatOut && i < M) {                                                // Imat(:,:,i) of the new generation
-      double* dst = a.ImatOut + (size_t)p * a.n * a.n;
+      double* dst = a.ImatOut + (size_t)p * a.imat_out_stride;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        if (j[q] < M) __builtin_nontemporal_store(v[q], &dst[(size_t)i + (size_t)a.n * j[q]]);
+        if (j[q] < M && (!a.imat_packed || i >= j[q])) __builtin_nontemporal_store(v[q], &dst[idx[q]]);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] += ad[q];                               // :225
@@ -700,10 +720,14 @@ static size_t chol_factor_doubles(int M) { const size_t mp = (size_t)16 * ((M + 
 // and the per-step decrement (:194-201).  sign = +1 accumulates steps [t0,t1), -1 subtracts them.
 __global__ void info_addt_kernel(int n, int d, int t0, int t1, double sign, const double* __restrict__ dyref,
                                  const double* __restrict__ Rinv, const double* __restrict__ y,
-                                 double* __restrict__ ImatAdd, double* __restrict__ ivecAdd) {
-  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                 double* __restrict__ ImatAdd, double* __restrict__ ivecAdd, int packed) {
+  size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= (size_t)n * n) return;
   const int i = (int)(q % n), j = (int)(q / n);
+  if (packed) {                                   // block-lower storage (imat_packed_index)
+    if (i < j) return;
+    q = imat_packed_index(i, j);
+  }
   double acc = ImatAdd[q];
   double av = (j == 0) ? ivecAdd[i] : 0.0;
   for (int t = t0; t < t1; ++t) {
@@ -756,6 +780,22 @@ __global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, c
 }  // namespace rbpf
 
 using namespace rbpf;
+
+// Packed storage of the information matrices: whenever the default arithmetic runs them through the 64-column kernel (more than
+// eleven row tiles, i.e. nLin >= 176).  With carried factors the banks stay full squares: there they are written by the G'G product
+// of the refreshes only.
+static bool imat_storage_packed(int n, int d, int chol_refresh) {
+  return chol_refresh <= 1 && ((n + 1 + 15) >> 4) > 11 && chol64_lds_bytes(n, d) <= kC64MaxLds;
+}
+
+// host copy of Imat0 (column-major n x n) in the storage of the banks
+static std::vector<double> imat_host_storage(const std::vector<double>& full, int n, bool packed) {
+  if (!packed) return full;
+  std::vector<double> pk(imat_packed_doubles(n), 0.0);
+  for (int j = 0; j < n; ++j)
+    for (int i = j; i < n; ++i) pk[imat_packed_index(i, j)] = full[(size_t)i + (size_t)n * j];
+  return pk;
+}
 
 // information-form hooks (defined below)
 static int info_begin_iteration(rbpf_ctx* c, const double* ivec0, double hld0, double qf0, double halfLogDetR, const double* d_Rinv);
@@ -936,8 +976,11 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       set_error("particleSmootherInformationForm: x0_lin must be nLin x 1 (the reference repmat's it, :109)");
       return RBPF_ERR_INVALID_ARG;
     }
+    s->imat_packed = imat_storage_packed(n, d, c->opt.chol_refresh);
+    s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
     for (int b = 0; b < 2; ++b) {
-      RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * n * n));
+      RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
+      if (s->imat_packed) HIPCHK(hipMemsetAsync(s->d_Imat[b], 0, (size_t)N * s->imat_len * 8, st));   // the never-written upper halves of the diagonal tiles
       RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
       RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
       RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
@@ -973,7 +1016,8 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       for (int cc = 0; cc < n; ++cc) sacc += c->h_P0[r + (size_t)n * cc] * ivec0[cc];
       qf0 += ivec0[r] * sacc;
     }
-    HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+    const std::vector<double> Imat0s = imat_host_storage(Imat0, n, s->imat_packed);
+    HIPCHK(hipMemcpy(s->d_Imat0, Imat0s.data(), Imat0s.size() * 8, hipMemcpyHostToDevice));
   }
 
   std::vector<double> xnk_h((size_t)nN * T);
@@ -997,7 +1041,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, st));
         HIPCHK(hipMemsetAsync(s->d_ivecAdd, 0, (size_t)n * 8, st));
         hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, 0, T,
-                           1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+                           1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd, s->imat_packed ? 1 : 0);
         HIPCHK(hipGetLastError());
       }
     }
@@ -1057,7 +1101,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         } else {
           // the (t-1) term leaves the suffix sums (:194-201)
           hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d,
-                             t - 1, t, -1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+                             t - 1, t, -1.0, s->d_dyref, d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd, s->imat_packed ? 1 : 0);
           HIPCHK(hipGetLastError());
           const bool carry = s->refresh > 1;
           const bool fresh = !carry || t == 1 || ((t - 1) % s->refresh) == 0;
@@ -1199,9 +1243,9 @@ static int info_fill_chol_args(rbpf_ctx* c, CholArgs& ca, const double* d_Rinv, 
   const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
   ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
   ca.Imat = s->imat_valid ? s->d_Imat[s->imat_cur] : s->d_Imat0;
-  ca.imat_stride = s->imat_valid ? (long)((size_t)n * n) : 0;
+  ca.imat_stride = s->imat_valid ? (long)s->imat_len : 0;
   ca.imat_anc = s->imat_valid ? anc : nullptr;
-  ca.ImatOut = s->d_Imat[ni];
+  ca.ImatOut = s->d_Imat[ni]; ca.imat_out_stride = (long)s->imat_len; ca.imat_packed = s->imat_packed ? 1 : 0;
   ca.Hb = s->d_Hb[s->icur]; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
   ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
   s->imat_cur = ni;                 // after the launch the new bank is the current one
@@ -1252,8 +1296,8 @@ extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_proble
 // on the rank that holds each particle, all-gathered (N doubles), and normalised / sampled identically on every
 // rank, so a W-rank run equals the single-GPU smoother with N = W * N_local particles bit for bit.
 // =============================================================================================================
-size_t rbpf::smoother_record_matrix_doubles(int n, int chol_refresh) {
-  return chol_refresh > 1 ? sweep_factor_doubles(n) : (size_t)n * n;
+size_t rbpf::smoother_record_matrix_doubles(int n, int d, int chol_refresh) {
+  return chol_refresh > 1 ? sweep_factor_doubles(n) : imat_storage_packed(n, d, chol_refresh) ? imat_packed_doubles(n) : (size_t)n * n;
 }
 
 int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
@@ -1269,7 +1313,7 @@ int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
   if (with_imat && !(carry ? s->sw_valid : s->imat_valid)) { set_error("pack before the ancestor weights of this step"); return RBPF_ERR_STATE; }
   // carried factors: the record takes the particle's factor (sweep layout) along instead of Imat, which is rebuilt at refreshes
   const double* im = !with_imat ? nullptr : (carry ? s->d_Lsw[s->sw_cur] : s->d_Imat[s->imat_cur]);
-  const size_t stride = carry ? sweep_factor_doubles(n) : (size_t)n * n;
+  const size_t stride = carry ? sweep_factor_doubles(n) : s->imat_len;
   hipLaunchKernelGGL(pack_info_kernel, dim3(count, with_imat ? 8 : 1), dim3(256), 0, c->stream, n, d, L.ldx, d_idx,
                      s->d_ivec[s->icur], s->d_hld[s->icur], s->d_Hb[s->icur], im, stride, stride, sh->send_rec, sh->recsz,
                      sh->rec_off_I, sh->rec_off_hld, sh->rec_off_Hb, sh->rec_off_Imat);
@@ -1298,8 +1342,11 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
   RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
   RB_TRY(dmalloc(&s->d_ak, 4));
+  s->imat_packed = imat_storage_packed(n, d, c->opt.chol_refresh);
+  s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
   for (int b = 0; b < 2; ++b) {
-    RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * n * n));
+    RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
+    if (s->imat_packed) HIPCHK(hipMemset(s->d_Imat[b], 0, (size_t)N * s->imat_len * 8));
     RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
     RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
     RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
@@ -1316,7 +1363,10 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   s->h_ivec0.assign(L.ldx, 0.0);
   info_initial_values(c, s->h_ivec0, Imat0, s->hld0);
   HIPCHK(hipMemcpy(s->d_Rinv, Rinv.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(s->d_Imat0, Imat0.data(), (size_t)n * n * 8, hipMemcpyHostToDevice));
+  {
+    const std::vector<double> Imat0s = imat_host_storage(Imat0, n, s->imat_packed);
+    HIPCHK(hipMemcpy(s->d_Imat0, Imat0s.data(), Imat0s.size() * 8, hipMemcpyHostToDevice));
+  }
   if (s->refresh) {
     // carried ancestor-weight factors (rbpf_chol_sweep.hpp): factor banks, the buffers of the refresh from the state history,
     // and the exchange buffers for base matrices that sit on another rank
@@ -1375,7 +1425,7 @@ int rbpf_shard_smoother_begin(rbpf_ctx* c, int32_t k) {
     HIPCHK(hipMemsetAsync(s->d_ImatAdd, 0, (size_t)n * n * 8, c->stream));
     HIPCHK(hipMemsetAsync(s->d_ivecAdd, 0, (size_t)n * 8, c->stream));
     hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, c->stream, n, d, 0, T,
-                       1.0, s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);   // :132-146
+                       1.0, s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd, s->imat_packed ? 1 : 0);   // :132-146
     HIPCHK(hipGetLastError());
   }
   return RBPF_OK;
@@ -1406,7 +1456,7 @@ static int shard_anc_meas_begin(rbpf_ctx* c) {
   HIPCHK(hipMemsetAsync(sh->anc_local, 0, (size_t)sh->Nloc * sizeof(double), st));
   // the (t-1) term leaves the suffix sums (:194-201)
   hipLaunchKernelGGL(info_addt_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, st, n, d, t - 1, t, -1.0,
-                     s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd);
+                     s->d_dyref, s->d_Rinv, c->d_y, s->d_ImatAdd, s->d_ivecAdd, s->imat_packed ? 1 : 0);
   HIPCHK(hipGetLastError());
   return RBPF_OK;
 }
