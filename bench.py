@@ -249,7 +249,8 @@ def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed, **opts):
                                                     rng=pkg.PhiloxRNG(3), **opts)
     secs = time.perf_counter() - t0
     its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
-    share = "1/8 of N=65536" if N_share == 8192 else f"{N_share / 65536:g} of N=65536: the largest power-of-two particle count whose smoother state fits one 288 GB GPU"
+    share = ("1/8 of N=65536" if N_share == 8192 else f"{N_share / 65536:g} of N=65536" +
+             (": the largest power-of-two particle count whose smoother state fits one 288 GB GPU" if N_share == 32768 or opts.get("chol_refresh", 0) > 1 else ""))
     return {"workload": f"slam-dense-mag N_P={N_share} ({share}) T={T} m={m} N_K={N_K} fp64, information form, complete run",
             "options": opts, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
             "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
@@ -419,6 +420,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
+    ap.add_argument("--smoother-32k", action="store_true", help="also run the complete smoother at N_P = 32768 on this one GPU (the reference's arithmetic: a fresh "
+                    "factorisation per particle and step; information matrices in packed storage; about 4.5 minutes)")
     ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of EACH sharded smoother leg, seconds (a leg that does not return ends every rank with exit code 3)")
     args = ap.parse_args()
 
@@ -578,16 +581,25 @@ def main():
                 if "seconds" in sm["share_full_carried_factors"]:
                     line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
                 if not args.no_smoother_largest:
-                    # the largest smoother one GPU holds: per particle 2 x 1.19 MB covariance banks (symmetric storage; 2 x 2.12
-                    # MB full), 2 x 2.12 MB Imat, 2.23 MB factorisation workspace (+ 2 x 1.21 MB carried factors + 0.4 MB refresh
-                    # scratch) = 8.9 (11.7) MB at nLin = 515 -> N_P = 16 384 needs 145 (191) GB of the 288 GB; 32 768 would need
-                    # 290 (383) GB.  Complete run with the carried factors.
+                    # the largest smoother one GPU holds WITH CARRIED FACTORS: per particle 2 x 1.19 MB covariance banks (symmetric
+                    # storage), 2 x 2.12 MB Imat (full squares: the refreshes' G'G writes them), 2.23 MB factorisation workspace,
+                    # 2 x 1.21 MB carried factors + 0.4 MB refresh scratch = 11.7 MB at nLin = 515 -> N_P = 16 384 needs 191 GB of the
+                    # 288 GB.  (The reference's arithmetic keeps 6.9 MB per particle and runs N_P = 32 768: --smoother-32k.)
                     sm["largest_single_gpu_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
                                                                                                    lazy_depth=3, chol_refresh=32, storage=sm_storage))
                     if "seconds" in sm["largest_single_gpu_carried_factors"]:
                         line["smoother_wall_clock_largest_single_gpu_s"] = sm["largest_single_gpu_carried_factors"]["seconds"]
                         line["smoother_wall_clock_largest_single_gpu_workload"] = (sm["largest_single_gpu_carried_factors"]["workload"] +
                                                                                    ", lazy_depth 3, chol_refresh 32")
+                if args.smoother_32k:
+                    # half of the metric's N on ONE GPU, the reference's arithmetic: per particle 2 x 1.19 MB covariance banks, 2 x 1.15 MB
+                    # information matrices (packed block-lower storage), 2.23 MB factorisation workspace = 6.9 MB at nLin = 515 -> 226 GB
+                    sm["N32768_single_gpu"] = guarded(lambda: smoother_share_full(pkg, datagen, 32768, 3000, 512, 2, args.seed, lazy_depth=3,
+                                                                                  storage=sm_storage))
+                    if "seconds" in sm["N32768_single_gpu"]:
+                        line["smoother_wall_clock_N32768_single_gpu_s"] = sm["N32768_single_gpu"]["seconds"]
+                        line["smoother_wall_clock_N32768_single_gpu_workload"] = (sm["N32768_single_gpu"]["workload"] +
+                                                                                  ", lazy_depth 3, fresh factorisation every step")
             if not args.no_large:
                 sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
             line["smoother"] = sm
