@@ -29,8 +29,14 @@
 // goes through LDS and the inverse is directly an MFMA A operand (4.5 K clocks per tile instead of 15 K).
 //
 // Measured (MI355X, n = 515): 3.50 ms per 2048 matrices standalone (26.6 TFLOP/s = 34 % of the fp64 matrix peak; the
-// 16-column kernel: 5.1-5.7 ms), 16.6 ms per launch of 8192 inside the information-form smoother (29.5 ms), where it moves
-// 77.6 GB (stored matrix + ImatAddt + factor re-reads in, factor + Imat(:,:,ai) out) = 4.7 TB/s: HBM-bound.
+// 16-column kernel: 5.1-5.7 ms), 15.8 ms per launch of 8192 inside the information-form smoother (r01: 29.5 ms, r02: 16.6 ms), where
+// it moves ~80 GB (stored matrix + ImatAddt + factor re-reads in, factor + Imat(:,:,ai) out) at 5-5.5 TB/s: bound by the memory
+// system (DESIGN.md 4.3 has the measurements: per-CU rates, clock stamps, CU mask, loader variants).
+//
+// Element loaders.  chol_aug_elems (a call: c64_elems_general) handles every edge -- clamps, triangle mask, jitter, right-hand-side
+// row; interior strips, the tiles of interior diagonal blocks and the last row tile have call-free loaders with all loads of a
+// strip in flight at once (c64_strip_fast, c64_diag_elems_fast).  The information matrices may come in packed block-lower storage
+// (CholArgs::imat_packed, imat_packed_index in rbpf_smoother.hip): a 16 x 64 strip is then 8 KB of consecutive memory.
 //
 // Factor storage: row-tile major, fragment order — the 64 values L(16 rt + r, 4 kg + kk) sit at
 // ((rt * KGS + kg) * 64 + kk * 16 + r), KGS = 4 RT, so a row tile streams through consecutive 512 B fragments.
@@ -46,6 +52,15 @@
 #endif
 #ifndef RBPF_C64_LASTFAST
 #define RBPF_C64_LASTFAST 1                      // call-free loader for the last row tile (right-hand-side row)
+#endif
+#ifndef RBPF_C64_LOOKAHEAD
+#define RBPF_C64_LOOKAHEAD 0                     // 1: the diagonal block's tiles are formed one block column ahead (off the serial chain).
+                                                 // Measured r03 (n = 515, 8192 matrices, in the smoother): 16.2 ms against 15.8 ms with 0 -- it
+                                                 // reads the next diagonal rows before their owners stream them (+ 0.8 MB per particle) and
+                                                 // the kernel is bound by the memory system
+#endif
+#ifndef RBPF_C64_RING4
+#define RBPF_C64_RING4 4                         // operand ring depth of the four-row-tile panel product (3: sixteen registers less)
 #endif
 #ifndef RBPF_C64_DIAGFAST
 #define RBPF_C64_DIAGFAST 1                      // call-free loader for the tiles of an interior diagonal block
@@ -314,9 +329,9 @@ __device__ inline void c64_diag_elems_fast(const CholArgs& a, int p, int J, int 
   }
 }
 
-// Row tile I of the diagonal block of block column J, formed ONE BLOCK COLUMN AHEAD by a worker wave: elements and the
-// panel product of its I + 1 lower tiles over the block columns < J - 1 (block column J - 1 is still being solved: wave 0
-// adds that part before it factorises), left in LDS (Zd: [10][4][64]).
+// Row tile I of the diagonal block of block column J (one of waves 4..7): elements and panel product of its I + 1 lower tiles,
+// handed to wave 0 through LDS (Zd: [10][4][64]).  RBPF_C64_LOOKAHEAD = 1: formed ONE BLOCK COLUMN AHEAD, over the block columns
+// < J - 1 only (block column J - 1 is still being solved: wave 0 adds that part before it factorises).
 template <int I, int MODE, bool CALLS>
 __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* __restrict__ Lt, int KGS, int J, int M,
                                         const double* rhs_s, const double* Hs, const double* RH, double jit, int lane,
@@ -337,11 +352,11 @@ __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* 
     }
   }
   C64_STAMP(0);
-  if (J > 1) {                                    // look-ahead: block column J - 1 is not final yet, wave 0 adds its part
+  if (J > RBPF_C64_LOOKAHEAD) {                   // look-ahead: block column J - 1 is not final yet, wave 0 adds its part
     const double* pf[I + 1];
 #pragma unroll
     for (int c = 0; c <= I; ++c) pf[c] = Lt + (size_t)(4 * J + c) * KGS * 64;   // wave-uniform bases, + lane per load
-    const int nkg = 16 * (J - 1);
+    const int nkg = 16 * (J - RBPF_C64_LOOKAHEAD);
     constexpr int kRing = RBPF_C64_LARING;                      // I + 1 products per column group cover little latency: a deep ring
     double F[kRing][I + 1];
 #pragma unroll
@@ -384,7 +399,7 @@ __device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int
     for (int c = 0; c <= i; ++c)
 #pragma unroll
       for (int q = 0; q < 4; ++q) Z[i][c][q] = (i < nd) ? Zd[(c64_tri(i, c) * 4 + q) * 64 + lane] : 0.0;
-  if (J > 0) {
+  if (RBPF_C64_LOOKAHEAD && J > 0) {
     // the part of the panel product the look-ahead could not have: block column J - 1, final since the last barrier
     const int RTc = KGS >> 2;
     const double* pf[4];
@@ -500,9 +515,10 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
 #pragma unroll
     for (int s = 0; s < NT; ++s) pb[s] = Lt + (size_t)rt[s] * ts;
     const int nkg = 16 * J;
-    double A[4][4], B[4][NT];
+    constexpr int kR = (NT == 4) ? RBPF_C64_RING4 : 4;                      // ring depth (column groups in flight)
+    double A[kR][4], B[kR][NT];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < kR; ++b) {
       C64_PIN();                                                            // same issue order as in the loop: the wait
 #pragma unroll                                                              // counts at the loop head then match
       for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + (size_t)b * 64)[lane];
@@ -510,14 +526,16 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
       for (int s = 0; s < NT; ++s) B[b][s] = (pb[s] + (size_t)b * 64)[lane];
       C64_PIN();
     }
-    for (int kg = 0; kg < nkg; kg += 4) {
+    for (int kg = 0; kg < nkg; kg += kR) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < kR; ++b) {
+        if (kR == 4 || kg + b < nkg) {                                      // (nkg is a multiple of 4)
 #pragma unroll
-        for (int s = 0; s < NT; ++s)
+          for (int s = 0; s < NT; ++s)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Z[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c], 0, 0, 0);
-        const size_t kn = (size_t)min(kg + 4 + b, nkg - 1) * 64;
+            for (int c = 0; c < 4; ++c) Z[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c], 0, 0, 0);
+        }
+        const size_t kn = (size_t)min(kg + kR + b, nkg - 1) * 64;
         C64_PIN();
 #pragma unroll
         for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + kn)[lane];
@@ -586,8 +604,8 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
   const int RT = (M + 1 + 15) >> 4, KGS = 4 * RT;
   double* Lt = a.Lbuf + (size_t)(nslots > 0 ? (int)blockIdx.x : p) * a.ldL;
   // two 20 KB buffers, block column J uses buffer J & 1:
-  //   Zd  [10][4][64]  the diagonal block's tiles (elements + panel product over the block columns < J - 1), formed by the worker
-  //                    waves ONE BLOCK COLUMN AHEAD (during the products of block column J - 1), so that they are off the serial chain
+  //   Zd  [10][4][64]  the diagonal block's tiles (elements + panel product) on their way from waves 4..7 to wave 0 (with
+  //                    RBPF_C64_LOOKAHEAD formed one block column ahead, during the products of block column J - 1)
   //   NLs [4][4][64]   -inv(Ld_cc) as MFMA A fragments          } written by wave 0 over Zd (which it holds in registers by then),
   //   Lds [6][4][64]   Ld(c',c), c' > c, as MFMA A fragments    } read by the workers' solves of block column J
   double* red = csm + 5120;                       // [32]
@@ -605,6 +623,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
   double jit = 0.0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if (tid == 0) { sfail[0] = 0; sfail[1] = 0; }
+    int* ready = sfail + 2;                       // (without look-ahead) tiles of the diagonal block handed over so far
     // row tile i of the diagonal block of block column JL is formed by wave W - 1 - i % (W - 1): waves 7, 6, 5, 4 (W = 8: the longest
     // row on wave 4, which shares its SIMD with wave 0, idle half of the time) or 3, 2, 1, 3 (W = 4)
     auto lookahead = [&](int JL) {
@@ -619,25 +638,43 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
           default: RBPF_C64D(3); break;
         }
 #undef RBPF_C64D
+        if (!RBPF_C64_LOOKAHEAD) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
       }
     };
+    int handed = 0;
+    if (tid == 0) *ready = 0;
     __syncthreads();
-    if (wv != 0) lookahead(0);
-    __syncthreads();
+    if (RBPF_C64_LOOKAHEAD) {
+      if (wv != 0) lookahead(0);
+      __syncthreads();
+    }
     for (int J = 0; J < NJ; ++J) {
       const int nd = min(4, RT - 4 * J);
       const int first = 4 * J + nd, count = RT - first;
       const int npass = max(1, (count + kTilesPerPass - 1) / kTilesPerPass);
       double* NLs = csm + (size_t)(J & 1) * 2560;
       double* Lds = NLs + 1024;
+      handed += nd;
       if (wv == 0) {
+        int spins = 0;
+        if (!RBPF_C64_LOOKAHEAD) {                // only this wave waits; bounded, so a lost hand-off cannot hang the GPU
+          while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(4);
+            ++spins;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         C64_STAMP(0);
-        const bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS);
+        const bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS) || spins >= (1 << 24);
         if (bad && lane == 0) sfail[J & 1] = 1;
         __syncthreads();
         C64_STAMP(3);
       } else {
-        if (J + 1 < NJ) lookahead(J + 1);
+        if (RBPF_C64_LOOKAHEAD) { if (J + 1 < NJ) lookahead(J + 1); }
+        else lookahead(J);
         for (int pass = 0; pass < npass; ++pass) {
           int rt[4], nt = 0;
 #pragma unroll
