@@ -115,13 +115,15 @@ __device__ inline void cs_wave(const CholArgs& a, int p, int M, int RT, const do
         v4d V = -T[cs_tile_idx(j, j) / NW], NI;
         const bool bad = chol_diag_tile_frag(V, NI, M - 16 * j, lane);
         if (bad && lane == 0) *sfail = 1;
-#pragma unroll
+        double dv = 1.0;                                                     // this lane's diagonal entry, if it holds one (log 1 = 0):
+#pragma unroll                                                               // ONE log per tile and lane, not four -- 12 % of the kernel
         for (int q = 0; q < 4; ++q) {
           NIs[q * 64 + lane] = NI[q];
           const int c = 16 * j + 4 * q + g;                                  // column of this register
-          if (r == 4 * q + g && c < M) sl += log(V[q]);                      // diagonal entry (column < M: not padding)
+          if (r == 4 * q + g && c < M) dv = V[q];                            // diagonal entry (column < M: not padding)
           if (j == tM && r == rM && c < M) vv = fma(V[q], V[q], vv);         // right-hand-side row inside the diagonal tile
         }
+        sl += log(dv);
       }
       __syncthreads();
       double ni[4];                                                          // 2. solves of column j
@@ -261,6 +263,163 @@ __global__ __launch_bounds__(64 * NW, (NW == 1 ? 1 : 2)) void chol_smallw_kernel
   }
 }
 
+// ---- one wave per particle, LEFT-looking on register tiles (r03) -----------------------------------------------
+// chol_smallw_kernel<., 1> above loads the whole matrix first and then works right-looking: all 45 tiles plus every load of the
+// particle and of ImatAddt in flight at once do not fit 512 registers.  Left-looking, a tile is only needed when its block column
+// comes up: block column ct's tiles are formed from the raw loads issued one block column earlier (so their latency hides behind
+// that column's products, factorisation and solves), Z(rt, ct) = -(A) + sum_{k < ct} X(ct, k) X(rt, k)' is accumulated from the
+// finished tiles in registers (a solved tile's layout is at once the A and the B operand layout), the diagonal tile is factorised
+// in the wave (chol_diag_tile_frag) and the tiles below it are solved with four MFMAs each.  Live registers peak at the 46 tile
+// equivalents of block column 6 (368 of the 512 a wave has at one wave per SIMD); no LDS traffic, no barrier, no other wave on the
+// SIMD to stretch the serial chain of the diagonal tiles.  Four particles per CU, as with two waves per particle.
+// The element arithmetic is cs_elems' (split into the issue of the loads and the rest), tile by tile the same operations as
+// chol_small_kernel except that the products of a tile are summed column by column (left-looking) instead of applied one block
+// column at a time in the same order -- i.e. the same sums in the same order.
+template <int MODE>
+__device__ inline void cs1_issue(const CholArgs& a, int i, int jb, int M, double (&v)[4], double (&ad)[4]) {
+  const int ld = (MODE == 0) ? M : a.n;
+  const int ic = min(i, M - 1);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned off = (unsigned)(ic + ld * min(jb + 4 * q, M - 1));
+    v[q] = a.Imat[off];                                                      // a.Imat: resolved by the caller
+    ad[q] = a.ImatAdd[off];
+  }
+}
+
+template <int MODE>
+__device__ inline v4d cs1_finish(const CholArgs& a, int p, int i, int jb, int M, const double* rhs_s, const double* Hs, const double* RH,
+                                 const double (&vin)[4], const double (&ad)[4]) {
+  const int ld = (MODE == 0) ? M : a.n;
+  const int ic = min(i, M - 1);
+  int j[4], jc[4];
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { j[q] = jb + 4 * q; jc[q] = min(j[q], M - 1); v[q] = vin[q]; }
+  if (Hs) {                                                                  // + dyi'/R*dyi of the last update (:334)
+    double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int aa = 0; aa < a.d; ++aa) {
+      const double h = Hs[aa * M + ic];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sacc[q] = fma(h, RH[aa * M + jc[q]], sacc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += sacc[q];
+  }
+  if (a.ImatOut && i < M) {                                                  // Imat(:,:,i) of the new generation
+    double* dst = a.ImatOut + (size_t)p * a.imat_out_stride;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (j[q] < M) __builtin_nontemporal_store(v[q], &dst[(unsigned)(ic + ld * jc[q])]);
+  }
+  v4d z;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] += ad[q];                                                           // :225
+    if (i == M) v[q] = rhs_s[jc[q]];
+    z[q] = (j[q] < M && i <= M && i >= j[q]) ? -v[q] : 0.0;
+  }
+  return z;
+}
+
+// block column CT of the one-wave kernel (a template so that every tile index is a compile-time constant: the nine columns in one
+// unrolled loop exceed the unroller's size limit and the tiles would live in scratch)
+template <int MODE, int CT>
+__device__ __forceinline__ void cs1_column(const CholArgs& a, int p, int M, int RT, const double* rhs_s, const double* Hs, const double* RH,
+                                           int lane, v4d (&T)[kCsTiles], double (&rv)[kCsMaxRT][4], double (&ra)[kCsMaxRT][4],
+                                           double& sl, double& vv, bool& bad) {
+  if (CT >= RT) return;                                                      // wave-uniform
+  const int r = lane & 15, g = lane >> 4;
+  const int rM = M & 15, tM = M >> 4;                                        // the right-hand-side row: row rM of row tile tM
+#pragma unroll
+  for (int rt = CT; rt < kCsMaxRT; ++rt)
+    if (rt < RT) T[cs_tile_idx(rt, CT)] = cs1_finish<MODE>(a, p, 16 * rt + r, 16 * CT + g, M, rhs_s, Hs, RH, rv[rt], ra[rt]);
+#pragma unroll
+  for (int rt = CT + 1; rt < kCsMaxRT; ++rt)                                 // the next block column's loads, a column's work ahead
+    if (rt < RT) cs1_issue<MODE>(a, 16 * rt + r, 16 * (CT + 1) + g, M, rv[rt], ra[rt]);
+#pragma unroll
+  for (int k = 0; k < CT; ++k) {                                             // Z(rt, CT) += X(CT, k) X(rt, k)'
+#pragma unroll
+    for (int rt = CT; rt < kCsMaxRT; ++rt) {
+      if (rt < RT) {
+        v4d& Z = T[cs_tile_idx(rt, CT)];
+        const v4d xa = T[cs_tile_idx(CT, k)];
+        const v4d xb = T[cs_tile_idx(rt, k)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Z = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[q], xb[q], Z, 0, 0, 0);
+      }
+    }
+  }
+  v4d V = -T[cs_tile_idx(CT, CT)], NI;                                        // diagonal tile
+#ifdef RBPF_CS1_NODIAG                            // timing experiment only (wrong results): what does the serial chain cost?
+  NI = V;
+#else
+  bad |= chol_diag_tile_frag(V, NI, M - 16 * CT, lane);
+#endif
+  double dv = 1.0;                                                           // this lane's diagonal entry, if it holds one (log 1 = 0)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 16 * CT + 4 * q + g;                                       // column of this register
+    if (r == 4 * q + g && c < M) dv = V[q];                                  // diagonal entry (column < M: not padding)
+    if (CT == tM && r == rM && c < M) vv = fma(V[q], V[q], vv);              // right-hand-side row inside the diagonal tile
+  }
+#ifdef RBPF_CS1_NOLOG
+  sl += dv;
+#else
+  sl += log(dv);
+#endif
+#pragma unroll
+  for (int rt = CT + 1; rt < kCsMaxRT; ++rt) {                               // solves of block column CT
+    if (rt < RT) {
+      const v4d x = mfma4(NI, T[cs_tile_idx(rt, CT)], (v4d){0.0, 0.0, 0.0, 0.0});   // X' = inv(Ld) V' (NI = -inv, T = -V')
+      T[cs_tile_idx(rt, CT)] = x;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (rt == tM && r == rM && 16 * CT + 4 * q + g < M) vv = fma(x[q], x[q], vv);
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64, 1) void chol_small1_kernel(CholArgs a_in) {
+  extern __shared__ double csm[];
+  CholArgs a = a_in;
+  const int p = blockIdx.x, lane = threadIdx.x, M = a.Msz;
+  if (MODE == 1) {
+    const int src = a.imat_anc ? a.imat_anc[p] : p;
+    const bool remote = a.rec != nullptr && src >= a.n_bank_local;
+    a.Imat = remote ? a.rec + (size_t)(src - a.n_bank_local) * a.rec_stride + a.rec_off_Imat
+                    : a.Imat + (size_t)src * a.imat_stride;
+    a.imat_stride = 0;
+  }
+  const int RT = (M + 1 + 15) >> 4;
+  double* rhs_s = csm;                            // [M]
+  const bool pend = (MODE == 1 && a.Hb != nullptr);
+  double* Hs = pend ? rhs_s + M + 2 : nullptr;
+  double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
+  chol_prologue(a, p, lane, 64, M, rhs_s, Hs, RH, pend);
+  __syncthreads();
+  v4d T[kCsTiles];                                                           // static indices only: every tile is a named register set
+  double rv[kCsMaxRT][4], ra[kCsMaxRT][4];                                   // raw loads of the next block column, by row tile
+  double sl = 0.0, vv = 0.0;
+  bool bad = false;
+#pragma unroll
+  for (int rt = 0; rt < kCsMaxRT; ++rt)
+    if (rt < RT) cs1_issue<MODE>(a, 16 * rt + (lane & 15), lane >> 4, M, rv[rt], ra[rt]);
+#define RBPF_CS1(CT_) cs1_column<MODE, CT_>(a, p, M, RT, rhs_s, Hs, RH, lane, T, rv, ra, sl, vv, bad)
+  RBPF_CS1(0); RBPF_CS1(1); RBPF_CS1(2); RBPF_CS1(3); RBPF_CS1(4); RBPF_CS1(5); RBPF_CS1(6); RBPF_CS1(7); RBPF_CS1(8);
+#undef RBPF_CS1
+  static_assert(kCsMaxRT == 9, "nine block columns are written out");
+  sl = wave_sum(sl); vv = wave_sum(vv);
+  const bool failed = __any(bad);
+  if (lane == 0) {
+    if (!failed) a.pant_log[p] += -0.5 * a.qf[p] - a.hld[p] - sl + 0.5 * vv;
+    else { atomicOr(a.status, 2); a.pant_log[p] = nan(""); }
+  }
+}
+
+static size_t chol_small1_lds_bytes(int M, int d) { return ((size_t)M + 2 + 2 * (size_t)d * M) * sizeof(double); }
+
 static size_t chol_small_lds_bytes(int M, int d) {
   return ((size_t)256 + kCsMaxRT * 256 + 16 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double);
 }
@@ -278,7 +437,8 @@ static hipError_t launch_chol_small(const CholArgs& ca, int batch, int d_lds, hi
   // does not fit the registers (449 spilled), and its matrices are small problems anyway (they keep the 16-column kernel)
   if (ca.mode != 1) return hipErrorInvalidValue;
   const int nw = waves ? waves : RBPF_CS_WAVES;
-  if (nw == 1) hipLaunchKernelGGL((chol_smallw_kernel<1, 1>), dim3(batch), dim3(64), lds, st, ca);
+  if (nw == 10) hipLaunchKernelGGL((chol_small1_kernel<1>), dim3(batch), dim3(64), chol_small1_lds_bytes(ca.Msz, d_lds), st, ca);
+  else if (nw == 1) hipLaunchKernelGGL((chol_smallw_kernel<1, 1>), dim3(batch), dim3(64), lds, st, ca);
   else if (nw == 2) hipLaunchKernelGGL((chol_smallw_kernel<1, 2>), dim3(batch), dim3(128), lds, st, ca);
   else hipLaunchKernelGGL((chol_small_kernel<1>), dim3(batch), dim3(kCsThreads), lds, st, ca);
   return hipGetLastError();

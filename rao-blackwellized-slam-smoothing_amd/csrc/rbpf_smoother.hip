@@ -668,7 +668,7 @@ static bool chol_variant_ok(const CholArgs& ca, int d_lds, int variant) {
   switch (variant) {
     case 0: case 16: return true;
     case 64: case 648: case 644: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
-    case 1: case 11: case 12: case 14: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
+    case 1: case 10: case 11: case 12: case 14: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
     default: return false;
   }
 }
@@ -679,6 +679,7 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
     if (!chol_variant_ok(ca, d_lds, ca.variant)) return hipErrorInvalidValue;
     if (ca.variant == 1) return launch_chol_small(ca, batch, d_lds, st);          // register-resident kernel, default shape
     if (ca.variant == 11 || ca.variant == 12 || ca.variant == 14) return launch_chol_small(ca, batch, d_lds, st, ca.variant - 10);   // 1 / 2 / 4 waves per matrix
+    if (ca.variant == 10) return launch_chol_small(ca, batch, d_lds, st, 10);                                                         // one wave, left-looking
     if (ca.variant == 16) return launch_chol16(ca, batch, d_lds, st);
     return launch_chol64(ca, batch, d_lds, st, ca.variant == 648 ? 8 : ca.variant == 644 ? 4 : 0);
   }
@@ -1707,8 +1708,8 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   const bool info = variant >= 1000;                 // information-form expression and loaders (see rbpf.h)
   if (info) variant -= 1000;
   if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 ||
-      (variant != 0 && variant != 1 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644) ||
-      ((variant == 1 || variant == 11 || variant == 12 || variant == 14) && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
+      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644) ||
+      ((variant == 1 || variant == 10 || variant == 11 || variant == 12 || variant == 14) && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
   }
   double *dS = nullptr, *de = nullptr, *dL = nullptr, *dlw = nullptr; int* dst = nullptr;

@@ -144,7 +144,7 @@ def numpy_logw_info(S, e):
     return out
 
 
-@pytest.mark.parametrize("variant", [1, 11, 12, 14, 16, 644])
+@pytest.mark.parametrize("variant", [1, 10, 11, 12, 14, 16, 644])
 @pytest.mark.parametrize("M", [64, 65, 79, 80, 100, 127, 128, 129, 143])
 def test_information_form_factorisation_of_small_matrices(rbpf, M, variant):
     """5..9 row tiles: the register-resident kernel (variant 1; 11 / 12 / 14 = one / two / four waves per matrix) against numpy
