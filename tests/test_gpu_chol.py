@@ -112,6 +112,18 @@ def test_smoother_with_the_16_column_kernel_forced(rbpf):
         ts.run_both(rbpf, c, info_form=True, chol_variant=7)
 
 
+@pytest.mark.parametrize("kind,m,variant", [("mag", 256, 16), ("mag", 200, 16), ("mag", 256, 644), ("mag", 256, 648), ("mag", 173, 16)])
+def test_packed_information_matrices_through_every_loader(rbpf, kind, m, variant):
+    """nLin >= 176: the banks, Imat0, ImatAddt hold the information matrices in packed block-lower storage (imat_packed_index).
+    The 16-column kernel reads them through the general loader (chol_aug_elems), the 64-column kernel through its call-free strip /
+    diagonal-block / last-row-tile loaders as well -- every path against the oracle (nLin = 259: no partial last tile row;
+    203: 11 valid rows in it; 176 = the first packed size, a right-hand-side row alone in its tile)."""
+    import test_gpu_smoother as ts
+    c = cases.mag_case(7, 6, m, seed=23, N_K=3)
+    ref, out = ts.run_both(rbpf, c, info_form=True, chol_variant=variant)
+    ts.check(ref, out, 3)
+
+
 @pytest.mark.parametrize("m", [256, 300])
 def test_information_form_smoother_at_the_benchmark_basis_sizes(rbpf, m):
     """m = 256 (nLin = 259, 17 row tiles) and m = 300 (nLin = 303, 19 row tiles): the size class of the 4-wave shape of the
