@@ -15,6 +15,21 @@ inline const char* tuning_env(const char* key) { return getenv(key); }
 inline const char* tuning_env(const char*) { return nullptr; }
 #endif
 
+// Workgroup -> processing position of the step kernels.  The hardware deals consecutive workgroups round-robin to the 8 XCDs, each
+// with its own L2; the positions are sorted by the stored covariance ("base") a particle reads, and between two flushes of the lazy
+// update 40-70 % of the particles share theirs with a sibling or cousin (tools/base_sharing_stats.py).  With position = workgroup
+// the family is spread over eight L2s and every member fetches the matrix from memory; dealing each XCD a CONTIGUOUS range of
+// positions puts a family on one XCD, back to back in its dispatch order, where the followers stream the leader's lines out of
+// the L2.  Bijective for any grid size.
+#ifndef RBPF_XCD_CHUNKS
+#define RBPF_XCD_CHUNKS 8
+#endif
+__device__ __forceinline__ int xcd_position(int wg, int grid) {
+  if (RBPF_XCD_CHUNKS <= 1) return wg;
+  const int x = wg % RBPF_XCD_CHUNKS, q = grid / RBPF_XCD_CHUNKS, r = grid % RBPF_XCD_CHUNKS;
+  return x * q + (x < r ? x : r) + wg / RBPF_XCD_CHUNKS;
+}
+
 constexpr int kThreads = 256;      // stream-kernel workgroup: 4 wave64
 constexpr int kWaves = kThreads / 64;
 constexpr int kChunkRows = 128;    // rows covered by one wave-wide 16-B-per-lane load

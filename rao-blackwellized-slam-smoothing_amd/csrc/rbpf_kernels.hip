@@ -495,7 +495,8 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   // children are processed in ancestor order so that siblings' reads of the same covariance hit the
   // Infinity Cache; the order only permutes the schedule, slot i still reads / writes slot i's data.
   // propagate_kernel resolved the indirections of this workgroup into one descriptor.
-  const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
+  const int pos = xcd_position((int)blockIdx.x, (int)gridDim.x);   // rbpf_internal.hpp: a family of siblings on ONE XCD
+  const int* pre_i = a.pre_i + (size_t)pos * kPreInts;
   if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;                         // bank entry the rewritten matrix goes to
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   const int nN = M.nN;
 
   // ---- A: fetch the propagated non-linear state (propagate_kernel ran first), stage xl / pending K / ivec ----
-  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];   // xn_new[0..8), Rnb[8..17)
+  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)pos * kPreDoubles + tid];   // xn_new[0..8), Rnb[8..17)
   {
     // all loads of a pass are issued before the first LDS store (clamped indices, predicated stores): the
     // sources are scattered small arrays, so this phase is pure latency

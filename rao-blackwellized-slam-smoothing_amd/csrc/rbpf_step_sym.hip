@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   const ModelDev& M = a.mdl;
   const Layout& Ly = a.lay;
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
-  const int* pre_i = a.pre_i + (size_t)blockIdx.x * kPreInts;
+  const int pos = xcd_position((int)blockIdx.x, (int)gridDim.x);   // processing position (sorted by the matrix the particle reads)
+  const int* pre_i = a.pre_i + (size_t)pos * kPreInts;
   if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   }
 
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
-  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)blockIdx.x * kPreDoubles + tid];
+  if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)pos * kPreDoubles + tid];
   constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
   if (kXlLds) for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
   double Riy[D];                                               // R^-1 y (:292)
