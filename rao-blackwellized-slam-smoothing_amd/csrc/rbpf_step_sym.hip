@@ -279,7 +279,11 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   double* tabC = tabS + (M.ktot > 0 ? M.ktot : 1);
   double* misc = smem + lp.off_misc;
   double* red = smem + lp.off_red;
+#ifdef RBPF_SYM_DIAG_SAMEBASE                    // timing experiment only (wrong results): every particle streams one of 64 matrices
+  const int ancb = pre_i[2], baseb = pre_i[3] & 63;
+#else
   const int ancb = pre_i[2], baseb = pre_i[3];
+#endif
   // sharded filter: a bank index >= n_bank_local refers to a received record [T | B | F | xl] (same layout as the banks)
   const bool remote = a.rec != nullptr && ancb >= a.n_bank_local;
   const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
