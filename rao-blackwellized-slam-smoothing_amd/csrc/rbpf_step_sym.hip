@@ -251,6 +251,78 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
   }
 }
 
+// ---- read-only steps, CH = 8: the "quad" mapping ------------------------------------------------------------------------------
+// sym_block gives a lane ONE row of a tile and both columns of a column pair, so every column sum of the transposed product is a
+// 64-lane reduction -- 1.5 wave_sum4 per column pair, half of the read-only kernel's instructions.  Here a lane
+// (r16 = lane & 15, g = lane >> 4) takes FOUR rows of a tile, r16 + 16 rq, of the column pair 4 t + g: one wave load still moves
+// 1 KB (four pairs x 16 rows x 2 columns), but a lane now sums its 4 rows x 2 tile rows per column before anything crosses lanes,
+// and a column sum is a 16-lane reduction (four DPP rotate-adds) shared by the four pairs of the quad: 72 instead of 150
+// instructions per four column pairs, and 3 instead of 12 LDS reads of H.  The row sums of a row are then spread over the four
+// lane groups (each saw a quarter of the columns); they are folded once after the stream (fold32 / fold16: no rotate-adds).
+// src[q]: the tile's base + 128 g + 2 r16;  Hc: H of the block's first column;  colp: the wave's strip at the block's first column.
+#ifndef RBPF_SYM_QUAD
+#define RBPF_SYM_QUAD 1
+#endif
+template <int D, int DE, int NACT, bool DIAG, int Q0>
+__device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRows], const double* __restrict__ Hc,
+                                               const double (&hown)[kSymRows][4][DE], double (&accr)[kSymRows][4][DE],
+                                               double* __restrict__ colp, int ldc, int lane) {
+  const int r16 = lane & 15, g = lane >> 4;
+  constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
+  constexpr int TQ = 2 / NACT;                          // quads per round: eight wave loads in flight whatever the active rows
+  for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
+    dbl2s v[TQ][NACT][4];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+      for (int q = 0; q < NACT; ++q)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          v[u][q][rq] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(t0 + u) * (8 * kSymChunk) + rq * 32);
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) {
+      const int t = t0 + u;
+      double h0[DE], h1[DE];
+      {
+        double hb[2 * DE + 2];                          // the pair's 2 * DE values of [H | ivec] sit contiguously
+#pragma unroll
+        for (int k2 = 0; k2 < (2 * DE + 1) / 2; ++k2) {
+          const dbl2s tt = *reinterpret_cast<const dbl2s*>(Hc + (size_t)(4 * t + g) * 2 * DE + 2 * k2);
+          hb[2 * k2] = tt.x; hb[2 * k2 + 1] = tt.y;
+        }
+#pragma unroll
+        for (int k = 0; k < DE; ++k) { h0[k] = hb[k]; h1[k] = hb[DE + k]; }
+      }
+      double pc[2][DE];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k = 0; k < DE; ++k) pc[e][k] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NACT; ++q)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const double p0v = v[u][q][rq].x, p1v = v[u][q][rq].y;
+#pragma unroll
+          for (int k = 0; k < DE; ++k) accr[Q0 + q][rq][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][rq][k]));
+          if (!(DIAG && q == 0)) {
+#pragma unroll
+            for (int k = 0; k < DE; ++k) { pc[0][k] = fma(p0v, hown[Q0 + q][rq][k], pc[0][k]); pc[1][k] = fma(p1v, hown[Q0 + q][rq][k], pc[1][k]); }
+          }
+        }
+      if (kCol) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int k = 0; k < DE; ++k) {
+            const double r = row16_sum(pc[e][k]);
+            if (r16 == 0) colp[(size_t)k * ldc + 2 * (4 * t + g) + e] = r;
+          }
+      }
+    }
+  }
+}
+
 // E = 1: information form (particleSmootherInformationForm.m:274-335): one more streamed right-hand side, P * ivec.  The
 // reference also needs P * ivecPlus with ivecPlus = ivec + H' R^-1 y (:292) -- that is P * ivec + (P H') (R^-1 y), formed from
 // the accumulated columns instead of streamed (same algebra; step_kernel<.., E = 2> streams both).
@@ -346,7 +418,17 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   // ---- D: stream the stored tiles once ----
   const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
   const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
+  constexpr bool kQuad = RBPF_SYM_QUAD && !WR && NPH == 1 && E == 0;   // read-only steps at CH = 8: sym_block_quad
   double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSplit ? 1 : kSymRows][NDA];
+  double accq[kQuad ? kSymRows : 1][4][DE], hq[kQuad ? kSymRows : 1][4][DE];
+  if constexpr (kQuad) {
+#pragma unroll
+    for (int q = 0; q < kSymRows; ++q)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+        for (int k = 0; k < DE; ++k) { accq[q][rq][k] = 0.0; hq[q][rq][k] = Hs[(nb + rows[q] * kSymChunk + 16 * rq + (lane & 15)) * DE + k]; }
+  }
 #pragma unroll
   for (int q = 0; q < kSymRows; ++q) {
     const int r = nb + rows[q] * kSymChunk + lane;
@@ -403,7 +485,16 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
       }
       const double* Hc = Hcore + (size_t)J * kSymChunk * DE;
       double* colp = colw + (size_t)J * kSymChunk;
-      if constexpr (!kSplit) {
+      if constexpr (kQuad) {
+        const double* srq[kSymRows];
+#pragma unroll
+        for (int q = 0; q < kSymRows; ++q)
+          srq[q] = srcT + ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * kSymChunk * (lane >> 4) + 2 * (lane & 15);
+        if (J < rows[0]) sym_block_quad<D, DE, 2, false, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+        else if (J == rows[0]) sym_block_quad<D, DE, 2, true, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+        else if (J < last) sym_block_quad<D, DE, 1, false, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+        else sym_block_quad<D, DE, 1, true, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+      } else if constexpr (!kSplit) {
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
           if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
@@ -486,10 +577,23 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   if (cp == 0) {
 #pragma unroll
     for (int q = 0; q < kSymRows; ++q) {
-      const int rc = rows[q] * kSymChunk + lane;              // core coordinate
+      // quad mapping: the four lane groups hold the row sums of rows r16 + 16 rq over their quarter of the columns; two folds add the
+      // groups and leave row 16 * {0, 2, 1, 3}[lane >> 4] + r16 in this lane (wave_sum4's order), plus the border columns' part,
+      // which the plain mapping accumulated for row `lane`
+      const int rho = lane >> 4;
+      const int rc = rows[q] * kSymChunk + (kQuad ? 16 * ((rho & 1) * 2 + (rho >> 1)) + (lane & 15) : lane);   // core coordinate
       double s[DE];
 #pragma unroll
       for (int k = 0; k < DE; ++k) s[k] = accr[q][k];
+      if constexpr (kQuad) {
+        double* rowx = red + wave * kSymRed;                  // the border part changes lanes through the wave's scratch
+#pragma unroll
+        for (int k = 0; k < DE; ++k) {
+          rowx[lane] = accr[q][k];
+          const double bpart = rowx[rc - rows[q] * kSymChunk];
+          s[k] = fold16(fold32(accq[q][0][k], accq[q][1][k]), fold32(accq[q][2][k], accq[q][3][k])) + bpart;
+        }
+      }
       if (NPH > 1) {
         const double* rowp = smem + lp.off_row;
 #pragma unroll
