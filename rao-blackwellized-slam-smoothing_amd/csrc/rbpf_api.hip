@@ -371,6 +371,13 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     HIPCHK(hipMemsetAsync(c->xl[b], 0, c->bank_cap * L.ldx * sizeof(double), c->stream));
   }
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
+  // shared flush: with ping-pong banks the children of one parent store ONE copy of their (identical) flushed matrix
+  c->share_flush = c->lazy_depth >= 2 && !c->inplace && !smoother && !ex && c->lay.sym && c->lay.CH64 == 8 && !c->fp32;
+  if (c->share_flush) {
+    RB_TRY(dmalloc(&c->d_share, (size_t)3 * N));
+    RB_TRY(dmalloc(&c->d_share_writers, 1));
+    HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));
+  }
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
     if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
@@ -447,7 +454,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
-  hipFree(c->d_ip);
+  hipFree(c->d_ip); hipFree(c->d_share); hipFree(c->d_share_writers);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
@@ -649,7 +656,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   bool flush = true;
   for (int q = 0; q < kMaxSets; ++q) { a.fset[q] = nullptr; a.fset_idx_old[q] = nullptr; a.fset_idx_new[q] = nullptr; }
   a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
-  a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1;
+  a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1; a.share_flush = 0;
   a.fp32 = c->fp32 ? 1 : 0;
   a.xn_ext = c->ext_xn; a.H_ext = c->ext_H;
   if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE && (!a.xn_ext || !a.H_ext)) {
@@ -714,6 +721,13 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     HIPCHK(launch_inplace_plan(N, a.order, A_t, c->base[told], dst, ph, c->d_ip + 2 * (size_t)N, c->stream));
     a.dst_slot = dst; a.phase_of = ph;
   }
+  const bool share = c->share_flush && lazy && flush && t > 0 && !two_phase && a.n_sets >= 1 && a.n_sets <= 7;
+  if (share) {
+    // the children of one parent flush to ONE entry (launch_share_plan): the smallest child stores it, its siblings only read
+    int* lead = c->d_share; int* dst = c->d_share + N; int* ph = c->d_share + 2 * (size_t)N;
+    HIPCHK(launch_share_plan(N, A_t, lead, dst, ph, c->timing_on ? c->d_share_writers : nullptr, c->stream));
+    a.dst_slot = dst; a.phase_of = ph; a.share_flush = 1;
+  }
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) {
@@ -723,6 +737,12 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   if (two_phase) {
     a.phase = 0; HIPCHK(launch_step(a, c->stream));
     a.phase = 1; HIPCHK(launch_step(a, c->stream));
+  } else if (share) {
+    a.phase = 1; HIPCHK(launch_step(a, c->stream));                 // writers: the flush variant
+    StepArgs rd = a;
+    rd.phase = 0; rd.write_base = 0;                                // readers: the read-only variant with the same pending sets
+    HIPCHK(launch_step(rd, c->stream));
+    if (c->timing_on) c->share_flush_particles += N;
   } else {
     HIPCHK(launch_step(a, c->stream));
   }
@@ -991,11 +1011,21 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
   out->stream_kernel_launches = (int64_t)c->events.size();
   const double n = c->mdl.n, nN = c->mdl.nN;
   out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * (c->fp32 ? 4.0 : 8.0);   // SURVEY 8d, s = 4 | 8
-  out->scheduled_bytes_per_launch = c->events.empty() ? 0.0 : c->sched_bytes / (double)c->events.size();
+  double sched = c->sched_bytes;
+  if (c->share_flush && c->share_flush_particles > 0) {
+    // shared flushes: only the writers stored a matrix (the accounting above charged every particle of a flush step with one)
+    unsigned long long wr = 0;
+    HIPCHK(hipMemcpy(&wr, c->d_share_writers, sizeof(wr), hipMemcpyDeviceToHost));
+    const double stored = c->lay.sym ? (double)(c->lay.szT + c->lay.szB) : n * n;
+    sched -= ((double)c->share_flush_particles - (double)wr) * stored * (c->fp32 ? 4.0 : 8.0);
+  }
+  out->scheduled_bytes_per_launch = c->events.empty() ? 0.0 : sched / (double)c->events.size();
   if (reset) {
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     c->events.clear();
     c->sched_bytes = 0.0;
+    c->share_flush_particles = 0;
+    if (c->d_share_writers) HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));
   }
   return RBPF_OK;
 }

@@ -86,6 +86,11 @@ struct rbpf_ctx {
   bool fp32 = false;        // the covariance banks hold float (rbpf_options.storage = 1)
   bool inplace = false;     // single covariance bank, rewritten in place at every flush (rbpf_options.inplace)
   int* d_ip = nullptr;      // [5][N] in-place flush plan: destination entry, phase, scratch
+  // shared flush (filter, ping-pong banks, symmetric storage at eight tile rows): one child per parent stores the flushed matrix
+  bool share_flush = false;
+  int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)
+  unsigned long long* d_share_writers = nullptr;   // writers of the timed shared flushes (device counter)
+  long long share_flush_particles = 0;          // particles of the timed shared flushes (N per flush step)
   // history
   int hist_slabs = 2;
   double* X = nullptr;      // [slabs][nN][N]

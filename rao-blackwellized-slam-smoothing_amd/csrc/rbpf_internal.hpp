@@ -105,6 +105,7 @@ struct StepArgs {
   int* fset_idx_new[kMaxSets];   // propagated entries of the surviving sets (light steps)
   int* fself_idx_new;            // index table of the set this step produces: [i] = i
   const int* base_old; int* base_new;   // slot of the stored matrix of each particle's lineage
+  int share_flush;                      // shared flush: a read-only workgroup's stored matrix becomes its family writer's new entry (descriptor [4])
   // single-bank ("in place") flush: the rewritten matrix of slot i goes to bank entry dst_slot[i] (null: i) and the
   // launch only processes the slots whose phase_of[i] equals `phase` (phase < 0: all).  Phase 0 = children that move
   // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.
@@ -208,6 +209,7 @@ hipError_t launch_order(int n_slots, int range, const int* key, int* order, int*
 // matrix.  dst [N] / phase [N] out; scratch: 3 N ints.
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase,
                                int* scratch, hipStream_t s);
+hipError_t launch_share_plan(int N, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s);
 // multi-workgroup equivalent for large N (rbpf_resample.hip); sa may be null (normalise only)
 size_t resample_scratch_doubles(int N);
 hipError_t launch_resample_pipeline(const NormArgs& nm, const SearchArgs* sa, int* order, int* counts, const int* remap,

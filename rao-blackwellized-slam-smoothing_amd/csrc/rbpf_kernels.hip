@@ -497,7 +497,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
   // propagate_kernel resolved the indirections of this workgroup into one descriptor.
   const int pos = xcd_position((int)blockIdx.x, (int)gridDim.x);   // rbpf_internal.hpp: a family of siblings on ONE XCD
   const int* pre_i = a.pre_i + (size_t)pos * kPreInts;
-  if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
+  if (a.phase >= 0 && pre_i[5] != a.phase) return;     // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;                         // bank entry the rewritten matrix goes to
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
     if (tid == 0) {
       // lineage bookkeeping of the multi-step lazy update: where this particle's stored matrix and its
       // surviving pending sets live (a flush makes them all obsolete)
-      if (a.base_new) a.base_new[i] = WR ? dslot : baseb;
+      if (a.base_new) a.base_new[i] = WR ? dslot : (a.share_flush ? pre_i[4] : baseb);
       if (!WR) {
 #pragma unroll
         for (int sset = 0; sset < NS; ++sset)

@@ -259,6 +259,35 @@ __global__ void ip_assign_kernel(int N, const int* __restrict__ order, const int
   phase[i] = first ? 1 : 0;
 }
 
+// ---- shared flush (ping-pong banks): the children of one parent have the SAME prior covariance at a flush step (their lineage's
+// stored matrix with the same pending sets applied), so only one of them -- the child with the smallest slot, the "writer" -- runs
+// the flush variant and stores it; its siblings run the read-only variant of the step over the same source and take the writer's
+// new entry as their stored matrix.  lead[j] = smallest child of parent j;  dst[i] = lead[ai[i]];  phase[i] = 1 for writers.
+__global__ void share_fill_kernel(int N, int* lead) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) lead[i] = 0x7fffffff;
+}
+__global__ void share_min_kernel(int N, const int* __restrict__ ai, int* lead) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) atomicMin(&lead[ai[i]], i);
+}
+__global__ void share_assign_kernel(int N, const int* __restrict__ ai, const int* __restrict__ lead, int* __restrict__ dst,
+                                    int* __restrict__ phase, unsigned long long* writers) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool w = i < N && lead[ai[i]] == i;
+  if (i < N) { dst[i] = lead[ai[i]]; phase[i] = w ? 1 : 0; }
+  const unsigned long long m = __ballot(w);
+  if (writers && (threadIdx.x & 63) == 0 && m) atomicAdd(writers, (unsigned long long)__popcll(m));
+}
+
+hipError_t launch_share_plan(int N, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s) {
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(share_fill_kernel, dim3(nb), dim3(256), 0, s, N, lead);
+  hipLaunchKernelGGL(share_min_kernel, dim3(nb), dim3(256), 0, s, N, ai, lead);
+  hipLaunchKernelGGL(share_assign_kernel, dim3(nb), dim3(256), 0, s, N, ai, lead, dst, phase, writers);
+  return hipGetLastError();
+}
+
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
                                hipStream_t s) {
   int* has = scratch; int* nzp = scratch + N; int* freelist = scratch + 2 * (size_t)N;

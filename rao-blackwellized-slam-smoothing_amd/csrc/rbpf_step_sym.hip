@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   const int n = Ly.n, nb = Ly.nb, mc = Ly.mc, ldx = Ly.ldx, ldb = Ly.ldb;
   const int pos = xcd_position((int)blockIdx.x, (int)gridDim.x);   // processing position (sorted by the matrix the particle reads)
   const int* pre_i = a.pre_i + (size_t)pos * kPreInts;
-  if (WR && a.phase >= 0 && pre_i[5] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
+  if (a.phase >= 0 && pre_i[5] != a.phase) return;      // single-bank flush: not this launch's share (workgroup-uniform)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     double* KSn = a.F_new + ((size_t)i * 2 + 0) * D * ldx;
     double* Kn = a.F_new + ((size_t)i * 2 + 1) * D * ldx;
     if (tid == 0) {
-      if (a.base_new) a.base_new[i] = WR ? dslot : baseb;
+      if (a.base_new) a.base_new[i] = WR ? dslot : (a.share_flush ? pre_i[4] : baseb);
       if (!WR) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)

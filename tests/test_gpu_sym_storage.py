@@ -82,7 +82,9 @@ def test_symmetric_storage_against_the_c_restatement(rbpf, tmp_path_factory):
 @pytest.mark.parametrize("lazy_depth", [3, 4])
 def test_symmetric_storage_equals_full_storage_on_philox_streams(rbpf, lazy_depth):
     """N = 4096, m = 512, 21 steps on the device generator: same resampling indices as the full-square storage, outputs to
-    1e-9; the in-place schedule equals the ping-pong schedule bit for bit; two runs are bit-identical."""
+    1e-9; the in-place schedule gives the same indices and the same outputs to rounding as the ping-pong schedule (with two banks
+    the children of one parent share ONE flushed matrix and the siblings of its writer run the read-only arithmetic at a flush
+    step: shared flush); two runs are bit-identical."""
     from test_gpu_configs import check_filter_properties, mag_inputs, run_session
     N, steps = 4096, 21
     d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
@@ -96,8 +98,11 @@ def test_symmetric_storage_equals_full_storage_on_philox_streams(rbpf, lazy_dept
     for k in ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "xl_mean"):
         sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis   # NaN beyond the steps run
         assert rel(a[k][sl], full[k][sl]) <= RTOL, k
+    np.testing.assert_array_equal(a["trace_ai"], b["trace_ai"])
     for k in want:
-        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
+        if k != "trace_ai":
+            assert rel(a[k][sl], b[k][sl]) <= 1e-11, k
         np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
 
 
