@@ -103,9 +103,12 @@ def roofline_of(tm):
             "scheduled_bytes_per_launch": sched,
             "algorithmic_bytes_per_launch": tm["bytes_per_launch"], "algorithmic_GBps": alg,
             "algorithmic_ratio": alg / HBM_PEAK_GBPS,
-            "note": "achieved/frac: bytes the schedule has to move (covariance read every step, rewritten every lazy_depth-th) / "
-                    "HIP-event launch time; algorithmic_*: SURVEY 8d's one read + one write per step over the same time (not a "
-                    "roofline fraction: the lazy update elides writes)"}
+            "note": "achieved/frac: bytes the schedule has to move (every particle's read of its stored covariance every step; the "
+                    "matrices written at every lazy_depth-th step, one per parent with children: shared flush) / HIP-event launch "
+                    "time.  Particles that share a stored matrix (siblings, cousins) are processed on one XCD, so part of these reads is "
+                    "served by its L2: `traffic` (HBM counters) can be well below the scheduled bytes -- hbm_counter_GBps / "
+                    "frac_hbm_counters price the launch by the counters instead.  algorithmic_*: SURVEY 8d's one read + one write per "
+                    "step over the same time (not a roofline fraction: the lazy update elides writes)"}
 
 
 def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True):
@@ -559,6 +562,8 @@ def main():
                 line["roofline"]["traffic"] = tr["bytes_per_launch"]
                 line["roofline"]["traffic_detail"] = tr
                 line["roofline"]["traffic_over_scheduled"] = tr["bytes_per_launch"] / line["roofline"]["scheduled_bytes_per_launch"]
+                line["roofline"]["hbm_counter_GBps"] = tr["bytes_per_launch"] / (line["roofline"]["avg_launch_ms"] * 1e-3) / 1e9
+                line["roofline"]["frac_hbm_counters"] = line["roofline"]["hbm_counter_GBps"] / HBM_PEAK_GBPS
             else:
                 line["roofline"]["traffic_note"] = why
         if solo and not args.no_smoother:
