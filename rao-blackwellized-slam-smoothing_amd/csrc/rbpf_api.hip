@@ -725,7 +725,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   if (share) {
     // the children of one parent flush to ONE entry (launch_share_plan): the smallest child stores it, its siblings only read
     int* lead = c->d_share; int* dst = c->d_share + N; int* ph = c->d_share + 2 * (size_t)N;
-    HIPCHK(launch_share_plan(N, A_t, lead, dst, ph, c->timing_on ? c->d_share_writers : nullptr, c->stream));
+    HIPCHK(launch_share_plan(N, N, A_t, lead, dst, ph, c->timing_on ? c->d_share_writers : nullptr, c->stream));
     a.dst_slot = dst; a.phase_of = ph; a.share_flush = 1;
   }
   HIPCHK(launch_propagate(a, c->stream));

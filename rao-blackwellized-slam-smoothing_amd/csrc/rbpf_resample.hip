@@ -280,9 +280,10 @@ __global__ void share_assign_kernel(int N, const int* __restrict__ ai, const int
   if (writers && (threadIdx.x & 63) == 0 && m) atomicAdd(writers, (unsigned long long)__popcll(m));
 }
 
-hipError_t launch_share_plan(int N, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s) {
+// nkeys: range of the parent keys ai[.] (N on one GPU; bank entries + received records in the sharded filter)
+hipError_t launch_share_plan(int N, int nkeys, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s) {
   const int nb = (N + 255) / 256;
-  hipLaunchKernelGGL(share_fill_kernel, dim3(nb), dim3(256), 0, s, N, lead);
+  hipLaunchKernelGGL(share_fill_kernel, dim3((nkeys + 255) / 256), dim3(256), 0, s, nkeys, lead);
   hipLaunchKernelGGL(share_min_kernel, dim3(nb), dim3(256), 0, s, N, ai, lead);
   hipLaunchKernelGGL(share_assign_kernel, dim3(nb), dim3(256), 0, s, N, ai, lead, dst, phase, writers);
   return hipGetLastError();

@@ -23,7 +23,7 @@ void shard_free(rbpf_ctx* c) {
   if (!s) return;
   hipFree(s->fwd_local); hipFree(s->fwd_gather); hipFree(s->logw_glob); hipFree(s->xn_glob); hipFree(s->w_glob);
   hipFree(s->wc_glob); hipFree(s->ai_glob); hipFree(s->perm); hipFree(s->ai_bank); hipFree(s->slot_ids);
-  hipFree(s->pack_idx); hipFree(s->send_rec); hipFree(s->recv_rec);
+  hipFree(s->pack_idx); hipFree(s->send_rec); hipFree(s->recv_rec); hipFree(s->d_share_lead); hipFree(s->d_share);
   hipFree(s->pb.key); hipFree(s->pb.counts); hipFree(s->pb.offsets); hipFree(s->pb.fill); hipFree(s->pb.tmp);
   hipFree(s->pb.order); hipFree(s->pb.mv_child); hipFree(s->pb.mv_src); hipFree(s->pb.mv_q); hipFree(s->pb.pref);
   hipFree(s->pb.slot_ids); hipFree(s->pb.anc_bank); hipFree(s->pb.send_idx); hipFree(s->pb.scalars); hipFree(s->pb.counts_dev);
@@ -361,10 +361,33 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.status = c->d_flags;
   a.stamps = nullptr;
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d; a.u_next = nullptr;
+  // shared flush (see ctx_step): the children of one parent -- one bank entry or one received record -- store ONE flushed matrix
+  const bool share = lazy && flush && t > 0 && dev_plan && !info && L.sym && L.CH64 == 8 && !c->fp32 && a.n_sets >= 1 && a.n_sets <= 7;
+  if (share) {
+    const size_t keys = (size_t)N + s->recv_cap;
+    if (s->share_keys < keys) {
+      HIPCHK(hipStreamSynchronize(c->stream));
+      hipFree(s->d_share_lead); s->d_share_lead = nullptr;
+      RB_TRY(dmalloc(&s->d_share_lead, keys));
+      s->share_keys = keys;
+    }
+    if (!s->d_share) RB_TRY(dmalloc(&s->d_share, (size_t)2 * N));
+    if (!c->d_share_writers) { RB_TRY(dmalloc(&c->d_share_writers, 1)); HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long))); c->share_flush = true; }
+    HIPCHK(launch_share_plan(N, (int)keys, a.ai_bank, s->d_share_lead, s->d_share, s->d_share + N, c->timing_on ? c->d_share_writers : nullptr, c->stream));
+    a.dst_slot = s->d_share; a.phase_of = s->d_share + N; a.share_flush = 1;
+  }
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }
-  HIPCHK(launch_step(a, c->stream));
+  if (share) {
+    a.phase = 1; HIPCHK(launch_step(a, c->stream));                 // writers: the flush variant
+    StepArgs rd = a;
+    rd.phase = 0; rd.write_base = 0;                                // readers: the read-only variant with the same pending sets
+    HIPCHK(launch_step(rd, c->stream));
+    if (c->timing_on) c->share_flush_particles += N;
+  } else {
+    HIPCHK(launch_step(a, c->stream));
+  }
   if (c->timing_on) { HIPCHK(hipEventRecord(e1, c->stream)); c->events.emplace_back(e0, e1); ctx_account_launch(c, a); }
   // fwd_local feeds the next collective; host arrays (anc_bank / slot_ids) are caller memory behind asynchronous copies
   if (!s->async || anc_bank_host || slot_ids_host) HIPCHK(hipStreamSynchronize(c->stream));

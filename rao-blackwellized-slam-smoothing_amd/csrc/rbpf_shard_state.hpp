@@ -36,6 +36,9 @@ struct ShardState {
   // multi-step lazy update: received records persist until the next flush (imported lineages use them as base)
   std::vector<int> rec_used_all;   // records alive in every rank's receive buffer (replicated bookkeeping)
   size_t step_cap = 0;             // records one rank may send / receive per step (identical on every rank)
+  // shared flush (rbpf_api.hip): smallest child per parent key (bank entry or received record), destination entry, phase
+  int* d_share_lead = nullptr; size_t share_keys = 0;
+  int* d_share = nullptr;          // [2][Nloc]
   int regrown = 0;                 // times the exchange buffers were grown (rbpf_shard_plan): callers re-read rbpf_shard_views
   bool async = false;              // no stream synchronisation at the end of pack / step (collectives on the same stream)
   int rec_used = 0;                // records currently alive in recv_rec
