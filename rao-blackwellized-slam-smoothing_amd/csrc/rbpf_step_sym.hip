@@ -107,6 +107,19 @@ __device__ __forceinline__ double dpp_mov(double x) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// one butterfly stage: the lane keeps u (sel = false) or v (sel = true), passes the other one on by the row rotation CTRL and adds what arrives
+// (bit blends of the 32-bit halves, m = 0 or ~0: with selects on a lane predicate the register allocation of the whole kernel fell
+// apart -- 359 spilled registers)
+template <int CTRL>
+__device__ __forceinline__ double bfly_pair(double u, double v, unsigned m) {
+  const unsigned ulo = (unsigned)__double2loint(u), uhi = (unsigned)__double2hiint(u);
+  const unsigned vlo = (unsigned)__double2loint(v), vhi = (unsigned)__double2hiint(v);
+  const unsigned klo = (vlo & m) | (ulo & ~m), khi = (vhi & m) | (uhi & ~m);
+  const unsigned slo = (ulo & m) | (vlo & ~m), shi = (uhi & m) | (vhi & ~m);
+  const int rlo = __builtin_amdgcn_update_dpp(0, (int)slo, CTRL, 0xf, 0xf, false);
+  const int rhi = __builtin_amdgcn_update_dpp(0, (int)shi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double((int)khi, (int)klo) + __hiloint2double(rhi, rlo);
+}
 // every lane of a 16-lane row gets the row's sum (rotations by 8, 4, 2, 1: a fixed order)
 __device__ __forceinline__ double row16_sum(double x) {
   x += dpp_mov<0x128>(x);      // row_ror:8
@@ -263,6 +276,9 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #ifndef RBPF_SYM_QUAD
 #define RBPF_SYM_QUAD 1
 #endif
+#ifndef RBPF_SYM_BUTTERFLY
+#define RBPF_SYM_BUTTERFLY 1
+#endif
 template <int D, int DE, int NACT, bool DIAG, int Q0>
 __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRows], const double* __restrict__ Hc,
                                                const double (&hown)[kSymRows][4][DE], double (&accr)[kSymRows][4][DE],
@@ -311,13 +327,32 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
           }
         }
       if (kCol) {
+        if constexpr (DE == 3 && RBPF_SYM_BUTTERFLY) {
+          // six 16-lane sums as a butterfly: rotations by 1, 2, 4, 8 (in this order a lane's selection bit of one stage is untouched by
+          // the later rotations); a stage pairs two registers -- every lane keeps the one its bit selects, passes the other one on,
+          // and adds what arrives -- so the register count halves while it can: 43 instead of 72 instructions.  Afterwards lane l
+          // holds in q the sum (0,0) (0,1) (0,2) (1,0) for l & 3 = 0..3 and in w the sum (1,1) (1,2) for l & 1 = 0, 1.
+          __builtin_amdgcn_sched_barrier(0);      // (left to itself the scheduler spreads these chains over the next round's loads: 359 spills)
+          const unsigned b0 = 0u - (unsigned)(lane & 1), b1 = 0u - (unsigned)((lane >> 1) & 1);
+          const double r0 = bfly_pair<0x121>(pc[0][0], pc[0][1], b0), r1 = bfly_pair<0x121>(pc[0][2], pc[1][0], b0);
+          double w = bfly_pair<0x121>(pc[1][1], pc[1][2], b0);
+          double q = bfly_pair<0x122>(r0, r1, b1);
+          w += dpp_mov<0x122>(w);
+          q += dpp_mov<0x124>(q); w += dpp_mov<0x124>(w);
+          q += dpp_mov<0x128>(q); w += dpp_mov<0x128>(w);
+          const int col = 2 * (4 * t + g);
+          if (r16 < 4) colp[(size_t)(r16 == 3 ? 0 : r16) * ldc + col + (r16 == 3 ? 1 : 0)] = q;
+          if (r16 < 2) colp[(size_t)(1 + r16) * ldc + col + 1] = w;
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+          for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int k = 0; k < DE; ++k) {
-            const double r = row16_sum(pc[e][k]);
-            if (r16 == 0) colp[(size_t)k * ldc + 2 * (4 * t + g) + e] = r;
-          }
+            for (int k = 0; k < DE; ++k) {
+              const double r = row16_sum(pc[e][k]);
+              if (r16 == 0) colp[(size_t)k * ldc + 2 * (4 * t + g) + e] = r;
+            }
+        }
       }
     }
   }
