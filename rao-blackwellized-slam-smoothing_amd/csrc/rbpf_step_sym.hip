@@ -22,6 +22,11 @@
 #include "rbpf_device.hpp"
 #include "rbpf_model_dev.hpp"
 
+#ifdef RBPF_STAMPS                               // diagnostic builds: phase times of one workgroup (100 MHz ticks), printed by ctx_step
+#define RBPF_SYM_KSTAMP(k) if (blockIdx.x == 4000 && threadIdx.x == 0 && a.stamps) a.stamps[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RBPF_SYM_KSTAMP(k)
+#endif
 #ifndef RBPF_SYM_LIGHT_WGS
 #define RBPF_SYM_LIGHT_WGS 2       // workgroups per CU the read-only filter variant is compiled for (3: xl stays in global memory)
 #endif
@@ -408,6 +413,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     else Fs[s] = remote ? recp + a.rec_off_F : a.F_old + (size_t)ancb * 2 * D * ldx;
   }
 
+  RBPF_SYM_KSTAMP(0);
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)pos * kPreDoubles + tid];
   constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
@@ -425,9 +431,11 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     }
   }
   __syncthreads();
+  RBPF_SYM_KSTAMP(1);
   // ---- B: per-axis sin / cos tables ----
   for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
   __syncthreads();
+  RBPF_SYM_KSTAMP(2);
   // ---- C: measurement Jacobian, one column per thread ----
   for (int c = tid; c < n; c += kThreads) {
     double h[D];
@@ -450,6 +458,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   }
   __syncthreads();
 
+  RBPF_SYM_KSTAMP(3);
   // ---- D: stream the stored tiles once ----
   const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
   const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
@@ -697,6 +706,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     __syncthreads();
   }
 
+  RBPF_SYM_KSTAMP(4);
   // ---- E: S = H (P H') + R, e = y - H xl   (particleFilter.m:139-150) ----
   constexpr int NRED = D * D + D + 2 * E;
   {
@@ -775,6 +785,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   }
   __syncthreads();
 
+  RBPF_SYM_KSTAMP(5);
   // ---- F: Kalman gain rows, mean update, new pending factors (particleFilter.m:194-198) ----
   {
     double cS[D * D], SS[D * D], e[D];
@@ -856,6 +867,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
       }
     }
   }
+  RBPF_SYM_KSTAMP(6);
 }
 
 template <int D, int NS, bool WR, int E, int CH>
