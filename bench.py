@@ -103,12 +103,13 @@ def roofline_of(tm):
             "scheduled_bytes_per_launch": sched,
             "algorithmic_bytes_per_launch": tm["bytes_per_launch"], "algorithmic_GBps": alg,
             "algorithmic_ratio": alg / HBM_PEAK_GBPS,
-            "note": "achieved/frac: bytes the schedule has to move (every particle's read of its stored covariance every step; the "
-                    "matrices written at every lazy_depth-th step, one per parent with children: shared flush) / HIP-event launch "
-                    "time.  Particles that share a stored matrix (siblings, cousins) are processed on one XCD, so part of these reads is "
-                    "served by its L2: `traffic` (HBM counters) can be well below the scheduled bytes -- hbm_counter_GBps / "
-                    "frac_hbm_counters price the launch by the counters instead.  algorithmic_*: SURVEY 8d's one read + one write per "
-                    "step over the same time (not a roofline fraction: the lazy update elides writes)"}
+            "note": "achieved/frac: bytes the schedule has to move from / to memory -- every DISTINCT stored covariance read per step "
+                    "(particles that share one, siblings and cousins of the lazy update, are processed on one XCD and read it through "
+                    "its L2: counted on the device), the matrices written at every lazy_depth-th step (one per parent with children: "
+                    "shared flush), the factor sets and states -- / HIP-event launch time.  `traffic` (HBM counters) / "
+                    "hbm_counter_GBps / frac_hbm_counters price the same launch by the counters.  algorithmic_*: SURVEY 8d's one read + "
+                    "one write of a full-square covariance per particle-step over the same time (not a roofline fraction: the "
+                    "symmetric storage, the lazy update and the shared reads all elide bytes)"}
 
 
 def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True):

@@ -454,7 +454,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
-  hipFree(c->d_ip); hipFree(c->d_share); hipFree(c->d_share_writers);
+  hipFree(c->d_ip); hipFree(c->d_share); hipFree(c->d_share_writers); hipFree(c->d_distinct_mark); hipFree(c->d_distinct_counter);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
   for (int b = 0; b <= kMaxSets; ++b) hipFree(c->Fb[b]);
@@ -533,6 +533,26 @@ int generic_finish_inputs(rbpf_ctx* c, const double* xref_host) {
 // Bytes a timed launch of the step kernel has to move (rbpf_timing.scheduled_bytes_per_launch): the stored covariance in
 // (and out when it is rewritten), the pending factor sets it applies and the one it produces, the means and the states in
 // and out (+ ivec in / out and H out for the information form).
+// Timed launches: let propagate_kernel count the distinct stored matrices this step reads (`keys`: range of the slots).
+int ctx_arm_distinct(rbpf_ctx* c, StepArgs& a, size_t keys) {
+  a.distinct_mark = nullptr; a.distinct_counter = nullptr; a.distinct_tag = 0;
+  if (!c->timing_on || a.t == 0) return RBPF_OK;
+  if (c->distinct_keys < keys) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(c->d_distinct_mark); c->d_distinct_mark = nullptr;
+    HIPCHK(hipMalloc(&c->d_distinct_mark, keys * sizeof(int)));
+    HIPCHK(hipMemset(c->d_distinct_mark, 0, keys * sizeof(int)));
+    c->distinct_keys = keys;
+  }
+  if (!c->d_distinct_counter) {
+    HIPCHK(hipMalloc(&c->d_distinct_counter, sizeof(unsigned long long)));
+    HIPCHK(hipMemset(c->d_distinct_counter, 0, sizeof(unsigned long long)));
+  }
+  a.distinct_mark = c->d_distinct_mark; a.distinct_counter = c->d_distinct_counter; a.distinct_tag = ++c->distinct_epoch;
+  c->distinct_nominal += a.N;
+  return RBPF_OK;
+}
+
 void ctx_account_launch(rbpf_ctx* c, const StepArgs& a) {
   const double sP = c->fp32 ? 4.0 : 8.0, nn = (double)c->mdl.n, d = (double)c->mdl.d, nN = (double)c->mdl.nN;
   // stored elements of one covariance: n^2, or the lower block triangle + border rows of the symmetric layout
@@ -728,6 +748,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     HIPCHK(launch_share_plan(N, N, A_t, lead, dst, ph, c->timing_on ? c->d_share_writers : nullptr, c->stream));
     a.dst_slot = dst; a.phase_of = ph; a.share_flush = 1;
   }
+  RB_TRY(ctx_arm_distinct(c, a, (size_t)N + 1));
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) {
@@ -1019,6 +1040,13 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
     const double stored = c->lay.sym ? (double)(c->lay.szT + c->lay.szB) : n * n;
     sched -= ((double)c->share_flush_particles - (double)wr) * stored * (c->fp32 ? 4.0 : 8.0);
   }
+  if (c->d_distinct_counter && c->distinct_nominal > 0) {
+    // particles that share a stored matrix (siblings, cousins) read it once from memory: charge the distinct matrices
+    unsigned long long dn = 0;
+    HIPCHK(hipMemcpy(&dn, c->d_distinct_counter, sizeof(dn), hipMemcpyDeviceToHost));
+    const double stored = c->lay.sym ? (double)(c->lay.szT + c->lay.szB) : n * n;
+    sched -= ((double)c->distinct_nominal - (double)dn) * stored * (c->fp32 ? 4.0 : 8.0);
+  }
   out->scheduled_bytes_per_launch = c->events.empty() ? 0.0 : sched / (double)c->events.size();
   if (reset) {
     for (auto& ev : c->events) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
@@ -1026,6 +1054,8 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
     c->sched_bytes = 0.0;
     c->share_flush_particles = 0;
     if (c->d_share_writers) HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));
+    c->distinct_nominal = 0;
+    if (c->d_distinct_counter) HIPCHK(hipMemset(c->d_distinct_counter, 0, sizeof(unsigned long long)));
   }
   return RBPF_OK;
 }

@@ -91,6 +91,9 @@ struct rbpf_ctx {
   int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)
   unsigned long long* d_share_writers = nullptr;   // writers of the timed shared flushes (device counter)
   long long share_flush_particles = 0;          // particles of the timed shared flushes (N per flush step)
+  // timed launches: reads of stored matrices counted per particle (nominal) and per DISTINCT matrix (device counter)
+  int* d_distinct_mark = nullptr; size_t distinct_keys = 0; unsigned long long* d_distinct_counter = nullptr;
+  long long distinct_nominal = 0; int distinct_epoch = 0;
   // history
   int hist_slabs = 2;
   double* X = nullptr;      // [slabs][nN][N]
@@ -136,6 +139,7 @@ int generic_draw_propagate(rbpf_ctx* c, int k_iter, int n_draw);
 int generic_finish_inputs(rbpf_ctx* c, const double* xref_host);
 int ctx_call_on_step(rbpf_ctx* c, int t, bool is_smoother);
 void ctx_account_launch(rbpf_ctx* c, const StepArgs& a);
+int ctx_arm_distinct(rbpf_ctx* c, StepArgs& a, size_t keys);
 int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
 // in-library multi-device driver (rbpf_multi.hip): rbpf_options.n_devices

@@ -106,6 +106,8 @@ struct StepArgs {
   int* fself_idx_new;            // index table of the set this step produces: [i] = i
   const int* base_old; int* base_new;   // slot of the stored matrix of each particle's lineage
   int share_flush;                      // shared flush: a read-only workgroup's stored matrix becomes its family writer's new entry (descriptor [4])
+  // timed launches: how many DISTINCT stored matrices does this step read?  (mark[slot] <- tag; a changed mark counts once)
+  int* distinct_mark; unsigned long long* distinct_counter; int distinct_tag;
   // single-bank ("in place") flush: the rewritten matrix of slot i goes to bank entry dst_slot[i] (null: i) and the
   // launch only processes the slots whose phase_of[i] equals `phase` (phase < 0: all).  Phase 0 = children that move
   // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.

@@ -459,6 +459,11 @@ __global__ void propagate_kernel(const StepArgs a) {
   }
   pi[4] = a.dst_slot ? a.dst_slot[i] : i;
   pi[5] = a.phase_of ? a.phase_of[i] : 0;
+  if (a.distinct_mark) {                                    // accounting of the timed launches only
+    const bool fresh = atomicExch(&a.distinct_mark[pi[3]], a.distinct_tag) != a.distinct_tag;
+    const unsigned long long m = __ballot(fresh);
+    if (fresh && (__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63)) atomicAdd(a.distinct_counter, (unsigned long long)__popcll(m));
+  }
   double* pd = a.pre_d + (size_t)b * kPreDoubles;
 #pragma unroll
   for (int c = 0; c < 8; ++c) pd[c] = xp[c];

@@ -376,6 +376,7 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
     HIPCHK(launch_share_plan(N, (int)keys, a.ai_bank, s->d_share_lead, s->d_share, s->d_share + N, c->timing_on ? c->d_share_writers : nullptr, c->stream));
     a.dst_slot = s->d_share; a.phase_of = s->d_share + N; a.share_flush = 1;
   }
+  RB_TRY(ctx_arm_distinct(c, a, (size_t)N + s->recv_cap + 1));
   HIPCHK(launch_propagate(a, c->stream));
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->timing_on) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, c->stream)); }

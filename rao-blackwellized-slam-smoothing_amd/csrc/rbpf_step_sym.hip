@@ -281,6 +281,9 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #ifndef RBPF_SYM_QUAD
 #define RBPF_SYM_QUAD 1
 #endif
+#ifndef RBPF_SYM_QUAD_LOADS
+#define RBPF_SYM_QUAD_LOADS 16     // wave loads in flight per round (8: 218 registers; 16: 256 with two spilled, 3.5 % faster)
+#endif
 #ifndef RBPF_SYM_BUTTERFLY
 #define RBPF_SYM_BUTTERFLY 1
 #endif
@@ -290,7 +293,7 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
                                                double* __restrict__ colp, int ldc, int lane) {
   const int r16 = lane & 15, g = lane >> 4;
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
-  constexpr int TQ = 2 / NACT;                          // quads per round: eight wave loads in flight whatever the active rows
+  constexpr int TQ = (RBPF_SYM_QUAD_LOADS / 4) / NACT;   // quads per round: RBPF_SYM_QUAD_LOADS wave loads in flight whatever the active rows
   for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
     dbl2s v[TQ][NACT][4];
 #pragma unroll
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
       for (int k = 0; k < D; ++k) ks[kSplit ? 0 : q][s * D + k] = (WR && !kSplit) ? Fs[s][(size_t)k * ldx + r] : 0.0;
     // the border COLUMNS of this row, P(r, b) = B(b, r), downdated like the border phase does when this is a flush.  Read here,
     // before anything is stored: in the second launch of a single-bank flush the border phase overwrites these very values.
-    for (int b = 0; b < nb && cp == 0; ++b) {                  // (once per row: the first column phase)
+    for (int b = 0; b < nb && cp == 0 && !kQuad; ++b) {        // (once per row: the first column phase; quad mapping: after the stream)
       double pv = srcB[(size_t)b * ldb + r];
       if (WR) {
 #pragma unroll
@@ -630,13 +633,17 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 #pragma unroll
       for (int k = 0; k < DE; ++k) s[k] = accr[q][k];
       if constexpr (kQuad) {
-        double* rowx = red + wave * kSymRed;                  // the border part changes lanes through the wave's scratch
+        // the border columns of this lane's row, P(r, b) = B(b, r) (not live across the stream: twelve registers for its loads)
 #pragma unroll
-        for (int k = 0; k < DE; ++k) {
-          rowx[lane] = accr[q][k];
-          const double bpart = rowx[rc - rows[q] * kSymChunk];
-          s[k] = fold16(fold32(accq[q][0][k], accq[q][1][k]), fold32(accq[q][2][k], accq[q][3][k])) + bpart;
+        for (int k = 0; k < DE; ++k) s[k] = 0.0;
+        for (int b = 0; b < nb; ++b) {
+          const double pv = srcB[(size_t)b * ldb + nb + rc];
+#pragma unroll
+          for (int k = 0; k < DE; ++k) s[k] = fma(pv, Hs[b * DE + k], s[k]);
         }
+#pragma unroll
+        for (int k = 0; k < DE; ++k)
+          s[k] = fold16(fold32(accq[q][0][k], accq[q][1][k]), fold32(accq[q][2][k], accq[q][3][k])) + s[k];
       }
       if (NPH > 1) {
         const double* rowp = smem + lp.off_row;
