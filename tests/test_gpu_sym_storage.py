@@ -210,3 +210,47 @@ def test_carried_factors_on_symmetric_storage(rbpf):
     assert np.max(np.abs(a[3]["paNt"][1, 1:] - b[3]["paNt"][1, 1:])) <= 1e-9
     assert rel(b[3]["w"], a[3]["w"]) <= 1e-9
     assert rel(b[0], a[0]) <= RTOL and rel(b[1], a[1]) <= RTOL and rel(b[2], a[2]) <= RTOL
+
+
+def test_scheduled_bytes_count_distinct_matrices_and_shared_flush_writers(rbpf):
+    """rbpf_timing.scheduled_bytes_per_launch on symmetric storage with two banks: every DISTINCT stored covariance a step reads
+    (families of siblings / cousins share theirs) and, at a flush, one written matrix per parent with children (shared flush).
+    Recomputed here from the ancestor trace of the same run: base slots propagate down the lineages, a flush step rebases every
+    child on the smallest child of its parent."""
+    from test_gpu_configs import mag_inputs
+    N, C, W, K = 1024, 4, 5, 8
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
+    with rbpf.FilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rbpf.PhiloxRNG(5),
+                            keep_history=True, trace=True, lazy_depth=C, inplace=-1, storage="fp64sym") as s:
+        s.advance(W)
+        s.sync()
+        s.timing(enable=True)
+        s.advance(K)
+        s.sync()
+        tm = s.timing(reset=True)
+        ai = s.finish(want=("trace_ai",))["trace_ai"]
+    n = mdl.nLin
+    # stored doubles of one covariance: lower block triangle of 64 x 64 tiles over the 512 core rows + 3 border rows of ldb
+    # (the library's own figure is not exposed: bound it from both sides instead)
+    stored_lo, stored_hi = 0.5 * n * n * 8, 0.62 * n * n * 8
+    base = np.arange(N)                                  # after step 0 (a flush) every particle sits on its own entry
+    reads = writes = 0
+    for t in range(1, W + K):
+        anc = ai[:, t]
+        ell = (t - 1) % C + 1
+        src = base[anc]                                  # the matrix each child reads
+        if t >= W:
+            reads += np.unique(src).size
+        if ell == C:                                     # flush: one entry per parent with children, the smallest child's
+            lead = np.full(N, N, dtype=np.int64)
+            np.minimum.at(lead, anc, np.arange(N))
+            if t >= W:
+                writes += np.unique(anc).size
+            base = lead[anc]
+        else:
+            base = src
+    fixed = 8.0 * N * K * (2.0 * n * 3 + 2.0 * n + 2.0 * 7)          # at least: one factor set out, means, states
+    total = tm["scheduled_bytes_per_launch"] * tm["launches"]
+    assert tm["launches"] == K
+    assert (reads + writes) * stored_lo + fixed <= total <= (reads + writes) * stored_hi + 6.0 * fixed
+    assert reads < 0.8 * N * K and writes < 0.8 * N * (K // C + 1)   # the sharing is real on this workload
