@@ -17,7 +17,16 @@
 //   multiply-adds in the stream (same algebra, agreement to rounding as for lazy_depth itself).  A flush applies the sets
 //   element-wise as before (it has to write P+), with the column factors of the current 64 columns in a wave-private LDS stage.
 //
-// Supported: dense families with ny = 3, fp64, 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]), filter.
+// * Read-only steps at eight tile rows use the QUAD mapping (sym_block_quad): a lane takes four rows of a tile and one column pair
+//   of a quad of four, sums its 4 rows x 2 tile rows per column before anything crosses lanes, and the six column sums of a quad
+//   are one 16-lane butterfly -- the cross-lane reductions were half of the kernel's instructions, and once the families of
+//   particles that share a stored matrix sit on one XCD (xcd_position, rbpf_internal.hpp) the kernel is bound by its instruction
+//   stream and by one memory round trip per round of loads, not by HBM.
+// * At a flush step of the filter with two banks only one child per parent runs the flush variant; its siblings run the read-only
+//   variant over the same source and point at the writer's new entry (shared flush: launch_share_plan, StepArgs::share_flush).
+//
+// Supported: dense families with ny = 3, fp64, 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]) or four tile rows
+// (nLin = 259), filter and both smoothers, single-GPU and sharded.
 #include "rbpf_internal.hpp"
 #include "rbpf_device.hpp"
 #include "rbpf_model_dev.hpp"
