@@ -221,7 +221,9 @@ template <int D, int NS, bool VLDS>
 __global__ __launch_bounds__(256, VLDS ? 2 : 1) void chol_sweep_kernel(const SweepArgs a) {
   extern __shared__ double sweep_lds[];
   const int lane = threadIdx.x & 63;
-  const int pb = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // (processing positions dealt to the XCDs in contiguous ranges: siblings, side by side in `order`, read their ancestor's factor
+  //  out of one L2 -- xcd_position, rbpf_internal.hpp)
+  const int pb = xcd_position((int)blockIdx.x, (int)gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (pb >= a.N) return;                                 // wave-uniform
   const int p = a.order ? a.order[pb] : pb;
   const int src_p = a.anc ? a.anc[p] : p;
