@@ -216,20 +216,49 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
         // NACT == 1) the next chunk is only read after the previous one was applied
         constexpr int kChunk = 4 * D, NCH = (ND + kChunk - 1) / kChunk;
         double kc0[kChunk], kc1[kChunk];
-        if (WR && NCH == 1) {
+        // up to four sets: the column factors go through the registers ONE SET (D values per column) AT A TIME, the next set's LDS
+        // reads in flight during the multiply-adds of the current one (all 2 * ND of them live across both rows' downdates cost 48
+        // registers at four sets: 256 -> 215).  Measured: the same 16 ms per flush launch, with four or with eight wave loads per
+        // round -- the flush is bound by its instruction stream (~500 cycles per column pair and wave: 72 multiply-adds, twelve
+        // LDS reads, 1.5 wave_sum4), not by loads in flight
+        double pq0[NACT], pq1[NACT];
 #pragma unroll
-          for (int k = 0; k < ND; ++k) {
+        for (int q = 0; q < NACT; ++q) { pq0[q] = v[u][q].x; pq1[q] = v[u][q].y; }
+        if (WR && NCH == 1 && ND > 0) {
+          double ca[D], cb[D], na[D], nb_[D];
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
             const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)(p % (kSymStage / 2)) * ND + k) * 2);
-            kc0[k] = t.x; kc1[k] = t.y;
+            ca[k] = t.x; cb[k] = t.y;
+          }
+#pragma unroll
+          for (int s = 0; s < NS; ++s) {
+            if (s + 1 < NS) {
+#pragma unroll
+              for (int k = 0; k < D; ++k) {
+                const dbl2s t = *reinterpret_cast<const dbl2s*>(kst + ((size_t)(p % (kSymStage / 2)) * ND + (s + 1) * D + k) * 2);
+                na[k] = t.x; nb_[k] = t.y;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < NACT; ++q)
+#pragma unroll
+              for (int k = 0; k < D; ++k) {
+                pq0[q] = fma(-ks[KR == 1 ? 0 : Q0 + q][s * D + k], ca[k], pq0[q]);
+                pq1[q] = fma(-ks[KR == 1 ? 0 : Q0 + q][s * D + k], cb[k], pq1[q]);
+              }
+            if (s + 1 < NS) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int k = 0; k < D; ++k) { ca[k] = na[k]; cb[k] = nb_[k]; }
+            }
           }
         }
 #pragma unroll
         for (int q = 0; q < NACT; ++q) {
-          double p0v = v[u][q].x, p1v = v[u][q].y;
+          double p0v = pq0[q], p1v = pq1[q];
           if (WR) {
             if (NCH == 1) {
-#pragma unroll
-              for (int k = 0; k < ND; ++k) { p0v = fma(-ks[KR == 1 ? 0 : Q0 + q][k], kc0[k], p0v); p1v = fma(-ks[KR == 1 ? 0 : Q0 + q][k], kc1[k], p1v); }
             } else {
 #pragma unroll
               for (int ch = 0; ch < NCH; ++ch) {
