@@ -93,13 +93,14 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
 # ------------------------------------------------------------------------------------------------------------------
 # the filter leg (headline and the extra configurations)
 # ------------------------------------------------------------------------------------------------------------------
-def roofline_of(tm):
+def roofline_of(tm, storage="fp64"):
     avg_ms = tm["ms"] / max(tm["launches"], 1)
     sched = tm["scheduled_bytes_per_launch"]
     ach = sched / (avg_ms * 1e-3) / 1e9
     alg = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "step_kernel", "avg_launch_ms": avg_ms, "launches": tm["launches"],
+            "kernel": "step_sym_kernel (all variants of a lazy cycle; a flush step = its two launches)" if storage == "fp64sym" else "step_kernel",
+            "avg_launch_ms": avg_ms, "launches": tm["launches"],
             "scheduled_bytes_per_launch": sched,
             "algorithmic_bytes_per_launch": tm["bytes_per_launch"], "algorithmic_GBps": alg,
             "algorithmic_ratio": alg / HBM_PEAK_GBPS,
@@ -137,7 +138,7 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, 
     if keep_history and not np.all(np.isfinite(chk["traj_sample_iwmax"][:, :W + K])):
         raise RuntimeError("non-finite back-traced trajectory")
     return {"value": N * K / dt_s, "unit": "particle-steps/s", "steps": K, "warmup": W, "ms_per_step": dt_s / K * 1e3,
-            "roofline": roofline_of(tm)}, data, model, x0_lin, P0, R
+            "roofline": roofline_of(tm, storage)}, data, model, x0_lin, P0, R
 
 
 def bank_bytes_per_particle(n, storage):
@@ -530,7 +531,7 @@ def main():
             sess.close()
         except Exception as exc:                                   # the diagnostic must never cost the measurement
             shard_stats["phase_ms_per_step_synchronised"] = {"error": f"{type(exc).__name__}: {exc}"}
-        head = {"value": N_total * K / dt_s, "ms_per_step": dt_s / K * 1e3, "roofline": roofline_of(tm)}
+        head = {"value": N_total * K / dt_s, "ms_per_step": dt_s / K * 1e3, "roofline": roofline_of(tm, args.storage)}
         single_bank = False
     else:
         barrier()
