@@ -319,6 +319,9 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #ifndef RBPF_SYM_QUAD
 #define RBPF_SYM_QUAD 1
 #endif
+#ifndef RBPF_SYM_QUAD_EMAX
+#define RBPF_SYM_QUAD_EMAX 1                     // quad mapping for the filter (0) and the information-form step (1)
+#endif
 #ifndef RBPF_SYM_QUAD_LOADS
 #define RBPF_SYM_QUAD_LOADS 16     // wave loads in flight per round (8: 218 registers; 16: 256 with two spilled, 3.5 % faster)
 #endif
@@ -331,7 +334,9 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
                                                double* __restrict__ colp, int ldc, int lane) {
   const int r16 = lane & 15, g = lane >> 4;
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
-  constexpr int TQ = (RBPF_SYM_QUAD_LOADS / 4) / NACT;   // quads per round: RBPF_SYM_QUAD_LOADS wave loads in flight whatever the active rows
+  // quads per round: RBPF_SYM_QUAD_LOADS wave loads in flight whatever the active rows (information form, DE = 4: eight -- its
+  // four more row-sum and four more H registers per row do not leave room for sixteen)
+  constexpr int TQ = ((DE > 3 ? 8 : RBPF_SYM_QUAD_LOADS) / 4) / NACT;
   for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
     dbl2s v[TQ][NACT][4];
 #pragma unroll
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   // ---- D: stream the stored tiles once ----
   const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
   const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
-  constexpr bool kQuad = RBPF_SYM_QUAD && !WR && NPH == 1 && E == 0;   // read-only steps at CH = 8: sym_block_quad
+  constexpr bool kQuad = RBPF_SYM_QUAD && !WR && NPH == 1 && E <= RBPF_SYM_QUAD_EMAX;   // read-only steps at CH = 8: sym_block_quad
   double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSplit ? 1 : kSymRows][NDA];
   double accq[kQuad ? kSymRows : 1][4][DE], hq[kQuad ? kSymRows : 1][4][DE];
   if constexpr (kQuad) {
