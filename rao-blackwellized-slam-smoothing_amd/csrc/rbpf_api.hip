@@ -372,7 +372,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
   // shared flush: with ping-pong banks the children of one parent store ONE copy of their (identical) flushed matrix
-  c->share_flush = c->lazy_depth >= 2 && !c->inplace && !smoother && !ex && c->lay.sym && c->lay.CH64 == 8 && !c->fp32;
+  c->share_flush = c->lazy_depth >= 2 && !c->inplace && !ex && c->lay.sym && c->lay.CH64 == 8 && !c->fp32;   // (smoothers: the information form)
   if (c->share_flush) {
     RB_TRY(dmalloc(&c->d_share, (size_t)3 * N));
     RB_TRY(dmalloc(&c->d_share_writers, 1));
@@ -741,7 +741,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     HIPCHK(launch_inplace_plan(N, a.order, A_t, c->base[told], dst, ph, c->d_ip + 2 * (size_t)N, c->stream));
     a.dst_slot = dst; a.phase_of = ph;
   }
-  const bool share = c->share_flush && lazy && flush && t > 0 && !two_phase && a.n_sets >= 1 && a.n_sets <= 7;
+  const bool share = c->share_flush && lazy && flush && t > 0 && !two_phase && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
   if (share) {
     // the children of one parent flush to ONE entry (launch_share_plan): the smallest child stores it, its siblings only read
     int* lead = c->d_share; int* dst = c->d_share + N; int* ph = c->d_share + 2 * (size_t)N;

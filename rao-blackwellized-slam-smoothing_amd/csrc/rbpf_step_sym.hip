@@ -956,6 +956,7 @@ hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
     switch (a.n_sets) {
       case 1: return launch_sym_k<3, 1, false, 1>(a, s);
       case 2: return launch_sym_k<3, 2, false, 1>(a, s);
+      case 3: return launch_sym_k<3, 3, false, 1>(a, s);     // the readers of a shared flush at lazy_depth 3
       default: return hipErrorInvalidValue;
     }
   }
