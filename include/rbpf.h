@@ -212,7 +212,7 @@ typedef struct {
                           * send / recv of the migrating particle records, on each context's stream), so a single host process   *
                           * (a MATLAB session behind the MEX gateway: particleSmootherInformationForm.m is one call) reaches all  *
                           * GPUs.  N_P must be a multiple of W; recognised dense model families; results equal the single-GPU run *
-                          * (bit for bit without lazy_depth, 1e-9 with it), outputs without xn_traj / traces / final banks.       */
+                          * (bit for bit without lazy_depth, 1e-9 with it), every reference output incl. xn_traj; no traces / final banks. */
   const int32_t* device_ids; /* [n_devices] HIP device of every rank, NULL = 0 .. n_devices-1.  A device named more than once makes *
                           * its ranks share that GPU over a host-staged transport (no RCCL) -- how a one-GPU machine exercises the  *
                           * multi-rank loop; n_devices = 1 with device_ids set runs the loop with a world of one.                  */
@@ -299,6 +299,10 @@ int rbpf_sync(rbpf_ctx* ctx);
 int rbpf_filter_finish(rbpf_ctx* ctx, rbpf_filter_out* out);
 /* Current step index (number of steps processed).                                                 */
 int rbpf_filter_tell(const rbpf_ctx* ctx, int32_t* t);
+/* The covariance-bank schedule the context chose (rbpf_options.inplace = 0 is automatic): banks = 1 (single bank
+ * rewritten in place at every flush) or 2 (ping-pong banks); shared_flush = 1 when a flush step writes one matrix
+ * per parent for all its children (two banks, block-lower storage).  What particleFilter.m:112-113's gather became. */
+int rbpf_filter_schedule(const rbpf_ctx* ctx, int32_t* banks, int32_t* shared_flush);
 /* Generic model family (RBPF_MODEL_GENERIC_DENSE), one time step at a time:
  *   t = 0:  rbpf_filter_step_external(ctx, xn0, measModel(xn0))
  *   t > 0:  rbpf_filter_ancestors(ctx, ai, xn_prev); xn(:,i) = dynModel(xn_prev(:,ai(i)+1), ...); 
@@ -372,6 +376,10 @@ int rbpf_shard_plan_read(rbpf_ctx* ctx, int32_t* slot_ids, int32_t* anc_bank, in
                          int32_t n_send, int32_t* new_gid);
 /* traj_max / traj_mean [n_nonlin x N_T] of the steps normalised so far (identical on every rank).     */
 int rbpf_shard_trajectories(rbpf_ctx* ctx, double* traj_max, double* traj_mean);
+/* xn_traj [n_nonlin x N_global x t] of the steps finished so far (particleFilter.m:117-118: every logical slot's path traced
+ * back through the ancestor table; needs keep_history).  The state history and the ancestor table are replicated (they come with
+ * the all-gather of the forward bank), so any one rank returns the whole array.                                              */
+int rbpf_shard_xn_traj(rbpf_ctx* ctx, double* xn_traj);
 /* The HIP stream a context enqueues on (hipStream_t).  A caller that issues its collectives on this stream
  * (torch.cuda.ExternalStream) needs no host synchronisation between the library calls and the collectives.      */
 int rbpf_stream_get(rbpf_ctx* ctx, void** hip_stream);
@@ -444,7 +452,17 @@ int rbpf_shard_smoother_anc_sample(rbpf_ctx* ctx, int32_t separate_gather);
  *        refresh_recv
  * (after the gather and normalise of the finished step: the walk reads the state history), then all_gather(anc_local ->
  * anc_gather) and rbpf_shard_smoother_anc_sample(ctx, 1).                                           */
+ /* (the plan: rbpf_plan_refresh below -- the one implementation both multi-GPU drivers use) */
 int rbpf_shard_smoother_refresh_begin(rbpf_ctx* ctx, int32_t* owner_now, int32_t* base_loc);
+/* Fetch plan of one refresh for `rank`, from the two replicated tables (host arithmetic only, no device access): rank q sends
+ * rank r each matrix some particle on r needs, once (siblings share it), ordered by (destination, source, slot).  send_slots
+ * [<= send_capacity] bank slots to pack, concatenated per destination (*n_send of them); send_counts / recv_counts [world] of
+ * this rank; send_totals / recv_totals [world]: every rank's totals (capacity check, identical on all ranks); base_index
+ * [n_local]: a slot of the own bank, or n_local + position in refresh_recv.  Used by the in-library driver (rbpf_options.
+ * n_devices) and by multigpu.ShardedSmootherSession alike; multigpu.plan_refresh (numpy) is its specification in the tests. */
+int rbpf_plan_refresh(const int32_t* owner_now, const int32_t* base_loc, int32_t N_global, int32_t n_local, int32_t world,
+                      int32_t rank, int32_t* send_slots, int32_t send_capacity, int32_t* n_send, int64_t* send_counts,
+                      int64_t* recv_counts, int64_t* send_totals, int64_t* recv_totals, int32_t* base_index);
 int rbpf_shard_smoother_refresh_pack(rbpf_ctx* ctx, const int32_t* slots, int32_t count);
 int rbpf_shard_smoother_refresh_end(rbpf_ctx* ctx, const int32_t* base_index, int32_t n_recv);
 /* One information-form time step of my particles (:256-335), using the plan of rbpf_shard_plan for t > 0.        */

@@ -284,7 +284,11 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 // Options that change the schedule or the arithmetic, not the interface (include/rbpf.h `rbpf_options`): they cannot travel in
 // the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
 // matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
-struct SessionOptions { int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0; double jitter = 0.0, rng_seed = 0.0; };
+struct SessionOptions {
+  int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0;
+  double jitter = 0.0, rng_seed = 0.0;
+  std::vector<int32_t> device_ids;                 // [n_devices] HIP device of every rank (empty: 0 .. n_devices-1)
+};
 SessionOptions g_session;
 
 void session_field(const mxArray* s, const char* name, int& v) {
@@ -306,6 +310,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   opt.lazy_depth = g_session.lazy_depth; opt.chol_refresh = g_session.chol_refresh; opt.chol_variant = g_session.chol_variant;
   opt.storage = g_session.storage; opt.inplace = g_session.inplace; opt.fix_p_mean = g_session.fix_p_mean; opt.jitter = g_session.jitter;
   opt.n_devices = g_session.n_devices;                       // > 1: the library shards the particles over that many GPUs itself (RCCL)
+  opt.device_ids = g_session.device_ids.empty() ? nullptr : g_session.device_ids.data();
   if (cmd == "options") {
     if (nrhs > 2 || (nrhs == 2 && !mxIsStruct(prhs[1]))) mexErrMsgIdAndTxt("rbpf:usage", "options expects one struct (or nothing: query)");
     if (nrhs == 2) {
@@ -316,17 +321,30 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       session_field(prhs[1], "n_devices", o.n_devices); session_field(prhs[1], "rng_mode", o.rng_mode);
       if (const mxArray* f = mxGetField(prhs[1], 0, "rng_seed")) { if (!mxIsEmpty(f)) o.rng_seed = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
+      if (const mxArray* f = mxGetField(prhs[1], 0, "device_ids")) {
+        if (!mxIsEmpty(f)) {
+          if (!mxIsDouble(f) || (int)mxGetNumberOfElements(f) != o.n_devices) mexErrMsgIdAndTxt("rbpf:usage", "options: device_ids must hold n_devices device numbers");
+          const double* dv = mxGetPr(f);
+          for (int q = 0; q < o.n_devices; ++q) {
+            if (dv[q] < 0 || dv[q] != (double)(int)dv[q]) mexErrMsgIdAndTxt("rbpf:usage", "options: device_ids must be non-negative integers (0-based HIP devices)");
+            o.device_ids.push_back((int32_t)dv[q]);
+          }
+        }
+      }
       if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
       g_session = o;
     }
     // rng_mode / rng_seed are consumed by the .m wrappers (matlab/rbpf_rngblock.m): 0 = MATLAB's stream in the reference's
     // interleaved order (seed-exact), 1 = MATLAB's stream, vectorised draws, 2 = the device Philox generator keyed by rng_seed
-    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 10, names);
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed", "device_ids"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
     const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
                            (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter,
                            (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed};
     for (int q = 0; q < 10; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+    mxArray* ids = mxCreateDoubleMatrix(1, g_session.device_ids.size(), mxREAL);
+    for (size_t q = 0; q < g_session.device_ids.size(); ++q) mxGetPr(ids)[q] = (double)g_session.device_ids[q];
+    mxSetField(plhs[0], 0, "device_ids", ids);
   } else if (cmd == "filter") {
     if (nrhs != 12 && nrhs != 13) mexErrMsgIdAndTxt("rbpf:usage", "filter expects 11 or 12 arguments after the command");
     rbpf_model m = model_from(prhs[1], nn, g, cb);
@@ -338,7 +356,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       r.Z = zeroZ.data();
     }
     g.prob = &p;
-    if (nrhs == 13 && is_handle(prhs[12])) { g.h_plots = const_cast<mxArray*>(prhs[12]); opt.on_step = cb_on_step; opt.on_step_user = &g; }
+    if (nrhs == 13 && is_handle(prhs[12])) {
+      if (opt.n_devices > 1 || opt.device_ids) mexErrMsgIdAndTxt("rbpf:unsupported", "particleFilter with rbpf_options('n_devices', W): the makePlots hook needs the particle cloud of every step on the host and is not served by the sharded filter -- pass makePlots = [] or reset n_devices");
+      g.h_plots = const_cast<mxArray*>(prhs[12]); opt.on_step = cb_on_step; opt.on_step_user = &g;
+    }
     const mwSize nN = p.n_nonlin, n = p.n_lin, N = p.N_P, T = p.N_T;
     rbpf_filter_out o;
     std::memset(&o, 0, sizeof(o));

@@ -16,8 +16,10 @@ function o = rbpf_options(varargin)
 %                 2: double precision, lower block triangle only (particleFilter keeps P symmetric: 0.56 x the memory and
 %                 traffic, results within 1e-9; dense-mag filter with 512 basis functions)
 %   n_devices     W > 1: particleFilter / particleSmootherInformationForm shard their N_P particles over W GPUs of this
-%                 machine inside the library (one thread per GPU, RCCL collectives); N_P must be a multiple of W; the
-%                 reference's outputs, without xn_traj
+%                 machine inside the library (one thread per GPU, RCCL collectives); N_P must be a multiple of W; all of the
+%                 reference's outputs (particleFilter: makePlots must be empty)
+%   device_ids    [1 x W] 0-based HIP device of every rank (default 0 .. W-1); a device named twice makes its ranks share
+%                 that GPU over a host-staged transport (a one-GPU machine can so exercise the multi-rank loop)
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
 %   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
 %   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)

@@ -98,7 +98,7 @@ EXPORTS = [
     "rbpf_abi_version", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
     "rbpf_particle_filter", "rbpf_particle_smoother",
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
-    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
+    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_chol_sweep_probe", "rbpf_quat_helpers", "rbpf_probe_wave_reduce",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
@@ -167,6 +167,7 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_sync.argtypes = [C.c_void_p]
     lib.rbpf_filter_finish.argtypes = [C.c_void_p, C.POINTER(rbpf_filter_out)]
     lib.rbpf_filter_tell.argtypes = [C.c_void_p, c_int32_p]
+    lib.rbpf_filter_schedule.argtypes = [C.c_void_p, c_int32_p, c_int32_p]
     lib.rbpf_filter_ancestors.argtypes = [C.c_void_p, c_int32_p, c_double_p]
     lib.rbpf_filter_step_external.argtypes = [C.c_void_p, c_double_p, c_double_p]
     lib.rbpf_timing_enable.argtypes = [C.c_void_p, C.c_int32]

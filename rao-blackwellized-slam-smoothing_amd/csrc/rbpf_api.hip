@@ -1012,6 +1012,13 @@ int rbpf_filter_tell(const rbpf_ctx* c, int32_t* t) {
   return RBPF_OK;
 }
 
+int rbpf_filter_schedule(const rbpf_ctx* c, int32_t* banks, int32_t* shared_flush) {
+  if (!c || !banks || !shared_flush) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  *banks = c->inplace ? 1 : 2;
+  *shared_flush = c->share_flush ? 1 : 0;
+  return RBPF_OK;
+}
+
 int rbpf_timing_enable(rbpf_ctx* c, int32_t on) {
   if (!c) { set_error("ctx is NULL"); return RBPF_ERR_INVALID_ARG; }
   c->timing_on = on != 0;

@@ -757,12 +757,8 @@ static size_t chol64_lds_bytes(int M, int d) {
 
 template <int MODE, int W>
 static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE, W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC64MaxLds);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE, W>), (int)kC64MaxLds, attr)) return e;
   CholArgs cb = ca;
   cb.batch = batch;
   const int grid = (cb.l_slots > 0) ? std::min(batch, cb.l_slots) : batch;

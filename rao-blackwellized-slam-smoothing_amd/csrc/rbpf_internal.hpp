@@ -4,8 +4,24 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <stdlib.h>
+#include <atomic>
 
 namespace rbpf {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device only: the opt-in is made once per (kernel, device) --
+// `done` is the launcher's own bit set, one bit per device ordinal.  (The in-library multi-device driver launches the same kernels
+// from one thread per GPU: a process-wide flag would opt in the first device only.)
+inline hipError_t lds_opt_in(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return e;
+  if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // Tuning overrides read from the environment exist only in diagnostic builds (-DRBPF_TUNING, tools/tune_variants.py);
 // the product library never consults the environment.

@@ -867,13 +867,8 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 
 template <typename TS, int D, int E, int CPL, int NS, bool WR, int UFX, bool KB>
 static hipError_t launch_step_k(const StepArgs& a, size_t lds, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR, UFX, KB>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_kernel<TS, D, E, CPL, NS, WR, UFX, KB>), 160 * 1024, attr_done)) return e;
   hipLaunchKernelGGL((step_kernel<TS, D, E, CPL, NS, WR, UFX, KB>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
 }

@@ -34,6 +34,7 @@ struct Rccl {
   void* h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -48,7 +49,7 @@ struct Rccl {
     }
     if (!h) { why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return false; }
 #define RB_SYM(field, sym) field = reinterpret_cast<decltype(field)>(dlsym(h, sym)); if (!field) { why = std::string("RCCL lacks ") + sym; return false; }
-    RB_SYM(CommInitAll, "ncclCommInitAll") RB_SYM(CommDestroy, "ncclCommDestroy") RB_SYM(AllGather, "ncclAllGather")
+    RB_SYM(CommInitAll, "ncclCommInitAll") RB_SYM(CommDestroy, "ncclCommDestroy") RB_SYM(CommAbort, "ncclCommAbort") RB_SYM(AllGather, "ncclAllGather")
     RB_SYM(Send, "ncclSend") RB_SYM(Recv, "ncclRecv") RB_SYM(GroupStart, "ncclGroupStart") RB_SYM(GroupEnd, "ncclGroupEnd")
     RB_SYM(GetErrorString, "ncclGetErrorString")
 #undef RB_SYM
@@ -91,6 +92,19 @@ struct Multi {
   // per-rank status of the last parallel section
   std::vector<int> status; std::vector<std::string> msg;
   long long migrated = 0, sent_records = 0;
+  // RCCL transport: a rank that fails between collectives aborts EVERY communicator of this process (ncclCommAbort makes the
+  // collective kernels its peers wait behind give up), so that the peers' stream synchronisations return, their threads join and the
+  // entry point reports the first failure instead of hanging; communicators are never destroyed after that, only aborted.
+  std::mutex abort_m;
+  bool comms_aborted = false;
+  int home_device = -1;                            // the caller's current device, restored when the call returns
+  void abort_comms() {
+    std::lock_guard<std::mutex> lk(abort_m);
+    if (comms_aborted || host_staged || !g_rccl.CommAbort) return;
+    comms_aborted = true;
+    for (auto& c : comm) if (c) { g_rccl.CommAbort(c); c = nullptr; }
+  }
+  Multi() { if (hipGetDevice(&home_device) != hipSuccess) home_device = -1; }
   ~Multi() {
     for (size_t r = 0; r < ctx.size(); ++r) {
       if (!ctx[r]) continue;
@@ -98,6 +112,7 @@ struct Multi {
       rbpf_destroy(ctx[r]);
     }
     for (auto c : comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+    if (home_device >= 0) hipSetDevice(home_device);
   }
 };
 
@@ -112,7 +127,7 @@ int run_ranks(Multi& M, F fn) {
     int s = (hipSetDevice(M.devs[r]) == hipSuccess) ? RBPF_OK : RBPF_ERR_HIP;
     if (s == RBPF_OK) s = fn(r);
     M.status[r] = s;
-    if (s != RBPF_OK) { const char* e = rbpf_last_error(); M.msg[r] = e ? e : ""; M.bar.abort(); }
+    if (s != RBPF_OK) { const char* e = rbpf_last_error(); M.msg[r] = e ? e : ""; M.bar.abort(); M.abort_comms(); }
   };
   if (M.W == 1) body(0);
   else {
@@ -120,8 +135,10 @@ int run_ranks(Multi& M, F fn) {
     for (int r = 0; r < M.W; ++r) th.emplace_back(body, r);
     for (auto& t : th) t.join();
   }
+  int first = -1;                                  // the rank that failed on its own, not one released by its abort
   for (int r = 0; r < M.W; ++r)
-    if (M.status[r] != RBPF_OK) { set_error("device " + std::to_string(M.devs[r]) + " (rank " + std::to_string(r) + "): " + M.msg[r]); return M.status[r]; }
+    if (M.status[r] != RBPF_OK && (first < 0 || (M.msg[first].find("another rank failed") != std::string::npos && M.msg[r].find("another rank failed") == std::string::npos))) first = r;
+  if (first >= 0) { set_error("device " + std::to_string(M.devs[first]) + " (rank " + std::to_string(first) + "): " + M.msg[first]); return M.status[first]; }
   return RBPF_OK;
 }
 
@@ -199,9 +216,8 @@ struct RefreshPlan {
   std::vector<int32_t> send_slots, base_index;
   std::vector<long long> send_counts, recv_counts, send_totals, recv_totals;
 };
-RefreshPlan plan_refresh(const std::vector<int32_t>& owner_now, const std::vector<int32_t>& base_loc, int n_local, int world, int rank) {
+RefreshPlan plan_refresh(const int32_t* owner_now, const int32_t* base_loc, size_t N, int n_local, int world, int rank) {
   RefreshPlan P;
-  const size_t N = owner_now.size();
   std::vector<long long> keys;
   keys.reserve(N);
   for (size_t j = 0; j < N; ++j) {
@@ -236,7 +252,7 @@ int refresh(Multi& M, int r) {
   std::vector<int32_t> own(M.Nglob), bl(M.Nglob);
   MT_TRY(rbpf_shard_smoother_refresh_begin(M.ctx[r], own.data(), bl.data()));
   if (bl[0] < 0) return rbpf_shard_smoother_refresh_end(M.ctx[r], nullptr, 0);     // first refresh of an iteration: the common initial matrix
-  RefreshPlan P = plan_refresh(own, bl, M.Nloc, M.W, r);
+  RefreshPlan P = plan_refresh(own.data(), bl.data(), own.size(), M.Nloc, M.W, r);
   long long worst = 0, ns = 0, nr = 0;
   for (int q = 0; q < M.W; ++q) { worst = std::max(worst, std::max(P.send_totals[q], P.recv_totals[q])); ns += P.send_counts[q]; nr += P.recv_counts[q]; }
   if (worst > (long long)M.sv[r].refresh_capacity) {                                // replicated plan: every rank reaches this verdict
@@ -319,9 +335,10 @@ int filter_steps(Multi& M, int r, int n_steps) {
 int multi_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
                           rbpf_filter_out* out) {
   if (!model || !prob || !rng || !opt || !out) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
-  if (out->xn_traj || out->trace_logw || out->trace_w || out->trace_ai || out->final_xn || out->final_xl || out->final_P) {
-    set_error("options.n_devices: xn_traj, the traces and the final particle banks are not gathered from the sharded filter"); return RBPF_ERR_UNSUPPORTED;
+  if (out->trace_logw || out->trace_w || out->trace_ai || out->final_xn || out->final_xl || out->final_P) {
+    set_error("options.n_devices: the traces and the final particle banks are not gathered from the sharded filter"); return RBPF_ERR_UNSUPPORTED;
   }
+  if ((out->xn_traj || out->traj_sample_iwmax) && !opt->keep_history) { set_error("traj_sample_iwmax / xn_traj need keep_history=1"); return RBPF_ERR_STATE; }
   Multi M;
   MT_TRY(create(M, model, prob, rng, opt, false, 1));
   MT_TRY(run_ranks(M, [&](int r) { return filter_steps(M, r, M.T); }));
@@ -338,6 +355,7 @@ int multi_particle_filter(const rbpf_model* model, const rbpf_problem* prob, con
     MT_TRY(rbpf_shard_finish(M.ctx[r], 0, out->xl_max ? xl_max[r].data() : nullptr, out->P_max ? P_max[r].data() : nullptr,
                              need_mean ? xl_mean[r].data() : nullptr, nullptr, (r == 0) ? out->traj_sample_iwmax : nullptr, &iw[r]));
     if (r == 0) MT_TRY(rbpf_shard_trajectories(M.ctx[r], out->traj_max, out->traj_mean));
+    if (r == 0 && out->xn_traj) MT_TRY(rbpf_shard_xn_traj(M.ctx[r], out->xn_traj));   // replicated history: one rank has it all
     return RBPF_OK;
   }));
   // the owner's rows (zeros elsewhere) / the ranks' shares of the weighted mean, summed in rank order
@@ -406,7 +424,8 @@ int multi_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, c
     if (out->PK) { double* d = out->PK + (size_t)k * n * n; std::memset(d, 0, (size_t)n * n * sizeof(double)); for (int r = 0; r < W; ++r) for (size_t q = 0; q < (size_t)n * n; ++q) d[q] += pk[r][q]; }
     if (out->trace_ak) out->trace_ak[k] = ak[0];
     if (opt->on_step) {                                                     // makePlots(xnk,xlk,k,XNK,XLK,PK), particleSmoother.m:360-362
-      rbpf_view vw; vw.ctx = nullptr; vw.t = k; vw.is_smoother = 1;
+      rbpf_view vw{};
+      vw.ctx = nullptr; vw.t = k; vw.is_smoother = 1;
       if (opt->on_step(&vw, opt->on_step_user) != 0) { set_error("the on_step hook returned non-zero"); return RBPF_ERR_CALLBACK; }
     }
   }
@@ -414,3 +433,26 @@ int multi_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, c
 }
 
 }  // namespace rbpf
+
+extern "C" int rbpf_plan_refresh(const int32_t* owner_now, const int32_t* base_loc, int32_t N_global, int32_t n_local, int32_t world,
+                                 int32_t rank, int32_t* send_slots, int32_t send_capacity, int32_t* n_send, int64_t* send_counts,
+                                 int64_t* recv_counts, int64_t* send_totals, int64_t* recv_totals, int32_t* base_index) {
+  using namespace rbpf;
+  if (!owner_now || !base_loc || !n_send || !send_counts || !recv_counts || !send_totals || !recv_totals || !base_index ||
+      N_global < 1 || n_local < 1 || world < 1 || rank < 0 || rank >= world || N_global != n_local * world) {
+    set_error("rbpf_plan_refresh: NULL argument or inconsistent sizes"); return RBPF_ERR_INVALID_ARG;
+  }
+  for (int32_t j = 0; j < N_global; ++j)
+    if (owner_now[j] < 0 || owner_now[j] >= N_global || base_loc[j] < 0 || base_loc[j] >= N_global) {
+      set_error("rbpf_plan_refresh: table entry out of range"); return RBPF_ERR_INVALID_ARG;
+    }
+  RefreshPlan P = plan_refresh(owner_now, base_loc, (size_t)N_global, n_local, world, rank);
+  *n_send = (int32_t)P.send_slots.size();
+  if ((int32_t)P.send_slots.size() > send_capacity || (P.send_slots.size() && !send_slots)) { set_error("rbpf_plan_refresh: send_slots too small"); return RBPF_ERR_OUT_OF_MEMORY; }
+  std::copy(P.send_slots.begin(), P.send_slots.end(), send_slots);
+  for (int q = 0; q < world; ++q) {
+    send_counts[q] = P.send_counts[q]; recv_counts[q] = P.recv_counts[q]; send_totals[q] = P.send_totals[q]; recv_totals[q] = P.recv_totals[q];
+  }
+  std::copy(P.base_index.begin(), P.base_index.end(), base_index);
+  return RBPF_OK;
+}

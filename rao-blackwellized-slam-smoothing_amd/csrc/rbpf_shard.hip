@@ -663,6 +663,25 @@ int rbpf_shard_finish(rbpf_ctx* c, int32_t phase, double* xl_max, double* P_max,
   return RBPF_OK;
 }
 
+int rbpf_shard_xn_traj(rbpf_ctx* c, double* xn_traj) {
+  if (!c || !c->sh || !xn_traj) { set_error("not a shard context / NULL output"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  ShardState* s = c->sh;
+  if (s->smoother) { set_error("smoother context: xn_traj is a particleFilter output"); return RBPF_ERR_STATE; }
+  if (!s->Xhist) { set_error("xn_traj needs keep_history = 1"); return RBPF_ERR_STATE; }
+  if (c->t < 1) { set_error("xn_traj needs at least one finished step"); return RBPF_ERR_STATE; }
+  RB_TRY(ctx_check_flags(c));
+  const int nN = c->mdl.nN, N = s->Nglob, Td = c->t;
+  double* dout = nullptr;
+  RB_TRY(dmalloc(&dout, (size_t)nN * N * Td));
+  hipError_t e = launch_backtrace(N, nN, Td, s->Xhist, s->Ahist, nullptr, N, dout, c->stream);   // particleFilter.m:117-118
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(xn_traj, dout, (size_t)nN * N * Td * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(dout);
+  HIPCHK(e);
+  return RBPF_OK;
+}
+
 int rbpf_shard_trajectories(rbpf_ctx* c, double* traj_max, double* traj_mean) {
   if (!c || !c->sh) { set_error("not a shard context"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));

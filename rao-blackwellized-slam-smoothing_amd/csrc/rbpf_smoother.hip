@@ -623,12 +623,8 @@ __global__ __launch_bounds__(W * 64, 4) void chol_solve_kernel(CholArgs a_in) {
 static size_t chol_lds_bytes(int M, int d) { return ((size_t)256 + 256 + 32 + M + 2 + (d ? 2 * (size_t)d * M : (size_t)M)) * sizeof(double); }
 template <int W, int NTMAX>
 static hipError_t launch_chol_w(const CholArgs& ca, int batch, size_t lds, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&chol_solve_kernel<W, NTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&chol_solve_kernel<W, NTMAX>), 150 * 1024, attr)) return e;
   hipLaunchKernelGGL((chol_solve_kernel<W, NTMAX>), dim3(batch), dim3(W * 64), lds, st, ca);
   return hipGetLastError();
 }

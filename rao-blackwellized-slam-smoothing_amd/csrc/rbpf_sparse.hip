@@ -180,12 +180,8 @@ size_t sparse_step_lds_bytes(int n, int d) {
 hipError_t launch_sparse_step(const SparseStepArgs& a, hipStream_t s) {
   if (a.d > 32 || a.n > 96) return hipErrorInvalidValue;
   const size_t lds = sparse_step_lds_bytes(a.n, a.d);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&sparse_step_kernel), 150 * 1024, attr)) return e;
   hipLaunchKernelGGL(sparse_step_kernel, dim3(a.N), dim3(64), lds, s, a);
   return hipGetLastError();
 }
@@ -230,12 +226,8 @@ __global__ __launch_bounds__(256) void sparse_anc_kernel(const SparseAncArgs a) 
 hipError_t launch_sparse_anc(const SparseAncArgs& a, int N, hipStream_t s) {
   if (a.M <= 0) return hipSuccess;
   const size_t lds = ((size_t)a.n * a.n + 2 * (size_t)a.M) * sizeof(double) + 2 * (size_t)a.M * sizeof(int);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_anc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static std::atomic<uint64_t> attr{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&sparse_anc_kernel), 150 * 1024, attr)) return e;
   hipLaunchKernelGGL(sparse_anc_kernel, dim3(N), dim3(256), lds, s, a);
   return hipGetLastError();
 }

@@ -922,13 +922,8 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 
 template <int D, int NS, bool WR, int E, int CH>
 static hipError_t launch_sym_kc(const StepArgs& a, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH>), 160 * 1024, attr_done)) return e;
   const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E);
   hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E, CH>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();

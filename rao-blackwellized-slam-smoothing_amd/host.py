@@ -523,7 +523,8 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     makePlots is called after every step with the reference's nine arguments (particleFilter.m:215-217) through the
     library's on_step hook.
     n_devices = W > 1 (rbpf_options.n_devices): the library shards the N_P particles over W GPUs itself -- one host thread per
-    device, RCCL collectives -- and returns the reference's outputs without xn_traj (None); device_ids names the HIP devices
+    device, RCCL collectives -- and returns the reference's eight outputs (xn_traj from the replicated state history; None with
+    want_xn_traj=False); device_ids names the HIP devices
     (a device named twice makes its ranks share it over a host-staged transport: tests on one GPU)."""
     model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
     generic = model is None
@@ -555,10 +556,13 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
         b = dict(traj_max=np.full((nN, T), np.nan, order="F"), traj_mean=np.full((nN, T), np.nan, order="F"), xl_max=np.empty(n),
                  P_max=np.empty((n, n), order="F"), xl_mean=np.empty(n), P_mean=np.empty((n, n), order="F"),
                  traj_sample_iwmax=np.empty((nN, T), order="F"), iw_max=np.zeros(1, dtype=np.int32))
+        if want_xn_traj:
+            b["xn_traj"] = np.empty((nN, N, T), order="F")
         for k, v in b.items():
             setattr(o, k, _ip(v) if v.dtype == np.int32 else _dp(v))
         check(lib.rbpf_particle_filter(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(opt), C.byref(o)))
-        return (b["traj_max"], b["traj_mean"], b["xl_max"], b["xl_mean"], b["P_max"], b["P_mean"], b["traj_sample_iwmax"], None)
+        return (b["traj_max"], b["traj_mean"], b["xl_max"], b["xl_mean"], b["P_max"], b["P_mean"], b["traj_sample_iwmax"],
+                b.get("xn_traj"))
 
     def alloc_out(Tdone, full):
         o = _ffi.rbpf_filter_out()
@@ -860,6 +864,16 @@ class FilterSession:
         t = C.c_int32(0)
         check(self.lib.rbpf_filter_tell(self.ctx, C.byref(t)))
         return t.value
+
+    def schedule(self):
+        """(banks, shared_flush) the context chose (rbpf_filter_schedule)."""
+        b, sf = C.c_int32(0), C.c_int32(0)
+        check(self.lib.rbpf_filter_schedule(self.ctx, C.byref(b), C.byref(sf)))
+        return b.value, bool(sf.value)
+
+    @property
+    def banks(self):
+        return self.schedule()[0]
 
     def timing(self, enable=None, reset=False):
         if enable is not None:

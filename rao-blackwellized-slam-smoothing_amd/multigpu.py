@@ -473,8 +473,29 @@ class RefreshPlan:
         self.base_index, self.send_totals, self.recv_totals = base_index, send_totals, recv_totals
 
 
+def plan_refresh_lib(lib, owner_now, base_loc, n_local, world, rank):
+    """The fetch plan of one refresh from the library's planner (rbpf_plan_refresh, csrc/rbpf_multi.hip) -- the implementation
+    both drivers run (this one under torchrun, the in-library multi-device driver behind rbpf_options.n_devices).  The numpy
+    function below is its specification: tests/test_multigpu_plan.py holds the two equal."""
+    owner_now = np.ascontiguousarray(owner_now, dtype=np.int32)
+    base_loc = np.ascontiguousarray(base_loc, dtype=np.int32)
+    N = owner_now.size
+    send_slots = np.zeros(max(N, 1), dtype=np.int32)
+    n_send = C.c_int32(0)
+    sc, rc, st, rt = (np.zeros(world, dtype=np.int64) for _ in range(4))
+    base_index = np.zeros(n_local, dtype=np.int32)
+    lp = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))                   # noqa: E731
+    lib.rbpf_plan_refresh.argtypes = [_ffi.c_int32_p, _ffi.c_int32_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ffi.c_int32_p, C.c_int32,
+                                      _ffi.c_int32_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int64), _ffi.c_int32_p]
+    check(lib.rbpf_plan_refresh(_ip(owner_now), _ip(base_loc), int(N), int(n_local), int(world), int(rank), _ip(send_slots), int(send_slots.size),
+                                C.byref(n_send), lp(sc), lp(rc), lp(st), lp(rt), _ip(base_index)))
+    return RefreshPlan(send_slots[:n_send.value].copy(), sc, rc, base_index, st, rt)
+
+
 def plan_refresh(owner_now, base_loc, n_local, world, rank):
-    """Which base matrices cross ranks at a refresh of the carried factors (rbpf_shard_smoother_refresh_*).
+    """Which base matrices cross ranks at a refresh of the carried factors (rbpf_shard_smoother_refresh_*).  SPECIFICATION of
+    rbpf_plan_refresh (the sessions call the library's planner, plan_refresh_lib).
 
     owner_now[j] = r * n_local + p: rank and physical slot of logical slot j's particle; base_loc[j] = q * n_local + s: rank
     and bank slot of the matrix its information matrix is rebuilt from.  Both tables are replicated, so every rank derives the
@@ -586,7 +607,7 @@ class ShardedSmootherSession(ShardedFilterSession):
         if bl[0] < 0:                                    # first refresh of an iteration: the common initial matrix
             check(lib.rbpf_shard_smoother_refresh_end(self.ctx, None, 0))
             return
-        rp = plan_refresh(own, bl, self.N_local, W, self.rank)
+        rp = plan_refresh_lib(lib, own, bl, self.N_local, W, self.rank)
         worst = int(max(rp.send_totals.max(), rp.recv_totals.max()))
         if worst > self.refresh_capacity:                # replicated plan: every rank reaches this verdict
             raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"refresh of the carried factors moves up to {worst} matrices per rank, "

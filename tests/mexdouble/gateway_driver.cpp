@@ -336,6 +336,32 @@ int main(int argc, char** argv) {
       cur = gateway1({cmd, none});
       mxDestroyArray(cur); mxDestroyArray(cmd); mxDestroyArray(so); mxDestroyArray(none);
     }
+    {   // 9. the particleFilter route with n_devices = 2 on ONE GPU (device_ids = [0 0]: two ranks share it over the host-staged
+        //    transport): matlab/particleFilter.m always asks for all 8 outputs, xn_traj included; a makePlots handle
+        //    is refused with a message of its own
+      const char* names[] = {"n_devices", "device_ids"};
+      mxArray* so = mxCreateStructMatrix(1, 1, 2, names);
+      mxSetField(so, 0, "n_devices", mxCreateDoubleScalar(2));
+      mxArray* ids = mxCreateDoubleMatrix(1, 2, mxREAL);
+      mxGetPr(ids)[0] = 0; mxGetPr(ids)[1] = 0;
+      mxSetField(so, 0, "device_ids", ids);
+      mxArray* cmd = mxCreateString("options");
+      mxArray* cur = gateway1({cmd, so});
+      report << "options_device_ids " << mxGetNumberOfElements(mxGetField(cur, 0, "device_ids")) << "\n";
+      mxDestroyArray(cur);
+      mxArray* desc = family_desc(); mxArray* rng = rng_block(true, true); mxArray* rngf = rng_block(true, false);
+      try { run_filter("filter_multi", desc, rngf, nullptr); report << "multi_filter ran\n"; }
+      catch (const MatlabError& e) { report << "multi_filter " << e.id << " " << e.what() << "\n"; }
+      try { run_smoother("smoother_multi2", desc, rng, 1, nullptr); report << "multi_smoother ran\n"; }
+      catch (const MatlabError& e) { report << "multi_smoother " << e.id << " " << e.what() << "\n"; }
+      mxArray* plots = mexdouble::make_function_handle([&](int, mxArray**, int, mxArray**) {}, "@makePlots");
+      try { run_filter("bad_multi", desc, rngf, plots); report << "multi_plots_error MISSING\n"; }
+      catch (const MatlabError& e) { report << "multi_plots_error " << e.id << "\n"; }
+      mxDestroyArray(plots); mxDestroyArray(desc); mxDestroyArray(rng); mxDestroyArray(rngf);
+      mxArray* none = mxCreateStructMatrix(1, 1, 0, nullptr);
+      cur = gateway1({cmd, none});
+      mxDestroyArray(cur); mxDestroyArray(cmd); mxDestroyArray(so); mxDestroyArray(none);
+    }
   } catch (const std::exception& e) {
     report << "DRIVER_FAILED " << e.what() << "\n";
     fprintf(stderr, "gateway_driver: %s\n", e.what());

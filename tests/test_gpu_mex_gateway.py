@@ -120,6 +120,20 @@ def test_gateway_matches_the_ctypes_path(rbpf, tmp_path, kind):
     # rbpf_options('n_devices', 2): the call reaches the in-library multi-device driver (an error about the missing second GPU on
     # a one-GPU box, a sharded run where two GPUs exist)
     assert rep["options_n_devices"] == "2" and (rep["multi_route"] == "ran" or rep["multi_route"].startswith("rbpf:"))
+    # rbpf_options('n_devices', 2, 'device_ids', [0 0]): matlab/particleFilter.m's call (all 8 outputs, xn_traj included) and the
+    # information-form smoother through the in-library multi-device driver, two ranks sharing this GPU == the single-GPU run
+    assert rep["options_device_ids"] == "2" and rep["multi_filter"] == "ran" and rep["multi_smoother"] == "ran", rep
+    assert rep["multi_plots_error"] == "rbpf:unsupported"
+    for k, name in enumerate(names):
+        got = read(tmp, "filter_multi", name).reshape(ref[k].shape, order="F")
+        if name in ("xl_mean", "P_mean"):                                       # sums of the ranks' shares
+            np.testing.assert_allclose(got, ref[k], rtol=1e-9, atol=1e-12, err_msg=name)
+        else:
+            np.testing.assert_array_equal(got, ref[k], err_msg="multi " + name)
+    XNK, XLK, PK = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
+                                                        c["Q"], R, N, N_K, c["dt"], rng=rngs)
+    for name, want in (("XNK", XNK), ("XLK", XLK), ("PK", PK)):
+        np.testing.assert_array_equal(read(tmp, "smoother_multi2", name).reshape(want.shape, order="F"), want, err_msg="multi " + name)
     XNK, XLK, PK = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0,
                                                         c["Q"], R, N, N_K, c["dt"], rng=rngs, chol_refresh=3)
     for name, want in (("XNK", XNK), ("XLK", XLK), ("PK", PK)):

@@ -40,7 +40,12 @@ def test_multi_device_filter_equals_single_gpu(rbpf, m, N, ids):
         np.testing.assert_array_equal(out[k], ref[k], err_msg=str(k))
     np.testing.assert_allclose(out[3], ref[3], rtol=1e-9, atol=1e-12)      # xl_mean: sum of the ranks' shares
     np.testing.assert_allclose(out[5], ref[5], rtol=1e-9, atol=1e-12)      # P_mean (quirk Q3: the last particle's term)
-    assert out[7] is None
+    assert out[7] is None                                                    # want_xn_traj=False
+    full = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01,
+                               rng=rbpf.PhiloxRNG(11))
+    multi = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01,
+                                rng=rbpf.PhiloxRNG(11), n_devices=len(ids), device_ids=ids)
+    np.testing.assert_array_equal(multi[7], full[7])                         # xn_traj from the replicated state history
 
 
 @pytest.mark.parametrize("storage,lazy_depth,m", [("fp64", 3, 130), ("fp64sym", 4, 512), ("fp64sym", 0, 512)])

@@ -27,6 +27,12 @@ def _mg():
     return importlib.import_module("rao-blackwellized-slam-smoothing_amd.multigpu")
 
 
+def _load_lib():
+    sys.path.insert(0, ROOT)
+    import importlib
+    return importlib.import_module("rao-blackwellized-slam-smoothing_amd").load_library()
+
+
 def _simulate(mg, world, nl, steps, peaked, seed):
     """Runs the planner for several generations on replicated inputs and checks every invariant."""
     rs = np.random.RandomState(seed)
@@ -161,6 +167,12 @@ def test_refresh_plan_fetches_every_remote_base_matrix_once(world, nl, seed):
     base_loc = rs.choice(N, size=N, p=w / w.sum())                 # few distinct ancestors: siblings share a base
     bank = [np.arange(q * nl, (q + 1) * nl, dtype=np.int64) for q in range(world)]   # matrix id = its location
     plans = [mg.plan_refresh(owner_now, base_loc, nl, world, r) for r in range(world)]
+    # the library's planner (rbpf_plan_refresh: what the sessions and the in-library driver run) == the numpy specification
+    lib = _load_lib()
+    for r in range(world):
+        got = mg.plan_refresh_lib(lib, owner_now, base_loc, nl, world, r)
+        for f in ("send_slots", "send_counts", "recv_counts", "base_index", "send_totals", "recv_totals"):
+            np.testing.assert_array_equal(getattr(got, f), getattr(plans[r], f), err_msg=f"rank {r} {f}")
     pairs = {(int(o) // nl, int(b)) for o, b in zip(owner_now, base_loc) if int(o) // nl != int(b) // nl}
     assert sum(int(p.send_counts.sum()) for p in plans) == len(pairs)            # unique (destination, matrix) pairs
     for r in range(world):
@@ -194,7 +206,7 @@ def _refresh_worker(rank, world, port, nl, seed, q):
             owner_now = rs.permutation(N)
             w = rs.random_sample(N) ** (2 + rnd)
             base_loc = rs.choice(N, size=N, p=w / w.sum())
-            rp = mg.plan_refresh(owner_now, base_loc, nl, world, rank)
+            rp = mg.plan_refresh_lib(_load_lib(), owner_now, base_loc, nl, world, rank)
             bank = (torch.arange(rank * nl, (rank + 1) * nl, dtype=torch.float64)[:, None] * 10.0
                     + torch.arange(width, dtype=torch.float64)[None, :])
             ns, nr = int(rp.send_counts.sum()), int(rp.recv_counts.sum())
