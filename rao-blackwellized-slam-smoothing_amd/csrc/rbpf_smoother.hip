@@ -640,6 +640,7 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 }
 
 #include "rbpf_chol64.hpp"
+#include "rbpf_chol128.hpp"
 #include "rbpf_chol_small.hpp"
 #include "rbpf_chol_sweep.hpp"
 
@@ -664,6 +665,7 @@ static bool chol_variant_ok(const CholArgs& ca, int d_lds, int variant) {
   switch (variant) {
     case 0: case 16: return true;
     case 64: case 648: case 644: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
+    case 128: return chol128_ok(ca, d_lds);
     case 1: case 10: case 11: case 12: case 14: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
     default: return false;
   }
@@ -677,11 +679,14 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
     if (ca.variant == 11 || ca.variant == 12 || ca.variant == 14) return launch_chol_small(ca, batch, d_lds, st, ca.variant - 10);   // 1 / 2 / 4 waves per matrix
     if (ca.variant == 10) return launch_chol_small(ca, batch, d_lds, st, 10);                                                         // one wave, left-looking
     if (ca.variant == 16) return launch_chol16(ca, batch, d_lds, st);
+    if (ca.variant == 128) return launch_chol128(ca, batch, d_lds, st);
     return launch_chol64(ca, batch, d_lds, st, ca.variant == 648 ? 8 : ca.variant == 644 ? 4 : 0);
   }
   // diagnostic builds (-DRBPF_TUNING) can override the choice from the environment
   static const int w_env = tuning_env("RBPF_CHOL_WAVES") ? atoi(tuning_env("RBPF_CHOL_WAVES")) : 0;      // force 4 / 8 / 16
   const char* v64 = tuning_env("RBPF_CHOL64");
+  const char* v128 = tuning_env("RBPF_CHOL128");                                  // 0: keep the 64-column kernel above 27 row tiles
+  if (!v64 && chol128_ok(ca, d_lds) && !(v128 && atoi(v128) == 0)) return launch_chol128(ca, batch, d_lds, st);
   if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   const char* vsm = tuning_env("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
   if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
@@ -1704,7 +1709,8 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   const bool info = variant >= 1000;                 // information-form expression and loaders (see rbpf.h)
   if (info) variant -= 1000;
   if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 ||
-      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644) ||
+      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644 && variant != 128) ||
+      (variant == 128 && (!info || ((M + 16) >> 4) <= 27)) ||
       ((variant == 1 || variant == 10 || variant == 11 || variant == 12 || variant == 14) && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
   }
@@ -1752,6 +1758,13 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
     total += t;
   }
   if (err == hipSuccess) err = hipMemcpy(logw, dlw, (size_t)batch * 8, hipMemcpyDeviceToHost);
+#ifdef RBPF_TUNING
+  if (const char* dump = tuning_env("RBPF_CHOL_DUMP")) {                      // diagnostic builds: the factor workspace of matrix 0
+    std::vector<double> hl(chol_factor_doubles(M));
+    if (err == hipSuccess) err = hipMemcpy(hl.data(), dL, hl.size() * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(dump, "wb")) { fwrite(hl.data(), 8, hl.size(), f); fclose(f); }
+  }
+#endif
   int flags[4] = {0, 0, 0, 0};
   if (err == hipSuccess) err = hipMemcpy(flags, dst, 16, hipMemcpyDeviceToHost);
   if (e0) hipEventDestroy(e0);

@@ -167,6 +167,36 @@ def test_information_form_factorisation_of_small_matrices(rbpf, M, variant):
     np.testing.assert_allclose(got, numpy_logw_info(S, e), rtol=1e-11, atol=1e-9)
 
 
+@pytest.mark.parametrize("M", [432, 433, 447, 448, 449, 463, 464, 465, 500, 511, 512, 513, 515, 516, 527, 528, 529, 559, 560, 561, 575, 576, 577, 600,
+                               639, 640, 641, 700])
+def test_128_column_kernel_matches_numpy(rbpf, M):
+    """rbpf_chol128.hpp (28 .. 44 row tiles: every residue of the row-tile count modulo 8 -- the last super-block holds 1 .. 8 diagonal
+    tiles -- and matrix sizes around the tile boundaries; one, two and three passes per super-block) against numpy and the
+    64-column kernel, badly scaled rows included."""
+    S, e = spd_batch(5, M, seed=300 + M, scale_spread=1.0 if M % 2 else 0.0)
+    got, status, _ = rbpf.chol_weights(S, e, variant=128, info_form=True)
+    assert status == 0
+    want = numpy_logw_info(S, e)
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-9)
+    got64, status, _ = rbpf.chol_weights(S, e, variant=648, info_form=True)
+    np.testing.assert_allclose(got, got64, rtol=1e-11, atol=1e-9)
+
+
+def test_128_column_kernel_flags_a_failed_factorisation(rbpf):
+    S, e = spd_batch(4, 515, seed=19)
+    w, V = np.linalg.eigh(S[1])
+    w[0] = -1.0
+    S[1] = (V * w) @ V.T
+    got, status, _ = rbpf.chol_weights(S, e, variant=128, info_form=True)
+    assert status & 2 and np.isnan(got[1])
+    ok = [0, 2, 3]
+    np.testing.assert_allclose(got[ok], numpy_logw_info(S[ok], e[ok]), rtol=1e-11, atol=1e-9)
+    with pytest.raises(rbpf.RBPFError):                                     # not an information-form launch / too few row tiles
+        rbpf.chol_weights(S, e, variant=128)
+    with pytest.raises(rbpf.RBPFError):
+        rbpf.chol_weights(S[:, :300, :300], e[:, :300], variant=128, info_form=True)
+
+
 def test_information_form_failure_is_flagged(rbpf):
     """particleSmootherInformationForm.m:224-236 has no usable retry (quirk Q4): a failed factorisation is an error."""
     S, e = spd_batch(5, 128, seed=9)
