@@ -34,8 +34,12 @@
 #endif
 #ifdef RBPF_C128_STAMPS                          // tuning aid: per-phase clocks of waves 0 / 1 / 4 of workgroup 0
 #define C128_STAMP(k) do { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } while (0)
+#define C128_STAMP_ARGS , long long (&cst)[14], long long& clast
+#define C128_STAMP_PASS , cst, clast
 #else
 #define C128_STAMP(k) do { } while (0)
+#define C128_STAMP_ARGS
+#define C128_STAMP_PASS
 #endif
 
 constexpr int kC128Workers = 7;
@@ -169,13 +173,15 @@ __device__ inline void c128_solve_half(v4d (&Z)[2][2][4], int h, const double* N
 template <int NS, int DI, bool FIRST>
 __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int RT, int J2, const int (&rt)[2], int nd2,
                                  int M, const double* rhs_s, const double* Hs, const double* RH, double jit, int lane, double* hb0, double* hb1,
-                                 double* Lds2, const double* ring, int* filled, int* done, int g0, int nch, int* sfail) {
+                                 double* Lds2, const double* ring, int* filled, int* done, int g0, int nch, int* sfail, v4d (&Zn)[2][4], bool pre,
+                                 const int (&rtn)[2], int nsn, int J2n C128_STAMP_ARGS) {
   constexpr int I = DI < 0 ? 0 : DI, E = DI < 0 ? 0 : 3 - DI;
   constexpr bool DG = DI >= 0;
   const bool hasA = DG && I < nd2, hasB = DG && 4 + E < nd2;                 // wave-uniform
   v4d Z[2][2][4];                                                            // [strip][half][sub-column]
   v4d ZA[I + 1], ZB0[4], ZB1[E + 1];
-  // ---- elements ------------------------------------------------------------------------------------------------------
+  // ---- elements of the FIRST half (the second half's are subtracted after the product, while wave 0 factorises) ---------------
+  // pre: this pass's strips came prefetched from the previous pass (Zn: loaded while that pass waited for its second diagonal block)
   if (DG) {
     if (hasA) c128_tri64<I>(a, p, 2 * J2, M, rhs_s, Hs, RH, jit, lane, ZA);
     else {
@@ -186,26 +192,26 @@ __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ 
     for (int c = 0; c < 4; ++c) ZB0[c] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c <= E; ++c) ZB1[c] = (v4d){0.0, 0.0, 0.0, 0.0};
-    if (hasB) {
-      c128_strip64<true>(a, p, 8 * J2 + 4 + E, 2 * J2, M, rhs_s, Hs, RH, jit, lane, ZB0);
-      c128_tri64<E>(a, p, 2 * J2 + 1, M, rhs_s, Hs, RH, jit, lane, ZB1);
-    }
+    if (hasB) c128_strip64<true>(a, p, 8 * J2 + 4 + E, 2 * J2, M, rhs_s, Hs, RH, jit, lane, ZB0);
   }
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NS; ++s) {
+    if (pre) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (DG || RBPF_C128_DBG == 2) {
+      for (int c = 0; c < 4; ++c) Z[s][0][c] = Zn[s][c];
+    } else if (DG) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Z[s][h][c] = (v4d){0.0, 0.0, 0.0, 0.0};
-        c128_strip64<true>(a, p, rt[s], 2 * J2 + h, M, rhs_s, Hs, RH, jit, lane, Z[s][h]);
-      } else {
-        c128_strip64<false>(a, p, rt[s], 2 * J2 + h, M, rhs_s, Hs, RH, jit, lane, Z[s][h]);
-      }
+      for (int c = 0; c < 4; ++c) Z[s][0][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+      c128_strip64<true>(a, p, rt[s], 2 * J2, M, rhs_s, Hs, RH, jit, lane, Z[s][0]);
+    } else {
+      c128_strip64<false>(a, p, rt[s], 2 * J2, M, rhs_s, Hs, RH, jit, lane, Z[s][0]);
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Z[s][1][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  C128_STAMP(5);
   // ---- panel product over the finished columns: A operands (and, for the diagonal strips, B operands) from the ring -----
   if (nch > 0) {
-    if (RBPF_C128_DBG == 1 && !DG) { for (int z = 0; z < 2000; ++z) __builtin_amdgcn_s_sleep(127); }
     const double* pb[NS > 0 ? NS : 1];
 #pragma unroll
     for (int s = 0; s < NS; ++s) pb[s] = Lt + (size_t)rt[s] * KGS * 64;       // wave-uniform base, + lane per load
@@ -255,6 +261,7 @@ __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ 
     }
     if (!ok && lane == 0) *sfail = 1;
   }
+  C128_STAMP(6);
   // ---- first half: hand d_DI to wave 0, wait for its factorisation, solve ---------------------------------------------
   const int nh1 = max(0, nd2 - 4);
   if (FIRST) {
@@ -265,8 +272,19 @@ __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ 
         for (int q = 0; q < 4; ++q) hb0[(c64_tri(I, c) * 4 + q) * 64 + lane] = ZA[c][q];
     }
     __syncthreads();                                                          // B1: the first half's diagonal tiles are in LDS
-    __syncthreads();                                                          // B2: wave 0 has factorised them
   }
+  // the second half's elements, while wave 0 factorises the first diagonal block (FIRST) -- the product ran from zero
+#pragma unroll
+  for (int s = 0; s < NS; ++s) c128_strip64<true>(a, p, rt[s], 2 * J2 + 1, M, rhs_s, Hs, RH, jit, lane, Z[s][1]);
+  if (DG && hasB) {
+    v4d T[E + 1];
+    c128_tri64<E>(a, p, 2 * J2 + 1, M, rhs_s, Hs, RH, jit, lane, T);
+#pragma unroll
+    for (int c = 0; c <= E; ++c) ZB1[c] += T[c];
+  }
+  C128_STAMP(12);
+  if (FIRST) __syncthreads();                                                 // B2: wave 0 has factorised the first half
+  C128_STAMP(7);
   const double* NL0 = hb0;
   const double* Ld0 = hb0 + 1024;
   if (nd2 > 4) {                                                              // (strips below the first half exist)
@@ -285,6 +303,7 @@ __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ 
       }
     }
   }
+  C128_STAMP(8);
   if (FIRST) __syncthreads();                                                 // B3: rows 4..7 of the diagonal block, first half, are in LDS
   // ---- second half: update with the first half's solved tiles (no memory), hand d_{4+E} to wave 0, solve --------------
   if (nh1 > 0) {
@@ -309,10 +328,30 @@ __device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; ++q) hb1[(c64_tri(E, c) * 4 + q) * 64 + lane] = ZB1[c][q];
     }
+    C128_STAMP(9);
     __syncthreads();                                                          // B4: the second half's diagonal tiles are in LDS
-    __syncthreads();                                                          // B5: wave 0 has factorised them
+  }
+  // the next pass's first-half elements, while wave 0 factorises the second diagonal block (FIRST): the solved first-half tiles
+  // are dead by now, their registers take the prefetch
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      if (s < nsn) {
+        c128_strip64<false>(a, p, rtn[s], 2 * J2n, M, rhs_s, Hs, RH, jit, lane, Zn[s]);
+      } else {                                                                // (every pass redefines all of Zn: nothing of it lives through a pass)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Zn[s][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+      }
+  };
+  if (FIRST) {
+    prefetch();
+    C128_STAMP(13);
+    __syncthreads();                                                          // B5: wave 0 has factorised the second half
+    C128_STAMP(10);
   }
   if (nd2 == 8) c128_solve_half<NS>(Z, 1, hb1, hb1 + 1024, Lt, KGS, rt, 32 * J2 + 16, lane);
+  if (!FIRST) prefetch();
+  C128_STAMP(11);
 }
 
 constexpr size_t kC128MaxLds = 160 * 1024;
@@ -355,11 +394,13 @@ __global__ __launch_bounds__(512, 1) void chol_solve128_kernel(CholArgs a_in) {
   if (tid < 8) flags[tid] = 0;
   __syncthreads();
 #ifdef RBPF_C128_STAMPS
-  long long cst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, clast = clock64();
+  long long cst[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clast = clock64();
 #endif
   const double jit = 0.0;
   const int NJ2 = (RT + 7) >> 3;
   int g = 0;                                                          // chunks staged so far (every wave keeps the same count)
+  v4d Zn[2][4];                                                       // workers: the next pass's first-half elements, prefetched
+  bool pre = false;
   for (int J2 = 0; J2 < NJ2; ++J2) {
     const int nd2 = min(8, RT - 8 * J2), nh0 = min(4, nd2), nh1 = nd2 - nh0;
     const int first_below = 8 * J2 + 8, n_below = max(0, RT - first_below), nch = 8 * J2;
@@ -384,45 +425,43 @@ __global__ __launch_bounds__(512, 1) void chol_solve128_kernel(CholArgs a_in) {
       if ((bad || !ok) && lane == 0) *sfail = 1;
       C128_STAMP(3);
     } else {
-      // first pass: waves 1..3 two strips below (u = w - 1, w + 2), waves 4..7 the diagonal strips and one strip below (u = w + 2)
-      {
-        int rt[2], ns = 0;
+      // pass q of super-block J2: first pass = waves 1..3 two strips below (u = w - 1, w + 2), waves 4..7 the diagonal strips and one
+      // strip below (u = w + 2); later passes two strips per worker (u = 10 + 14 (q - 1) + (w - 1) + 7 s)
+      auto assign = [&](int J2a, int q, int (&rta)[2]) -> int {
+        const int fb = 8 * J2a + 8, nb = max(0, RT - fb);
+        int ns = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const int u = (wv <= 3) ? (wv - 1) + 3 * s : (s == 0 ? wv + 2 : n_below);
-          rt[s] = first_below + min(u, max(n_below - 1, 0));
-          ns += (u < n_below) ? 1 : 0;
+          const int u = (q == 0) ? ((wv <= 3) ? (wv - 1) + 3 * s : (s == 0 ? wv + 2 : nb)) : 10 + 14 * (q - 1) + (wv - 1) + 7 * s;
+          rta[s] = fb + min(u, max(nb - 1, 0));
+          ns += (u < nb) ? 1 : 0;
         }
-#define RBPF_C128(NS_, DI_) c128_pass<NS_, DI_, true>(a, p, Lt, KGS, RT, J2, rt, nd2, M, rhs_s, Hs, RH, jit, lane, hb0, hb1, Lds2, ring, filled, done, g, nch, sfail)
-        if (wv <= 3) {
-          if (ns == 2) RBPF_C128(2, -1); else if (ns == 1) RBPF_C128(1, -1); else RBPF_C128(0, -1);
+        return ns;
+      };
+      for (int q = 0; q <= nlate; ++q) {
+        int rt[2], rtn[2] = {0, 0};
+        const int ns = assign(J2, q, rt);
+        const int J2n = (q < nlate) ? J2 : J2 + 1, qn = (q < nlate) ? q + 1 : 0;
+        const int nsn = (J2n < NJ2) ? assign(J2n, qn, rtn) : 0;
+#define RBPF_C128(NS_, DI_, F_) c128_pass<NS_, DI_, F_>(a, p, Lt, KGS, RT, J2, rt, nd2, M, rhs_s, Hs, RH, jit, lane, hb0, hb1, Lds2, ring, filled, done, g, nch, sfail, Zn, pre, rtn, nsn, J2n C128_STAMP_PASS)
+        if (q > 0) {
+          if (ns == 2) RBPF_C128(2, -1, false); else if (ns == 1) RBPF_C128(1, -1, false); else RBPF_C128(0, -1, false);
+        } else if (wv <= 3) {
+          if (ns == 2) RBPF_C128(2, -1, true); else if (ns == 1) RBPF_C128(1, -1, true); else RBPF_C128(0, -1, true);
         } else {
           switch (2 * (7 - wv) + ns) {
-            case 0: RBPF_C128(0, 0); break;
-            case 1: RBPF_C128(1, 0); break;
-            case 2: RBPF_C128(0, 1); break;
-            case 3: RBPF_C128(1, 1); break;
-            case 4: RBPF_C128(0, 2); break;
-            case 5: RBPF_C128(1, 2); break;
-            case 6: RBPF_C128(0, 3); break;
-            default: RBPF_C128(1, 3); break;
+            case 0: RBPF_C128(0, 0, true); break;
+            case 1: RBPF_C128(1, 0, true); break;
+            case 2: RBPF_C128(0, 1, true); break;
+            case 3: RBPF_C128(1, 1, true); break;
+            case 4: RBPF_C128(0, 2, true); break;
+            case 5: RBPF_C128(1, 2, true); break;
+            case 6: RBPF_C128(0, 3, true); break;
+            default: RBPF_C128(1, 3, true); break;
           }
         }
 #undef RBPF_C128
-        g += nch;
-      }
-      C128_STAMP(0);
-      for (int lp = 0; lp < nlate; ++lp) {
-        int rt[2], ns = 0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int u = 10 + 14 * lp + (wv - 1) + 7 * s;
-          rt[s] = first_below + min(u, n_below - 1);
-          ns += (u < n_below) ? 1 : 0;
-        }
-#define RBPF_C128(NS_) c128_pass<NS_, -1, false>(a, p, Lt, KGS, RT, J2, rt, nd2, M, rhs_s, Hs, RH, jit, lane, hb0, hb1, Lds2, ring, filled, done, g, nch, sfail)
-        if (ns == 2) RBPF_C128(2); else if (ns == 1) RBPF_C128(1); else RBPF_C128(0);
-#undef RBPF_C128
+        pre = true;
         g += nch;
       }
       C128_STAMP(1);
@@ -432,7 +471,8 @@ __global__ __launch_bounds__(512, 1) void chol_solve128_kernel(CholArgs a_in) {
   }
 #ifdef RBPF_C128_STAMPS
   if (p == 0 && lane == 0 && (wv == 0 || wv == 1 || wv == 4))
-    printf("chol128 M=%d wave %d clocks: [0] %lld [1] %lld [2] %lld [3] %lld wait-end %lld\n", M, wv, cst[0], cst[1], cst[2], cst[3], cst[4]);
+    printf("chol128 M=%d wave %d clocks: w0 produce %lld D0 %lld D1 %lld late-produce %lld | end-barrier %lld | elems0 %lld product %lld elems1 %lld wait-D0 %lld solve0 %lld miniP %lld prefetch %lld wait-D1 %lld solve1 %lld\n",
+           M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], cst[12], cst[7], cst[8], cst[9], cst[13], cst[10], cst[11]);
 #endif
   const int failed = *sfail;
   __syncthreads();
