@@ -180,8 +180,8 @@ typedef struct {
                           * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]): filter *
                           * and both smoothers, single-GPU and sharded; RBPF_ERR_UNSUPPORTED elsewhere.                         */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
-                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 / 10-14 as*
-                          * the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
+                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 128 / 1 /   *
+                          * 10-14 as the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
   int32_t chol_refresh;  /* information-form smoother: 0 / 1 = factorise Imat_i + ImatAddt from scratch at every step, as           *
                           * particleSmootherInformationForm.m:228 does (default).  K > 1: CARRY the factor along every lineage   *
                           * -- per step n_y rank-1 updates (the particle's own H' R^-1 H) and n_y rank-1 downdates (the reference *

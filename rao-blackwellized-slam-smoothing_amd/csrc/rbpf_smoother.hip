@@ -685,8 +685,10 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
   // diagnostic builds (-DRBPF_TUNING) can override the choice from the environment
   static const int w_env = tuning_env("RBPF_CHOL_WAVES") ? atoi(tuning_env("RBPF_CHOL_WAVES")) : 0;      // force 4 / 8 / 16
   const char* v64 = tuning_env("RBPF_CHOL64");
-  const char* v128 = tuning_env("RBPF_CHOL128");                                  // 0: keep the 64-column kernel above 27 row tiles
-  if (!v64 && chol128_ok(ca, d_lds) && !(v128 && atoi(v128) == 0)) return launch_chol128(ca, batch, d_lds, st);
+  // the 128-column kernel (rbpf_chol128.hpp) is selectable (chol_variant = 128, RBPF_CHOL128 = 1 in diagnostic builds) but NOT the default:
+  // measured r04 in the smoother at N_P = 8192, n = 515: 20.1 ms per launch against 16.2 ms for the 64-column kernel
+  const char* v128 = tuning_env("RBPF_CHOL128");
+  if (!v64 && v128 && atoi(v128) == 1 && chol128_ok(ca, d_lds)) return launch_chol128(ca, batch, d_lds, st);
   if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   const char* vsm = tuning_env("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
   if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);

@@ -124,6 +124,19 @@ def test_packed_information_matrices_through_every_loader(rbpf, kind, m, variant
     ts.check(ref, out, 3)
 
 
+@pytest.mark.parametrize("m,storage", [(512, "fp64sym"), (512, "fp64"), (445, "fp64"), (600, "fp64")])
+def test_information_form_smoother_through_the_128_column_kernel(rbpf, m, storage):
+    """rbpf_options.chol_variant = 128: particleSmootherInformationForm.m:224-236 through rbpf_chol128.hpp inside the smoother -- packed
+    information matrices, the pending H' R^-1 H of the last update folded into the element load, Imat(:,:,ai) written on the way
+    (nLin = 515: 33 row tiles, the metric's size; 448 = 29 row tiles, a right-hand-side row alone in its tile; 603 = 38 row tiles)
+    -- against the numpy oracle, N_K = 3."""
+    import test_gpu_smoother as ts
+    c = cases.mag_case(7, 6, m, seed=29, N_K=3)
+    kw = dict(storage=storage, lazy_depth=3) if storage == "fp64sym" else {}
+    ref, out = ts.run_both(rbpf, c, info_form=True, chol_variant=128, **kw)
+    ts.check(ref, out, 3)
+
+
 @pytest.mark.parametrize("m", [256, 300])
 def test_information_form_smoother_at_the_benchmark_basis_sizes(rbpf, m):
     """m = 256 (nLin = 259, 17 row tiles) and m = 300 (nLin = 303, 19 row tiles): the size class of the 4-wave shape of the

@@ -13,12 +13,12 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 
 
-def run_both(rbpf, c, info_form, chol_variant=0):
+def run_both(rbpf, c, info_form, chol_variant=0, **kw):
     ref = cases.oracle_smoother(c, info_form)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     f = rbpf.particleSmootherInformationForm if info_form else rbpf.particleSmoother
     out = f(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
-            c["N_P"], c["N_K"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, chol_variant=chol_variant)
+            c["N_P"], c["N_K"], c["dt"], rng=cases.device_rng(rbpf, c), extras=True, chol_variant=chol_variant, **kw)
     return ref, out
 
 
