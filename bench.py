@@ -369,9 +369,96 @@ def smoother_kernel_roofline(pkg):
     logw, status, ms = pkg.chol_weights(S, e, reps=5)
     flops = B * M ** 3 / 3.0
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "chol_solve64_kernel", "workload": f"{B} matrices, n={M}, fp64", "bound": "mfma", "achieved": ach, "peak": 78.6,
+    return {"kernel": "chol_solve64_kernel", "workload": f"{B} matrices, n={M}, fp64, standalone (covariance-form loaders; the figure inside the smoother is "
+                                                         "smoother.kernel_roofline_in_smoother)", "bound": "mfma", "achieved": ach, "peak": 78.6,
             "unit": "TFLOP/s", "frac": ach / 78.6, "avg_launch_ms": ms, "algorithmic_flop_per_launch": flops, "traffic": None,
             "finite": bool(np.all(np.isfinite(logw))) and status == 0}
+
+
+def smoother_trace_child(args):
+    """Child of smoother_kernel_in_smoother: a short run of the metric's smoother configuration, nothing else (runs under
+    rocprofv3 --kernel-trace --stats)."""
+    pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
+    datagen = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
+    Q = q_mag()
+    d = datagen.bean_6D(args.T, Q, THETA_MAG, 0.01, seed=args.seed)
+    mdl, x0, P0, R = pkg.dense_mag_prior(args.m, d["LL"], THETA_MAG)
+    pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R,
+                                        args.particles, 2, 0.01, rng=pkg.PhiloxRNG(3), lazy_depth=3, storage="fp64sym" if args.m == 512 else "fp64")
+
+
+def smoother_kernel_in_smoother(args, N_P=8192, T=24):
+    """The ancestor-weight factorisation AS THE SMOOTHER RUNS IT (packed information matrices in, Imat(:,:,ai) out, siblings sharing
+    their ancestor's matrix): mean launch time from a `rocprofv3 --kernel-trace --stats` child run of the metric's smoother
+    configuration (N_P = 8192, m = 512, lazy_depth 3, N_K = 2, T = 24 steps), priced against the fp64 matrix peak with n^3/3 flop per
+    particle.  The step kernels of the same run are listed beside it."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return {"error": "rocprofv3 not on PATH"}
+    if under_profiler():
+        return {"error": "bench.py itself runs under a profiler: nested trace pass skipped"}
+    tmp = tempfile.mkdtemp(prefix="rbpf_trace_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "sm", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--smoother-trace-child", "--particles", str(N_P), "--m", str(args.m), "--T", str(T),
+               "--seed", str(args.seed)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return {"error": f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {r.stdout[-300:]}"}
+        rows = list(csv.DictReader(open(files[0])))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    n = args.m + 3
+    out = {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_P} T={T} m={args.m} N_K=2 lazy_depth 3 (rocprofv3 --kernel-trace --stats child run)",
+           "kernels": {}}
+    for x in rows:
+        name = x["Name"].split("(")[0].replace("void rbpf::", "").replace("rbpf::", "")
+        if "chol_solve" in name or "step_sym_kernel" in name or "step_kernel" in name:
+            out["kernels"][name] = {"calls": int(x["Calls"]), "avg_launch_ms": float(x["AverageNs"]) / 1e6, "share_of_gpu_time_pct": float(x["Percentage"])}
+    chol = [(k, v) for k, v in out["kernels"].items() if "chol_solve" in k]
+    if not chol:
+        out["error"] = "no chol_solve kernel in the trace"
+        return out
+    k, v = max(chol, key=lambda kv: kv[1]["calls"])
+    flops = N_P * n ** 3 / 3.0
+    ach = flops / (v["avg_launch_ms"] * 1e-3) / 1e12
+    out.update({"kernel": k, "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                "avg_launch_ms": v["avg_launch_ms"], "launches": v["calls"], "algorithmic_flop_per_launch": flops})
+    return out
+
+
+def filter_full_run(pkg, datagen, N, m, T, seed, lazy_depth, inplace, storage, window=500):
+    """A COMPLETE filter run (particleFilter.m:100-218 loops to N_T): all T steps of the headline configuration, timed as a whole and
+    in windows of `window` steps -- how many distinct stored covariances a step reads depends on the ancestry, so the throughput of the
+    first steps is not by construction that of the rest.  Per window: particle-steps/s (host clock around advance + sync), the step
+    kernels' own time (HIP events) and the bytes the schedule moved per step (counted on the device)."""
+    import numpy as np
+    Q = q_mag()
+    data = datagen.bean_6D(T, Q, THETA_MAG, 0.01, seed=seed)
+    model, x0_lin, P0, R = pkg.dense_mag_prior(m, data["LL"], THETA_MAG)
+    wins = []
+    with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N, 0.01, rng=pkg.PhiloxRNG(seed),
+                           keep_history=True, lazy_depth=lazy_depth, inplace=inplace, storage=storage) as sess:
+        sess.timing(enable=True)
+        t_all = time.perf_counter()
+        done = 0
+        while done < T:
+            k = min(window, T - done)
+            t0 = time.perf_counter()
+            sess.advance(k)
+            sess.sync()
+            dt_s = time.perf_counter() - t0
+            tm = sess.timing(reset=True)
+            wins.append({"steps": [done, done + k], "particle_steps_per_s": N * k / dt_s, "ms_per_step": dt_s / k * 1e3,
+                         "kernel_ms_per_step": tm["ms"] / max(tm["launches"], 1),
+                         "scheduled_GB_per_step": tm["scheduled_bytes_per_launch"] / 1e9})
+            done += k
+        secs = time.perf_counter() - t_all
+        chk = sess.finish(want=("traj_mean", "traj_sample_iwmax"))
+    ok = bool(np.all(np.isfinite(chk["traj_mean"])) and np.all(np.isfinite(chk["traj_sample_iwmax"])))
+    return {"workload": f"slam-dense-mag N={N} T={T} m={m} {storage}, lazy_depth {lazy_depth}: all {T} steps, state history and ancestor table kept",
+            "seconds": secs, "particle_steps_per_s": N * T / secs, "ms_per_step": secs / T * 1e3, "windows": wins, "finite": ok}
 
 
 def smoother_sweep_roofline(pkg):
@@ -412,7 +499,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother", action="store_true", help="skip every smoother leg")
     ap.add_argument("--no-smoother-full", action="store_true", help="skip the complete T=3000 smoother run of the per-GPU share (about a minute)")
-    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 16384, about 75 s)")
+    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 32768, the "
+                    "reference's arithmetic, about 4 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
+    ap.add_argument("--no-filter-full", action="store_true", help="skip the complete T-step filter run (about 40 s)")
+    ap.add_argument("--time-budget", type=float, default=300.0, help="seconds of wall clock after which the longest optional leg (the N_P = 32768 smoother) is not started")
+    ap.add_argument("--smoother-trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-large", action="store_true", help="skip the extra filter configurations (configs[1], configs[4] share) and the N=65536 radio smoother")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
@@ -425,14 +516,18 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
-    ap.add_argument("--smoother-32k", action="store_true", help="also run the complete smoother at N_P = 32768 on this one GPU (the reference's arithmetic: a fresh "
-                    "factorisation per particle and step; information matrices in packed storage; about 4.5 minutes)")
+    ap.add_argument("--smoother-16k-carried", action="store_true", help="also run the complete smoother at N_P = 16384 with carried factors (the largest that option "
+                    "fits on one GPU: its refreshes keep full-square information matrices; about a minute)")
     ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of EACH sharded smoother leg, seconds (a leg that does not return ends every rank with exit code 3)")
     args = ap.parse_args()
 
     if args.traffic_child:
         traffic_child(args)
         return
+    if args.smoother_trace_child:
+        smoother_trace_child(args)
+        return
+    t_start = time.perf_counter()
 
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
@@ -570,6 +665,7 @@ def main():
                 line["roofline"]["traffic_note"] = why
         if solo and not args.no_smoother:
             sm = {"reference_size": guarded(smoother_reference_size, pkg, datagen),
+                  "kernel_roofline_in_smoother": guarded(smoother_kernel_in_smoother, args),
                   "kernel_roofline": guarded(smoother_kernel_roofline, pkg),
                   "sweep_kernel_roofline": guarded(smoother_sweep_roofline, pkg)}
             # the smoothers take the filter's storage option where it applies to them (symmetric covariance storage: nLin = 515)
@@ -587,26 +683,12 @@ def main():
                     line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3, fresh factorisation every step"
                 if "seconds" in sm["share_full_carried_factors"]:
                     line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
-                if not args.no_smoother_largest:
+                if args.smoother_16k_carried:
                     # the largest smoother one GPU holds WITH CARRIED FACTORS: per particle 2 x 1.19 MB covariance banks (symmetric
                     # storage), 2 x 2.12 MB Imat (full squares: the refreshes' G'G writes them), 2.23 MB factorisation workspace,
-                    # 2 x 1.21 MB carried factors + 0.4 MB refresh scratch = 11.7 MB at nLin = 515 -> N_P = 16 384 needs 191 GB of the
-                    # 288 GB.  (The reference's arithmetic keeps 6.9 MB per particle and runs N_P = 32 768: --smoother-32k.)
-                    sm["largest_single_gpu_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
-                                                                                                   lazy_depth=3, chol_refresh=32, storage=sm_storage))
-                    if "seconds" in sm["largest_single_gpu_carried_factors"]:
-                        line["smoother_wall_clock_largest_single_gpu_s"] = sm["largest_single_gpu_carried_factors"]["seconds"]
-                        line["smoother_wall_clock_largest_single_gpu_workload"] = (sm["largest_single_gpu_carried_factors"]["workload"] +
-                                                                                   ", lazy_depth 3, chol_refresh 32")
-                if args.smoother_32k:
-                    # half of the metric's N on ONE GPU, the reference's arithmetic: per particle 2 x 1.19 MB covariance banks, 2 x 1.15 MB
-                    # information matrices (packed block-lower storage), 2.23 MB factorisation workspace = 6.9 MB at nLin = 515 -> 226 GB
-                    sm["N32768_single_gpu"] = guarded(lambda: smoother_share_full(pkg, datagen, 32768, 3000, 512, 2, args.seed, lazy_depth=3,
-                                                                                  storage=sm_storage))
-                    if "seconds" in sm["N32768_single_gpu"]:
-                        line["smoother_wall_clock_N32768_single_gpu_s"] = sm["N32768_single_gpu"]["seconds"]
-                        line["smoother_wall_clock_N32768_single_gpu_workload"] = (sm["N32768_single_gpu"]["workload"] +
-                                                                                  ", lazy_depth 3, fresh factorisation every step")
+                    # 2 x 1.21 MB carried factors + 0.4 MB refresh scratch = 11.7 MB at nLin = 515 -> N_P = 16 384 needs 191 GB of the 288 GB
+                    sm["N16384_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
+                                                                                       lazy_depth=3, chol_refresh=32, storage=sm_storage))
             if not args.no_large:
                 sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
             line["smoother"] = sm
@@ -619,6 +701,25 @@ def main():
             # workgroups, ~58 us each), not by bytes -- symmetric storage (supported at this size too) gives the same 8.0-8.2 M/s
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")
             line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]
+        if solo and not args.no_filter_full:
+            line["filter_full_T"] = guarded(lambda: filter_full_run(pkg, datagen, N_local, args.m, T, args.seed, args.lazy_depth, args.inplace, args.storage))
+            if "seconds" in line["filter_full_T"]:
+                line["filter_full_T_s"] = line["filter_full_T"]["seconds"]
+        if solo and not args.no_smoother and not args.no_smoother_full and not args.no_smoother_largest:
+            # The largest smoother ONE GPU holds, the reference's arithmetic (a fresh factorisation per particle and step): half of the
+            # metric's N.  Per particle 2 x 1.19 MB covariance banks, 2 x 1.15 MB information matrices (packed block-lower storage),
+            # 2.23 MB factorisation workspace = 6.9 MB at nLin = 515 -> 226 GB of the 288 GB.  The longest leg of the run (about four
+            # minutes), so it goes last and only while the run is inside its time budget.
+            elapsed = time.perf_counter() - t_start
+            if elapsed > args.time_budget:
+                line["smoother"]["largest_single_gpu"] = {"skipped": f"{elapsed:.0f} s of wall clock used before this leg (--time-budget {args.time_budget:.0f})"}
+            else:
+                sm_storage = args.storage if args.storage in ("fp64", "fp64sym") and args.m == 512 else "fp64"
+                r32 = guarded(lambda: smoother_share_full(pkg, datagen, 32768, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage))
+                line["smoother"]["largest_single_gpu"] = r32
+                if "seconds" in r32:
+                    line["smoother_wall_clock_largest_single_gpu_s"] = r32["seconds"]
+                    line["smoother_wall_clock_largest_single_gpu_workload"] = r32["workload"] + ", lazy_depth 3, fresh factorisation every step"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)
