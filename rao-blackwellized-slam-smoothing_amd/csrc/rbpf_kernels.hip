@@ -151,7 +151,11 @@ Layout make_layout_low_regs(int n, int d) {
 #define RBPF_KB_THRESHOLD_KB 72
 #endif
 bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets) {
-  if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;
+  // (CPL <= 2: the blocked variants are only instantiated for one or two row chunks per wave -- launch_step_t; with three chunks,
+  //  384 <= nLin < 512, the plain plan stays whatever its size.  r04: this function used to say "blocked" there, the launch sized
+  //  the LDS for the blocked plan and then ran the plain kernel over it: wrong results for nLin 441..511 and for the information
+  //  form from nLin = 384 on, sizes no test had touched; tests/test_gpu_filter.py test_three_row_chunks)
+  if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CPL > 2 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;
   return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, 0).total * sizeof(double) > (size_t)RBPF_KB_THRESHOLD_KB * 1024;
 }
 

@@ -244,3 +244,19 @@ def test_exception_inside_a_model_handle_surfaces(rbpf):
     with pytest.raises(FloatingPointError):
         rbpf.particleFilter(dyn, lambda xn: c["model"].measModel(xn), c["odometry"], c["y"], c["x0_nonLin"], c["x0_lin"], c["P0_lin"],
                             c["Q"], c["R"], 6, c["dt"], rng=cases.device_rng(rbpf, c))
+
+
+@pytest.mark.parametrize("m", [381, 400, 438, 445, 500, 508, 650, 765, 900])
+def test_every_row_chunk_count(rbpf, m):
+    """Basis sizes between the benchmark's: the covariance stream splits into 128-row chunks, and how the four waves share them
+    depends on their number -- three chunks (384 <= nLin < 512: whole columns per wave, CPL = 3), five to seven (one round of four
+    plus a remainder chunk).  r04 found the three-chunk sizes WRONG once the per-column LDS records pass 72 KB (nLin >= 441; the
+    information form from 384 on): the launch sized the LDS for the blocked plan and ran the plain kernel (step_use_blocked).
+    Filter and both smoothers against the numpy oracle at every chunk count the benchmark sizes do not cover."""
+    import test_gpu_smoother as ts
+    c = cases.mag_case(6, 5, m, seed=31, N_K=2)
+    ref, out = run_both(rbpf, c)
+    check_filter(ref, out)
+    for info_form in (True, False):
+        ref, out = ts.run_both(rbpf, c, info_form=info_form)
+        ts.check(ref, out, 2)
