@@ -502,6 +502,11 @@ def main():
     ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 32768, the "
                     "reference's arithmetic, about 4 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
     ap.add_argument("--no-filter-full", action="store_true", help="skip the complete T-step filter run (about 40 s)")
+    ap.add_argument("--driver", default="torchrun", choices=["torchrun", "inlib"],
+                    help="inlib: ALSO time the in-library multi-device driver (rbpf_options.n_devices, csrc/rbpf_multi.hip: one host process, one thread "
+                         "per GPU, RCCL issued by the library -- the path a MATLAB session behind the MEX gateway uses) on the same particles: rank 0 "
+                         "calls the one-shot entry point over all --gpus devices while the other ranks wait; reported under `inlib_driver`")
+    ap.add_argument("--inlib-steps", type=int, default=120, help="time steps of the --driver inlib run (a complete one-shot call: upload, steps, extraction)")
     ap.add_argument("--time-budget", type=float, default=300.0, help="seconds of wall clock after which the longest optional leg (the N_P = 32768 smoother) is not started")
     ap.add_argument("--smoother-trace-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-large", action="store_true", help="skip the extra filter configurations (configs[1], configs[4] share) and the N=65536 radio smoother")
@@ -637,6 +642,27 @@ def main():
         single_bank = args.inplace > 0 or (args.inplace == 0 and args.lazy_depth >= 2 and
                                            2.0 * N_local * bank_bytes_per_particle(n_, args.storage) > 0.85 * tot_b)
 
+    inlib = None
+    if args.driver == "inlib":
+        # every rank has finished its own leg; rank 0 now owns all --gpus devices through the library's threads
+        barrier()
+        if rank == 0:
+            try:
+                Ti = min(args.inlib_steps, T)
+                di = datagen.bean_6D(Ti, Q, THETA_MAG, 0.01, seed=args.seed)
+                mi, x0i, P0i, Ri = pkg.dense_mag_prior(args.m, di["LL"], THETA_MAG)
+                kw = dict(n_devices=world, device_ids=list(range(world))) if world > 1 else dict(n_devices=1, device_ids=[local_rank])
+                t0 = time.perf_counter()
+                out = pkg.particleFilter(mi.dynModel, mi.measModel, di["dx"], di["y"], di["initState"], x0i, P0i, Q, Ri, N_total, 0.01,
+                                         rng=pkg.PhiloxRNG(args.seed), want_xn_traj=False, lazy_depth=args.lazy_depth, storage=args.storage, **kw)
+                dt_i = time.perf_counter() - t0
+                inlib = {"workload": f"slam-dense-mag N={N_total} m={args.m} {args.storage} lazy_depth {args.lazy_depth}, {Ti} time steps, ONE host process, "
+                                     f"{world} device(s) through rbpf_options.n_devices (one-shot rbpf_particle_filter: upload + steps + extraction)",
+                         "seconds": dt_i, "particle_steps_per_s_incl_setup": N_total * Ti / dt_i, "finite": bool(np.all(np.isfinite(out[1])))}
+            except Exception as exc:                               # report, never hide
+                inlib = {"error": f"{type(exc).__name__}: {exc}"}
+        barrier()
+
     if rank == 0:
         n = model.nLin
         line = {
@@ -652,6 +678,8 @@ def main():
         }
         if shard_stats:
             line["config"]["sharding"] = shard_stats
+        if inlib is not None:
+            line["inlib_driver"] = inlib
         solo = world == 1 and not args.force_sharded
         if solo and not args.no_traffic:
             tr, why = measure_traffic(args, args.lazy_depth)

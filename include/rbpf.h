@@ -463,6 +463,10 @@ int rbpf_shard_smoother_refresh_begin(rbpf_ctx* ctx, int32_t* owner_now, int32_t
 int rbpf_plan_refresh(const int32_t* owner_now, const int32_t* base_loc, int32_t N_global, int32_t n_local, int32_t world,
                       int32_t rank, int32_t* send_slots, int32_t send_capacity, int32_t* n_send, int64_t* send_counts,
                       int64_t* recv_counts, int64_t* send_totals, int64_t* recv_totals, int32_t* base_index);
+/* Before refresh_pack, when the plan's largest per-rank total exceeds rbpf_shard_smoother_views.refresh_capacity: every rank
+ * (the plan is replicated) enlarges its refresh buffers to hold `count` matrices -- rbpf_shard_smoother_views_get then returns the
+ * new pointers / capacity -- unless rbpf_options.exchange_capacity > 0 made the capacity a hard limit (RBPF_ERR_OUT_OF_MEMORY).  */
+int rbpf_shard_smoother_refresh_reserve(rbpf_ctx* ctx, int64_t count);
 int rbpf_shard_smoother_refresh_pack(rbpf_ctx* ctx, const int32_t* slots, int32_t count);
 int rbpf_shard_smoother_refresh_end(rbpf_ctx* ctx, const int32_t* base_index, int32_t n_recv);
 /* One information-form time step of my particles (:256-335), using the plan of rbpf_shard_plan for t > 0.        */

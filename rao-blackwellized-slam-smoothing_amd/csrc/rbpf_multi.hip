@@ -256,9 +256,8 @@ int refresh(Multi& M, int r) {
   long long worst = 0, ns = 0, nr = 0;
   for (int q = 0; q < M.W; ++q) { worst = std::max(worst, std::max(P.send_totals[q], P.recv_totals[q])); ns += P.send_counts[q]; nr += P.recv_counts[q]; }
   if (worst > (long long)M.sv[r].refresh_capacity) {                                // replicated plan: every rank reaches this verdict
-    set_error("refresh of the carried factors moves up to " + std::to_string(worst) + " matrices per rank, above the capacity " +
-              std::to_string((long long)M.sv[r].refresh_capacity) + " (raise exchange_capacity)");
-    return RBPF_ERR_OUT_OF_MEMORY;
+    MT_TRY(rbpf_shard_smoother_refresh_reserve(M.ctx[r], worst));                  // grows by a replicated rule, or fails on every rank
+    MT_TRY(rbpf_shard_smoother_views_get(M.ctx[r], &M.sv[r]));
   }
   MT_TRY(rbpf_shard_smoother_refresh_pack(M.ctx[r], ns ? P.send_slots.data() : nullptr, (int32_t)ns));
   MT_TRY(exchange_rows(M, r, M.sv[r].refresh_send, M.sv[r].refresh_recv, P.send_counts.data(), P.recv_counts.data(),

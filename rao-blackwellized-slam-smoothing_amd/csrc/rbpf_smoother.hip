@@ -1391,7 +1391,9 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     RB_TRY(dmalloc(&s->d_base_loc, (size_t)sh->Nglob));
     // every particle needs one base matrix at most; half of the local particles importing theirs is far beyond what the
     // owner-computes placement produces between two refreshes (identical on every rank: a function of the options only)
-    s->rf_cap = (world > 1) ? std::min<size_t>((size_t)N, std::max<size_t>(2 * sh->step_cap, 64)) : 1;
+    // (a starting value: rbpf_shard_smoother_refresh_reserve grows the buffers when a refresh needs more; exchange_capacity < 0 asks for
+    //  a small start, which is how the tests reach the growth path)
+    s->rf_cap = (world > 1) ? std::min<size_t>((size_t)N, std::max<size_t>(2 * sh->step_cap, c->opt.exchange_capacity < 0 ? 1 : 64)) : 1;
     RB_TRY(dmalloc(&s->d_rf_send, s->rf_cap * (size_t)n * n));
     RB_TRY(dmalloc(&s->d_rf_recv, s->rf_cap * (size_t)n * n));
     RB_TRY(dmalloc(&s->d_rf_idx, s->rf_cap));
@@ -1529,6 +1531,33 @@ int rbpf_shard_smoother_refresh_begin(rbpf_ctx* c, int32_t* owner_now, int32_t* 
   HIPCHK(hipMemcpyAsync(base_loc, s->d_base_loc, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   s->rf_stage = 1; s->rf_Kp = Kp;
+  return RBPF_OK;
+}
+
+// The refresh buffers GROW on demand like the record buffers (rbpf_options.exchange_capacity <= 0): `count` = the largest number of
+// matrices any rank sends or receives at this refresh -- a function of the replicated plan, so every rank calls this with the same
+// value and enlarges by the same rule (at least `count`, at least twice the old capacity, at most N_local) without communicating.
+// Nothing in the buffers outlives a refresh.  exchange_capacity > 0 is a hard limit: RBPF_ERR_OUT_OF_MEMORY on every rank.
+int rbpf_shard_smoother_refresh_reserve(rbpf_ctx* c, int64_t count) {
+  if (!c || !c->sh || !c->sm || count < 0) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
+  HIPCHK(hipSetDevice(c->device));
+  SmootherState* s = c->sm;
+  if ((size_t)count <= s->rf_cap) return RBPF_OK;
+  if (c->opt.exchange_capacity > 0 || (size_t)count > (size_t)c->sh->Nloc) {
+    set_error("refresh of the carried factors moves up to " + std::to_string((long long)count) + " matrices per rank, above the capacity " +
+              std::to_string((long long)s->rf_cap) + " (exchange_capacity > 0 is a hard limit)");
+    return RBPF_ERR_OUT_OF_MEMORY;
+  }
+  const size_t cap = std::min<size_t>((size_t)c->sh->Nloc, std::max<size_t>((size_t)count, 2 * s->rf_cap));
+  const size_t nn = (size_t)c->mdl.n * c->mdl.n;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  double *ns_ = nullptr, *nr_ = nullptr; int* ni_ = nullptr;
+  int rc = dmalloc(&ns_, cap * nn);
+  if (rc == RBPF_OK) rc = dmalloc(&nr_, cap * nn);
+  if (rc == RBPF_OK) rc = dmalloc(&ni_, cap);
+  if (rc != RBPF_OK) { hipFree(ns_); hipFree(nr_); hipFree(ni_); return rc; }
+  hipFree(s->d_rf_send); hipFree(s->d_rf_recv); hipFree(s->d_rf_idx);
+  s->d_rf_send = ns_; s->d_rf_recv = nr_; s->d_rf_idx = ni_; s->rf_cap = cap;
   return RBPF_OK;
 }
 

@@ -679,7 +679,7 @@ def model_dyn_res_norm(dynModel):
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
               sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None,
-              storage="fp64"):
+              storage="fp64", exchange_capacity=0):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -704,6 +704,7 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
         if extras:
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "n_devices: traces are not gathered from the sharded smoother")
         opt.n_devices = int(n_devices)
+        opt.exchange_capacity = int(exchange_capacity)
         if device_ids is not None:
             _ids = (C.c_int32 * int(n_devices))(*[int(v) for v in device_ids])
             opt.device_ids = C.cast(_ids, C.POINTER(C.c_int32))
@@ -754,14 +755,16 @@ def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0
 
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
-                                    chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None, storage="fp64"):
+                                    chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None, storage="fp64",
+                                    exchange_capacity=0):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
     covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
     chol_refresh = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1 up/down-dates and
     recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default).
     n_devices = W > 1: the particles of every iteration are sharded over W GPUs inside the library (rbpf_options.n_devices)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
-                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids, storage)
+                     dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids, storage,
+                     exchange_capacity)
 
 
 def sample(w, u):

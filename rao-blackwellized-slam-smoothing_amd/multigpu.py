@@ -559,6 +559,13 @@ class ShardedSmootherSession(ShardedFilterSession):
         super().__init__(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=rng, rank=rank, world=world,
                          transport=transport, planner="device", lazy_depth=lazy_depth, exchange_capacity=exchange_capacity,
                          sync_phases=sync_phases, force_collectives=force_collectives, storage=storage)
+        self.lib.rbpf_shard_smoother_refresh_reserve.argtypes = [C.c_void_p, C.c_int64]
+        self._smoother_views()
+        self.stats["refreshes"] = 0
+        self.stats["refresh_fetched"] = 0
+
+    def _smoother_views(self):
+        """(Re-)read the smoother's device buffers: the refresh buffers move when they grow (rbpf_shard_smoother_refresh_reserve)."""
         sv = rbpf_shard_smoother_views()
         check(self.lib.rbpf_shard_smoother_views_get(self.ctx, C.byref(sv)))
         self.t_anc_local = _view(self.torch, sv.anc_local, (self.N_local,), self.device)
@@ -569,8 +576,6 @@ class ShardedSmootherSession(ShardedFilterSession):
             shape = (self.refresh_capacity, int(sv.matrix_doubles))
             self.t_rf_send = _view(self.torch, sv.refresh_send, shape, self.device)
             self.t_rf_recv = _view(self.torch, sv.refresh_recv, shape, self.device)
-        self.stats["refreshes"] = 0
-        self.stats["refresh_fetched"] = 0
 
     def _n_iter(self):
         return self.N_K
@@ -609,9 +614,9 @@ class ShardedSmootherSession(ShardedFilterSession):
             return
         rp = plan_refresh_lib(lib, own, bl, self.N_local, W, self.rank)
         worst = int(max(rp.send_totals.max(), rp.recv_totals.max()))
-        if worst > self.refresh_capacity:                # replicated plan: every rank reaches this verdict
-            raise _ffi.RBPFError(_ffi.RBPF_ERR_OUT_OF_MEMORY, f"refresh of the carried factors moves up to {worst} matrices per rank, "
-                                 f"above the capacity {self.refresh_capacity} (raise exchange_capacity)")
+        if worst > self.refresh_capacity:                # replicated plan: every rank reaches this verdict and grows alike
+            check(lib.rbpf_shard_smoother_refresh_reserve(self.ctx, worst))      # (exchange_capacity > 0: a hard limit, fails on every rank)
+            self._smoother_views()
         ns, nr = int(rp.send_counts.sum()), int(rp.recv_counts.sum())
         slots = np.ascontiguousarray(rp.send_slots)
         check(lib.rbpf_shard_smoother_refresh_pack(self.ctx, _ip(slots) if ns else None, ns))

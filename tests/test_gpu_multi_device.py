@@ -106,8 +106,8 @@ def test_multi_device_smoother_on_symmetric_storage(rbpf, lazy_depth):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
 
 
-@pytest.mark.parametrize("kind,ids", [("radio", [0, 0]), ("mag", [0, 0, 0]), ("mag", [0])])
-def test_multi_device_smoother_with_carried_factors(rbpf, kind, ids):
+@pytest.mark.parametrize("kind,ids,cap", [("radio", [0, 0], 0), ("mag", [0, 0, 0], 0), ("mag", [0], 0), ("radio", [0, 0], -1), ("mag", [0, 0, 0], -1)])
+def test_multi_device_smoother_with_carried_factors(rbpf, kind, ids, cap):
     """chol_refresh = K in the in-library driver: the factors migrate inside the particle records, the refreshes fetch base matrices
     across ranks by the plan every rank derives from the replicated tables (rbpf_multi.hip plan_refresh == multigpu.plan_refresh).
     Against the single-GPU smoother with the same options: same trajectory draws, outputs to 1e-9."""
@@ -120,6 +120,7 @@ def test_multi_device_smoother_with_carried_factors(rbpf, kind, ids):
         args = (mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, 36, 3, 0.01)
     kw = dict(lazy_depth=3, chol_refresh=4)
     ref = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), **kw)
-    out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), n_devices=len(ids), device_ids=ids, **kw)
+    # exchange_capacity = -1: record AND refresh buffers start at one / two entries and grow on demand (every rank by the same rule)
+    out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), n_devices=len(ids), device_ids=ids, exchange_capacity=cap, **kw)
     for a, b in zip(out, ref):
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
