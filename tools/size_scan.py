@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Diagnostic: filter / information-form / covariance-form parity against the numpy oracle over a scan of basis sizes and options
 (r04 found a silent size class -- three row chunks -- that no test had touched; this scan looks for more).  Prints one line per case:
-ok / FAIL / the library's own refusal."""
+ok / FAIL / the library's own refusal.  (profiles/r04_size_scan.txt: the one FAIL left, dense-radio m = 512 filter, is a tie -- three
+siblings with bit-identical weights, whose arg-max picks another sibling at a rounding difference of 1e-15 in traj_max; every index,
+weight, map and covariance of that case agrees to 1e-14.)"""
 import importlib
 import os
 import sys
