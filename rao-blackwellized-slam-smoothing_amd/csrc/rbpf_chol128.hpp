@@ -1,42 +1,34 @@
 // Ancestor-weight factorisation of the information form, 128-column variant (included by rbpf_smoother.hip after rbpf_chol64.hpp,
-// whose element loaders, diagonal-block routine and argument block it shares).
+// whose element loaders, diagonal-tile product, diagonal-block routine and argument block it shares).
 //
 //   particleSmootherInformationForm.m:224-236   cIend = chol(Imat_i + ImatAddt), v = cIend \ (ivec_i + ivecAddt)
 //
 // Why a third kernel.  Counters of the 64-column kernel at n = 515 (profiles/r03_mag_chol64_pmc_summary.txt): 85 GB per launch of
 // 8192 matrices against 19 GB of matrix in / out -- the left-looking panel products re-read the finished factor once per 64 columns
-// as B operands (3.05 MB per matrix) and the rows of the diagonal block as A operands by seven waves each (1.2-1.9 MB reach the
-// memory), at 5.4 TB/s: the kernel is bound by traffic it creates itself.  Here
+// as B operands (3.05 MB per matrix), at 5.25 TB/s: the kernel is bound by traffic it creates itself.  Here the factor is re-read once
+// per 128 columns, in the 64-column kernel's own asynchronous schedule:
 //
-//   * a SUPER-BLOCK is 128 columns (8 sub-columns of 16): the panel product of a row tile accumulates 8 tiles per pass over the
-//     finished columns, so the factor is re-read once per 128 columns (B operands: n^3 / 768 elements);
-//   * the 128 x 128 diagonal block is factorised as two 64 x 64 halves by wave 0 with the routine of the 64-column kernel
-//     (c64_diag_block); between the halves a strip solves its first four sub-columns, keeps the solved tiles in registers (they are the
-//     B operands of the next step as they stand) and updates its last four sub-columns with rows 4..7 of the diagonal block
-//     (a K = 64 product whose B operands never touch memory);
-//   * the workgroup is TWO TEAMS that only meet through flags in LDS, never at a workgroup barrier (a first version that ran all
-//     eight waves in lockstep -- elements, product, wait for the diagonal block, solve -- took 18.0 ms per 8192 matrices against the
-//     64-column kernel's 15.5: every phase idled either the memory or the matrix pipes):
-//       - the CRITICAL team, wave 0 + waves 4..7, carries the chain  rows of the next diagonal block -> their panel product ->
-//         64 x 64 factorisation -> solve -> update -> 64 x 64 factorisation.  Per super-block s the four waves first finish the
-//         eight row tiles of block s as strips BELOW block s - 1 (two each), then form them as DIAGONAL strips of block s
-//         (d_i and d_{7-i}: 9 tiles each); both products take their A operands -- and the diagonal strips their B operands too --
-//         from a ring of 16 KB LDS chunks that wave 0 stages (one producer, a fill counter and one drain counter per slot);
-//       - the BULK team, waves 1..3, owns every row tile from the second block below the diagonal on (row tile r belongs to wave
-//         1 + r % 3 for the whole factorisation, so it meets no other wave's writes of its own rows), two strips at a time, A
-//         operands straight from the L2: elements, product, then -- when the flags say the diagonal block is there -- solve,
-//         update, solve.  Its element streams and products overlap the critical team's serial sections by construction.
-//     The operands of the solves (-inv(Ld_cc), Ld(c', c), rows 4..7 of the first half) are read from the factor itself, where wave 0
-//     and the critical team leave them (the inverse of a diagonal tile in the otherwise unused tile to its right).
+//   * a SUPER-BLOCK is 128 columns = two 64-column blocks J0, J1.  A strip (row tile) below J0's diagonal block accumulates the panel
+//     product over the finished columns for BOTH blocks at once (8 accumulator tiles): its own rows stream through once per 128
+//     columns (B operands: n^3 / 768 elements instead of n^3 / 384);
+//   * J0's diagonal block: its four row tiles are formed FIRST by waves 7..4 (c64_diag_product, as in the 64-column kernel) and
+//     handed to wave 0 through LDS and a counter, so that wave 0 factorises it (c64_diag_block) WHILE the seven workers load their
+//     elements and run their products -- nobody waits for it before the solve;
+//   * after the solve against J0 the solved tiles stay in registers: they are the B operands of the K = 64 update of the strip's J1
+//     half with the rows of J1's diagonal block (published in LDS by their owners, waves 4..7, which carry them as ordinary strips);
+//     those owners then hand J1's diagonal tiles to wave 0, and while it factorises them the workers load the J1 half of their
+//     ELEMENTS, which the product did not need (it ran from zero): the second diagonal block hides behind a memory stream;
+//   * row tiles beyond the ten of the first pass run in further passes of fourteen, with both diagonal blocks' operands still in LDS.
+//
+// r04 history: a lock-step version with the A operands staged through an LDS ring (18.0 ms per 8192 against the
+// 64-column kernel's 15.5) and a two-team version that left its operands to the L2 (19.1 ms, 82 GB: the L2 retains nothing) came
+// before this one.
 //
 // Factor storage: as in the 64-column kernel (row-tile major, fragment order; complete, so the carried-factor refresh can read it).
 #pragma once
 
-#ifndef RBPF_C128_NB
-#define RBPF_C128_NB 4                           // ring buffers (16 KB each)
-#endif
 #ifndef RBPF_C128_GRING
-#define RBPF_C128_GRING 3                        // bulk team: column groups of A / B operand loads in flight
+#define RBPF_C128_GRING 3                        // column groups of A / B operand loads in flight
 #endif
 #ifdef RBPF_C128_STAMPS                          // tuning aid: per-phase clocks of waves 0 / 1 / 4 of workgroup 0
 #define C128_STAMP(k) do { const long long now_ = clock64(); cst[k] += now_ - clast; clast = now_; } while (0)
@@ -48,13 +40,7 @@
 #define C128_STAMP_PASS
 #endif
 
-constexpr int kC128Crit = 4;                     // consumers of the ring: waves 4..7
-constexpr int kC128ChunkDoubles = 2048;          // [4 column groups][8 row tiles][64]
 constexpr int kC128MaxSpins = 1 << 18;           // ~ 10 ms: a legitimate wait is a few ten thousand clocks
-
-// LDS flags (ints)
-enum { C128_SFAIL = 0, C128_FILLED, C128_CB, C128_DDONE, C128_X2DONE, C128_C1DONE, C128_DONE0 /* [NB <= 8] */, C128_BPRIO0 = C128_DONE0 + 8 /* [16] */,
-       C128_NFLAGS = C128_BPRIO0 + 16 };
 
 __device__ inline bool c128_wait_ge(int* ctr, int target) {
   int spins = 0;
@@ -64,66 +50,6 @@ __device__ inline bool c128_wait_ge(int* ctr, int target) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   return spins < kC128MaxSpins;
-}
-
-// my global stores are on their way to the L2 (which the whole workgroup reads through one L1) before the flag moves
-__device__ inline void c128_publish(int* ctr, int add, int lane) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_fetch_add(ctr, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// barrier of the critical team (five waves), k = how many the caller has passed
-__device__ inline bool c128_cbar(int* cb, int& k, int lane) {
-  c128_publish(cb, 1, lane);
-  ++k;
-  return c128_wait_ge(cb, 5 * k);
-}
-
-// Wave 0: chunks g0 .. g0 + nch - 1 of the ring = column groups 4 s .. 4 s + 3 of the eight row tiles rt0 .. rt0 + 7.
-// Two chunks of loads in flight (registers); a ring slot is rewritten once all four consumers have drained it.
-__device__ inline bool c128_produce(const double* __restrict__ Lt, int KGS, int RT, int rt0, int nch, int lane, double* ring,
-                                    int* flags, int g0) {
-  if (nch <= 0) return true;
-  const double* src[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) src[r] = Lt + (size_t)min(rt0 + r, RT - 1) * KGS * 64 + 4 * lane;   // 256 doubles per (row tile, chunk)
-  const int wofs = ((lane >> 4) * 8) * 64 + 4 * (lane & 15);                  // [column group l / 16][row tile r][4 (l % 16) ..]
-  v4d R0[8], R1[8];
-  bool ok = true;
-#pragma unroll
-  for (int r = 0; r < 8; ++r) R0[r] = *reinterpret_cast<const v4d*>(src[r]);
-#pragma unroll
-  for (int r = 0; r < 8; ++r) R1[r] = *reinterpret_cast<const v4d*>(src[r] + (size_t)min(1, nch - 1) * 256);
-  for (int s = 0; s < nch; s += 2) {
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int sc = s + b;
-      if (sc < nch) {
-        const int g = g0 + sc;
-        // (one drain counter PER SLOT: a sum over all chunks would let fast consumers vouch for a slow one)
-        if (g >= RBPF_C128_NB) ok = c128_wait_ge(flags + C128_DONE0 + g % RBPF_C128_NB, kC128Crit * (g / RBPF_C128_NB)) && ok;
-        double* dst = ring + (size_t)(g % RBPF_C128_NB) * kC128ChunkDoubles + wofs;
-        const size_t nxt = (size_t)min(sc + 2, nch - 1) * 256;
-        if (b == 0) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) *reinterpret_cast<v4d*>(dst + r * 64) = R0[r];
-          C64_PIN();
-#pragma unroll
-          for (int r = 0; r < 8; ++r) R0[r] = *reinterpret_cast<const v4d*>(src[r] + nxt);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) *reinterpret_cast<v4d*>(dst + r * 64) = R1[r];
-          C64_PIN();
-#pragma unroll
-          for (int r = 0; r < 8; ++r) R1[r] = *reinterpret_cast<const v4d*>(src[r] + nxt);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __hip_atomic_store(flags + C128_FILLED, g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-  }
-  return ok;
 }
 
 // Elements of a 16 x 64 strip (row tile rt, 64-column block J) through the loader that fits it: interior strips and the last row
@@ -160,252 +86,157 @@ __device__ inline void c128_tri64(const CholArgs& a, int p, int J, int M, const 
   }
 }
 
-// Where the factorised diagonal block of 64-column block J leaves the operands of the solves, all as MFMA A fragments (+ q * 64):
-//   -inv(Ld_cc)   in the tile to the right of diagonal tile c (row tile 4 J + c, column tile 4 J + c + 1: never part of the factor)
-//   Ld(cp, c)     the factor's own tile (row tile 4 J + cp, sub-column c of the block)
-__device__ inline const double* c128_nl(const double* Lt, int KGS, int J, int c) { return Lt + ((size_t)(4 * J + c) * KGS + 4 * (4 * J + c + 1)) * 64; }
-__device__ inline const double* c128_ld(const double* Lt, int KGS, int J, int cp, int c) { return Lt + ((size_t)(4 * J + cp) * KGS + 16 * J + 4 * c) * 64; }
-
-// X = V inv(Ld)' for the four sub-columns of half h of the strips' super-block (64-column block J); the solved tiles replace the
-// accumulators (they are the B operands of what follows) and go to the factor.
-template <int NS>
-__device__ inline void c128_solve_half(v4d (&Z)[2][2][4], int h, double* __restrict__ Lt, int KGS, int J, const int (&rt)[2], int lane) {
+// X = V inv(Ld)' for the four sub-columns of half h (NLs: -inv(Ld_cc), Lds: Ld(c', c), both as MFMA A fragments in LDS) of the strips
+// S0 .. NS - 1; the solved tiles replace the accumulators (they are the B operands of what follows) and go to the factor at column
+// group kg0.
+template <int NS, int S0>
+__device__ inline void c128_solve_half(v4d (&Z)[2][2][4], int h, const double* NLs, const double* Lds, double* __restrict__ Lt, int KGS,
+                                       const int (&rt)[2], int kg0, int lane) {
+  if (S0 >= NS) return;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     double ni[4];
-    const double* np_ = c128_nl(Lt, KGS, J, c) + lane;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ni[q] = np_[q * 64];
-    v4d x[NS > 0 ? NS : 1];
+    for (int q = 0; q < 4; ++q) ni[q] = NLs[(c * 4 + q) * 64 + lane];
+    v4d x[2];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = S0; s < NS; ++s) {
       x[s] = mfma4(ni, Z[s][h][c], (v4d){0.0, 0.0, 0.0, 0.0});
-      double* dx = Lt + ((size_t)rt[s] * KGS + 16 * J + 4 * c) * 64 + lane;
+      double* dx = Lt + ((size_t)rt[s] * KGS + kg0 + 4 * c) * 64 + lane;
 #pragma unroll
       for (int q = 0; q < 4; ++q) dx[q * 64] = x[s][q];
     }
 #pragma unroll
     for (int cp = c + 1; cp < 4; ++cp) {
       double lf[4];
-      const double* lp_ = c128_ld(Lt, KGS, J, cp, c) + lane;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) lf[q] = lp_[q * 64];
+      for (int q = 0; q < 4; ++q) lf[q] = Lds[(c64_pair(cp, c) * 4 + q) * 64 + lane];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) Z[s][h][cp] = mfma4(lf, x[s], Z[s][h][cp]);
+      for (int s = S0; s < NS; ++s) Z[s][h][cp] = mfma4(lf, x[s], Z[s][h][cp]);
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) Z[s][h][c] = x[s];
+    for (int s = S0; s < NS; ++s) Z[s][h][c] = x[s];
   }
 }
 
-// second half += first half's solved tiles * (rows 4..7 of the diagonal block, first-half columns)'   (operands from the factor)
-template <int NS>
-__device__ inline void c128_update_half(v4d (&Z)[2][2][4], const double* __restrict__ Lt, int KGS, int j, int lane) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      double lf[4];
-      const double* lp_ = Lt + ((size_t)(8 * j + 4 + e) * KGS + 32 * j + 4 * c) * 64 + lane;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) lf[q] = lp_[q * 64];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) Z[s][1][e] = mfma4(lf, Z[s][0][c], Z[s][1][e]);
-    }
-}
-
-// NS strips (row tiles rt[0..NS)) below the diagonal block of super-block j, from their elements to the factor.
-// RING: the critical team's pass -- A operands from the LDS ring (chunks g0 .. g0 + 8 j - 1), its flags are behind it by
-// construction except the second diagonal block's; otherwise the bulk team's -- A operands from the L2, every operand behind a flag.
-template <int NS, bool RING>
-__device__ inline void c128_below(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int j, const int (&rt)[2], int M,
-                                  const double* rhs_s, const double* Hs, const double* RH, int lane, const double* ring, int* flags, int g0,
-                                  int x2_target, bool& ok C128_STAMP_ARGS) {
+// One pass of a worker wave over super-block J2 (64-column blocks 2 J2 and 2 J2 + 1): NS strips, row tiles rt[0..NS).
+// DI >= 0 (waves 7 - DI = 4..7, first pass): strip 0 is row 4 + E, E = 3 - DI, of the super-block's diagonal rows -- an ordinary
+// strip below block 2 J2 whose second half holds the tiles 0..E of block 2 J2 + 1's diagonal block; its solved first half is
+// published in LDS (Lds2) and its second half handed to wave 0 after the update.
+// FIRST: the pass that runs beside wave 0's factorisations (four workgroup barriers); later passes find every operand in LDS.
+template <int NS, int DI, bool FIRST>
+__device__ inline void c128_pass(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int J2, const int (&rt)[2], bool hasB, int nd2,
+                                 int M, const double* rhs_s, const double* Hs, const double* RH, int lane, double* hb0, double* hb1,
+                                 double* Lds2 C128_STAMP_ARGS) {
+  constexpr int E = DI < 0 ? 0 : 3 - DI;
+  constexpr bool DG = DI >= 0;
+  constexpr int SD = DG ? 1 : 0;                                              // first ordinary strip
+  const bool dstrip = DG && hasB;                                             // strip 0 is a diagonal row of block 2 J2 + 1 (wave-uniform)
+  const int nkg = 32 * J2, nh1 = max(0, nd2 - 4);
   v4d Z[2][2][4];                                                            // [strip][half][sub-column]
-  const int nch = 8 * j;
+  // ---- elements: first halves; second halves only where nothing hides them (later passes, the diagonal row) --------------
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
+  for (int s = 0; s < NS; ++s) {
+    c128_strip64<false>(a, p, rt[s], 2 * J2, M, rhs_s, Hs, RH, 0.0, lane, Z[s][0]);
+    if (DG && s == 0) {
+      v4d T[E + 1];
+      if (dstrip) c128_tri64<E>(a, p, 2 * J2 + 1, M, rhs_s, Hs, RH, 0.0, lane, T);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) c128_strip64<false>(a, p, rt[s], 2 * j + h, M, rhs_s, Hs, RH, 0.0, lane, Z[s][h]);
+      for (int c = 0; c < 4; ++c) Z[0][1][c] = (dstrip && c <= E) ? T[c <= E ? c : 0] : (v4d){0.0, 0.0, 0.0, 0.0};
+    } else if (FIRST) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Z[s][1][c] = (v4d){0.0, 0.0, 0.0, 0.0};
+    } else {
+      c128_strip64<false>(a, p, rt[s], 2 * J2 + 1, M, rhs_s, Hs, RH, 0.0, lane, Z[s][1]);
+    }
+  }
   C128_STAMP(5);
-  if (nch > 0) {
-    const double* pb[NS > 0 ? NS : 1];
+  // ---- panel product over the finished columns, both halves: A operands = the eight diagonal row tiles, B operands = own rows --
+  if (nkg > 0 && NS > 0) {
+    constexpr int kR = RBPF_C128_GRING;
+    const double* pa = Lt + (size_t)(8 * J2) * KGS * 64;
+    const size_t ts = (size_t)KGS * 64;
+    const double* pb[2];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) pb[s] = Lt + (size_t)rt[s] * KGS * 64;       // wave-uniform base, + lane per load
-    if (RING) {
-      double B0[NS > 0 ? NS : 1][4], B1[NS > 0 ? NS : 1][4];
+    for (int s = 0; s < 2; ++s) pb[s] = Lt + (size_t)rt[s < NS ? s : 0] * ts;
+    double A[kR][8], B[kR][2];
+#pragma unroll
+    for (int b = 0; b < kR; ++b) {
       C64_PIN();
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int r = 0; r < 8; ++r) A[b][r] = (pa + r * ts + (size_t)min(b, nkg - 1) * 64)[lane];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) B0[s][k] = (pb[s] + (size_t)k * 64)[lane];
+      for (int s = 0; s < NS; ++s) B[b][s] = (pb[s] + (size_t)min(b, nkg - 1) * 64)[lane];
       C64_PIN();
-      auto chunk = [&](int sc, double (&Bc)[NS > 0 ? NS : 1][4], double (&Bn)[NS > 0 ? NS : 1][4]) {
-        const size_t kn = (size_t)min(sc + 1, nch - 1) * 4 * 64;
-        C64_PIN();
+    }
+    for (int kg = 0; kg < nkg; kg += kR) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-          for (int k = 0; k < 4; ++k) Bn[s][k] = (pb[s] + kn + (size_t)k * 64)[lane];
-        C64_PIN();
-        const int g = g0 + sc;
-        ok = c128_wait_ge(flags + C128_FILLED, g + 1) && ok;
-        const double* rp = ring + (size_t)(g % RBPF_C128_NB) * kC128ChunkDoubles + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          double F[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) F[r] = rp[(k * 8 + r) * 64];
+      for (int b = 0; b < kR; ++b) {
+        if (kg + b < nkg) {
 #pragma unroll
           for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int c = 0; c < 8; ++c) Z[s][c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[c], Bc[s][k], Z[s][c >> 2][c & 3], 0, 0, 0);
+            for (int c = 0; c < 8; ++c) Z[s][c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c >> 2][c & 3], 0, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_fetch_add(flags + C128_DONE0 + g % RBPF_C128_NB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      };
-      for (int sc = 0; sc < nch; sc += 2) {                                   // (nch = 8 j: even)
-        chunk(sc, B0, B1);
-        chunk(sc + 1, B1, B0);
-      }
-    } else {
-      // A operands (the eight row tiles of the diagonal block) and B operands (own rows) straight from the L2, a ring of column groups
-      constexpr int kR = RBPF_C128_GRING;
-      const double* pa = Lt + (size_t)(8 * j) * KGS * 64;
-      const size_t ts = (size_t)KGS * 64;
-      const int nkg = 32 * j;
-      double A[kR][8], B[kR][NS > 0 ? NS : 1];
-#pragma unroll
-      for (int b = 0; b < kR; ++b) {
+        const size_t kn = (size_t)min(kg + kR + b, nkg - 1) * 64;
         C64_PIN();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) A[b][r] = (pa + r * ts + (size_t)min(b, nkg - 1) * 64)[lane];
+        for (int r = 0; r < 8; ++r) A[b][r] = (pa + r * ts + kn)[lane];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) B[b][s] = (pb[s] + (size_t)min(b, nkg - 1) * 64)[lane];
+        for (int s = 0; s < NS; ++s) B[b][s] = (pb[s] + kn)[lane];
         C64_PIN();
-      }
-      for (int kg = 0; kg < nkg; kg += kR) {
-#pragma unroll
-        for (int b = 0; b < kR; ++b) {
-          if (kg + b < nkg) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-              for (int c = 0; c < 8; ++c) Z[s][c >> 2][c & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c >> 2][c & 3], 0, 0, 0);
-          }
-          const size_t kn = (size_t)min(kg + kR + b, nkg - 1) * 64;
-          C64_PIN();
-#pragma unroll
-          for (int r = 0; r < 8; ++r) A[b][r] = (pa + r * ts + kn)[lane];
-#pragma unroll
-          for (int s = 0; s < NS; ++s) B[b][s] = (pb[s] + kn)[lane];
-          C64_PIN();
-        }
       }
     }
   }
   C128_STAMP(6);
-  if (!RING) ok = c128_wait_ge(flags + C128_DDONE, 2 * j + 1) && ok;          // the first diagonal block of super-block j
+  if (FIRST) __syncthreads();                                                 // BA: wave 0 has factorised block 2 J2 (it ran beside the product)
   C128_STAMP(7);
-  c128_solve_half<NS>(Z, 0, Lt, KGS, 2 * j, rt, lane);
-  if (!RING) ok = c128_wait_ge(flags + C128_X2DONE, x2_target) && ok;         // rows 4..7 of the diagonal block, first-half columns
-  C128_STAMP(8);
-  c128_update_half<NS>(Z, Lt, KGS, j, lane);
-  C128_STAMP(9);
-  ok = c128_wait_ge(flags + C128_DDONE, 2 * j + 2) && ok;                     // the second diagonal block
-  C128_STAMP(10);
-  c128_solve_half<NS>(Z, 1, Lt, KGS, 2 * j + 1, rt, lane);
-  C128_STAMP(11);
-}
-
-// The diagonal strips of super-block s on critical wave 7 - DI: d_DI (tiles 0..DI) and d_{7-DI} (tiles 0..3 of the first half,
-// 0..3-DI of the second): elements, product with both operands from the ring, the tiles of the two 64 x 64 blocks handed to wave 0.
-template <int DI>
-__device__ inline void c128_diag(const CholArgs& a, int p, double* __restrict__ Lt, int KGS, int s, int nd2, int M, const double* rhs_s,
-                                 const double* Hs, const double* RH, int lane, double* hb0, double* hb1, const double* ring, int* flags,
-                                 int g0, int& kbar, bool& ok C128_STAMP_ARGS) {
-  constexpr int I = DI, E = 3 - DI;
-  const bool hasA = I < nd2, hasB = 4 + E < nd2;                             // wave-uniform
-  const int nch = 8 * s;
-  v4d ZA[I + 1], ZB0[4], ZB1[E + 1];
-  if (hasA) c128_tri64<I>(a, p, 2 * s, M, rhs_s, Hs, RH, 0.0, lane, ZA);
-  else {
+  if (nd2 > 4) {
+    c128_solve_half<NS, 0>(Z, 0, hb0, hb0 + 1024, Lt, KGS, rt, 32 * J2, lane);
+    if (dstrip) {
 #pragma unroll
-    for (int c = 0; c <= I; ++c) ZA[c] = (v4d){0.0, 0.0, 0.0, 0.0};
-  }
-  if (hasB) {
-    c128_strip64<false>(a, p, 8 * s + 4 + E, 2 * s, M, rhs_s, Hs, RH, 0.0, lane, ZB0);
-    c128_tri64<E>(a, p, 2 * s + 1, M, rhs_s, Hs, RH, 0.0, lane, ZB1);
-  } else {
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) ZB0[c] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int c = 0; c <= E; ++c) ZB1[c] = (v4d){0.0, 0.0, 0.0, 0.0};
-  }
-  C128_STAMP(12);
-  for (int sc = 0; sc < nch; ++sc) {
-    const int g = g0 + sc;
-    ok = c128_wait_ge(flags + C128_FILLED, g + 1) && ok;
-    const double* rp = ring + (size_t)(g % RBPF_C128_NB) * kC128ChunkDoubles + lane;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double F[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) F[r] = rp[(k * 8 + r) * 64];
-#pragma unroll
-      for (int c = 0; c <= I; ++c) ZA[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[c], F[I], ZA[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) ZB0[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[c], F[4 + E], ZB0[c], 0, 0, 0);
-#pragma unroll
-      for (int c = 0; c <= E; ++c) ZB1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[4 + c], F[4 + E], ZB1[c], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) Lds2[((E * 4 + c) * 4 + q) * 64 + lane] = Z[0][0][c][q];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(flags + C128_DONE0 + g % RBPF_C128_NB, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  C128_STAMP(13);
-  if (hasA) {
-#pragma unroll
-    for (int c = 0; c <= I; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) hb0[(c64_tri(I, c) * 4 + q) * 64 + lane] = ZA[c][q];
-  }
-  ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;                          // (2) the first half's diagonal tiles are in LDS
-  ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;                          // (3) wave 0 has factorised them (operands in the factor)
-  C128_STAMP(14);
-  if (hasB) {                                                                 // d_{4+E} is a strip below the first half: solve
-    v4d ZT[2][2][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ZT[0][0][c] = ZB0[c];
-    const int rtb[2] = {8 * s + 4 + E, 8 * s + 4 + E};
-    c128_solve_half<1>(ZT, 0, Lt, KGS, 2 * s, rtb, lane);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ZB0[c] = ZT[0][0][c];
-  }
-  ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;                          // (4) rows 4..7, first-half columns, are in the factor
-  if (hasB) {
+  C128_STAMP(8);
+  if (FIRST) __syncthreads();                                                 // BB: rows 4..7 of the diagonal rows, first-half columns, are in LDS
+  // ---- second half += first half's solved tiles * (those rows)'  -- B operands straight from the registers ---------------
+  if (nh1 > 0) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int e = 0; e <= E; ++e) {
+      for (int e = 0; e < 4; ++e) {
         double lf[4];
-        const double* lp_ = Lt + ((size_t)(8 * s + 4 + e) * KGS + 32 * s + 4 * c) * 64 + lane;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lf[q] = lp_[q * 64];
-        ZB1[e] = mfma4(lf, ZB0[c], ZB1[e]);
+        for (int q = 0; q < 4; ++q) lf[q] = Lds2[((e * 4 + c) * 4 + q) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) Z[s][1][e] = mfma4(lf, Z[s][0][c], Z[s][1][e]);
       }
-#pragma unroll
-    for (int c = 0; c <= E; ++c)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) hb1[(c64_tri(E, c) * 4 + q) * 64 + lane] = ZB1[c][q];
   }
-  ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;                          // (5) the second half's diagonal tiles are in LDS
-  C128_STAMP(15);
+  C128_STAMP(9);
+  if (FIRST) {
+    if (dstrip) {
+#pragma unroll
+      for (int c = 0; c <= E; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hb1[(c64_tri(E, c) * 4 + q) * 64 + lane] = Z[0][1][c][q];
+    }
+    __syncthreads();                                                          // BC: block 2 J2 + 1's diagonal tiles are in LDS
+    // the second half's elements of the ordinary strips, while wave 0 factorises (the product ran from zero)
+#pragma unroll
+    for (int s = SD; s < NS; ++s) c128_strip64<true>(a, p, rt[s], 2 * J2 + 1, M, rhs_s, Hs, RH, 0.0, lane, Z[s][1]);
+    C128_STAMP(12);
+    __syncthreads();                                                          // BD: wave 0 has factorised block 2 J2 + 1
+    C128_STAMP(10);
+  }
+  if (nd2 == 8) c128_solve_half<NS, SD>(Z, 1, hb1, hb1 + 1024, Lt, KGS, rt, 32 * J2 + 16, lane);
+  C128_STAMP(11);
 }
 
 constexpr size_t kC128MaxLds = 160 * 1024;
-static size_t chol128_lds_doubles(int M, int d) {
-  return (size_t)5120 + (size_t)RBPF_C128_NB * kC128ChunkDoubles + 32 + M + C128_NFLAGS / 2 + 2 * (size_t)d * M;
-}
+static size_t chol128_lds_doubles(int M, int d) { return (size_t)5120 + 4096 + 32 + M + 4 + 2 * (size_t)d * M; }
 static size_t chol128_lds_bytes(int M, int d) { return chol128_lds_doubles(M, d) * sizeof(double); }
 
 __global__ __launch_bounds__(512, 1) void chol_solve128_kernel(CholArgs a_in) {
@@ -423,124 +254,110 @@ __global__ __launch_bounds__(512, 1) void chol_solve128_kernel(CholArgs a_in) {
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int RT = (M + 1 + 15) >> 4, KGS = 4 * RT;
   double* Lt = a.Lbuf + (size_t)p * a.ldL;
-  // LDS: hb0 / hb1 [2560] the two halves' diagonal tiles on their way to wave 0 (then its scratch for -inv(Ld_cc), Ld(c',c)); the ring;
-  //      scalars, vectors, flags
+  // LDS: hb0 / hb1 [2560] a 64 x 64 diagonal block's tiles on their way to wave 0, then -inv(Ld_cc) [4][4][64] and Ld(c',c) [6][4][64];
+  //      Lds2 [4][4][4][64] rows 4..7 of the super-block's diagonal rows, first-half columns, as MFMA A fragments; scalars and vectors
   double* hb0 = csm;
   double* hb1 = csm + 2560;
-  double* ring = csm + 5120;
-  double* red = ring + (size_t)RBPF_C128_NB * kC128ChunkDoubles;     // [32]
+  double* Lds2 = csm + 5120;
+  double* red = Lds2 + 4096;                                          // [32]
   double* rhs_s = red + 32;                                           // [M]
-  int* flags = reinterpret_cast<int*>(rhs_s + M);                     // [C128_NFLAGS]
+  int* flags = reinterpret_cast<int*>(rhs_s + M);                     // sfail, ready: 4 doubles
   const bool pend = a.Hb != nullptr;
-  double* Hs = pend ? rhs_s + M + C128_NFLAGS / 2 : nullptr;
+  double* Hs = pend ? rhs_s + M + 4 : nullptr;
   double* RH = pend ? Hs + (size_t)a.d * M : nullptr;
   chol_prologue(a, p, tid, kThreads, M, rhs_s, Hs, RH, pend);
-  if (tid < C128_NFLAGS) flags[tid] = 0;
+  int* sfail = flags;
+  int* ready = flags + 1;
+  if (tid < 8) flags[tid] = 0;
   __syncthreads();
 #ifdef RBPF_C128_STAMPS
   long long cst[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clast = clock64();
 #endif
   const int NJ2 = (RT + 7) >> 3;
-  bool ok = true;
-  if (wv == 0) {
-    // ---- wave 0: ring producer of the critical team and the diagonal blocks ---------------------------------------------
-    int g = 0, kbar = 0;
-    bool bad = false;
-    auto diag_block = [&](int J, int nd, double* hb) {
-      bad = c64_diag_block(Lt, KGS, J, nd, M, lane, hb, hb, hb + 1024) || bad;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)                                     // -inv(Ld_cc) into the tile to the right of the diagonal tile
-        if (c < nd && 4 * J + c + 1 < RT) {
-          double* dst = Lt + ((size_t)(4 * J + c) * KGS + 4 * (4 * J + c + 1)) * 64 + lane;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) dst[q * 64] = hb[(c * 4 + q) * 64 + lane];
-        }
-      c128_publish(flags + C128_DDONE, 1, lane);
-    };
-    for (int s = 0; s < NJ2; ++s) {
-      const int nd2 = min(8, RT - 8 * s), nh0 = min(4, nd2), nh1 = nd2 - nh0;
-      if (s >= 1) {                                                   // rows of block s as strips below block s - 1
-        ok = c128_produce(Lt, KGS, RT, 8 * (s - 1), 8 * (s - 1), lane, ring, flags, g) && ok;
-        g += 8 * (s - 1);
-      }
+  int handed = 0;
+  for (int J2 = 0; J2 < NJ2; ++J2) {
+    const int nd2 = min(8, RT - 8 * J2), nh0 = min(4, nd2), nh1 = nd2 - nh0;
+    const int first_below = 8 * J2 + 8, n_below = max(0, RT - first_below);
+    const int nlate = n_below > 10 ? (n_below - 10 + 13) / 14 : 0;
+    handed += nh0;
+    if (wv == 0) {
+      const bool okw = c128_wait_ge(ready, handed);                   // the four row tiles of block 2 J2's diagonal block (waves 7..4)
       C128_STAMP(0);
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (1) rows of block s are final left of it
-      ok = c128_produce(Lt, KGS, RT, 8 * s, 8 * s, lane, ring, flags, g) && ok;
-      g += 8 * s;
+      bool bad = c64_diag_block(Lt, KGS, 2 * J2, nh0, M, lane, hb0, hb0, hb0 + 1024) || !okw;
       C128_STAMP(1);
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (2)
-      diag_block(2 * s, nh0, hb0);
+      __syncthreads();                                                // BA
+      __syncthreads();                                                // BB
+      __syncthreads();                                                // BC
+      if (nh1 > 0) bad = c64_diag_block(Lt, KGS, 2 * J2 + 1, nh1, M, lane, hb1, hb1, hb1 + 1024) || bad;
       C128_STAMP(2);
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (3)
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (4)
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (5)
-      if (nh1 > 0) diag_block(2 * s + 1, nh1, hb1);
-      else c128_publish(flags + C128_DDONE, 1, lane);
+      __syncthreads();                                                // BD
+      if (bad && lane == 0) *sfail = 1;
       C128_STAMP(3);
-    }
-    if ((bad || !ok) && lane == 0) flags[C128_SFAIL] = 1;
-  } else if (wv >= 4) {
-    // ---- critical team ------------------------------------------------------------------------------------------------
-    int g = 0, kbar = 0;
-    const int DIw = 7 - wv;
-    for (int s = 0; s < NJ2; ++s) {
-      const int nd2 = min(8, RT - 8 * s);
-      if (s >= 1) {
-        // my two rows of block s (8 s + DI, 8 s + 7 - DI) as strips below block s - 1; their columns left of block s - 1 are the bulk
-        // team's work at the super-blocks before
-        int rt[2] = {8 * s + DIw, 8 * s + 7 - DIw};
-        const int ns = (rt[0] < RT ? 1 : 0) + (rt[1] < RT ? 1 : 0);
-        if (rt[0] >= RT) rt[0] = RT - 1;
-        if (rt[1] >= RT) rt[1] = rt[0];
-        if (s >= 2) ok = c128_wait_ge(flags + C128_BPRIO0 + (s - 2), min(8, RT - 8 * s)) && ok;
-#define RBPF_C128B(NS_) c128_below<NS_, true>(a, p, Lt, KGS, s - 1, rt, M, rhs_s, Hs, RH, lane, ring, flags, g, 0, ok C128_STAMP_PASS)
-        if (ns == 2) RBPF_C128B(2); else if (ns == 1) RBPF_C128B(1); else RBPF_C128B(0);
-#undef RBPF_C128B
-        g += 8 * (s - 1);
-      }
-      ok = c128_cbar(flags + C128_CB, kbar, lane) && ok;             // (1)
-      if (lane == 0 && wv == 4) __hip_atomic_store(flags + C128_C1DONE, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#define RBPF_C128D(DI_) c128_diag<DI_>(a, p, Lt, KGS, s, nd2, M, rhs_s, Hs, RH, lane, hb0, hb1, ring, flags, g, kbar, ok C128_STAMP_PASS)
-      switch (DIw) {
-        case 0: RBPF_C128D(0); break;
-        case 1: RBPF_C128D(1); break;
-        case 2: RBPF_C128D(2); break;
-        default: RBPF_C128D(3); break;
-      }
+    } else {
+      const int DIw = 7 - wv;                                         // waves 4..7: 3..0
+      if (wv >= 4 && DIw < nd2) {
+        // row tile DIw of block 2 J2's diagonal block: elements + product over the finished columns, handed to wave 0 at once
+#define RBPF_C128D(I_) c64_diag_product<I_, 1, true>(a, p, Lt, KGS, 2 * J2, M, rhs_s, Hs, RH, 0.0, lane, hb0)
+        switch (DIw) {
+          case 0: RBPF_C128D(0); break;
+          case 1: RBPF_C128D(1); break;
+          case 2: RBPF_C128D(2); break;
+          default: RBPF_C128D(3); break;
+        }
 #undef RBPF_C128D
-      g += 8 * s;
-      // (after barrier (4) every existing row 4..7 of block s has its first-half columns in the factor)
-      if (lane == 0 && wv == 4) __hip_atomic_store(flags + C128_X2DONE, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (!ok && lane == 0) flags[C128_SFAIL] = 1;
-  } else {
-    // ---- bulk team: row tile r belongs to wave 1 + r % 3 --------------------------------------------------------------
-    for (int j = 0; 8 * (j + 2) < RT; ++j) {
-      // the diagonal rows of super-block j are final left of it once the critical team has passed barrier (1) of step j
-      ok = c128_wait_ge(flags + C128_C1DONE, j) && ok;
-      int r0 = 8 * (j + 2);
-      r0 += ((wv - 1) - r0 % 3 + 3) % 3;                              // my first row tile
-      for (; r0 < RT; r0 += 6) {
-        int rt[2] = {r0, r0 + 3};
-        const int ns = (rt[1] < RT) ? 2 : 1;
-        if (ns == 1) rt[1] = rt[0];
-#define RBPF_C128B(NS_) c128_below<NS_, false>(a, p, Lt, KGS, j, rt, M, rhs_s, Hs, RH, lane, ring, flags, 0, j + 1, ok C128_STAMP_PASS)
-        if (ns == 2) RBPF_C128B(2); else RBPF_C128B(1);
-#undef RBPF_C128B
-        const int prio = (rt[0] < 8 * (j + 3) ? 1 : 0) + ((ns == 2 && rt[1] < 8 * (j + 3)) ? 1 : 0);   // rows of the next diagonal block but one
-        if (prio) c128_publish(flags + C128_BPRIO0 + j, prio, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      C128_STAMP(13);
+      for (int q = 0; q <= nlate; ++q) {
+        // first pass: waves 1..3 two strips below (u = w - 1, w + 2); waves 4..7 their diagonal row (8 J2 + 4 + E, E = w - 4) and one
+        // strip below (u = w + 2).  Later passes: two strips per worker (u = 10 + 14 (q - 1) + (w - 1) + 7 s)
+        int rt[2] = {0, 0}, ns = 0;
+        bool hasB = false;
+        if (q == 0 && wv >= 4) {
+          hasB = 4 + (wv - 4) < nd2;
+          const int u = wv + 2;
+          if (hasB) rt[ns++] = 8 * J2 + 4 + (wv - 4);
+          if (u < n_below) rt[ns++] = first_below + u;
+        } else {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const int u = (q == 0) ? (wv - 1) + 3 * s : 10 + 14 * (q - 1) + (wv - 1) + 7 * s;
+            if (u < n_below) rt[ns++] = first_below + u;
+          }
+        }
+        if (ns < 2) rt[1] = rt[0];
+#define RBPF_C128(NS_, DI_, F_) c128_pass<NS_, DI_, F_>(a, p, Lt, KGS, J2, rt, hasB, nd2, M, rhs_s, Hs, RH, lane, hb0, hb1, Lds2 C128_STAMP_PASS)
+        if (q > 0) {
+          if (ns == 2) RBPF_C128(2, -1, false); else if (ns == 1) RBPF_C128(1, -1, false);
+        } else if (wv <= 3 || !hasB) {
+          // (a wave 4..7 without a diagonal row -- the last, partial super-block -- runs the ordinary pass)
+          if (ns == 2) RBPF_C128(2, -1, true); else if (ns == 1) RBPF_C128(1, -1, true); else RBPF_C128(0, -1, true);
+        } else {
+          switch (2 * DIw + (ns - 1)) {
+            case 0: RBPF_C128(1, 0, true); break;
+            case 1: RBPF_C128(2, 0, true); break;
+            case 2: RBPF_C128(1, 1, true); break;
+            case 3: RBPF_C128(2, 1, true); break;
+            case 4: RBPF_C128(1, 2, true); break;
+            case 5: RBPF_C128(2, 2, true); break;
+            case 6: RBPF_C128(1, 3, true); break;
+            default: RBPF_C128(2, 3, true); break;
+          }
+        }
+#undef RBPF_C128
+      }
+      C128_STAMP(14);
     }
-    if (!ok && lane == 0) flags[C128_SFAIL] = 1;
+    __syncthreads();                                                  // BE: the super-block is visible to the next panel products
+    C128_STAMP(4);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();                                                    // the only workgroup barrier after the prologue
 #ifdef RBPF_C128_STAMPS
   if (p == 0 && lane == 0 && (wv == 0 || wv == 1 || wv == 4))
-    printf("chol128 M=%d wave %d clocks: w0 produce1 %lld produce2 %lld D0 %lld D1 %lld | below: elems %lld product %lld wait-D0 %lld solve0 %lld update %lld wait-D1 %lld solve1 %lld | diag: elems %lld product %lld wait-D0 %lld rest %lld\n",
-           M, wv, cst[0], cst[1], cst[2], cst[3], cst[5], cst[6], cst[7], cst[8], cst[9], cst[10], cst[11], cst[12], cst[13], cst[14], cst[15]);
+    printf("chol128 M=%d wave %d clocks: w0 wait-tiles %lld D0 %lld D1 %lld rest %lld | end-barrier %lld | diag-tiles %lld elems0 %lld product %lld wait-D0 %lld solve0 %lld update %lld elems1 %lld wait-D1 %lld solve1 %lld tail %lld\n",
+           M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[13], cst[5], cst[6], cst[7], cst[8], cst[9], cst[12], cst[10], cst[11], cst[14]);
 #endif
-  const int failed = flags[C128_SFAIL];
+  const int failed = *sfail;
   __syncthreads();
   if (!failed) {
     double sl = 0.0, vv = 0.0;
@@ -577,5 +394,5 @@ static hipError_t launch_chol128(const CholArgs& ca, int batch, int d_lds, hipSt
 // usable for: information form, more than 27 row tiles (the 8-wave shape), LDS fits
 static bool chol128_ok(const CholArgs& ca, int d_lds) {
   const int RT = (ca.Msz + 1 + 15) >> 4;
-  return ca.mode == 1 && RT > 27 && RT <= 16 * 8 && ca.l_slots == 0 && chol128_lds_bytes(ca.Msz, d_lds) <= kC128MaxLds;
+  return ca.mode == 1 && RT > 27 && ca.l_slots == 0 && chol128_lds_bytes(ca.Msz, d_lds) <= kC128MaxLds;
 }
