@@ -216,6 +216,13 @@ typedef struct {
   const int32_t* device_ids; /* [n_devices] HIP device of every rank, NULL = 0 .. n_devices-1.  A device named more than once makes *
                           * its ranks share that GPU over a host-staged transport (no RCCL) -- how a one-GPU machine exercises the  *
                           * multi-rank loop; n_devices = 1 with device_ids set runs the loop with a world of one.                  */
+  int32_t family_products; /* filter with storage = 2, lazy_depth >= 2, 515 <= n_lin <= 639 (also sharded): how a READ-ONLY step forms *
+                          * P_i * H_i' (particleFilter.m:139,194).  0 (default): one workgroup per particle streams the stored matrix   *
+                          * (siblings share it through the L2).  1: per FAMILY of particles that share a stored matrix --             *
+                          * P_base * [H_1' ... H_f'] on the fp64 matrix cores, the matrix read once per family -- followed by the     *
+                          * per-particle rest of the step (rbpf_family.hip).  Same algebra, sums in another order: results agree to  *
+                          * rounding (1e-9 tests); measured slower than 0 at lazy_depth 4 on MI355X, hence not the      *
+                          * default.  Ignored where it does not apply.                                                                */
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */
@@ -498,6 +505,13 @@ int rbpf_dyn_res_norm(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, in
 /* tools/sample.m:30-32 applied to n_draws uniforms: ind[j] = sum(cumsum(w) < u[j]) (0-based,
  * clamped to N-1).                                                                                */
 int rbpf_sample(int32_t N, const double* w, int32_t n_draws, const double* u, int32_t* ind);
+/* PROBE (tests / tools only) of the family product behind the filter's read-only steps: P_base * [H_1' ... H_f'] for families of particles that share one
+ * stored covariance (block-lower storage, CH = 4 or 8 tile rows), on the fp64 matrix cores -- particleFilter.m:139-141,185-198's
+ * P_i * H_i' for all members with one read of the matrix.  T [n_mat][CH (CH + 1) / 2][4096] (the layout of rbpf_options.storage = 2,
+ * core rows), H [N][3][64 CH], families = positions fam_start[f] .. fam_start[f + 1] - 1 reading matrix fam_base[f]; PHt
+ * [N][3][64 CH].  replicate_T > 1 tiles the host matrices on the device (timing with many distinct matrices).  *ms: mean launch time. */
+int rbpf_probe_family_pht(int32_t CH, int32_t n_mat, int32_t N, int32_t F, const double* T, const double* H, const int32_t* fam_start,
+                          const int32_t* fam_base, int32_t reps, int32_t replicate_T, double* PHt, double* ms);
 /* tools/JacobianPhi3D.m:29-64: x [3 x Np] -> J [3 x 3 x m x Np].                                  */
 int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
                         const double* lower, const double* upper, double* J);

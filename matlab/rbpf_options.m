@@ -20,6 +20,8 @@ function o = rbpf_options(varargin)
 %                 reference's outputs (particleFilter: makePlots must be empty)
 %   device_ids    [1 x W] 0-based HIP device of every rank (default 0 .. W-1); a device named twice makes its ranks share
 %                 that GPU over a host-staged transport (a one-GPU machine can so exercise the multi-rank loop)
+%   family_products  1: read-only steps of storage 2 with lazy_depth >= 2 form P*H' per family of particles that share a stored
+%                 matrix on the matrix cores (results to rounding; measured slower than the default on MI355X at lazy_depth 4)
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
 %   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
 %   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)

@@ -71,7 +71,8 @@ class rbpf_options(C.Structure):
     _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
                 ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
                 ("chol_variant", C.c_int32), ("chol_refresh", C.c_int32), ("exchange_capacity", C.c_int32), ("on_step", ON_STEP_FN),
-                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
+                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
+                ("family_products", C.c_int32)]
 
 
 class rbpf_filter_out(C.Structure):
@@ -98,7 +99,7 @@ EXPORTS = [
     "rbpf_abi_version", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
     "rbpf_particle_filter", "rbpf_particle_smoother",
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
-    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_shard_smoother_refresh_reserve", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
+    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_probe_family_pht", "rbpf_shard_smoother_refresh_reserve", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_chol_sweep_probe", "rbpf_quat_helpers", "rbpf_probe_wave_reduce",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",

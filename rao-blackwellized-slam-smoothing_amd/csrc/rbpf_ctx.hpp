@@ -91,6 +91,11 @@ struct rbpf_ctx {
   int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)
   unsigned long long* d_share_writers = nullptr;   // writers of the timed shared flushes (device counter)
   long long share_flush_particles = 0;          // particles of the timed shared flushes (N per flush step)
+  // family products (rbpf_options.family_products, rbpf_family.hip): workspace of the read-only steps, by processing position
+  bool family_on = false;
+  double* d_fam_H = nullptr;                    // [N][d][ldx]
+  double* d_fam_PHt = nullptr;                  // [N][d][mc]
+  int* d_fam_idx = nullptr;                     // fam_start [N + 1], fam_base [N], n_fam [1]
   // timed launches: reads of stored matrices counted per particle (nominal) and per DISTINCT matrix (device counter)
   int* d_distinct_mark = nullptr; size_t distinct_keys = 0; unsigned long long* d_distinct_counter = nullptr;
   long long distinct_nominal = 0; int distinct_epoch = 0;

@@ -361,6 +361,8 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.status = c->d_flags;
   a.stamps = nullptr;
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d; a.u_next = nullptr;
+  a.phase = -1;                                            // (every slot; the shared flush below launches by phase)
+  if (c->family_on) { a.fam_H = c->d_fam_H; a.fam_PHt = c->d_fam_PHt; a.fam_idx = c->d_fam_idx; }
   // shared flush (see ctx_step): the children of one parent -- one bank entry or one received record -- store ONE flushed matrix
   const bool share = lazy && flush && t > 0 && dev_plan && L.sym && L.CH64 == 8 && !c->fp32 && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
   if (share) {

@@ -168,7 +168,7 @@ class ShardedFilterSession:
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
                  transport="device", planner="device", lazy_depth=0, storage="fp64", keep_history=False, exchange_capacity=0,
-                 sync_phases=False, force_collectives=False):
+                 sync_phases=False, force_collectives=False, family_products=0):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -205,7 +205,7 @@ class ShardedFilterSession:
             raise ValueError("lazy_depth >= 2 needs planner='device'")
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth),
                                      jitter=0.0, storage=_storage_code(storage), exchange_capacity=int(exchange_capacity),
-                                     chol_refresh=int(getattr(self, "chol_refresh", 0)))
+                                     chol_refresh=int(getattr(self, "chol_refresh", 0)), family_products=int(family_products))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         self._create()
