@@ -536,11 +536,21 @@ __device__ inline void c64_tile_pass(const CholArgs& a, int p, double* __restric
             for (int c = 0; c < 4; ++c) Z[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[b][c], B[b][s], Z[s][c], 0, 0, 0);
         }
         const size_t kn = (size_t)min(kg + kR + b, nkg - 1) * 64;
+#ifdef RBPF_C64_DIAG_AFIXED                       // timing experiment only (wrong results): the common operand always out of the L1
+        const size_t kna = (size_t)b * 64;
+#else
+        const size_t kna = kn;
+#endif
+#ifdef RBPF_C64_DIAG_BFIXED                       // likewise the private operand
+        const size_t knb = (size_t)b * 64;
+#else
+        const size_t knb = kn;
+#endif
         C64_PIN();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + kn)[lane];
+        for (int c = 0; c < 4; ++c) A[b][c] = (pa + c * ts + kna)[lane];
 #pragma unroll
-        for (int s = 0; s < NT; ++s) B[b][s] = (pb[s] + kn)[lane];
+        for (int s = 0; s < NT; ++s) B[b][s] = (pb[s] + knb)[lane];
         C64_PIN();
       }
     }
@@ -706,7 +716,9 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
       }
       __syncthreads();                            // the block column is visible to the next panel products
       C64_STAMP(5);
+#if !defined(RBPF_C64_DIAG_AFIXED) && !defined(RBPF_C64_DIAG_BFIXED)       // (the timing experiments run every block column)
       if (sfail[J & 1]) break;
+#endif
     }
 #ifdef RBPF_C64_STAMPS
     if (p == 0 && lane == 0 && M >= 200)
