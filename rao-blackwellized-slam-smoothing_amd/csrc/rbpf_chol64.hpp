@@ -68,6 +68,19 @@
 #ifndef RBPF_C64_LARING
 #define RBPF_C64_LARING 8                        // operand ring depth of the look-ahead diagonal products
 #endif
+#ifndef RBPF_C64_SOLO_MAXJ
+#define RBPF_C64_SOLO_MAXJ 5                     // wave 0 forms the tiles of the diagonal block ITSELF (elements + panel product) in block columns
+                                                 // 0 .. this (interior blocks, 8-wave shape) instead of waiting for waves 4..7 to hand them over: the
+                                                 // phase clocks (r04) showed waves 1..3 a third of their time at the first barrier, waiting for
+                                                 // waves 4..7, which carry the diagonal rows on top of a full share of strips, while wave 0 spins for
+                                                 // those rows.  Late block columns keep the hand-over (few strips per worker, long diagonal rows).
+                                                 // -1: never.  Same sums in the same order either way (bit-identical factors).
+#endif
+#ifndef RBPF_C64_SOLO_REST4
+#define RBPF_C64_SOLO_REST4 0                    // 1: in those block columns wave 4 -- wave 0's neighbour on its SIMD -- takes no strips and the six
+                                                 // other workers share them.  Measured: wave 0's factorisation gets faster (0.24 -> 0.16 M clocks per
+                                                 // matrix), the six workers become the critical path: 15.4 ms per 8192 against 14.8
+#endif
 #ifndef RBPF_C64_INT1
 #define RBPF_C64_INT1 4                          // information form: first row tile below the diagonal block that takes the fast loader
 #endif
@@ -86,11 +99,39 @@
 // of two particles overlap).  Three or four workgroups per CU would need a call-free kernel below 170 registers; inlined,
 // the diagonal block and the general element loader spill (389 registers), and a callee does not honour the kernel's bound.
 
+// Pointers that reach a NON-inlined function as arguments, or are read from the kernel-argument segment there, are generic to the
+// compiler: it emits flat_load / flat_store, which count on BOTH memory counters -- every LDS wait (ds_bpermute in the tile
+// factorisation, operand reads) then also waits for the factor stores on their way to memory.  These casts restore global_* accesses.
+typedef __attribute__((address_space(1))) double c64_gdouble;
+__device__ inline c64_gdouble* c64_g(double* p) { return (c64_gdouble*)p; }
+__device__ inline const c64_gdouble* c64_g(const double* p) { return (const c64_gdouble*)p; }
+typedef __attribute__((address_space(3))) double c64_ldouble;                  // ... and ds_* accesses for LDS pointers
+__device__ inline c64_ldouble* c64_l(double* p) { return (c64_ldouble*)p; }
+__device__ inline const c64_ldouble* c64_l(const double* p) { return (const c64_ldouble*)p; }
+
 __device__ inline double bperm_f64(double v, int src_lane) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffLL));
   const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+#ifndef RBPF_DIAG_BCAST_SWAP
+#define RBPF_DIAG_BCAST_SWAP 0                   // 1: lane broadcasts of the 16 x 16 tile factorisation without the LDS crossbar (below).  Measured
+                                                 // r04 with wave 0 on the critical path (RBPF_C64_SOLO_MAXJ = 5): 15.1 ms per 8192 against 14.9 with
+                                                 // ds_bpermute -- the tile factorisation itself gets shorter (0.13 -> 0.09 M clocks per matrix), the
+                                                 // chain as a whole does not
+#endif
+// every lane (g, r) gets the value of lane (KK, r): v_permlane16_swap leaves rows [0, 0, 2, 2] / [1, 1, 3, 3] of a register swapped with
+// itself, v_permlane32_swap then the lower / upper half twice -- four VALU operations for a double, no LDS round trip
+__device__ __forceinline__ double bcast_group_f64(double v, int KK) {   // (KK: a constant after unrolling)
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto p0 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto p1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const unsigned alo = (KK & 1) ? p0[1] : p0[0], ahi = (KK & 1) ? p1[1] : p1[0];
+  const auto q0 = __builtin_amdgcn_permlane32_swap(alo, alo, false, false);
+  const auto q1 = __builtin_amdgcn_permlane32_swap(ahi, ahi, false, false);
+  return (KK >> 1) ? __hiloint2double((int)q1[1], (int)q0[1]) : __hiloint2double((int)q1[0], (int)q0[0]);
 }
 
 __device__ inline v4d mfma4(const double (&a)[4], const v4d& b, v4d acc) {
@@ -134,10 +175,22 @@ __device__ inline bool chol_diag_tile_frag(v4d& V, v4d& NI, int nvalid, int lane
       Lv[kb] = (g == kk) ? cv : Lv[kb];                                     // column k of Ld, row k of X are final
       XT[kb] *= (g == kk) ? rinv : 1.0;                                     // (selects, not branches: this is a serial chain)
       if (kk < 3) {
+#if RBPF_DIAG_BCAST_SWAP
+        // (the serial chain of a block column is sixty-four of these steps: with ds_bpermute each one is two LDS round trips)
+        const double lrk = bcast_group_f64(Lv[kb], kk);                     // Ld(r, k)
+        const double xk = bcast_group_f64(XT[kb], kk);                      // X(k, c), c = lane & 15
+        double mck = 0.0;                                                   // Ld(4 kb + g, k) for the groups right of column k
+#pragma unroll
+        for (int gg = kk + 1; gg < 4; ++gg) {
+          const double lg = readlane_f64(Lv[kb], kk * 16 + 4 * kb + gg);
+          mck = (g == gg) ? lg : mck;
+        }
+#else
         const double lrk = bperm_f64(Lv[kb], kk * 16 + r);                  // Ld(r, k)
         const double lck = bperm_f64(Lv[kb], kk * 16 + 4 * kb + g);         // Ld(4 kb + g, k)
         const double xk = bperm_f64(XT[kb], kk * 16 + r);                   // X(k, c), c = lane & 15
         const double mck = (g > kk) ? lck : 0.0;
+#endif
         Lv[kb] = fma(-lrk, mck, Lv[kb]);
         XT[kb] = fma(-mck, xk, XT[kb]);
       }
@@ -386,6 +439,43 @@ __device__ inline void c64_diag_product(const CholArgs& a, int p, const double* 
   C64_STAMP(1);
 }
 
+// Factorisation of a diagonal block whose (negated) tiles Z(i, c), c <= i, sit in this wave's registers: the four 16 x 16 tile
+// factorisations with the solves / updates between them; the factor goes to Lt, -inv(Ld_cc) and Ld(c', c) to LDS as MFMA operands.
+__device__ inline bool c64_diag_factor(v4d (&Z)[4][4], double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane, double* NLs,
+                                       double* Lds C64_STAMP_ARGS) {
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c < nd) {
+      v4d V = -Z[c][c], NI;
+
+      bad |= chol_diag_tile_frag(V, NI, M - (64 * J + 16 * c), lane);
+      C64_STAMP(2);
+      c64_gdouble* dst = c64_g(Lt) + ((size_t)(4 * J + c) * KGS + 16 * J + 4 * c) * 64 + lane;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { dst[q * 64] = V[q]; c64_l(NLs)[(c * 4 + q) * 64 + lane] = NI[q]; }
+      v4d xs[4];
+#pragma unroll
+      for (int i = c + 1; i < 4; ++i) {
+        xs[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+        if (i < nd) {
+          xs[i] = mfma4(NI, Z[i][c], xs[i]);                                // X' = inv(Ld) V'  (NI = -inv, Z = -V')
+          c64_gdouble* dx = c64_g(Lt) + ((size_t)(4 * J + i) * KGS + 16 * J + 4 * c) * 64 + lane;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { dx[q * 64] = xs[i][q]; c64_l(Lds)[(c64_pair(i, c) * 4 + q) * 64 + lane] = xs[i][q]; }
+        }
+      }
+      C64_STAMP(7);
+#pragma unroll
+      for (int i = c + 1; i < 4; ++i)
+#pragma unroll
+        for (int cp = c + 1; cp <= i; ++cp) Z[i][cp] = mfma4(xs[cp], xs[i], Z[i][cp]);   // Z(i,c') += Ld(c',c) X(i,c)'
+      C64_STAMP(4);
+    }
+  }
+  return bad;
+}
+
 // Wave 0: factorisation of the diagonal block of block column J from the tiles waves 4..7 left in LDS.  nd = number of
 // its row tiles that exist (4 except at the very end).
 // (noinline: as a real call it gets registers of its own — inlined, the values the kernel keeps live across the block
@@ -398,13 +488,13 @@ __device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int
 #pragma unroll
     for (int c = 0; c <= i; ++c)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) Z[i][c][q] = (i < nd) ? Zd[(c64_tri(i, c) * 4 + q) * 64 + lane] : 0.0;
+      for (int q = 0; q < 4; ++q) Z[i][c][q] = (i < nd) ? c64_l(Zd)[(c64_tri(i, c) * 4 + q) * 64 + lane] : 0.0;
   if (RBPF_C64_LOOKAHEAD && J > 0) {
     // the part of the panel product the look-ahead could not have: block column J - 1, final since the last barrier
     const int RTc = KGS >> 2;
-    const double* pf[4];
+    const c64_gdouble* pf[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) pf[c] = Lt + ((size_t)min(4 * J + c, RTc - 1) * KGS + 16 * (J - 1)) * 64;
+    for (int c = 0; c < 4; ++c) pf[c] = c64_g(Lt) + ((size_t)min(4 * J + c, RTc - 1) * KGS + 16 * (J - 1)) * 64;
     double F[4][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -436,40 +526,200 @@ __device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int
     }
   }
   C64_STAMP(1);
-  bool bad = false;
+  return c64_diag_factor(Z, Lt, KGS, J, nd, M, lane, NLs, Lds C64_STAMP_PASS);
+}
+
+// Wave 0 on its own (RBPF_C64_SOLO_MAXJ): the ten tiles of an INTERIOR diagonal block (64 J + 64 <= M).
+// Elements of all four row tiles in two rounds of loads (c64_diag_elems_fast row by row is four memory round trips); the operations on
+// an element and their order are c64_diag_elems_fast's.
+template <int MODE>
+__device__ inline void c64_solo_elems(const CholArgs& a, int p, int J, int M, const double* Hs, const double* RH, double jit, int lane,
+                                      v4d (&Z)[4][4]) {
+  const int r = lane & 15, g = lane >> 4;
+  const int ld = (MODE == 0) ? M : a.n;
+  const unsigned lo = (unsigned)(r + ld * g);
+  const bool pk = (MODE == 1) && a.imat_packed;
+  const c64_gdouble* src[4]; const c64_gdouble* add[4]; c64_gdouble* dst[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    if (c < nd) {
-      v4d V = -Z[c][c], NI;
-      bad |= chol_diag_tile_frag(V, NI, M - (64 * J + 16 * c), lane);
-      C64_STAMP(2);
-      double* dst = Lt + ((size_t)(4 * J + c) * KGS + 16 * J + 4 * c) * 64 + lane;
+  for (int I = 0; I < 4; ++I) {
+    const size_t t0 = pk ? imat_packed_row(4 * J + I) + (size_t)(16 * J) * 64 : (size_t)(16 * (4 * J + I)) + (size_t)ld * (64 * J);   // wave-uniform
+    src[I] = c64_g((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
+    add[I] = (MODE == 1) ? c64_g(a.ImatAdd) + t0 : nullptr;
+    dst[I] = (MODE == 1 && a.ImatOut) ? c64_g(a.ImatOut) + (size_t)p * a.imat_out_stride + t0 : nullptr;
+  }
+  unsigned off[4][4];                                                          // (per-lane offsets, opaque: see c64_strip_fast)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { dst[q * 64] = V[q]; NLs[(c * 4 + q) * 64 + lane] = NI[q]; }
-      v4d xs[4];
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int i = c + 1; i < 4; ++i) {
-        xs[i] = (v4d){0.0, 0.0, 0.0, 0.0};
-        if (i < nd) {
-          xs[i] = mfma4(NI, Z[i][c], xs[i]);                                // X' = inv(Ld) V'  (NI = -inv, Z = -V')
-          double* dx = Lt + ((size_t)(4 * J + i) * KGS + 16 * J + 4 * c) * 64 + lane;
+    for (int q = 0; q < 4; ++q) { off[c][q] = pk ? (unsigned)(lane + 64 * (4 * c + q)) : lo + (unsigned)(ld * (16 * c + 4 * q)); asm volatile("" : "+v"(off[c][q])); }
+  // two batches of loads (row tiles 0..2: six tiles, row tile 3: four): all ten at once are 160 registers of raw values beside the tiles
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { dx[q * 64] = xs[i][q]; Lds[(c64_pair(i, c) * 4 + q) * 64 + lane] = xs[i][q]; }
+  for (int batch = 0; batch < 2; ++batch) {
+    const int I0 = batch == 0 ? 0 : 3, I1 = batch == 0 ? 3 : 4;
+    double v[4][4][4], ad[4][4][4];
+    C64_PIN();
+#pragma unroll
+    for (int I = I0; I < I1; ++I)
+#pragma unroll
+      for (int c = 0; c <= I; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[I][c][q] = src[I][off[c][q]];
+          ad[I][c][q] = (MODE == 1) ? add[I][off[c][q]] : 0.0;
+        }
+    C64_PIN();
+#pragma unroll
+    for (int I = I0; I < I1; ++I) {
+      const int i0 = 16 * (4 * J + I);
+#pragma unroll
+      for (int c = 0; c <= I; ++c) {
+        if (MODE == 0) {
+          if (a.R) {                                                           // kron(eye, R)
+            const __attribute__((address_space(3))) int* dv = (const __attribute__((address_space(3))) int*)Hs;
+            const int di = dv[i0 + r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int dj = dv[64 * J + 16 * c + 4 * q + g];
+              const double rr = a.R[(di & 7) + a.d * (dj & 7)];
+              v[I][c][q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
+            }
+          }
+        } else {
+          if (Hs) {                                                            // + dyi'/R*dyi of the last update (:334)
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int aa = 0; aa < a.d; ++aa) {
+              const double h = c64_l(Hs)[aa * M + i0 + r];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sacc[q] = fma(h, c64_l(RH)[aa * M + 64 * J + 16 * c + 4 * q + g], sacc[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[I][c][q] += sacc[q];
+          }
+          if (dst[I]) {                                                        // Imat(:,:,i) of the new generation
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                                        // (packed storage: the lower triangle only)
+              if (!pk || 16 * I + r >= 16 * c + 4 * q + g) __builtin_nontemporal_store(v[I][c][q], &dst[I][off[c][q]]);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[I][c][q] += ad[I][c][q];               // :225
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = 16 * I + r, col = 16 * c + 4 * q + g;                // inside the block
+          if (row == col) v[I][c][q] += jit;
+          Z[I][c][q] = (row >= col) ? -v[I][c][q] : 0.0;
         }
       }
-#pragma unroll
-      for (int i = c + 1; i < 4; ++i)
-#pragma unroll
-        for (int cp = c + 1; cp <= i; ++cp) Z[i][cp] = mfma4(xs[cp], xs[i], Z[i][cp]);   // Z(i,c') += Ld(c',c) X(i,c)'
-      C64_STAMP(4);
     }
   }
-  return bad;
+}
+
+// ... their panel product: one MFMA per tile and column group, column groups ascending (the sums c64_diag_product forms)
+__device__ inline void c64_solo_product(const double* __restrict__ Lt, int KGS, int J, int lane, v4d (&Z)[4][4]) {
+  if (J <= 0) return;
+  constexpr int kRing = 8;
+  const c64_gdouble* pf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pf[c] = c64_g(Lt) + (size_t)(4 * J + c) * KGS * 64;   // wave-uniform bases, + lane per load
+  const int nkg = 16 * J;
+  double F[kRing][4];
+#pragma unroll
+  for (int b = 0; b < kRing; ++b) {
+    C64_PIN();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + (size_t)b * 64)[lane];
+    C64_PIN();
+  }
+  // (nkg is a multiple of 16.)  The last round is peeled and requests nothing: clamped re-reads at the end of the loop would sit in
+  // front of whatever the factorisation waits for next (the memory counter is in order)
+  for (int kg = 0; kg + kRing < nkg; kg += kRing) {
+#pragma unroll
+    for (int b = 0; b < kRing; ++b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c <= i; ++c) Z[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][i], Z[i][c], 0, 0, 0);
+      const size_t kn = (size_t)(kg + kRing + b) * 64;
+      C64_PIN();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + kn)[lane];
+      C64_PIN();
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < kRing; ++b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c <= i; ++c) Z[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][i], Z[i][c], 0, 0, 0);
+  }
 }
 
 __device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
                                                          const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
   return c64_diag_block_body(Lt, KGS, J, nd, M, lane, Zd, NLs, Lds C64_STAMP_PASS);
+}
+
+// does wave 0 form the tiles of block column J's diagonal block itself?  (interior blocks of the 8-wave shape)
+__device__ inline bool c64_solo(int W, int J, int RT, int M) {
+  return W == 8 && !RBPF_C64_LOOKAHEAD && RBPF_C64_DIAGFAST && J <= RBPF_C64_SOLO_MAXJ && RT - 4 * J >= 4 && 64 * J + 64 <= M;
+}
+
+// Wave 0's side of the block column loop, a function of its own (registers of its own: the tiles of the NEXT diagonal block stay
+// in registers across the two barriers).  Per block column: the diagonal block's tiles -- handed over by waves 4..7, or formed
+// here (c64_solo) --, factorisation, barrier A (the workers' solves may start); the ELEMENTS of the next diagonal block, which
+// depend on nothing, are loaded while the workers solve; barrier B.  Executes exactly the barriers of the workers' loop.
+template <int MODE, int W>
+__device__ __attribute__((noinline)) void c64_wave0_loop(const CholArgs* ka, const double* imat_src, int p, double* __restrict__ Lt,
+                                                         int KGS, int RT, int M, const double* Hs, const double* RH, double jit, int lane,
+                                                         double* csm, int* sfail, int* ready C64_STAMP_ARGS) {
+  CholArgs a = *ka;
+  a.Imat = imat_src;                              // (resolved by the kernel: ancestor's bank entry or received record)
+  a.imat_stride = 0;
+  const int NJ = (RT + 3) >> 2;
+  int handed = 0;
+  v4d Z[4][4];
+  bool have = false;                              // Z holds the elements of block column J's diagonal block
+  for (int J = 0; J < NJ; ++J) {
+    const int nd = min(4, RT - 4 * J);
+    double* NLs = csm + (size_t)(J & 1) * 2560;
+    double* Lds = NLs + 1024;
+    const bool solo = c64_solo(W, J, RT, M);
+    if (!solo) handed += nd;
+    bool bad;
+    if (solo) {
+      if (!have) c64_solo_elems<MODE>(a, p, J, M, Hs, RH, jit, lane, Z);
+      C64_STAMP(0);
+      c64_solo_product(Lt, KGS, J, lane, Z);
+      C64_STAMP(1);
+      bad = c64_diag_factor(Z, Lt, KGS, J, 4, M, lane, NLs, Lds C64_STAMP_PASS);
+    } else {
+      int spins = 0;
+      if (!RBPF_C64_LOOKAHEAD) {                  // only this wave waits; bounded, so a lost hand-off cannot hang the GPU
+        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
+          __builtin_amdgcn_s_sleep(4);
+          ++spins;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      }
+      C64_STAMP(0);
+      bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS) || spins >= (1 << 24);
+    }
+    if (bad && lane == 0) sfail[J & 1] = 1;
+    __syncthreads();                              // A
+    C64_STAMP(3);
+    have = false;
+    if (J + 1 < NJ && c64_solo(W, J + 1, RT, M)) {
+      c64_solo_elems<MODE>(a, p, J + 1, M, Hs, RH, jit, lane, Z);
+      have = true;
+    }
+    C64_STAMP(6);
+    __syncthreads();                              // B: the block column is visible to the next panel products
+    C64_STAMP(5);
+#if !defined(RBPF_C64_DIAG_AFIXED) && !defined(RBPF_C64_DIAG_BFIXED)
+    if (sfail[J & 1]) break;
+#endif
+  }
 }
 
 // Waves 1..7: NT row tiles below the diagonal block (all four sub-columns exist: nd == 4 whenever such tiles exist).
@@ -654,44 +904,36 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
         }
       }
     };
-    int handed = 0;
     if (tid == 0) *ready = 0;
     __syncthreads();
     if (RBPF_C64_LOOKAHEAD) {
       if (wv != 0) lookahead(0);
       __syncthreads();
     }
+    if (wv == 0) {
+      c64_wave0_loop<MODE, W>(c64_kernarg(), a.Imat, p, Lt, KGS, RT, M, Hs, RH, jit, lane, csm, sfail, ready C64_STAMP_PASS);
+    } else
     for (int J = 0; J < NJ; ++J) {
       const int nd = min(4, RT - 4 * J);
       const int first = 4 * J + nd, count = RT - first;
-      const int npass = max(1, (count + kTilesPerPass - 1) / kTilesPerPass);
       double* NLs = csm + (size_t)(J & 1) * 2560;
       double* Lds = NLs + 1024;
-      handed += nd;
-      if (wv == 0) {
-        int spins = 0;
-        if (!RBPF_C64_LOOKAHEAD) {                // only this wave waits; bounded, so a lost hand-off cannot hang the GPU
-          while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
-            __builtin_amdgcn_s_sleep(4);
-            ++spins;
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        C64_STAMP(0);
-        const bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS) || spins >= (1 << 24);
-        if (bad && lane == 0) sfail[J & 1] = 1;
-        __syncthreads();
-        C64_STAMP(3);
-      } else {
+      const bool solo = c64_solo(W, J, RT, M);   // wave 0 forms the diagonal block's tiles itself: no hand-over
+      // workers of this block column and this wave's place among them (RBPF_C64_SOLO_REST4: wave 4 rests beside a solo wave 0)
+      const bool rest4 = solo && RBPF_C64_SOLO_REST4 && W == 8;
+      const int nwork = rest4 ? W - 2 : W - 1, widx = (rest4 && wv > 4) ? wv - 2 : wv - 1;
+      const int tiles_per_pass = kNTMax * nwork;
+      const int npass = max(1, (count + tiles_per_pass - 1) / tiles_per_pass);
+      {
         if (RBPF_C64_LOOKAHEAD) { if (J + 1 < NJ) lookahead(J + 1); }
-        else lookahead(J);
+        else if (!solo) lookahead(J);
         for (int pass = 0; pass < npass; ++pass) {
           int rt[4], nt = 0;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const int u = kTilesPerPass * pass + (wv - 1) + (W - 1) * s;
+            const int u = tiles_per_pass * pass + widx + nwork * s;
             rt[s] = first + min(u, count - 1);
-            nt += (s < kNTMax && u < count) ? 1 : 0;
+            nt += (s < kNTMax && u < count && !(rest4 && wv == 4)) ? 1 : 0;
           }
 #define RBPF_C64(NT_, LATE_) c64_tile_pass<NT_, MODE, LATE_, true>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
 #if RBPF_C64_LATE
@@ -722,7 +964,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
     }
 #ifdef RBPF_C64_STAMPS
     if (p == 0 && lane == 0 && M >= 200)
-      printf("chol64 M=%d wave %d clocks: elems(w0:spin) %lld product %lld diagtile %lld waitA %lld solve/update %lld waitB %lld\n", M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5]);
+      printf("chol64 M=%d wave %d clocks: elems(w0:spin) %lld product %lld diagtile %lld waitA %lld solve/update %lld waitB %lld w0:prefetch %lld w0:stores+solves %lld\n", M, wv, cst[0], cst[1], cst[2], cst[3], cst[4], cst[5], cst[6], cst[7]);
 #endif
     __syncthreads();
     const int failed = sfail[0] | sfail[1];

@@ -640,7 +640,12 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 }
 
 #include "rbpf_chol64.hpp"
+#ifndef RBPF_C64_STAMPS                           // (the phase-clock build of the 64-column kernel changes its helpers' signatures)
 #include "rbpf_chol128.hpp"
+#else
+static bool chol128_ok(const CholArgs&, int) { return false; }
+static hipError_t launch_chol128(const CholArgs&, int, int, hipStream_t) { return hipErrorInvalidValue; }
+#endif
 #include "rbpf_chol_small.hpp"
 #include "rbpf_chol_sweep.hpp"
 
