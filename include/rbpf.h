@@ -180,7 +180,7 @@ typedef struct {
                           * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]): filter *
                           * and both smoothers, single-GPU and sharded; RBPF_ERR_UNSUPPORTED elsewhere.                         */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
-                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 128 / 1 /   *
+                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 649 / 128 / 1 / *
                           * 10-14 as the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
   int32_t chol_refresh;  /* information-form smoother: 0 / 1 = factorise Imat_i + ImatAddt from scratch at every step, as           *
                           * particleSmootherInformationForm.m:228 does (default).  K > 1: CARRY the factor along every lineage   *
@@ -518,7 +518,8 @@ int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
 /* particleSmoother.m:221-229 for a batch of matrices: cS = chol(S,'lower') (one retry with S + jitter*I),
  * v = cS \ e, logw[b] = -sum(log(diag(cS))) - v'v/2 - M/2*log(2*pi).  S [batch][M x M] column-major (lower
  * triangle read), e [batch][M].  variant 0: automatic kernel choice; 16: the 16-column kernel; 64 / 648 / 644: the
- * 64-column kernel (waves by size / 8 / 4); 1: the register-resident kernel in its default shape (64 <= M <= 143, information
+ * 64-column kernel (waves by size / 8 / 4); 649: its 8-wave shape with wave 0 forming the early diagonal blocks itself (same
+ * factors bit for bit; faster stand-alone, no gain inside the smoother); 1: the register-resident kernel in its default shape (64 <= M <= 143, information
  * form only; two waves per matrix); 11 / 12 / 14: the same with one / two / four waves per matrix (14: the r02 kernel); 10: one
  * wave per matrix, left-looking on register tiles (the next block column's loads in flight during a column's work).
  * variant + 1000: the information-form loaders and expression of particleSmootherInformationForm.m:224-236 with

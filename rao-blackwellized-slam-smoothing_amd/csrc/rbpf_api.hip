@@ -239,7 +239,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   {
     const int cv = c->opt.chol_variant;
-    if (cv != 0 && cv != 1 && cv != 10 && cv != 11 && cv != 12 && cv != 14 && cv != 16 && cv != 64 && cv != 648 && cv != 644 && cv != 128) { set_error("options.chol_variant must be 0, 1, 10, 11, 12, 14, 16, 64, 648, 644 or 128"); return RBPF_ERR_INVALID_ARG; }
+    if (cv != 0 && cv != 1 && cv != 10 && cv != 11 && cv != 12 && cv != 14 && cv != 16 && cv != 64 && cv != 648 && cv != 644 && cv != 649 && cv != 128) { set_error("options.chol_variant must be 0, 1, 10, 11, 12, 14, 16, 64, 648, 644, 649 or 128"); return RBPF_ERR_INVALID_ARG; }
   }
   if (model->kind == RBPF_MODEL_GENERIC_DENSE) {
     if (ex) { set_error("generic (host-callback) models are not sharded"); return RBPF_ERR_UNSUPPORTED; }

@@ -69,12 +69,14 @@
 #define RBPF_C64_LARING 8                        // operand ring depth of the look-ahead diagonal products
 #endif
 #ifndef RBPF_C64_SOLO_MAXJ
-#define RBPF_C64_SOLO_MAXJ 5                     // wave 0 forms the tiles of the diagonal block ITSELF (elements + panel product) in block columns
-                                                 // 0 .. this (interior blocks, 8-wave shape) instead of waiting for waves 4..7 to hand them over: the
-                                                 // phase clocks (r04) showed waves 1..3 a third of their time at the first barrier, waiting for
-                                                 // waves 4..7, which carry the diagonal rows on top of a full share of strips, while wave 0 spins for
-                                                 // those rows.  Late block columns keep the hand-over (few strips per worker, long diagonal rows).
-                                                 // -1: never.  Same sums in the same order either way (bit-identical factors).
+#define RBPF_C64_SOLO_MAXJ 5                     // variant 649 (rbpf_chol_weights / rbpf_options.chol_variant): wave 0 forms the tiles of the diagonal
+                                                 // block ITSELF (elements + panel product) in block columns 0 .. this (interior blocks, 8-wave shape)
+                                                 // instead of waiting for waves 4..7 to hand them over, and loads the next block's elements while the
+                                                 // workers solve.  The phase clocks (r04) showed waves 1..3 a third of their time at the first barrier,
+                                                 // waiting for waves 4..7, which carry the diagonal rows on top of a full share of strips, while wave 0
+                                                 // spins for those rows.  Late block columns keep the hand-over (few strips per worker, long diagonal
+                                                 // rows).  Same sums in the same order either way (bit-identical factors).  Stand-alone 15.6 -> 14.8 ms
+                                                 // per 8192 at n = 515; inside the smoother no change, hence a variant, not the default.
 #endif
 #ifndef RBPF_C64_SOLO_REST4
 #define RBPF_C64_SOLO_REST4 0                    // 1: in those block columns wave 4 -- wave 0's neighbour on its SIMD -- takes no strips and the six
@@ -661,8 +663,8 @@ __device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt
 }
 
 // does wave 0 form the tiles of block column J's diagonal block itself?  (interior blocks of the 8-wave shape)
-__device__ inline bool c64_solo(int W, int J, int RT, int M) {
-  return W == 8 && !RBPF_C64_LOOKAHEAD && RBPF_C64_DIAGFAST && J <= RBPF_C64_SOLO_MAXJ && RT - 4 * J >= 4 && 64 * J + 64 <= M;
+__device__ inline bool c64_solo(int W, int J, int RT, int M, int maxj) {
+  return W == 8 && !RBPF_C64_LOOKAHEAD && RBPF_C64_DIAGFAST && J <= maxj && RT - 4 * J >= 4 && 64 * J + 64 <= M;
 }
 
 // Wave 0's side of the block column loop, a function of its own (registers of its own: the tiles of the NEXT diagonal block stay
@@ -684,7 +686,7 @@ __device__ __attribute__((noinline)) void c64_wave0_loop(const CholArgs* ka, con
     const int nd = min(4, RT - 4 * J);
     double* NLs = csm + (size_t)(J & 1) * 2560;
     double* Lds = NLs + 1024;
-    const bool solo = c64_solo(W, J, RT, M);
+    const bool solo = c64_solo(W, J, RT, M, a.solo_maxj);
     if (!solo) handed += nd;
     bool bad;
     if (solo) {
@@ -709,7 +711,7 @@ __device__ __attribute__((noinline)) void c64_wave0_loop(const CholArgs* ka, con
     __syncthreads();                              // A
     C64_STAMP(3);
     have = false;
-    if (J + 1 < NJ && c64_solo(W, J + 1, RT, M)) {
+    if (J + 1 < NJ && c64_solo(W, J + 1, RT, M, a.solo_maxj)) {
       c64_solo_elems<MODE>(a, p, J + 1, M, Hs, RH, jit, lane, Z);
       have = true;
     }
@@ -918,7 +920,7 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
       const int first = 4 * J + nd, count = RT - first;
       double* NLs = csm + (size_t)(J & 1) * 2560;
       double* Lds = NLs + 1024;
-      const bool solo = c64_solo(W, J, RT, M);   // wave 0 forms the diagonal block's tiles itself: no hand-over
+      const bool solo = c64_solo(W, J, RT, M, a.solo_maxj);   // wave 0 forms the diagonal block's tiles itself: no hand-over
       // workers of this block column and this wave's place among them (RBPF_C64_SOLO_REST4: wave 4 rests beside a solo wave 0)
       const bool rest4 = solo && RBPF_C64_SOLO_REST4 && W == 8;
       const int nwork = rest4 ? W - 2 : W - 1, widx = (rest4 && wv > 4) ? wv - 2 : wv - 1;
@@ -1015,6 +1017,7 @@ static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, 
   if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE, W>), (int)kC64MaxLds, attr)) return e;
   CholArgs cb = ca;
   cb.batch = batch;
+  cb.solo_maxj = (ca.variant == 649) ? RBPF_C64_SOLO_MAXJ : -1;
   const int grid = (cb.l_slots > 0) ? std::min(batch, cb.l_slots) : batch;
   hipLaunchKernelGGL((chol_solve64_kernel<MODE, W>), dim3(grid), dim3(W * 64), lds, st, cb);
   return hipGetLastError();

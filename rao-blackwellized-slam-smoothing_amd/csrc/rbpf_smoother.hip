@@ -269,6 +269,8 @@ struct CholArgs {
   int* status;
   int variant;                      // host side only: rbpf_options.chol_variant (0: kernel by matrix size)
   int batch, l_slots;               // 64-column kernel: l_slots > 0 = persistent workgroups, Lbuf holds l_slots factor workspaces
+  int solo_maxj;                    // 64-column kernel, 8 waves: wave 0 forms the diagonal blocks of block columns 0 .. solo_maxj itself (-1: never;
+                                    // variant 649: rbpf_chol64.hpp, c64_solo)
   int imat_packed;                  // mode 1: Imat / ImatAdd / ImatOut / the records' matrices in packed storage (below)
   long imat_out_stride;             // doubles between two matrices of ImatOut (n * n, or imat_packed_doubles(n))
 };
@@ -669,7 +671,7 @@ static bool chol_variant_ok(const CholArgs& ca, int d_lds, int variant) {
   const int RT = (ca.Msz + 1 + 15) >> 4;
   switch (variant) {
     case 0: case 16: return true;
-    case 64: case 648: case 644: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
+    case 64: case 648: case 644: case 649: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
     case 128: return chol128_ok(ca, d_lds);
     case 1: case 10: case 11: case 12: case 14: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
     default: return false;
@@ -685,7 +687,7 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
     if (ca.variant == 10) return launch_chol_small(ca, batch, d_lds, st, 10);                                                         // one wave, left-looking
     if (ca.variant == 16) return launch_chol16(ca, batch, d_lds, st);
     if (ca.variant == 128) return launch_chol128(ca, batch, d_lds, st);
-    return launch_chol64(ca, batch, d_lds, st, ca.variant == 648 ? 8 : ca.variant == 644 ? 4 : 0);
+    return launch_chol64(ca, batch, d_lds, st, (ca.variant == 648 || ca.variant == 649) ? 8 : ca.variant == 644 ? 4 : 0);
   }
   // diagnostic builds (-DRBPF_TUNING) can override the choice from the environment
   static const int w_env = tuning_env("RBPF_CHOL_WAVES") ? atoi(tuning_env("RBPF_CHOL_WAVES")) : 0;      // force 4 / 8 / 16
@@ -1745,7 +1747,7 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   const bool info = variant >= 1000;                 // information-form expression and loaders (see rbpf.h)
   if (info) variant -= 1000;
   if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 ||
-      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644 && variant != 128) ||
+      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644 && variant != 649 && variant != 128) ||
       (variant == 128 && (!info || ((M + 16) >> 4) <= 27)) ||
       ((variant == 1 || variant == 10 || variant == 11 || variant == 12 || variant == 14) && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;

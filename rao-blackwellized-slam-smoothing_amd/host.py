@@ -800,7 +800,7 @@ def quat_helper(name, x):
 def chol_weights(S, e, jitter=0.0, variant=0, reps=1, info_form=False):
     """particleSmoother.m:221-229 for a batch: S [B, M, M] (symmetric; the lower triangle is read), e [B, M] ->
     (logw [B], status, mean kernel ms).  variant 0 / 16 / 64 selects the factorisation kernel (648 / 644: the 64-column kernel
-    with 8 / 4 waves; 128: the 128-column kernel, information form and M >= 432 only; 1: the register-resident kernel,
+    with 8 / 4 waves; 649: 8 waves, wave 0 forming the early diagonal blocks itself; 128: the 128-column kernel, information form and M >= 432 only; 1: the register-resident kernel,
     information form and 64 <= M <= 143 only).  info_form: the
     information-form loaders and expression of particleSmootherInformationForm.m:224-236 with ImatAddt = ivecAddt = 0:
     logw = -sum(log(diag(cI))) + v'v/2, no retry."""

@@ -43,7 +43,7 @@ def numpy_logw(S, e, jitter=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [16, 648, 644])
+@pytest.mark.parametrize("variant", [16, 648, 644, 649])
 @pytest.mark.parametrize("M", [5, 16, 63, 64, 65, 130, 259, 515, 516, 576, 640])
 def test_batched_factorisation_matches_numpy(rbpf, M, variant):
     B = 9 if M > 300 else 21
@@ -85,7 +85,7 @@ def test_jitter_retry_and_failure_flag(rbpf, M, variant):
 
 def test_largest_supported_size(rbpf):
     S, e = spd_batch(3, 1023, seed=11)
-    for variant in (16, 648, 644):
+    for variant in (16, 648, 644, 649):
         got, status, _ = rbpf.chol_weights(S, e, variant=variant)
         assert status == 0
         np.testing.assert_allclose(got, numpy_logw(S, e), rtol=1e-11, atol=1e-9)
@@ -112,7 +112,7 @@ def test_smoother_with_the_16_column_kernel_forced(rbpf):
         ts.run_both(rbpf, c, info_form=True, chol_variant=7)
 
 
-@pytest.mark.parametrize("kind,m,variant", [("mag", 256, 16), ("mag", 200, 16), ("mag", 256, 644), ("mag", 256, 648), ("mag", 173, 16)])
+@pytest.mark.parametrize("kind,m,variant", [("mag", 256, 16), ("mag", 200, 16), ("mag", 256, 644), ("mag", 256, 648), ("mag", 256, 649), ("mag", 173, 16)])
 def test_packed_information_matrices_through_every_loader(rbpf, kind, m, variant):
     """nLin >= 176: the banks, Imat0, ImatAddt hold the information matrices in packed block-lower storage (imat_packed_index).
     The 16-column kernel reads them through the general loader (chol_aug_elems), the 64-column kernel through its call-free strip /
@@ -231,7 +231,7 @@ def test_every_kernel_over_a_sweep_of_sizes(rbpf):
         S, e = spd_batch(3, M, seed=1000 + M)
         want0, want1 = numpy_logw(S, e), numpy_logw_info(S, e)
         rt = (M + 16) // 16
-        for variant in (0, 16, 644, 648):
+        for variant in (0, 16, 644, 648, 649):
             got, status, _ = rbpf.chol_weights(S, e, jitter=1e-2, variant=variant)
             assert status == 0, (M, variant)
             np.testing.assert_allclose(got, want0, rtol=1e-11, atol=1e-9, err_msg=f"M={M} variant={variant}")
