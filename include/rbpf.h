@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 7
+#define RBPF_ABI_VERSION 8   /* 8 (r04): rbpf_options grew by `family_products` -- a caller built against 7 passes a shorter struct */
 
 typedef enum {
   RBPF_OK = 0,
@@ -273,6 +273,10 @@ typedef struct {
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int rbpf_abi_version(void);
+/* sizeof of the library's own view of an interface struct -- a binding in another language (ctypes, MEX, a MATLAB loadlibrary
+ * prototype file) compares its mirror against it once at load time.  which: 0 rbpf_model, 1 rbpf_problem, 2 rbpf_rng, 3 rbpf_options,
+ * 4 rbpf_filter_out, 5 rbpf_smoother_out, 6 rbpf_timing, 7 rbpf_callbacks, 8 rbpf_view; -1 for any other value.               */
+int rbpf_abi_sizeof(int32_t which);
 const char* rbpf_status_string(int status);
 /* Thread-local text of the last error raised on this thread (HIP error string, argument name). */
 const char* rbpf_last_error(void);

@@ -94,9 +94,12 @@ class rbpf_timing(C.Structure):
                 ("algorithmic_bytes_per_launch", C.c_double), ("scheduled_bytes_per_launch", C.c_double)]
 
 
+# rbpf_abi_sizeof(which): the mirrors in the order of its `which` argument
+ABI_STRUCTS = [rbpf_model, rbpf_problem, rbpf_rng, rbpf_options, rbpf_filter_out, rbpf_smoother_out, rbpf_timing, rbpf_callbacks, rbpf_view]
+
 # every symbol include/rbpf.h declares (tests/test_abi.py checks the library exports all of them)
 EXPORTS = [
-    "rbpf_abi_version", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
+    "rbpf_abi_version", "rbpf_abi_sizeof", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
     "rbpf_particle_filter", "rbpf_particle_smoother",
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
     "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_probe_family_pht", "rbpf_shard_smoother_refresh_reserve", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
@@ -189,8 +192,13 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_chol_sweep_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
                                           c_double_p, c_double_p, c_int32_p, c_double_p]
     lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
-    if lib.rbpf_abi_version() != 7:
-        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 7 (rebuild)")
+    if lib.rbpf_abi_version() != 8:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 8 (rebuild)")
+    lib.rbpf_abi_sizeof.argtypes = [C.c_int32]
+    for which, mirror in enumerate(ABI_STRUCTS):
+        if lib.rbpf_abi_sizeof(which) != C.sizeof(mirror):
+            raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path}: sizeof({mirror.__name__}) is {lib.rbpf_abi_sizeof(which)}, this mirror has "
+                                                  f"{C.sizeof(mirror)} (include/rbpf.h and _ffi.py disagree)")
     _lib = lib
     return lib
 

@@ -906,6 +906,21 @@ extern "C" {
 
 int rbpf_abi_version(void) { return RBPF_ABI_VERSION; }
 
+int rbpf_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int)sizeof(rbpf_model);
+    case 1: return (int)sizeof(rbpf_problem);
+    case 2: return (int)sizeof(rbpf_rng);
+    case 3: return (int)sizeof(rbpf_options);
+    case 4: return (int)sizeof(rbpf_filter_out);
+    case 5: return (int)sizeof(rbpf_smoother_out);
+    case 6: return (int)sizeof(rbpf_timing);
+    case 7: return (int)sizeof(rbpf_callbacks);
+    case 8: return (int)sizeof(rbpf_view);
+    default: return -1;
+  }
+}
+
 const char* rbpf_status_string(int s) {
   switch (s) {
     case RBPF_OK: return "ok";

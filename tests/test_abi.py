@@ -26,7 +26,12 @@ def test_library_exports_every_declared_symbol(rbpf):
     lib = rbpf.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rbpf_abi_version() == 7
+    assert lib.rbpf_abi_version() == 8
+    import ctypes as C
+    ffi = __import__("importlib").import_module(rbpf.__name__ + "._ffi")
+    for which, mirror in enumerate(ffi.ABI_STRUCTS):                       # the ctypes mirror against the library's own sizeof
+        assert lib.rbpf_abi_sizeof(which) == C.sizeof(mirror), mirror.__name__
+    assert lib.rbpf_abi_sizeof(99) == -1
     assert lib.rbpf_status_string(0) == b"ok"
     assert b"positive definite" in lib.rbpf_status_string(rbpf.RBPF_ERR_CHOL_FAILED)
 
