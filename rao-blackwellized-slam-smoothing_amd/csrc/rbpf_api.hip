@@ -384,7 +384,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (c->family_on) {
     RB_TRY(dmalloc(&c->d_fam_H, (size_t)N * d * L.ldx));
     RB_TRY(dmalloc(&c->d_fam_PHt, (size_t)N * d * L.mc));
-    RB_TRY(dmalloc(&c->d_fam_idx, (size_t)2 * N + 2));
+    RB_TRY(dmalloc(&c->d_fam_idx, (size_t)2 * N + 2 + (N + 1023) / 1024));
   }
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }

@@ -95,7 +95,7 @@ struct rbpf_ctx {
   bool family_on = false;
   double* d_fam_H = nullptr;                    // [N][d][ldx]
   double* d_fam_PHt = nullptr;                  // [N][d][mc]
-  int* d_fam_idx = nullptr;                     // fam_start [N + 1], fam_base [N], n_fam [1]
+  int* d_fam_idx = nullptr;                     // fam_start [N + 1], fam_base [N], n_fam [1], heads per 1024 positions [ceil(N / 1024)]
   // timed launches: reads of stored matrices counted per particle (nominal) and per DISTINCT matrix (device counter)
   int* d_distinct_mark = nullptr; size_t distinct_keys = 0; unsigned long long* d_distinct_counter = nullptr;
   long long distinct_nominal = 0; int distinct_epoch = 0;

@@ -209,27 +209,49 @@ hipError_t launch_family_pht(int CH, const FamilyArgs& fa, int max_families, hip
 // pre_i: the step's descriptors (propagate_kernel), [3] = entry of the stored matrix.  The order is sorted by that entry when the
 // step has one (launch_order / the fused resample kernel); without it every run of equal neighbours is still a valid family.
 constexpr int kFamIndexThreads = 1024;
-__global__ __launch_bounds__(kFamIndexThreads) void family_index_kernel(int N, const int* __restrict__ pre_i, int* __restrict__ fam_start,
-                                                                         int* __restrict__ fam_base, int* __restrict__ n_fam) {
-  __shared__ int cnt[kFamIndexThreads];
-  const int tid = threadIdx.x, per = (N + kFamIndexThreads - 1) / kFamIndexThreads;
-  const int lo = min(N, tid * per), hi = min(N, lo + per);
-  auto base = [&](int p) { return pre_i[(size_t)p * kPreInts + 3]; };
-  int c = 0;
-  for (int p = lo; p < hi; ++p) c += (p == 0 || base(p) != base(p - 1)) ? 1 : 0;
-  cnt[tid] = c;
+// pass 1: heads per block of 1024 positions; pass 2: every block adds the counts of the blocks before it, ranks its own heads (wave
+// ballots + a scan of the sixteen wave totals) and writes the table
+__global__ __launch_bounds__(kFamIndexThreads) void family_count_kernel(int N, const int* __restrict__ pre_i, int* __restrict__ blk_count) {
+  __shared__ int wsum[kFamIndexThreads / 64];
+  const int p = blockIdx.x * kFamIndexThreads + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const bool head = p < N && (p == 0 || pre_i[(size_t)p * kPreInts + 3] != pre_i[(size_t)(p - 1) * kPreInts + 3]);
+  const unsigned long long m = __ballot(head);
+  if (lane == 0) wsum[wv] = __popcll(m);
   __syncthreads();
-  for (int off = 1; off < kFamIndexThreads; off <<= 1) {      // inclusive scan
-    const int v = (tid >= off) ? cnt[tid - off] : 0;
-    __syncthreads();
-    cnt[tid] += v;
-    __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < kFamIndexThreads / 64; ++w) c += wsum[w];
+    blk_count[blockIdx.x] = c;
   }
-  int f = cnt[tid] - c;
-  for (int p = lo; p < hi; ++p) {
-    if (p == 0 || base(p) != base(p - 1)) { fam_start[f] = p; fam_base[f] = base(p); ++f; }
+}
+
+__global__ __launch_bounds__(kFamIndexThreads) void family_index_kernel(int N, const int* __restrict__ pre_i, const int* __restrict__ blk_count,
+                                                                         int* __restrict__ fam_start, int* __restrict__ fam_base,
+                                                                         int* __restrict__ n_fam) {
+  __shared__ int wsum[kFamIndexThreads / 64];
+  __shared__ int red[kFamIndexThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // families in the blocks before this one
+  int before = 0;
+  for (int b = tid; b < (int)blockIdx.x; b += kFamIndexThreads) before += blk_count[b];
+  before = (int)wave_sum((double)before);                          // (< 2^24 families: exact in a double)
+  if (lane == 0) red[wv] = before;
+  const int p = blockIdx.x * kFamIndexThreads + tid;
+  const int base = p < N ? pre_i[(size_t)p * kPreInts + 3] : -1;
+  const bool head = p < N && (p == 0 || base != pre_i[(size_t)(p - 1) * kPreInts + 3]);
+  const unsigned long long m = __ballot(head);
+  if (lane == 0) wsum[wv] = __popcll(m);
+  __syncthreads();
+  int off = 0, mine = 0;
+  for (int w = 0; w < kFamIndexThreads / 64; ++w) { off += red[w]; if (w < wv) mine += wsum[w]; }
+  const int rank = off + mine + __popcll(m & ((1ull << lane) - 1ull));
+  if (head) { fam_start[rank] = p; fam_base[rank] = base; }
+  if (blockIdx.x == gridDim.x - 1 && tid == kFamIndexThreads - 1) {
+    int total = off;
+    for (int w = 0; w < kFamIndexThreads / 64; ++w) total += wsum[w];
+    fam_start[total] = N;
+    *n_fam = total;
   }
-  if (tid == kFamIndexThreads - 1) { fam_start[cnt[tid]] = N; *n_fam = cnt[tid]; }
 }
 
 // ---- measModel of every processing position (the step kernel's phases A-C on their own) ----------------------------------------
@@ -260,7 +282,11 @@ hipError_t launch_family_products(const StepArgs& a, hipStream_t s) {
   int* fam_start = a.fam_idx;
   int* fam_base = a.fam_idx + (size_t)N + 1;
   int* n_fam = a.fam_idx + 2 * (size_t)N + 1;
-  hipLaunchKernelGGL(family_index_kernel, dim3(1), dim3(kFamIndexThreads), 0, s, N, a.pre_i, fam_start, fam_base, n_fam);
+  int* blk_count = a.fam_idx + 2 * (size_t)N + 2;                  // [ceil(N / 1024)]
+  const int nblk = (N + kFamIndexThreads - 1) / kFamIndexThreads;
+  hipLaunchKernelGGL(family_count_kernel, dim3(nblk), dim3(kFamIndexThreads), 0, s, N, a.pre_i, blk_count);
+  if (hipError_t e = hipGetLastError()) return e;
+  hipLaunchKernelGGL(family_index_kernel, dim3(nblk), dim3(kFamIndexThreads), 0, s, N, a.pre_i, blk_count, fam_start, fam_base, n_fam);
   if (hipError_t e = hipGetLastError()) return e;
   const size_t lds = (size_t)(32 + 2 * (a.mdl.ktot > 0 ? a.mdl.ktot : 1)) * sizeof(double);
   hipLaunchKernelGGL(family_prepare_kernel<3>, dim3(N), dim3(kThreads), lds, s, a);

@@ -172,7 +172,7 @@ struct StepArgs {
   // one-workgroup-per-particle stream
   double* fam_H = nullptr;                                            // [N][d][ldx]
   double* fam_PHt = nullptr;                                          // [N][d][mc]
-  int* fam_idx = nullptr;                                             // fam_start [N + 1], fam_base [N], n_fam [1]
+  int* fam_idx = nullptr;                                             // fam_start [N + 1], fam_base [N], n_fam [1], scratch [ceil(N / 1024)]
 };
 
 struct NormArgs {

@@ -416,7 +416,7 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
 // PX (read-only filter steps, family products): the core rows of P_base * H_i' were formed per FAMILY on the matrix cores
 // (rbpf_family.hip: a.fam_PHt, with H_i in a.fam_H, both by processing position); this kernel then does everything else of the step.
 template <int D, int NS, bool WR, int E, int CH, bool PX = false>
-__global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 4) : ((!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)) void step_sym_kernel(const StepArgs a) {
+__global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)) void step_sym_kernel(const StepArgs a) {
   static_assert(!PX || (!WR && E == 0), "the family products serve the read-only filter step");
   constexpr int NPH = (CH == 8) ? 1 : 2;                       // column phases (waves per row pair)
   extern __shared__ double smem[];
