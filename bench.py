@@ -113,7 +113,7 @@ def roofline_of(tm, storage="fp64"):
                     "symmetric storage, the lazy update and the shared reads all elide bytes)"}
 
 
-def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True):
+def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True, family_products=0):
     """One single-GPU filter run: W warm-up steps, K timed steps.  keep_history: the state history and the ancestor table
     (particleFilter.m:117-118,233: xn_traj / traj_sample_iwmax) are written inside the timed steps, so the run could return the
     reference's full output set."""
@@ -123,7 +123,7 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, 
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, data["LL"], THETA_MAG)
     with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N, 0.01,
                            rng=pkg.PhiloxRNG(seed), keep_history=keep_history, lazy_depth=lazy_depth, inplace=inplace,
-                           storage=storage) as sess:
+                           storage=storage, family_products=family_products) as sess:
         sess.advance(W)
         sess.sync()
         sess.timing(enable=True)
@@ -729,6 +729,14 @@ def main():
             # workgroups, ~58 us each), not by bytes -- symmetric storage (supported at this size too) gives the same 8.0-8.2 M/s
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")
             line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]
+            if args.storage == "fp64sym" and args.m == 512 and args.lazy_depth >= 2:
+                # north_star's "MFMA for the batched P*H' where m >= 64", measured: the headline workload with the read-only steps formed per
+                # family of particles that share a stored matrix on the fp64 matrix cores (rbpf_options.family_products = 1)
+                def family():
+                    r, *_ = filter_leg(pkg, datagen, N_local, args.m, T, K, W, args.seed, args.lazy_depth, args.inplace, args.storage, family_products=1)
+                    r["workload"] = line["config"]["workload"] + ", read-only steps as family GEMMs on the matrix cores (family_products = 1; not the default: slower)"
+                    return r
+                line["family_products_filter"] = guarded(family)
         if solo and not args.no_filter_full:
             line["filter_full_T"] = guarded(lambda: filter_full_run(pkg, datagen, N_local, args.m, T, args.seed, args.lazy_depth, args.inplace, args.storage))
             if "seconds" in line["filter_full_T"]:
