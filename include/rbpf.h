@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define RBPF_ABI_VERSION 8   /* 8 (r04): rbpf_options grew by `family_products` -- a caller built against 7 passes a shorter struct */
+#define RBPF_ABI_VERSION 9   /* 9 (r05): rbpf_options starts with `struct_size` (checked by every entry point that takes options), lost
+                              * `family_products` (r04's family GEMM was measured slower and removed) and chol_refresh = 0 now means
+                              * "automatic"; rbpf_probe_family_pht is gone, rbpf_chol_refresh_resolve is new */
 
 typedef enum {
   RBPF_OK = 0,
@@ -152,6 +154,10 @@ typedef struct {
 typedef int (*rbpf_on_step_fn)(const rbpf_view* view, void* user);
 
 typedef struct {
+  int32_t struct_size;   /* = sizeof(rbpf_options) of the caller's build (rbpf_abi_sizeof(3) at run time): an entry  *
+                          * point handed options of another size returns RBPF_ERR_INVALID_ARG instead of reading past the caller's     *
+                          * struct.  0 is accepted from callers that zero the struct and fill fields by name (C designated             *
+                          * initialisers) -- they were compiled against this header by construction                                    */
   int32_t keep_history;  /* 1: keep xn history + ancestor table (needed for traj_sample_iwmax,  *
                           *    xn_traj and every smoother); 0: ping-pong only                   */
   int32_t trace;         /* 1: record per-step logw / w / ancestor indices (tests)              */
@@ -180,21 +186,28 @@ typedef struct {
                           * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]): filter *
                           * and both smoothers, single-GPU and sharded; RBPF_ERR_UNSUPPORTED elsewhere.                         */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
-                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 649 / 128 / 1 / *
+                          * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 /             *
+                          * (a non-zero value with chol_refresh = 0 selects the from-scratch factorisation, chol_refresh = 1)           *
                           * 10-14 as the `variant` of rbpf_chol_weights.  Same arithmetic, results to rounding (tests).                */
-  int32_t chol_refresh;  /* information-form smoother: 0 / 1 = factorise Imat_i + ImatAddt from scratch at every step, as           *
-                          * particleSmootherInformationForm.m:228 does (default).  K > 1: CARRY the factor along every lineage   *
-                          * -- per step n_y rank-1 updates (the particle's own H' R^-1 H) and n_y rank-1 downdates (the reference *
-                          * trajectory's term leaving ImatAddt) of the ancestor's factor, O(n^2) instead of n^3/3, the forward     *
-                          * solve carried as an augmented row -- and refactorise every K-th step (Imat rebuilt from the state       *
-                          * history).  Same algebra, different arithmetic: ancestor probabilities within 2e-9 of the default's      *
-                          * (8.8e-10 measured over T = 3000 at nLin = 515; tests/test_gpu_chol_carry.py), not         *
-                          * bit-wise.  nLin <= 575; also in the sharded smoother (rbpf_shard_smoother_refresh_*).                    *
-                          * Failure behaviour differs from the default: the reference retries a failed chol with the jitter       *
-                          * (:228-231); a carried DOWNDATE that loses definiteness cannot be retried in place -- it sets status      *
-                          * bit 2, the particle's ancestor log-weight becomes NaN and the run ends with RBPF_ERR_CHOL_FAILED when   *
-                          * the iteration's flags are checked; a factor obtained at a refresh WITH the jitter retry is carried for    *
-                          * up to K steps.  Use chol_refresh = 0 where near-singular Imat + ImatAddt are expected.                   */
+  int32_t chol_refresh;  /* information-form smoother, the ancestor-weight factorisation chol(Imat_i + ImatAddt) of                    *
+                          * particleSmootherInformationForm.m:224-236.                                                                 *
+                          * K > 1: CARRY the factor along every lineage -- per step n_y rank-1 updates (the particle's own           *
+                          * H' R^-1 H, :334) and n_y rank-1 downdates (the reference trajectory's term leaving ImatAddt, :194-201)    *
+                          * of the ancestor's factor, O(n^2) instead of n^3 / 3, the forward solve carried as an augmented row --     *
+                          * and refactorise every K-th step from Imat rebuilt along the state history (recognised families; the       *
+                          * information matrices are then only materialised at those steps).  Same algebra, different arithmetic:     *
+                          * every ancestor index and trajectory draw identical, ancestor probabilities within 2e-9 absolute, outputs *
+                          * within 1e-9 of the from-scratch factorisation (measured 8.8e-10 over T = 3000 at nLin = 515;             *
+                          * tests/test_gpu_chol_carry.py, test_gpu_r05_parity.py).  nLin <= 575, n_y = 1 or 3; also in *
+                          * the sharded smoother (rbpf_shard_smoother_refresh_*).                                                     *
+                          * 1: factorise from scratch at every step, the reference's own arithmetic.                                  *
+                          * 0 (default): AUTOMATIC = 32 where the carried factors apply and pay (recognised dense family, 128 <=      *
+                          * nLin <= 575), 1 elsewhere; rbpf_chol_refresh_resolve tells which.                                        *
+                          * Failure behaviour of K > 1: the reference's retry of a failed chol (:228-231) is unusable as written      *
+                          * (quirk Q4), so a failed factorisation is an error either way; a carried DOWNDATE that loses definiteness  *
+                          * sets status bit 2, the particle's ancestor log-weight becomes NaN and the run ends with                    *
+                          * RBPF_ERR_CHOL_FAILED when the iteration's flags are checked.  Use chol_refresh = 1 where near-singular     *
+                          * Imat + ImatAddt are expected.                                                                              */
   int32_t exchange_capacity; /* sharded sessions: particle records one rank can send / receive per time step (buffers are  *
                           * sized from it, identically on every rank; received records persist for lazy_depth steps).       *
                           * > 0: a hard limit -- a step that needs more fails on EVERY rank with RBPF_ERR_OUT_OF_MEMORY before   *
@@ -216,13 +229,6 @@ typedef struct {
   const int32_t* device_ids; /* [n_devices] HIP device of every rank, NULL = 0 .. n_devices-1.  A device named more than once makes *
                           * its ranks share that GPU over a host-staged transport (no RCCL) -- how a one-GPU machine exercises the  *
                           * multi-rank loop; n_devices = 1 with device_ids set runs the loop with a world of one.                  */
-  int32_t family_products; /* filter with storage = 2, lazy_depth >= 2, 515 <= n_lin <= 639 (also sharded): how a READ-ONLY step forms *
-                          * P_i * H_i' (particleFilter.m:139,194).  0 (default): one workgroup per particle streams the stored matrix   *
-                          * (siblings share it through the L2).  1: per FAMILY of particles that share a stored matrix --             *
-                          * P_base * [H_1' ... H_f'] on the fp64 matrix cores, the matrix read once per family -- followed by the     *
-                          * per-particle rest of the step (rbpf_family.hip).  Same algebra, sums in another order: results agree to  *
-                          * rounding (1e-9 tests); measured slower than 0 at lazy_depth 4 on MI355X, hence not the      *
-                          * default.  Ignored where it does not apply.                                                                */
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */
@@ -509,21 +515,13 @@ int rbpf_dyn_res_norm(const rbpf_model* model, int32_t n_nonlin, int32_t n_w, in
 /* tools/sample.m:30-32 applied to n_draws uniforms: ind[j] = sum(cumsum(w) < u[j]) (0-based,
  * clamped to N-1).                                                                                */
 int rbpf_sample(int32_t N, const double* w, int32_t n_draws, const double* u, int32_t* ind);
-/* PROBE (tests / tools only) of the family product behind the filter's read-only steps: P_base * [H_1' ... H_f'] for families of particles that share one
- * stored covariance (block-lower storage, CH = 4 or 8 tile rows), on the fp64 matrix cores -- particleFilter.m:139-141,185-198's
- * P_i * H_i' for all members with one read of the matrix.  T [n_mat][CH (CH + 1) / 2][4096] (the layout of rbpf_options.storage = 2,
- * core rows), H [N][3][64 CH], families = positions fam_start[f] .. fam_start[f + 1] - 1 reading matrix fam_base[f]; PHt
- * [N][3][64 CH].  replicate_T > 1 tiles the host matrices on the device (timing with many distinct matrices).  *ms: mean launch time. */
-int rbpf_probe_family_pht(int32_t CH, int32_t n_mat, int32_t N, int32_t F, const double* T, const double* H, const int32_t* fam_start,
-                          const int32_t* fam_base, int32_t reps, int32_t replicate_T, double* PHt, double* ms);
 /* tools/JacobianPhi3D.m:29-64: x [3 x Np] -> J [3 x 3 x m x Np].                                  */
 int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
                         const double* lower, const double* upper, double* J);
 /* particleSmoother.m:221-229 for a batch of matrices: cS = chol(S,'lower') (one retry with S + jitter*I),
  * v = cS \ e, logw[b] = -sum(log(diag(cS))) - v'v/2 - M/2*log(2*pi).  S [batch][M x M] column-major (lower
  * triangle read), e [batch][M].  variant 0: automatic kernel choice; 16: the 16-column kernel; 64 / 648 / 644: the
- * 64-column kernel (waves by size / 8 / 4); 649: its 8-wave shape with wave 0 forming the early diagonal blocks itself (same
- * factors bit for bit; faster stand-alone, no gain inside the smoother); 1: the register-resident kernel in its default shape (64 <= M <= 143, information
+ * 64-column kernel (waves by size / 8 / 4); 1: the register-resident kernel in its default shape (64 <= M <= 143, information
  * form only; two waves per matrix); 11 / 12 / 14: the same with one / two / four waves per matrix (14: the r02 kernel); 10: one
  * wave per matrix, left-looking on register tiles (the next block column's loads in flight during a column's work).
  * variant + 1000: the information-form loaders and expression of particleSmootherInformationForm.m:224-236 with
@@ -532,6 +530,10 @@ int rbpf_jacobian_phi3d(const rbpf_model* model, int32_t n_p, const double* x,
  * (its logw is NaN).                                                                               */
 int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e, double jitter,
                       int32_t variant, int32_t reps, double* logw, int32_t* status, double* ms);
+/* What rbpf_options.chol_refresh = `requested` means for an information-form smoother of this model family and size: the K in
+ * use (> 1: carried factors refreshed every K-th step; 1: from-scratch factorisation every step).  The multi-rank drivers need it
+ * to issue the refresh exchange at the right steps.                                                                          */
+int32_t rbpf_chol_refresh_resolve(int32_t model_kind, int32_t n_lin, int32_t n_y, int32_t requested);
 /* The sweep kernel of the carried factors (rbpf_options.chol_refresh) on its own, for the kernel-level parity test and the
  * bench: ONE augmented factor L [(n+1) x (n+1)] column-major lower = [chol(A) 0; z' *], z = chol(A) \ b, replicated `batch`
  * times; U, V [d x n] column-major (row a = update / downdate vector a), eta [d] = the entry both vectors carry in the augmented

@@ -285,7 +285,7 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 // the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
 // matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
 struct SessionOptions {
-  int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0, family_products = 0;
+  int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0;
   double jitter = 0.0, rng_seed = 0.0;
   std::vector<int32_t> device_ids;                 // [n_devices] HIP device of every rank (empty: 0 .. n_devices-1)
 };
@@ -297,6 +297,17 @@ void session_field(const mxArray* s, const char* name, int& v) {
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   if (nrhs < 1 || !mxIsChar(prhs[0])) mexErrMsgIdAndTxt("rbpf:usage", "first argument must be a command string");
+  {
+    // the gateway was compiled against include/rbpf.h; the library it is linked / loaded with must be the same ABI (a stale
+    // librbpf_hip.so would otherwise read option fields at other offsets)
+    static bool abi_checked = false;
+    if (!abi_checked) {
+      if (rbpf_abi_version() != RBPF_ABI_VERSION || rbpf_abi_sizeof(3) != (int)sizeof(rbpf_options) || rbpf_abi_sizeof(0) != (int)sizeof(rbpf_model) ||
+          rbpf_abi_sizeof(1) != (int)sizeof(rbpf_problem) || rbpf_abi_sizeof(2) != (int)sizeof(rbpf_rng))
+        mexErrMsgIdAndTxt("rbpf:abi", "librbpf_hip.so and this MEX gateway were built against different versions of include/rbpf.h: rebuild both");
+      abi_checked = true;
+    }
+  }
   char cmdbuf[24] = {0};
   mxGetString(prhs[0], cmdbuf, sizeof(cmdbuf));
   const std::string cmd(cmdbuf);
@@ -311,7 +322,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   opt.storage = g_session.storage; opt.inplace = g_session.inplace; opt.fix_p_mean = g_session.fix_p_mean; opt.jitter = g_session.jitter;
   opt.n_devices = g_session.n_devices;                       // > 1: the library shards the particles over that many GPUs itself (RCCL)
   opt.device_ids = g_session.device_ids.empty() ? nullptr : g_session.device_ids.data();
-  opt.family_products = g_session.family_products;
+  opt.struct_size = (int32_t)sizeof(opt);
   if (cmd == "options") {
     if (nrhs > 2 || (nrhs == 2 && !mxIsStruct(prhs[1]))) mexErrMsgIdAndTxt("rbpf:usage", "options expects one struct (or nothing: query)");
     if (nrhs == 2) {
@@ -320,7 +331,6 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       session_field(prhs[1], "chol_variant", o.chol_variant); session_field(prhs[1], "storage", o.storage);
       session_field(prhs[1], "inplace", o.inplace); session_field(prhs[1], "fix_p_mean", o.fix_p_mean);
       session_field(prhs[1], "n_devices", o.n_devices); session_field(prhs[1], "rng_mode", o.rng_mode);
-      session_field(prhs[1], "family_products", o.family_products);
       if (const mxArray* f = mxGetField(prhs[1], 0, "rng_seed")) { if (!mxIsEmpty(f)) o.rng_seed = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "device_ids")) {
@@ -333,17 +343,17 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
           }
         }
       }
-      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0 || o.family_products < 0 || o.family_products > 1) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
+      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
       g_session = o;
     }
     // rng_mode / rng_seed are consumed by the .m wrappers (matlab/rbpf_rngblock.m): 0 = MATLAB's stream in the reference's
     // interleaved order (seed-exact), 1 = MATLAB's stream, vectorised draws, 2 = the device Philox generator keyed by rng_seed
-    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed", "family_products", "device_ids"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 12, names);
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed", "device_ids"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
     const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
                            (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter,
-                           (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed, (double)g_session.family_products};
-    for (int q = 0; q < 11; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+                           (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed};
+    for (int q = 0; q < 10; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
     mxArray* ids = mxCreateDoubleMatrix(1, g_session.device_ids.size(), mxREAL);
     for (size_t q = 0; q < g_session.device_ids.size(); ++q) mxGetPr(ids)[q] = (double)g_session.device_ids[q];
     mxSetField(plhs[0], 0, "device_ids", ids);

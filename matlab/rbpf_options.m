@@ -5,12 +5,14 @@ function o = rbpf_options(varargin)
 %
 %   rbpf_options('lazy_depth', 3, 'chol_refresh', 32);   % before run_dense3D_magfield / run_dense2D_withHeading
 %   o = rbpf_options();                                   % query
-%   rbpf_options('reset');                                % all zero again = the reference's behaviour
+%   rbpf_options('reset');                                % all zero again = the defaults
 %
 %   lazy_depth    C >= 2: rewrite the stored covariances every C-th step only (filter: <= 4, information form: <= 3);
 %                 same algebra, results to rounding
 %   chol_refresh  K > 1: carry the ancestor-weight Cholesky factors of particleSmootherInformationForm along the lineages
-%                 (rank-1 up/down-dates), refactorise every K-th step; ancestor probabilities within 2e-9 of the default
+%                 (rank-1 up/down-dates), refactorise every K-th step: same ancestors and draws, ancestor probabilities within
+%                 2e-9, outputs within 1e-9 of 1 = chol(Imat_i + ImatAddt) from scratch at every step, the reference's own
+%                 arithmetic; 0 (default): automatic -- 32 for the recognised dense families with nLin >= 128, else 1
 %   chol_variant  which kernel factorises (0 automatic); same arithmetic
 %   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9);
 %                 2: double precision, lower block triangle only (particleFilter keeps P symmetric: 0.56 x the memory and
@@ -20,8 +22,6 @@ function o = rbpf_options(varargin)
 %                 reference's outputs (particleFilter: makePlots must be empty)
 %   device_ids    [1 x W] 0-based HIP device of every rank (default 0 .. W-1); a device named twice makes its ranks share
 %                 that GPU over a host-staged transport (a one-GPU machine can so exercise the multi-rank loop)
-%   family_products  1: read-only steps of storage 2 with lazy_depth >= 2 form P*H' per family of particles that share a stored
-%                 matrix on the matrix cores (results to rounding; measured slower than the default on MI355X at lazy_depth 4)
 %   inplace       1 / -1: force / forbid the single covariance bank rewritten in place (0 automatic)
 %   fix_p_mean    1: return the accumulated P_mean instead of the reference's overwritten one (particleFilter.m quirk)
 %   jitter        override of the Cholesky retry jitter (0: the reference's 1e-3 / 1e-2)

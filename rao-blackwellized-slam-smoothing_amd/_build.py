@@ -11,8 +11,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "librbpf_hip.so")
-SOURCES = ["rbpf_kernels.hip", "rbpf_step_sym.hip", "rbpf_api.hip", "rbpf_smoother.hip", "rbpf_shard.hip", "rbpf_multi.hip", "rbpf_plan.hip", "rbpf_resample.hip", "rbpf_sparse.hip", "rbpf_family.hip"]
-HEADERS = ["rbpf_model_dev.hpp", "rbpf_chol64.hpp", "rbpf_chol128.hpp", "rbpf_chol_small.hpp", "rbpf_chol_sweep.hpp", "rbpf_internal.hpp", "rbpf_device.hpp", "rbpf_ctx.hpp", "rbpf_plan.hpp", "rbpf_shard_state.hpp", "rbpf_sparse.hpp"]
+SOURCES = ["rbpf_kernels.hip", "rbpf_step_sym.hip", "rbpf_api.hip", "rbpf_smoother.hip", "rbpf_shard.hip", "rbpf_multi.hip", "rbpf_plan.hip", "rbpf_resample.hip", "rbpf_sparse.hip"]
+HEADERS = ["rbpf_model_dev.hpp", "rbpf_chol64.hpp", "rbpf_chol_small.hpp", "rbpf_chol_sweep.hpp", "rbpf_internal.hpp", "rbpf_device.hpp", "rbpf_ctx.hpp", "rbpf_plan.hpp", "rbpf_shard_state.hpp", "rbpf_sparse.hpp"]
 
 
 def _stale() -> bool:

@@ -68,11 +68,15 @@ ON_STEP_FN = C.CFUNCTYPE(C.c_int, C.POINTER(rbpf_view), C.c_void_p)
 
 
 class rbpf_options(C.Structure):
-    _fields_ = [("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
+    _fields_ = [("struct_size", C.c_int32), ("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
                 ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
                 ("chol_variant", C.c_int32), ("chol_refresh", C.c_int32), ("exchange_capacity", C.c_int32), ("on_step", ON_STEP_FN),
-                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
-                ("family_products", C.c_int32)]
+                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        if "struct_size" not in kw and not args:
+            self.struct_size = C.sizeof(rbpf_options)           # the library refuses options of another layout (ABI 9)
 
 
 class rbpf_filter_out(C.Structure):
@@ -102,7 +106,7 @@ EXPORTS = [
     "rbpf_abi_version", "rbpf_abi_sizeof", "rbpf_status_string", "rbpf_last_error", "rbpf_device_count",
     "rbpf_particle_filter", "rbpf_particle_smoother",
     "rbpf_filter_create", "rbpf_filter_workspace_bytes", "rbpf_filter_advance", "rbpf_filter_reset", "rbpf_sync",
-    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_probe_family_pht", "rbpf_shard_smoother_refresh_reserve", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
+    "rbpf_filter_finish", "rbpf_filter_tell", "rbpf_filter_schedule", "rbpf_plan_refresh", "rbpf_chol_refresh_resolve", "rbpf_shard_smoother_refresh_reserve", "rbpf_shard_xn_traj", "rbpf_filter_ancestors", "rbpf_filter_step_external", "rbpf_timing_enable", "rbpf_timing_read", "rbpf_destroy",
     "rbpf_philox_fill", "rbpf_meas_model", "rbpf_dyn_model", "rbpf_dyn_res_norm", "rbpf_sample",
     "rbpf_jacobian_phi3d", "rbpf_chol_weights", "rbpf_chol_sweep_probe", "rbpf_quat_helpers", "rbpf_probe_wave_reduce",
     "rbpf_shard_create", "rbpf_shard_views_get", "rbpf_shard_normalise_search", "rbpf_shard_pack", "rbpf_shard_step",
@@ -114,6 +118,7 @@ EXPORTS = [
     "rbpf_shard_smoother_step", "rbpf_shard_smoother_end",
 ]
 
+ABI_VERSION = 9            # RBPF_ABI_VERSION of include/rbpf.h this mirror was written against
 _lib = None
 
 
@@ -154,6 +159,17 @@ def load_library(build_if_missing: bool = True):
             raise RBPFError(RBPF_ERR_NO_DEVICE, f"{path} not built (run __graft_entry__.build())")
         _build.build()
     lib = C.CDLL(path)
+    # the version and struct-size checks come before anything touches a newer symbol: a stale .so then says "rebuild" instead of
+    # raising AttributeError on a missing entry point
+    if not hasattr(lib, "rbpf_abi_version") or not hasattr(lib, "rbpf_abi_sizeof"):
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} predates rbpf_abi_version / rbpf_abi_sizeof (rebuild)")
+    if lib.rbpf_abi_version() != ABI_VERSION:
+        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects {ABI_VERSION} (rebuild)")
+    lib.rbpf_abi_sizeof.argtypes = [C.c_int32]
+    for which, mirror in enumerate(ABI_STRUCTS):
+        if lib.rbpf_abi_sizeof(which) != C.sizeof(mirror):
+            raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path}: sizeof({mirror.__name__}) is {lib.rbpf_abi_sizeof(which)}, this mirror has "
+                                                  f"{C.sizeof(mirror)} (include/rbpf.h and _ffi.py disagree)")
     lib.rbpf_status_string.restype = C.c_char_p
     lib.rbpf_status_string.argtypes = [C.c_int]
     lib.rbpf_last_error.restype = C.c_char_p
@@ -192,13 +208,8 @@ def load_library(build_if_missing: bool = True):
     lib.rbpf_chol_sweep_probe.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int32,
                                           c_double_p, c_double_p, c_int32_p, c_double_p]
     lib.rbpf_quat_helpers.argtypes = [C.c_int32, C.c_int32, c_double_p, c_double_p]
-    if lib.rbpf_abi_version() != 8:
-        raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path} has ABI version {lib.rbpf_abi_version()}, this mirror expects 8 (rebuild)")
-    lib.rbpf_abi_sizeof.argtypes = [C.c_int32]
-    for which, mirror in enumerate(ABI_STRUCTS):
-        if lib.rbpf_abi_sizeof(which) != C.sizeof(mirror):
-            raise RBPFError(RBPF_ERR_INVALID_ARG, f"{path}: sizeof({mirror.__name__}) is {lib.rbpf_abi_sizeof(which)}, this mirror has "
-                                                  f"{C.sizeof(mirror)} (include/rbpf.h and _ffi.py disagree)")
+    lib.rbpf_chol_refresh_resolve.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.rbpf_chol_refresh_resolve.restype = C.c_int32
     _lib = lib
     return lib
 

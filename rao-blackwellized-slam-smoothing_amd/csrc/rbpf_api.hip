@@ -212,6 +212,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   *out = nullptr;
   RB_TRY(validate_problem(prob));
   if (!rng) { set_error("rng is NULL"); return RBPF_ERR_INVALID_ARG; }
+  RB_TRY(options_ok(opt));
   if (!have_device()) { set_error("no HIP device visible: the RBPF product path has no CPU fallback"); return RBPF_ERR_NO_DEVICE; }
   rbpf_ctx* c = new rbpf_ctx();
   std::unique_ptr<rbpf_ctx, void (*)(rbpf_ctx*)> guard(c, [](rbpf_ctx* p) { ctx_free(p); });
@@ -378,14 +379,6 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     RB_TRY(dmalloc(&c->d_share_writers, 1));
     HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));
   }
-  // read-only steps of the filter through the family products (also the sharded filter: N is the local count)
-  c->family_on = c->opt.family_products > 0 && c->lazy_depth >= 2 && !smoother && c->lay.sym && c->lay.CH64 == 8 && !c->fp32 && d == 3 &&
-                 c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;
-  if (c->family_on) {
-    RB_TRY(dmalloc(&c->d_fam_H, (size_t)N * d * L.ldx));
-    RB_TRY(dmalloc(&c->d_fam_PHt, (size_t)N * d * L.mc));
-    RB_TRY(dmalloc(&c->d_fam_idx, (size_t)2 * N + 2 + (N + 1023) / 1024));
-  }
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
     if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
@@ -462,7 +455,6 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
-  hipFree(c->d_fam_H); hipFree(c->d_fam_PHt); hipFree(c->d_fam_idx);
   hipFree(c->d_ip); hipFree(c->d_share); hipFree(c->d_share_writers); hipFree(c->d_distinct_mark); hipFree(c->d_distinct_counter);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
@@ -731,7 +723,6 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.status = c->d_flags;
   a.stamps = reinterpret_cast<unsigned long long*>(c->d_counts + 2 * N + 32);
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d;
-  if (c->family_on) { a.fam_H = c->d_fam_H; a.fam_PHt = c->d_fam_PHt; a.fam_idx = c->d_fam_idx; }
   // fused fast path with the device generator: the uniforms of step t+1 are produced here, in parallel
   a.u_next = (c->fuse_resample && c->rng_mode == RBPF_RNG_PHILOX && t + 1 < c->T) ? c->d_unext : nullptr;
   a.info = info ? 1 : 0;
@@ -945,6 +936,7 @@ int rbpf_device_count(void) {
 
 int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, const rbpf_options* opt, size_t* bytes) {
   if (!model || !p || !bytes) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
+  RB_TRY(options_ok(opt));
   const Layout L = (opt && opt->storage == 2 && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y) : make_layout(p->n_lin, p->n_y);
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;
@@ -1237,6 +1229,7 @@ int rbpf_filter_finish(rbpf_ctx* c, rbpf_filter_out* o) {
 
 int rbpf_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
                          rbpf_filter_out* out) {
+  RB_TRY(options_ok(opt));
   if (wants_multi(opt)) return multi_particle_filter(model, prob, rng, opt, out);      // sharded over several GPUs in this process
   rbpf_ctx* c = nullptr;
   int s = rbpf_filter_create(model, prob, rng, opt, &c);
@@ -1420,47 +1413,6 @@ int rbpf_probe_wave_reduce(const double* in, double* out) {
   HIPCHK(launch_probe_wave_reduce(di.as<double>(), dout.as<double>(), 0));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, dout.p, 4 * 8, hipMemcpyDeviceToHost));
-  return RBPF_OK;
-}
-
-// Probe entry (tests / tools only): host arrays in, PHt out, mean launch time of `reps` launches (HIP events).
-int rbpf_probe_family_pht(int32_t CH, int32_t n_mat, int32_t N, int32_t F, const double* T, const double* H, const int32_t* fam_start,
-                                     const int32_t* fam_base, int32_t reps, int32_t replicate_T, double* PHt, double* ms) {
-  if (!have_device()) { set_error("no HIP device"); return RBPF_ERR_NO_DEVICE; }
-  if ((CH != 8 && CH != 4) || n_mat < 1 || N < 1 || F < 1 || !T || !H || !fam_start || !fam_base || !PHt || reps < 1 || replicate_T < 1) {
-    set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
-  }
-  const size_t mc = (size_t)64 * CH, szT = (size_t)CH * (CH + 1) / 2 * 4096;
-  // replicate_T > 1: the n_mat host matrices are tiled replicate_T times on the device (timing runs with many distinct matrices
-  // without shipping them); fam_base then indexes the replicated bank
-  const size_t n_dev = (size_t)n_mat * replicate_T;
-  DevBuf dT, dH, dS, dB, dO;
-  RB_TRY(dT.alloc(n_dev * szT * 8)); RB_TRY(dH.alloc((size_t)N * mc * 3 * 8)); RB_TRY(dS.alloc((size_t)(F + 2) * 4)); RB_TRY(dB.alloc((size_t)F * 4));
-  RB_TRY(dO.alloc((size_t)N * 3 * mc * 8));
-  for (int rpl = 0; rpl < replicate_T; ++rpl)
-    HIPCHK(hipMemcpy(dT.as<double>() + (size_t)rpl * n_mat * szT, T, (size_t)n_mat * szT * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dH.p, H, (size_t)N * mc * 3 * 8, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dS.p, fam_start, (size_t)(F + 1) * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dB.p, fam_base, (size_t)F * 4, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(dS.as<int>() + F + 1, &F, 4, hipMemcpyHostToDevice));         // the family count lives on the device
-  HIPCHK(hipMemset(dO.p, 0, (size_t)N * 3 * mc * 8));
-  hipEvent_t e0, e1;
-  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-  FamilyArgs fa;
-  fa.T = dT.as<double>(); fa.t_stride = szT; fa.rec = nullptr; fa.rec_stride = 0; fa.n_bank_local = 0;
-  fa.H = dH.as<double>(); fa.ldh = mc; fa.h_off = 0;
-  fa.fam_start = dS.as<int>(); fa.fam_base = dB.as<int>(); fa.n_fam = dS.as<int>() + F + 1;
-  fa.PHt = dO.as<double>();
-  HIPCHK(launch_family_pht(CH, fa, F, 0));   // warm-up
-  HIPCHK(hipEventRecord(e0, 0));
-  for (int r = 0; r < reps; ++r) HIPCHK(launch_family_pht(CH, fa, F, 0));
-  HIPCHK(hipEventRecord(e1, 0));
-  HIPCHK(hipEventSynchronize(e1));
-  float t = 0.f;
-  HIPCHK(hipEventElapsedTime(&t, e0, e1));
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  HIPCHK(hipMemcpy(PHt, dO.p, (size_t)N * 3 * mc * 8, hipMemcpyDeviceToHost));
-  if (ms) *ms = (double)t / reps;
   return RBPF_OK;
 }
 

@@ -68,21 +68,6 @@
 #ifndef RBPF_C64_LARING
 #define RBPF_C64_LARING 8                        // operand ring depth of the look-ahead diagonal products
 #endif
-#ifndef RBPF_C64_SOLO_MAXJ
-#define RBPF_C64_SOLO_MAXJ 5                     // variant 649 (rbpf_chol_weights / rbpf_options.chol_variant): wave 0 forms the tiles of the diagonal
-                                                 // block ITSELF (elements + panel product) in block columns 0 .. this (interior blocks, 8-wave shape)
-                                                 // instead of waiting for waves 4..7 to hand them over, and loads the next block's elements while the
-                                                 // workers solve.  The phase clocks (r04) showed waves 1..3 a third of their time at the first barrier,
-                                                 // waiting for waves 4..7, which carry the diagonal rows on top of a full share of strips, while wave 0
-                                                 // spins for those rows.  Late block columns keep the hand-over (few strips per worker, long diagonal
-                                                 // rows).  Same sums in the same order either way (bit-identical factors).  Stand-alone 15.6 -> 14.8 ms
-                                                 // per 8192 at n = 515; inside the smoother no change, hence a variant, not the default.
-#endif
-#ifndef RBPF_C64_SOLO_REST4
-#define RBPF_C64_SOLO_REST4 0                    // 1: in those block columns wave 4 -- wave 0's neighbour on its SIMD -- takes no strips and the six
-                                                 // other workers share them.  Measured: wave 0's factorisation gets faster (0.24 -> 0.16 M clocks per
-                                                 // matrix), the six workers become the critical path: 15.4 ms per 8192 against 14.8
-#endif
 #ifndef RBPF_C64_INT1
 #define RBPF_C64_INT1 4                          // information form: first row tile below the diagonal block that takes the fast loader
 #endif
@@ -531,191 +516,39 @@ __device__ inline bool c64_diag_block_body(double* __restrict__ Lt, int KGS, int
   return c64_diag_factor(Z, Lt, KGS, J, nd, M, lane, NLs, Lds C64_STAMP_PASS);
 }
 
-// Wave 0 on its own (RBPF_C64_SOLO_MAXJ): the ten tiles of an INTERIOR diagonal block (64 J + 64 <= M).
-// Elements of all four row tiles in two rounds of loads (c64_diag_elems_fast row by row is four memory round trips); the operations on
-// an element and their order are c64_diag_elems_fast's.
-template <int MODE>
-__device__ inline void c64_solo_elems(const CholArgs& a, int p, int J, int M, const double* Hs, const double* RH, double jit, int lane,
-                                      v4d (&Z)[4][4]) {
-  const int r = lane & 15, g = lane >> 4;
-  const int ld = (MODE == 0) ? M : a.n;
-  const unsigned lo = (unsigned)(r + ld * g);
-  const bool pk = (MODE == 1) && a.imat_packed;
-  const c64_gdouble* src[4]; const c64_gdouble* add[4]; c64_gdouble* dst[4];
-#pragma unroll
-  for (int I = 0; I < 4; ++I) {
-    const size_t t0 = pk ? imat_packed_row(4 * J + I) + (size_t)(16 * J) * 64 : (size_t)(16 * (4 * J + I)) + (size_t)ld * (64 * J);   // wave-uniform
-    src[I] = c64_g((MODE == 0) ? a.S + (size_t)p * M * M : a.Imat + (size_t)p * a.imat_stride) + t0;
-    add[I] = (MODE == 1) ? c64_g(a.ImatAdd) + t0 : nullptr;
-    dst[I] = (MODE == 1 && a.ImatOut) ? c64_g(a.ImatOut) + (size_t)p * a.imat_out_stride + t0 : nullptr;
-  }
-  unsigned off[4][4];                                                          // (per-lane offsets, opaque: see c64_strip_fast)
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { off[c][q] = pk ? (unsigned)(lane + 64 * (4 * c + q)) : lo + (unsigned)(ld * (16 * c + 4 * q)); asm volatile("" : "+v"(off[c][q])); }
-  // two batches of loads (row tiles 0..2: six tiles, row tile 3: four): all ten at once are 160 registers of raw values beside the tiles
-#pragma unroll
-  for (int batch = 0; batch < 2; ++batch) {
-    const int I0 = batch == 0 ? 0 : 3, I1 = batch == 0 ? 3 : 4;
-    double v[4][4][4], ad[4][4][4];
-    C64_PIN();
-#pragma unroll
-    for (int I = I0; I < I1; ++I)
-#pragma unroll
-      for (int c = 0; c <= I; ++c)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          v[I][c][q] = src[I][off[c][q]];
-          ad[I][c][q] = (MODE == 1) ? add[I][off[c][q]] : 0.0;
-        }
-    C64_PIN();
-#pragma unroll
-    for (int I = I0; I < I1; ++I) {
-      const int i0 = 16 * (4 * J + I);
-#pragma unroll
-      for (int c = 0; c <= I; ++c) {
-        if (MODE == 0) {
-          if (a.R) {                                                           // kron(eye, R)
-            const __attribute__((address_space(3))) int* dv = (const __attribute__((address_space(3))) int*)Hs;
-            const int di = dv[i0 + r];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int dj = dv[64 * J + 16 * c + 4 * q + g];
-              const double rr = a.R[(di & 7) + a.d * (dj & 7)];
-              v[I][c][q] += ((di >> 3) == (dj >> 3)) ? rr : 0.0;
-            }
-          }
-        } else {
-          if (Hs) {                                                            // + dyi'/R*dyi of the last update (:334)
-            double sacc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int aa = 0; aa < a.d; ++aa) {
-              const double h = c64_l(Hs)[aa * M + i0 + r];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) sacc[q] = fma(h, c64_l(RH)[aa * M + 64 * J + 16 * c + 4 * q + g], sacc[q]);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[I][c][q] += sacc[q];
-          }
-          if (dst[I]) {                                                        // Imat(:,:,i) of the new generation
-#pragma unroll
-            for (int q = 0; q < 4; ++q)                                        // (packed storage: the lower triangle only)
-              if (!pk || 16 * I + r >= 16 * c + 4 * q + g) __builtin_nontemporal_store(v[I][c][q], &dst[I][off[c][q]]);
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[I][c][q] += ad[I][c][q];               // :225
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = 16 * I + r, col = 16 * c + 4 * q + g;                // inside the block
-          if (row == col) v[I][c][q] += jit;
-          Z[I][c][q] = (row >= col) ? -v[I][c][q] : 0.0;
-        }
-      }
-    }
-  }
-}
-
-// ... their panel product: one MFMA per tile and column group, column groups ascending (the sums c64_diag_product forms)
-__device__ inline void c64_solo_product(const double* __restrict__ Lt, int KGS, int J, int lane, v4d (&Z)[4][4]) {
-  if (J <= 0) return;
-  constexpr int kRing = 8;
-  const c64_gdouble* pf[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) pf[c] = c64_g(Lt) + (size_t)(4 * J + c) * KGS * 64;   // wave-uniform bases, + lane per load
-  const int nkg = 16 * J;
-  double F[kRing][4];
-#pragma unroll
-  for (int b = 0; b < kRing; ++b) {
-    C64_PIN();
-#pragma unroll
-    for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + (size_t)b * 64)[lane];
-    C64_PIN();
-  }
-  // (nkg is a multiple of 16.)  The last round is peeled and requests nothing: clamped re-reads at the end of the loop would sit in
-  // front of whatever the factorisation waits for next (the memory counter is in order)
-  for (int kg = 0; kg + kRing < nkg; kg += kRing) {
-#pragma unroll
-    for (int b = 0; b < kRing; ++b) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int c = 0; c <= i; ++c) Z[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][i], Z[i][c], 0, 0, 0);
-      const size_t kn = (size_t)(kg + kRing + b) * 64;
-      C64_PIN();
-#pragma unroll
-      for (int c = 0; c < 4; ++c) F[b][c] = (pf[c] + kn)[lane];
-      C64_PIN();
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < kRing; ++b) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int c = 0; c <= i; ++c) Z[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(F[b][c], F[b][i], Z[i][c], 0, 0, 0);
-  }
-}
-
 __device__ __attribute__((noinline)) bool c64_diag_block(double* __restrict__ Lt, int KGS, int J, int nd, int M, int lane,
                                                          const double* Zd, double* NLs, double* Lds C64_STAMP_ARGS) {
   return c64_diag_block_body(Lt, KGS, J, nd, M, lane, Zd, NLs, Lds C64_STAMP_PASS);
 }
 
-// does wave 0 form the tiles of block column J's diagonal block itself?  (interior blocks of the 8-wave shape)
-__device__ inline bool c64_solo(int W, int J, int RT, int M, int maxj) {
-  return W == 8 && !RBPF_C64_LOOKAHEAD && RBPF_C64_DIAGFAST && J <= maxj && RT - 4 * J >= 4 && 64 * J + 64 <= M;
-}
-
-// Wave 0's side of the block column loop, a function of its own (registers of its own: the tiles of the NEXT diagonal block stay
-// in registers across the two barriers).  Per block column: the diagonal block's tiles -- handed over by waves 4..7, or formed
-// here (c64_solo) --, factorisation, barrier A (the workers' solves may start); the ELEMENTS of the next diagonal block, which
-// depend on nothing, are loaded while the workers solve; barrier B.  Executes exactly the barriers of the workers' loop.
+// Wave 0's side of the block column loop, a function of its own (registers of its own).  Per block column: the diagonal block's
+// tiles handed over by waves 4..7, factorisation, barrier A (the workers' solves may start), barrier B.  Executes exactly the
+// barriers of the workers' loop.  (r04 also measured wave 0 forming the interior diagonal blocks itself and prefetching the next
+// block's elements behind the workers' solves -- "variant 649": 15.6 -> 14.8 ms per 8192 stand-alone, no gain inside the smoother;
+// removed in r05, see commit 4711b84 and DESIGN_NOTEBOOK.md 9.)
 template <int MODE, int W>
-__device__ __attribute__((noinline)) void c64_wave0_loop(const CholArgs* ka, const double* imat_src, int p, double* __restrict__ Lt,
-                                                         int KGS, int RT, int M, const double* Hs, const double* RH, double jit, int lane,
+__device__ __attribute__((noinline)) void c64_wave0_loop(double* __restrict__ Lt, int KGS, int RT, int M, int lane,
                                                          double* csm, int* sfail, int* ready C64_STAMP_ARGS) {
-  CholArgs a = *ka;
-  a.Imat = imat_src;                              // (resolved by the kernel: ancestor's bank entry or received record)
-  a.imat_stride = 0;
   const int NJ = (RT + 3) >> 2;
   int handed = 0;
-  v4d Z[4][4];
-  bool have = false;                              // Z holds the elements of block column J's diagonal block
   for (int J = 0; J < NJ; ++J) {
     const int nd = min(4, RT - 4 * J);
     double* NLs = csm + (size_t)(J & 1) * 2560;
     double* Lds = NLs + 1024;
-    const bool solo = c64_solo(W, J, RT, M, a.solo_maxj);
-    if (!solo) handed += nd;
-    bool bad;
-    if (solo) {
-      if (!have) c64_solo_elems<MODE>(a, p, J, M, Hs, RH, jit, lane, Z);
-      C64_STAMP(0);
-      c64_solo_product(Lt, KGS, J, lane, Z);
-      C64_STAMP(1);
-      bad = c64_diag_factor(Z, Lt, KGS, J, 4, M, lane, NLs, Lds C64_STAMP_PASS);
-    } else {
-      int spins = 0;
-      if (!RBPF_C64_LOOKAHEAD) {                  // only this wave waits; bounded, so a lost hand-off cannot hang the GPU
-        while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
-          __builtin_amdgcn_s_sleep(4);
-          ++spins;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    handed += nd;
+    int spins = 0;
+    if (!RBPF_C64_LOOKAHEAD) {                    // only this wave waits; bounded, so a lost hand-off cannot hang the GPU
+      while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < handed && spins < (1 << 24)) {
+        __builtin_amdgcn_s_sleep(4);
+        ++spins;
       }
-      C64_STAMP(0);
-      bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS) || spins >= (1 << 24);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    C64_STAMP(0);
+    const bool bad = c64_diag_block(Lt, KGS, J, nd, M, lane, NLs, NLs, Lds C64_STAMP_PASS) || spins >= (1 << 24);
     if (bad && lane == 0) sfail[J & 1] = 1;
     __syncthreads();                              // A
     C64_STAMP(3);
-    have = false;
-    if (J + 1 < NJ && c64_solo(W, J + 1, RT, M, a.solo_maxj)) {
-      c64_solo_elems<MODE>(a, p, J + 1, M, Hs, RH, jit, lane, Z);
-      have = true;
-    }
-    C64_STAMP(6);
     __syncthreads();                              // B: the block column is visible to the next panel products
     C64_STAMP(5);
 #if !defined(RBPF_C64_DIAG_AFIXED) && !defined(RBPF_C64_DIAG_BFIXED)
@@ -913,29 +746,26 @@ __global__ __launch_bounds__(W * 64, W == 8 ? 1 : 2) void chol_solve64_kernel(Ch
       __syncthreads();
     }
     if (wv == 0) {
-      c64_wave0_loop<MODE, W>(c64_kernarg(), a.Imat, p, Lt, KGS, RT, M, Hs, RH, jit, lane, csm, sfail, ready C64_STAMP_PASS);
+      c64_wave0_loop<MODE, W>(Lt, KGS, RT, M, lane, csm, sfail, ready C64_STAMP_PASS);
     } else
     for (int J = 0; J < NJ; ++J) {
       const int nd = min(4, RT - 4 * J);
       const int first = 4 * J + nd, count = RT - first;
       double* NLs = csm + (size_t)(J & 1) * 2560;
       double* Lds = NLs + 1024;
-      const bool solo = c64_solo(W, J, RT, M, a.solo_maxj);   // wave 0 forms the diagonal block's tiles itself: no hand-over
-      // workers of this block column and this wave's place among them (RBPF_C64_SOLO_REST4: wave 4 rests beside a solo wave 0)
-      const bool rest4 = solo && RBPF_C64_SOLO_REST4 && W == 8;
-      const int nwork = rest4 ? W - 2 : W - 1, widx = (rest4 && wv > 4) ? wv - 2 : wv - 1;
+      const int nwork = W - 1, widx = wv - 1;      // workers of this block column and this wave's place among them
       const int tiles_per_pass = kNTMax * nwork;
       const int npass = max(1, (count + tiles_per_pass - 1) / tiles_per_pass);
       {
         if (RBPF_C64_LOOKAHEAD) { if (J + 1 < NJ) lookahead(J + 1); }
-        else if (!solo) lookahead(J);
+        else lookahead(J);
         for (int pass = 0; pass < npass; ++pass) {
           int rt[4], nt = 0;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int u = tiles_per_pass * pass + widx + nwork * s;
             rt[s] = first + min(u, count - 1);
-            nt += (s < kNTMax && u < count && !(rest4 && wv == 4)) ? 1 : 0;
+            nt += (s < kNTMax && u < count) ? 1 : 0;
           }
 #define RBPF_C64(NT_, LATE_) c64_tile_pass<NT_, MODE, LATE_, true>(a, p, Lt, KGS, J, rt, M, rhs_s, Hs, RH, jit, lane, NLs, Lds, pass == 0 C64_STAMP_PASS)
 #if RBPF_C64_LATE
@@ -1017,7 +847,6 @@ static hipError_t launch_chol64_mode(const CholArgs& ca, int batch, size_t lds, 
   if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&chol_solve64_kernel<MODE, W>), (int)kC64MaxLds, attr)) return e;
   CholArgs cb = ca;
   cb.batch = batch;
-  cb.solo_maxj = (ca.variant == 649) ? RBPF_C64_SOLO_MAXJ : -1;
   const int grid = (cb.l_slots > 0) ? std::min(batch, cb.l_slots) : batch;
   hipLaunchKernelGGL((chol_solve64_kernel<MODE, W>), dim3(grid), dim3(W * 64), lds, st, cb);
   return hipGetLastError();

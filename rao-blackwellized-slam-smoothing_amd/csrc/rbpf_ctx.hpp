@@ -91,11 +91,6 @@ struct rbpf_ctx {
   int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)
   unsigned long long* d_share_writers = nullptr;   // writers of the timed shared flushes (device counter)
   long long share_flush_particles = 0;          // particles of the timed shared flushes (N per flush step)
-  // family products (rbpf_options.family_products, rbpf_family.hip): workspace of the read-only steps, by processing position
-  bool family_on = false;
-  double* d_fam_H = nullptr;                    // [N][d][ldx]
-  double* d_fam_PHt = nullptr;                  // [N][d][mc]
-  int* d_fam_idx = nullptr;                     // fam_start [N + 1], fam_base [N], n_fam [1], heads per 1024 positions [ceil(N / 1024)]
   // timed launches: reads of stored matrices counted per particle (nominal) and per DISTINCT matrix (device counter)
   int* d_distinct_mark = nullptr; size_t distinct_keys = 0; unsigned long long* d_distinct_counter = nullptr;
   long long distinct_nominal = 0; int distinct_epoch = 0;
@@ -148,6 +143,18 @@ int ctx_arm_distinct(rbpf_ctx* c, StepArgs& a, size_t keys);
 int ctx_unpack(rbpf_ctx* c, const int* d_index, int count, double* d_out);
 void smoother_free(rbpf_ctx* c);
 // in-library multi-device driver (rbpf_multi.hip): rbpf_options.n_devices
+// rbpf_options.struct_size (ABI 9): a caller compiled against another layout is refused before any field is trusted
+inline int options_ok(const rbpf_options* o) {
+  if (!o || o->struct_size == 0 || o->struct_size == (int32_t)sizeof(rbpf_options)) return RBPF_OK;
+  set_error("rbpf_options.struct_size = " + std::to_string(o->struct_size) + ", this library's rbpf_options has " + std::to_string(sizeof(rbpf_options)) +
+            " bytes (ABI " + std::to_string(RBPF_ABI_VERSION) + "): rebuild the binding against include/rbpf.h");
+  return RBPF_ERR_INVALID_ARG;
+}
+// the K rbpf_options.chol_refresh stands for (rbpf_chol_refresh_resolve; rbpf_smoother.hip)
+int resolve_chol_refresh(int model_kind, int n, int d, int requested);
+// an explicit kernel choice (chol_variant) names the kernel of the from-scratch factorisation: with chol_refresh left at 0
+// (automatic) it selects that factorisation at every step
+inline int effective_chol_refresh(const rbpf_options& o) { return (o.chol_refresh == 0 && o.chol_variant != 0) ? 1 : o.chol_refresh; }
 inline bool wants_multi(const rbpf_options* o) { return o && (o->n_devices > 1 || (o->n_devices == 1 && o->device_ids)); }
 int multi_particle_filter(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
                           rbpf_filter_out* out);

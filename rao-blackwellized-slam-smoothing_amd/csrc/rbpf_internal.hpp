@@ -168,11 +168,6 @@ struct StepArgs {
   const double* hld_old; size_t hld_old_stride; double* hld_new;      // halfLogDetP [N]
   double* qf_new;                                                     // ivec'*P*ivec after the update [N]
   double* Hb_new;                                                     // [N][d][ldx] H_i of this step
-  // family products (rbpf_family.hip): workspace of a read-only step on block-lower storage, by processing position; null: the
-  // one-workgroup-per-particle stream
-  double* fam_H = nullptr;                                            // [N][d][ldx]
-  double* fam_PHt = nullptr;                                          // [N][d][mc]
-  int* fam_idx = nullptr;                                             // fam_start [N + 1], fam_base [N], n_fam [1], scratch [ceil(N / 1024)]
 };
 
 struct NormArgs {
@@ -211,8 +206,7 @@ Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
 Layout make_layout_sym(int n, int d);            // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
 bool sym_supported(int n, int d);
-size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra = 0, int px = 0);   // extra = 1: information form
-bool sym_family_step(const StepArgs& a);         // does launch_step_sym take the family products for these arguments?
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra = 0);   // extra = 1: information form
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s);
 // wave-level reduction primitives of the symmetric step kernel on their own (tests): in [4][64] -> out [4] lane sums
 hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s);
@@ -254,17 +248,6 @@ hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, cons
                                 int count, double* P_colmajor, hipStream_t s, int fp32 = 0);
 hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
                                    hipStream_t s);
-// rbpf_family.hip: P_base * [H_1' ... H_f'] per family of particles that share a stored matrix, on the fp64 matrix cores (core rows)
-struct FamilyArgs {
-  const double* T; size_t t_stride;                       // block T of the bank ([entry][t_stride])
-  const double* rec; size_t rec_stride; int n_bank_local; // entries >= n_bank_local: records (sharded filter); rec null: none
-  const double* H; size_t ldh; int h_off;                 // [position][3][ldh], core column c at h_off + c
-  const int* fam_start; const int* fam_base; const int* n_fam;   // family table on the device
-  double* PHt;                                            // out [position][3][mc]
-};
-hipError_t launch_family_pht(int CH, const FamilyArgs& fa, int max_families, hipStream_t s);
-// index + measModel + product of a read-only filter step (a.fam_* set); launch_step_sym then runs the per-particle rest
-hipError_t launch_family_products(const StepArgs& a, hipStream_t s);
 hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,
                             int n_paths, double* out, hipStream_t s);
 hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,

@@ -285,7 +285,7 @@ int create(Multi& M, const rbpf_model* model, const rbpf_problem* prob, const rb
   }
   M.Nloc = prob->N_P / W; M.Nglob = prob->N_P; M.T = prob->N_T; M.nN = prob->n_nonlin; M.n = prob->n_lin;
   M.ctx.assign(W, nullptr); M.v.resize(W); M.stream.assign(W, nullptr); M.comm.assign(W, nullptr); M.sv.resize(W);
-  M.chol_refresh = smoother ? opt->chol_refresh : 0;
+  M.chol_refresh = smoother ? resolve_chol_refresh(model->kind, prob->n_lin, prob->n_y, effective_chol_refresh(*opt)) : 0;
   M.h_send.resize(W); M.h_cnt.resize(W); M.bar.n = W;
   if (!M.host_staged) {
     std::lock_guard<std::mutex> lk(g_rccl_mutex);

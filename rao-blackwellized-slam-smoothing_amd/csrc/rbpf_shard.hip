@@ -53,6 +53,7 @@ static int dmalloc(T** p, size_t count) {
 int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng, const rbpf_options* opt,
                             int32_t rank, int32_t world, bool smoother, int N_K, rbpf_ctx** out) {
   if (!prob || !out || world < 1 || rank < 0 || rank >= world) { set_error("bad shard arguments"); return RBPF_ERR_INVALID_ARG; }
+  RB_TRY(options_ok(opt));
   if (prob->x0_lin_cols != 1) { set_error("sharded filter: x0_lin must be nLin x 1"); return RBPF_ERR_UNSUPPORTED; }
   const size_t Nloc = (size_t)prob->N_P;
   if (world > kMaxWorld) { set_error("world size above 64 is not supported"); return RBPF_ERR_UNSUPPORTED; }
@@ -87,7 +88,7 @@ int rbpf::shard_create_impl(const rbpf_model* model, const rbpf_problem* prob, c
     s->rec_off_hld = s->rec_off_I + L.ldx;
     s->rec_off_Hb = s->rec_off_hld + 2;
     s->rec_off_Imat = s->rec_off_Hb + (size_t)d * L.ldx;
-    s->recsz = s->rec_off_Imat + smoother_record_matrix_doubles((int)n, (int)d, o.chol_refresh);
+    s->recsz = s->rec_off_Imat + smoother_record_matrix_doubles((int)n, (int)d, resolve_chol_refresh(c->mdl.kind, (int)n, (int)d, effective_chol_refresh(o)));
     s->recsz += s->recsz & 1;
   }
   if (world > 1) {
@@ -362,7 +363,6 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.stamps = nullptr;
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d; a.u_next = nullptr;
   a.phase = -1;                                            // (every slot; the shared flush below launches by phase)
-  if (c->family_on) { a.fam_H = c->d_fam_H; a.fam_PHt = c->d_fam_PHt; a.fam_idx = c->d_fam_idx; }
   // shared flush (see ctx_step): the children of one parent -- one bank entry or one received record -- store ONE flushed matrix
   const bool share = lazy && flush && t > 0 && dev_plan && L.sym && L.CH64 == 8 && !c->fp32 && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
   if (share) {

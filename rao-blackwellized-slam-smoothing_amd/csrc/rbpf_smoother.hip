@@ -57,6 +57,7 @@ struct SmootherState {
   bool imat_packed = false;     // the banks, Imat0 and ImatAdd in packed block-lower storage (imat_packed_index)
   size_t imat_len = 0;          // doubles per information matrix of the banks: n * n, or imat_packed_doubles(n)
   size_t Mmax = 0;
+  int l_chunk = 0;              // carried factors: matrices per launch of the refresh factorisation (d_L holds that many workspaces)
   // sharded information-form smoother
   double* d_Rinv = nullptr;     // [d*d]
   std::vector<double> h_ivec0;  // [ldx]
@@ -136,6 +137,19 @@ __global__ void anc_dyn_ext_kernel(int N, int nw, const double* __restrict__ e_d
   out[i] = log(w[i]) + (-0.5 * ss);
 }
 
+// Packed storage of the information matrices (r03; the default-arithmetic information-form smoother at nLin >= 176).  They are
+// symmetric and only their block-lower half is ever read (the factorisation), so a matrix is stored as its row tiles of 16 rows,
+// row tile rt holding its 4 (rt + 1) column groups of 4 columns, 64 values each at kk * 16 + r -- the fragment order of the factor
+// storage, i.e. the lane order of an MFMA operand.  A 16 x 64 strip of the matrix is then 8 KB of consecutive memory (16 wave loads
+// of 512 B) instead of 64 segments of 128 B at a stride of 8 n bytes, and a bank entry takes 128 RT (RT + 1) doubles
+// (1.15 MB at nLin = 515) instead of n * n (2.12 MB).  Inside the diagonal tiles the positions above the diagonal exist but are
+// never written and never read unmasked.
+__host__ __device__ inline size_t imat_packed_row(int rt) { return (size_t)128 * rt * (rt + 1); }
+__host__ __device__ inline size_t imat_packed_doubles(int n) { return imat_packed_row((n + 15) >> 4); }
+__host__ __device__ inline size_t imat_packed_index(int i, int j) {                // i >= j
+  return imat_packed_row(i >> 4) + (size_t)(j >> 2) * 64 + (size_t)((j & 3) * 16 + (i & 15));
+}
+
 // Generic strided fp64 GEMM on the matrix cores, batched over blockIdx.z:  C = A * B.
 // Element (i,k) of A at A[i*rsA + k*csA] etc.  64 x 64 output tile per workgroup, 4 waves of 32 x 32
 // (2 x 2 v_mfma_f64_16x16x4 tiles); 16-deep slices of A and B go through LDS k-major so that an MFMA operand
@@ -150,6 +164,9 @@ struct GemmArgs {
   // add_rec [..][M*N]; add_idx null: entry 0) -- the refresh of the carried factors adds the base matrix in the epilogue.
   int lower;
   const double* add; long add_stride; const int* add_idx; const double* add_rec; int add_nbank;
+  // packed (zero: off): C -- symmetric, M == N -- and the matrices `add` / `add_rec` point at are information matrices in packed
+  // block-lower storage (imat_packed_index below; bsC, add_stride and the records' pitch = imat_packed_doubles(M)); rsC / csC unused
+  int packed;
 };
 
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
@@ -213,7 +230,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const double* addp = nullptr;
   if (g.add) {
     const int e = g.add_idx ? g.add_idx[bz] : 0;
-    addp = (g.add_rec && e >= g.add_nbank) ? g.add_rec + (size_t)(e - g.add_nbank) * g.M * g.N : g.add + (size_t)e * g.add_stride;
+    const size_t rec_pitch = g.packed ? imat_packed_doubles(g.M) : (size_t)g.M * g.N;
+    addp = (g.add_rec && e >= g.add_nbank) ? g.add_rec + (size_t)(e - g.add_nbank) * rec_pitch : g.add + (size_t)e * g.add_stride;
+  }
+  if (g.packed) {
+    // the product is symmetric: this tile's element (a, b) is stored as row b, column a of the block-lower matrix -- the lanes
+    // of a result register (b = lane & 15 fastest, then a & 3 = lane >> 4) are then 64 consecutive doubles of the packed layout
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int y = 0; y < 2; ++y)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ca = i0 + wi + 16 * x + (lane >> 4) + 4 * r, rb = j0 + wj + 16 * y + (lane & 15);   // column, row
+          if (rb < g.M && ca < g.M && (ca >> 4) <= (rb >> 4)) {
+            const size_t o = imat_packed_index(rb, ca);
+            C[o] = addp ? acc[x][y][r] + addp[o] : acc[x][y][r];
+          }
+        }
+    return;
   }
 #pragma unroll
   for (int x = 0; x < 2; ++x)
@@ -269,24 +304,9 @@ struct CholArgs {
   int* status;
   int variant;                      // host side only: rbpf_options.chol_variant (0: kernel by matrix size)
   int batch, l_slots;               // 64-column kernel: l_slots > 0 = persistent workgroups, Lbuf holds l_slots factor workspaces
-  int solo_maxj;                    // 64-column kernel, 8 waves: wave 0 forms the diagonal blocks of block columns 0 .. solo_maxj itself (-1: never;
-                                    // variant 649: rbpf_chol64.hpp, c64_solo)
   int imat_packed;                  // mode 1: Imat / ImatAdd / ImatOut / the records' matrices in packed storage (below)
   long imat_out_stride;             // doubles between two matrices of ImatOut (n * n, or imat_packed_doubles(n))
 };
-
-// Packed storage of the information matrices (r03; the default-arithmetic information-form smoother at nLin >= 176).  They are
-// symmetric and only their block-lower half is ever read (the factorisation), so a matrix is stored as its row tiles of 16 rows,
-// row tile rt holding its 4 (rt + 1) column groups of 4 columns, 64 values each at kk * 16 + r -- the fragment order of the factor
-// storage, i.e. the lane order of an MFMA operand.  A 16 x 64 strip of the matrix is then 8 KB of consecutive memory (16 wave loads
-// of 512 B) instead of 64 segments of 128 B at a stride of 8 n bytes, and a bank entry takes 128 RT (RT + 1) doubles
-// (1.15 MB at nLin = 515) instead of n * n (2.12 MB).  Inside the diagonal tiles the positions above the diagonal exist but are
-// never written and never read unmasked.
-__host__ __device__ inline size_t imat_packed_row(int rt) { return (size_t)128 * rt * (rt + 1); }
-__host__ __device__ inline size_t imat_packed_doubles(int n) { return imat_packed_row((n + 15) >> 4); }
-__host__ __device__ inline size_t imat_packed_index(int i, int j) {                // i >= j
-  return imat_packed_row(i >> 4) + (size_t)(j >> 2) * 64 + (size_t)((j & 3) * 16 + (i & 15));
-}
 
 // Blocked left-looking Cholesky on the fp64 matrix cores, one workgroup (16 waves) per particle.
 //
@@ -642,12 +662,6 @@ static hipError_t launch_chol_nt(const CholArgs& ca, int batch, size_t lds, int 
 }
 
 #include "rbpf_chol64.hpp"
-#ifndef RBPF_C64_STAMPS                           // (the phase-clock build of the 64-column kernel changes its helpers' signatures)
-#include "rbpf_chol128.hpp"
-#else
-static bool chol128_ok(const CholArgs&, int) { return false; }
-static hipError_t launch_chol128(const CholArgs&, int, int, hipStream_t) { return hipErrorInvalidValue; }
-#endif
 #include "rbpf_chol_small.hpp"
 #include "rbpf_chol_sweep.hpp"
 
@@ -671,8 +685,7 @@ static bool chol_variant_ok(const CholArgs& ca, int d_lds, int variant) {
   const int RT = (ca.Msz + 1 + 15) >> 4;
   switch (variant) {
     case 0: case 16: return true;
-    case 64: case 648: case 644: case 649: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
-    case 128: return chol128_ok(ca, d_lds);
+    case 64: case 648: case 644: return chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds;
     case 1: case 10: case 11: case 12: case 14: return ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT;
     default: return false;
   }
@@ -686,16 +699,13 @@ static hipError_t launch_chol(const CholArgs& ca, int batch, int d_lds, hipStrea
     if (ca.variant == 11 || ca.variant == 12 || ca.variant == 14) return launch_chol_small(ca, batch, d_lds, st, ca.variant - 10);   // 1 / 2 / 4 waves per matrix
     if (ca.variant == 10) return launch_chol_small(ca, batch, d_lds, st, 10);                                                         // one wave, left-looking
     if (ca.variant == 16) return launch_chol16(ca, batch, d_lds, st);
-    if (ca.variant == 128) return launch_chol128(ca, batch, d_lds, st);
-    return launch_chol64(ca, batch, d_lds, st, (ca.variant == 648 || ca.variant == 649) ? 8 : ca.variant == 644 ? 4 : 0);
+    return launch_chol64(ca, batch, d_lds, st, ca.variant == 648 ? 8 : ca.variant == 644 ? 4 : 0);
   }
   // diagnostic builds (-DRBPF_TUNING) can override the choice from the environment
   static const int w_env = tuning_env("RBPF_CHOL_WAVES") ? atoi(tuning_env("RBPF_CHOL_WAVES")) : 0;      // force 4 / 8 / 16
   const char* v64 = tuning_env("RBPF_CHOL64");
-  // the 128-column kernel (rbpf_chol128.hpp) is selectable (chol_variant = 128, RBPF_CHOL128 = 1 in diagnostic builds) but NOT the default:
-  // measured r04 in the smoother at N_P = 8192, n = 515: 20.1 ms per launch against 16.2 ms for the 64-column kernel
-  const char* v128 = tuning_env("RBPF_CHOL128");
-  if (!v64 && v128 && atoi(v128) == 1 && chol128_ok(ca, d_lds)) return launch_chol128(ca, batch, d_lds, st);
+  // (a 128-column kernel -- factor re-read once per 128 columns -- was built and measured in r04: 17.1 against 16.2 ms per launch in the
+  //  smoother at N_P = 8192, n = 515; removed in r05, see commit 4711b84 and DESIGN_NOTEBOOK.md 9)
   if ((v64 ? atoi(v64) != 0 : RT > 11) && chol64_lds_bytes(ca.Msz, d_lds) <= kC64MaxLds) return launch_chol64(ca, batch, d_lds, st);
   const char* vsm = tuning_env("RBPF_CHOL_SMALL");                                // 0: keep the 16-column kernel for 5..9 row tiles
   if (!v64 && ca.mode == 1 && RT >= 5 && RT <= kCsMaxRT && !(vsm && atoi(vsm) == 0)) return launch_chol_small(ca, batch, d_lds, st);
@@ -792,11 +802,26 @@ __global__ __launch_bounds__(256) void pack_info_kernel(int n, int d, int ldx, c
 
 using namespace rbpf;
 
-// Packed storage of the information matrices: whenever the default arithmetic runs them through the 64-column kernel (more than
-// eleven row tiles, i.e. nLin >= 176).  With carried factors the banks stay full squares: there they are written by the G'G product
-// of the refreshes only.
-static bool imat_storage_packed(int n, int d, int chol_refresh) {
-  return chol_refresh <= 1 && ((n + 1 + 15) >> 4) > 11 && chol64_lds_bytes(n, d) <= kC64MaxLds;
+// Packed storage of the information matrices: whenever they go through the 64-column kernel (more than eleven row tiles, i.e.
+// nLin >= 176).  With carried factors (refresh = K > 1) the banks are written by the G'G product of the refreshes only, whose
+// epilogue writes the packed layout as well (r05) -- except for host-callback models (`lazy` false), whose matrices are advanced
+// every step by the copy kernel on full squares.
+static bool imat_storage_packed(int n, int d, int refresh, bool lazy) {
+  return (refresh <= 1 || lazy) && ((n + 1 + 15) >> 4) > 11 && chol64_lds_bytes(n, d) <= kC64MaxLds;
+}
+
+// rbpf_options.chol_refresh -> the K in use.  0 = automatic: the carried factors (K = 32) for the recognised dense families from
+// nLin = 128 on (dense-radio's 128, dense-mag's 259 / 515: the sizes they were validated and measured at; below that the
+// factorisation is not what a step costs), the from-scratch factorisation elsewhere.
+constexpr int kAutoCholRefresh = 32;
+static bool chol_carry_supported(int kind, int n, int d) {
+  return (kind == RBPF_MODEL_DENSE_MAG_6D || kind == RBPF_MODEL_DENSE_RADIO_2DH) && (d == 1 || d == 3) && sweep_slots(n) <= kSweepMaxSlots &&
+         chol64_lds_bytes(n, d) <= kC64MaxLds;
+}
+int rbpf::resolve_chol_refresh(int kind, int n, int d, int requested) {
+  if (requested > 1) return requested;
+  if (requested == 1 || requested < 0) return 1;
+  return (chol_carry_supported(kind, n, d) && n >= 128) ? kAutoCholRefresh : 1;
 }
 
 // host copy of Imat0 (column-major n x n) in the storage of the banks
@@ -906,6 +931,31 @@ static void whitening_factor(const std::vector<double>& Rh, int d, std::vector<d
     }
 }
 
+// Refresh of the carried factors, second half: factorise Imat + ImatAddt of the N particles whose information matrices the G'G product
+// has just materialised (bank s->imat_cur) with the 64-column kernel, add logwMeas to pant_log, and store the factors in the sweep
+// layout in the OTHER factor bank (the caller flips sw_cur).  Runs in chunks of s->l_chunk particles over one set of factor
+// workspaces: same launches per particle, 2.2 MB per particle less memory at nLin = 515.
+static int refresh_factorise(rbpf_ctx* c, const double* d_Rinv, double* pant_log, int N, hipStream_t st) {
+  SmootherState* s = c->sm;
+  const int n = c->mdl.n, d = c->mdl.d;
+  const size_t fd = chol_factor_doubles(n), sd = sweep_factor_doubles(n);
+  for (int p0 = 0; p0 < N; p0 += s->l_chunk) {
+    const int cnt = std::min(s->l_chunk, N - p0);
+    CholArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.status = c->d_flags; ca.pant_log = pant_log + p0;
+    ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)fd;
+    ca.Imat = s->d_Imat[s->imat_cur] + (size_t)p0 * s->imat_len; ca.imat_stride = (long)s->imat_len; ca.imat_packed = s->imat_packed ? 1 : 0;
+    ca.imat_anc = nullptr; ca.ImatOut = nullptr; ca.Hb = nullptr; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd;
+    ca.ivec = s->d_ivec[s->icur] + (size_t)p0 * c->lay.ldx; ca.ivecAdd = s->d_ivecAdd;
+    ca.qf = s->d_qf[s->icur] + p0; ca.hld = s->d_hld[s->icur] + p0;
+    ca.variant = 64;                                                   // the conversion below reads the 64-column kernel's layout
+    HIPCHK(launch_chol(ca, cnt, d, st));
+    HIPCHK(launch_sweep_from_chol64(n, cnt, s->d_L, fd, s->d_Lsw[s->sw_cur ^ 1] + (size_t)p0 * sd, sd, st));
+  }
+  return RBPF_OK;
+}
+
 static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* out) {
   const int N = c->N, T = c->T, nN = c->mdl.nN, n = c->mdl.n, d = c->mdl.d, nw = c->mdl.nw;
   const Layout& L = c->lay;
@@ -987,7 +1037,15 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       set_error("particleSmootherInformationForm: x0_lin must be nLin x 1 (the reference repmat's it, :109)");
       return RBPF_ERR_INVALID_ARG;
     }
-    s->imat_packed = imat_storage_packed(n, d, c->opt.chol_refresh);
+    {
+      const int K = resolve_chol_refresh(c->mdl.kind, n, d, effective_chol_refresh(c->opt));
+      s->refresh = K > 1 ? K : 0;
+    }
+    if (s->refresh && (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds || (d != 1 && d != 3))) {
+      set_error("chol_refresh > 1 supports nLin <= 575 and n_y = 1 or 3"); return RBPF_ERR_UNSUPPORTED;
+    }
+    s->lazy_imat = s->refresh && c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;     // needs measModel on the device
+    s->imat_packed = imat_storage_packed(n, d, s->refresh, s->lazy_imat);
     s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
     for (int b = 0; b < 2; ++b) {
       RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
@@ -997,19 +1055,19 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
       RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
     }
-    RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles(n)));
+    // factor workspaces of the 64-column kernel: one per particle -- or, with carried factors, per particle of a CHUNK of the
+    // refresh (they are converted to the sweep layout chunk by chunk): 2.2 MB per particle at nLin = 515 that N_P = 32 768 has no room for
+    s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
+    RB_TRY(dmalloc(&s->d_L, (size_t)s->l_chunk * chol_factor_doubles(n)));
     RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
     RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
     RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
-    s->refresh = c->opt.chol_refresh > 1 ? c->opt.chol_refresh : 0;
     if (s->refresh) {
-      if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds) { set_error("chol_refresh > 1 supports nLin <= 575"); return RBPF_ERR_UNSUPPORTED; }
       for (int b = 0; b < 2; ++b) RB_TRY(dmalloc(&s->d_Lsw[b], (size_t)N * sweep_factor_doubles(n)));
       RB_TRY(dmalloc(&s->d_W, (size_t)d * d));
       std::vector<double> Wm;
       whitening_factor(Rh, d, Wm);
       HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
-      s->lazy_imat = c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;     // needs measModel on the device
       if (s->lazy_imat) {
         RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
         RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
@@ -1148,18 +1206,17 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, st, rows, d, n, s->d_W, s->d_G);
             HIPCHK(hipGetLastError());
             const long Kd = (long)Kp * d;
-            GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
+            GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)s->imat_len};
             gg.lower = 1;                                                      // the factorisation reads the block-lower part
+            gg.packed = s->imat_packed ? 1 : 0;
             gg.add = t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur];             // + the base matrix, in the epilogue
-            gg.add_stride = t0 < 0 ? 0L : (long)((size_t)n * n);
+            gg.add_stride = t0 < 0 ? 0L : (long)s->imat_len;
             gg.add_idx = t0 < 0 ? (const int*)nullptr : s->d_base_slot;
             HIPCHK(launch_gemm(gg, N, st));                                   // Imat = base + G' G
             s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
-            ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
-            ca.Imat = s->d_Imat[ni]; ca.imat_stride = (long)((size_t)n * n); ca.imat_anc = nullptr; ca.ImatOut = nullptr;
-            ca.Hb = nullptr; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
-            ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
-            ca.variant = 64;
+            RB_TRY(refresh_factorise(c, d_Rinv, s->d_pant_log, N, st));        // chol(Imat + ImatAddt), chunk by chunk -> sweep layout
+            s->sw_cur ^= 1;
+            skip_chol = true;
           } else {
             RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
             if (carry) ca.variant = 64;            // the refresh reads the factor back in the 64-column kernel's layout
@@ -1167,7 +1224,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         }
         if (!skip_chol) HIPCHK(launch_chol(ca, N, ca.mode == 1 ? d : 0, st));
         HIPCHK(hipGetLastError());
-        if (info_form && s->refresh > 1 && !skip_chol) {                    // fresh factors -> sweep layout
+        if (info_form && s->refresh > 1 && !skip_chol) {                    // fresh factors -> sweep layout (host-callback models)
           HIPCHK(launch_sweep_from_chol64(n, N, s->d_L, chol_factor_doubles(n), s->d_Lsw[s->sw_cur ^ 1], sweep_factor_doubles(n), st));
           s->sw_cur ^= 1;
         }
@@ -1284,9 +1341,14 @@ static int info_step(rbpf_ctx* c, int k, int t, const double* xref, int n_draw, 
   return RBPF_OK;
 }
 
+extern "C" int32_t rbpf_chol_refresh_resolve(int32_t model_kind, int32_t n_lin, int32_t n_y, int32_t requested) {
+  return resolve_chol_refresh(model_kind, n_lin, n_y, requested);
+}
+
 extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng* rng,
                                       const rbpf_options* opt, int32_t N_K, int32_t info_form, rbpf_smoother_out* out) {
   if (!out || N_K < 1) { set_error("bad smoother arguments"); return RBPF_ERR_INVALID_ARG; }
+  RB_TRY(options_ok(opt));
   if (wants_multi(opt)) return multi_particle_smoother(model, prob, rng, opt, N_K, info_form, out);   // sharded over several GPUs
   rbpf_ctx* c = nullptr;
   int st = ctx_create(model, prob, rng, opt, true, N_K, &c);
@@ -1307,8 +1369,8 @@ extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_proble
 // on the rank that holds each particle, all-gathered (N doubles), and normalised / sampled identically on every
 // rank, so a W-rank run equals the single-GPU smoother with N = W * N_local particles bit for bit.
 // =============================================================================================================
-size_t rbpf::smoother_record_matrix_doubles(int n, int d, int chol_refresh) {
-  return chol_refresh > 1 ? sweep_factor_doubles(n) : imat_storage_packed(n, d, chol_refresh) ? imat_packed_doubles(n) : (size_t)n * n;
+size_t rbpf::smoother_record_matrix_doubles(int n, int d, int chol_refresh) {      // chol_refresh: the resolved K
+  return chol_refresh > 1 ? sweep_factor_doubles(n) : imat_storage_packed(n, d, chol_refresh, true) ? imat_packed_doubles(n) : (size_t)n * n;
 }
 
 int rbpf::shard_smoother_pack_info(rbpf_ctx* c, const int* d_idx, int count) {
@@ -1349,11 +1411,16 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   if (n > 1023) { set_error("information-form smoother supports nLin <= 1023"); return RBPF_ERR_UNSUPPORTED; }
   SmootherState* s = new SmootherState();
   c->sm = s;
-  s->refresh = c->opt.chol_refresh > 1 ? c->opt.chol_refresh : 0;
+  {
+    const int K = resolve_chol_refresh(c->mdl.kind, n, d, effective_chol_refresh(c->opt));
+    s->refresh = K > 1 ? K : 0;
+  }
+  if (s->refresh && c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) { set_error("chol_refresh > 1 in the sharded smoother needs measModel on the device"); return RBPF_ERR_UNSUPPORTED; }
+  s->lazy_imat = s->refresh > 1;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
   RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
   RB_TRY(dmalloc(&s->d_ak, 4));
-  s->imat_packed = imat_storage_packed(n, d, c->opt.chol_refresh);
+  s->imat_packed = imat_storage_packed(n, d, s->refresh, true);
   s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
   for (int b = 0; b < 2; ++b) {
     RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
@@ -1363,7 +1430,8 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
     RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
   }
-  RB_TRY(dmalloc(&s->d_L, (size_t)N * chol_factor_doubles(n)));
+  s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
+  RB_TRY(dmalloc(&s->d_L, (size_t)s->l_chunk * chol_factor_doubles(n)));
   RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
   RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
   RB_TRY(dmalloc(&s->d_Imat0, (size_t)n * n));
@@ -1381,15 +1449,13 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
   if (s->refresh) {
     // carried ancestor-weight factors (rbpf_chol_sweep.hpp): factor banks, the buffers of the refresh from the state history,
     // and the exchange buffers for base matrices that sit on another rank
-    if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds) { set_error("chol_refresh > 1 supports nLin <= 575"); return RBPF_ERR_UNSUPPORTED; }
-    if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) { set_error("chol_refresh > 1 in the sharded smoother needs measModel on the device"); return RBPF_ERR_UNSUPPORTED; }
+    if (sweep_slots(n) > kSweepMaxSlots || chol64_lds_bytes(n, d) > kC64MaxLds || (d != 1 && d != 3)) { set_error("chol_refresh > 1 supports nLin <= 575 and n_y = 1 or 3"); return RBPF_ERR_UNSUPPORTED; }
     ShardState* sh = c->sh;
     for (int b = 0; b < 2; ++b) RB_TRY(dmalloc(&s->d_Lsw[b], (size_t)N * sweep_factor_doubles(n)));
     RB_TRY(dmalloc(&s->d_W, (size_t)d * d));
     std::vector<double> Wm;
     whitening_factor(c->h_R, d, Wm);
     HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
-    s->lazy_imat = true;
     RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
     RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
     RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
@@ -1401,8 +1467,8 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     // (a starting value: rbpf_shard_smoother_refresh_reserve grows the buffers when a refresh needs more; exchange_capacity < 0 asks for
     //  a small start, which is how the tests reach the growth path)
     s->rf_cap = (world > 1) ? std::min<size_t>((size_t)N, std::max<size_t>(2 * sh->step_cap, c->opt.exchange_capacity < 0 ? 1 : 64)) : 1;
-    RB_TRY(dmalloc(&s->d_rf_send, s->rf_cap * (size_t)n * n));
-    RB_TRY(dmalloc(&s->d_rf_recv, s->rf_cap * (size_t)n * n));
+    RB_TRY(dmalloc(&s->d_rf_send, s->rf_cap * s->imat_len));
+    RB_TRY(dmalloc(&s->d_rf_recv, s->rf_cap * s->imat_len));
     RB_TRY(dmalloc(&s->d_rf_idx, s->rf_cap));
   }
   guard.release();
@@ -1414,7 +1480,7 @@ int rbpf_shard_smoother_views_get(rbpf_ctx* c, rbpf_shard_smoother_views* v) {
   if (!c || !c->sh || !c->sm || !v) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
   v->anc_local = c->sh->anc_local; v->anc_gather = c->sh->anc_gather;
   v->refresh_send = c->sm->d_rf_send; v->refresh_recv = c->sm->d_rf_recv;
-  v->refresh_capacity = (int64_t)c->sm->rf_cap; v->matrix_doubles = (int64_t)c->mdl.n * c->mdl.n;
+  v->refresh_capacity = (int64_t)c->sm->rf_cap; v->matrix_doubles = (int64_t)c->sm->imat_len;
   return RBPF_OK;
 }
 
@@ -1543,20 +1609,28 @@ int rbpf_shard_smoother_refresh_begin(rbpf_ctx* c, int32_t* owner_now, int32_t* 
 
 // The refresh buffers GROW on demand like the record buffers (rbpf_options.exchange_capacity <= 0): `count` = the largest number of
 // matrices any rank sends or receives at this refresh -- a function of the replicated plan, so every rank calls this with the same
-// value and enlarges by the same rule (at least `count`, at least twice the old capacity, at most N_local) without communicating.
+// value and enlarges by the same rule (at least `count`, at least twice the old capacity, at most (world - 1) x N_local: a matrix is packed once per destination) without communicating.
 // Nothing in the buffers outlives a refresh.  exchange_capacity > 0 is a hard limit: RBPF_ERR_OUT_OF_MEMORY on every rank.
 int rbpf_shard_smoother_refresh_reserve(rbpf_ctx* c, int64_t count) {
   if (!c || !c->sh || !c->sm || count < 0) { set_error("not a sharded smoother context"); return RBPF_ERR_INVALID_ARG; }
   HIPCHK(hipSetDevice(c->device));
   SmootherState* s = c->sm;
   if ((size_t)count <= s->rf_cap) return RBPF_OK;
-  if (c->opt.exchange_capacity > 0 || (size_t)count > (size_t)c->sh->Nloc) {
+  // a rank RECEIVES one base matrix per particle at most, but SENDS a matrix once per destination rank that asked for it: the plan's
+  // keys are unique per (destination, source, slot), so the send side can reach (W - 1) * N_local
+  const size_t hard = (size_t)c->sh->Nloc * (size_t)std::max(1, c->sh->world - 1);
+  if (c->opt.exchange_capacity > 0) {
     set_error("refresh of the carried factors moves up to " + std::to_string((long long)count) + " matrices per rank, above the capacity " +
-              std::to_string((long long)s->rf_cap) + " (exchange_capacity > 0 is a hard limit)");
+              std::to_string((long long)s->rf_cap) + " fixed by exchange_capacity > 0 (a hard limit)");
     return RBPF_ERR_OUT_OF_MEMORY;
   }
-  const size_t cap = std::min<size_t>((size_t)c->sh->Nloc, std::max<size_t>((size_t)count, 2 * s->rf_cap));
-  const size_t nn = (size_t)c->mdl.n * c->mdl.n;
+  if ((size_t)count > hard) {
+    set_error("refresh of the carried factors: " + std::to_string((long long)count) + " matrices per rank is more than any plan can need (" +
+              std::to_string((long long)hard) + " = (world - 1) x N_local)");
+    return RBPF_ERR_INVALID_ARG;
+  }
+  const size_t cap = std::min<size_t>(hard, std::max<size_t>((size_t)count, 2 * s->rf_cap));
+  const size_t nn = s->imat_len;
   HIPCHK(hipStreamSynchronize(c->stream));
   double *ns_ = nullptr, *nr_ = nullptr; int* ni_ = nullptr;
   int rc = dmalloc(&ns_, cap * nn);
@@ -1577,7 +1651,7 @@ int rbpf_shard_smoother_refresh_pack(rbpf_ctx* c, const int32_t* slots, int32_t 
   if ((size_t)count > s->rf_cap) { set_error("refresh exchange above its capacity"); return RBPF_ERR_OUT_OF_MEMORY; }
   if (count == 0) return RBPF_OK;
   for (int q = 0; q < count; ++q) if (slots[q] < 0 || slots[q] >= c->sh->Nloc) { set_error("refresh_pack: slot out of range"); return RBPF_ERR_INVALID_ARG; }
-  const size_t nn = (size_t)c->mdl.n * c->mdl.n;
+  const size_t nn = s->imat_len;
   HIPCHK(hipMemcpyAsync(s->d_rf_idx, slots, (size_t)count * sizeof(int), hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(gather_matrices_kernel, dim3(count, 8), dim3(256), 0, c->stream, nn, s->d_rf_idx, s->d_Imat[s->imat_cur], s->d_rf_send);
   HIPCHK(hipGetLastError());
@@ -1607,26 +1681,17 @@ int rbpf_shard_smoother_refresh_end(rbpf_ctx* c, const int32_t* base_index, int3
   hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, st, rows, d, n, s->d_W, s->d_G);
   HIPCHK(hipGetLastError());
   const long Kd = (long)Kp * d;
-  GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)((size_t)n * n)};
+  GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[ni], 1, n, (long)s->imat_len};
   gg.lower = 1;
+  gg.packed = s->imat_packed ? 1 : 0;
   gg.add = t0 < 0 ? s->d_Imat0 : s->d_Imat[s->imat_cur];               // base matrix: own bank entry or a fetched one
-  gg.add_stride = t0 < 0 ? 0L : (long)((size_t)n * n);
+  gg.add_stride = t0 < 0 ? 0L : (long)s->imat_len;
   gg.add_idx = t0 < 0 ? (const int*)nullptr : s->d_base_slot;
   gg.add_rec = t0 < 0 ? (const double*)nullptr : s->d_rf_recv; gg.add_nbank = N;
   HIPCHK(launch_gemm(gg, N, st));                                      // Imat = base + G' G
   s->imat_cur = ni; s->imat_valid = true; s->base_gen = t - 1;
   HIPCHK(hipMemcpyAsync(s->d_base_gid, s->d_owner_now, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToDevice, st));
-  CholArgs ca;
-  std::memset(&ca, 0, sizeof(ca));
-  ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.pant_log = sh->anc_local; ca.status = c->d_flags;
-  ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)chol_factor_doubles(n);
-  ca.Imat = s->d_Imat[ni]; ca.imat_stride = (long)((size_t)n * n); ca.imat_anc = nullptr; ca.ImatOut = nullptr;
-  ca.Hb = nullptr; ca.Rinv = s->d_Rinv; ca.ImatAdd = s->d_ImatAdd; ca.ivec = s->d_ivec[s->icur];
-  ca.ivecAdd = s->d_ivecAdd; ca.qf = s->d_qf[s->icur]; ca.hld = s->d_hld[s->icur];
-  ca.variant = 64;
-  HIPCHK(launch_chol(ca, N, d, st));
-  HIPCHK(hipGetLastError());
-  HIPCHK(launch_sweep_from_chol64(n, N, s->d_L, chol_factor_doubles(n), s->d_Lsw[s->sw_cur ^ 1], sweep_factor_doubles(n), st));
+  RB_TRY(refresh_factorise(c, s->d_Rinv, sh->anc_local, N, st));
   s->sw_cur ^= 1; s->sw_valid = true; s->rf_stage = 0;
   HIPCHK(hipStreamSynchronize(st));              // base_index is caller memory
   return RBPF_OK;
@@ -1747,8 +1812,7 @@ int rbpf_chol_weights(int32_t M, int32_t batch, const double* S, const double* e
   const bool info = variant >= 1000;                 // information-form expression and loaders (see rbpf.h)
   if (info) variant -= 1000;
   if (!S || !e || !logw || M < 1 || M > 1023 || batch < 1 || reps < 1 ||
-      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644 && variant != 649 && variant != 128) ||
-      (variant == 128 && (!info || ((M + 16) >> 4) <= 27)) ||
+      (variant != 0 && variant != 1 && variant != 10 && variant != 11 && variant != 12 && variant != 14 && variant != 16 && variant != 64 && variant != 648 && variant != 644) ||
       ((variant == 1 || variant == 10 || variant == 11 || variant == 12 || variant == 14) && (!info || ((M + 16) >> 4) > kCsMaxRT || ((M + 16) >> 4) < 5))) {
     set_error("bad argument"); return RBPF_ERR_INVALID_ARG;
   }

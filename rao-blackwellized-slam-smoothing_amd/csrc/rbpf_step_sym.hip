@@ -91,10 +91,9 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
   return p;
 }
 
-// px: the variant that reads P_base * H' (core rows) instead of streaming the tiles (family products) keeps no column strips
-size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra, int px) {
-  const int xl_lds = (RBPF_SYM_LIGHT_WGS > 2 && !write_base && extra == 0 && !px) ? 0 : 1;
-  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, px ? 2 : lay.CH64, xl_lds).total * sizeof(double);
+size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra) {
+  const int xl_lds = (RBPF_SYM_LIGHT_WGS > 2 && !write_base && extra == 0) ? 0 : 1;
+  return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, lay.CH64, xl_lds).total * sizeof(double);
 }
 
 // ---- wave-level reduction primitives ---------------------------------------------------------------------------------------
@@ -413,11 +412,11 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
 // E = 1: information form (particleSmootherInformationForm.m:274-335): one more streamed right-hand side, P * ivec.  The
 // reference also needs P * ivecPlus with ivecPlus = ivec + H' R^-1 y (:292) -- that is P * ivec + (P H') (R^-1 y), formed from
 // the accumulated columns instead of streamed (same algebra; step_kernel<.., E = 2> streams both).
-// PX (read-only filter steps, family products): the core rows of P_base * H_i' were formed per FAMILY on the matrix cores
-// (rbpf_family.hip: a.fam_PHt, with H_i in a.fam_H, both by processing position); this kernel then does everything else of the step.
-template <int D, int NS, bool WR, int E, int CH, bool PX = false>
-__global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)) void step_sym_kernel(const StepArgs a) {
-  static_assert(!PX || (!WR && E == 0), "the family products serve the read-only filter step");
+// (r04 also built the read-only filter step as a family GEMM on the matrix cores -- P_base * [H_1' ... H_f'] per family of particles
+// sharing a stored matrix -- and measured it 0.4-0.8 ms per step SLOWER than this kernel: removed in r05, see commit 4711b84 and
+// DESIGN_NOTEBOOK.md 10.)
+template <int D, int NS, bool WR, int E, int CH>
+__global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2) void step_sym_kernel(const StepArgs a) {
   constexpr int NPH = (CH == 8) ? 1 : 2;                       // column phases (waves per row pair)
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, PX ? 2 : CH, (RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0 && !PX) ? 0 : 1);
+  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH, (RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0) ? 0 : 1);
   double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;                            // [DE][ldx]
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
   RBPF_SYM_KSTAMP(0);
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)pos * kPreDoubles + tid];
-  constexpr bool kXlLds = PX || !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
+  constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
   if (kXlLds) for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
   double Riy[D];                                               // R^-1 y (:292)
   if (E > 0) {
@@ -483,18 +482,13 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
   __syncthreads();
   RBPF_SYM_KSTAMP(1);
   // ---- B: per-axis sin / cos tables ----
-  if constexpr (!PX) {
-    for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
-    __syncthreads();
-  }
+  for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
+  __syncthreads();
   RBPF_SYM_KSTAMP(2);
   // ---- C: measurement Jacobian, one column per thread ----
   for (int c = tid; c < n; c += kThreads) {
     double h[D];
-    if constexpr (PX) {                                        // family_prepare_kernel evaluated it
-#pragma unroll
-      for (int k = 0; k < D; ++k) h[k] = a.fam_H[((size_t)pos * D + k) * ldx + c];
-    } else if (a.H_ext != nullptr) {
+    if (a.H_ext != nullptr) {
 #pragma unroll
       for (int k = 0; k < D; ++k) h[k] = a.H_ext[((size_t)i * D + k) * ldx + c];
     } else {
@@ -514,38 +508,7 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
   __syncthreads();
 
   RBPF_SYM_KSTAMP(3);
-  if constexpr (PX) {
-    // ---- D': P_base * H' = the family product (core rows x core columns) + the border columns; border rows as below ----
-    for (int rc = tid; rc < mc; rc += kThreads) {
-      double sp[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) sp[k] = a.fam_PHt[((size_t)pos * D + k) * mc + rc];
-      for (int b = 0; b < nb; ++b) {
-        const double pv = srcB[(size_t)b * ldb + nb + rc];                   // P(r, b) = B(b, r)
-#pragma unroll
-        for (int k = 0; k < D; ++k) sp[k] = fma(pv, Hs[b * DE + k], sp[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < D; ++k) PHt[(size_t)k * ldx + nb + rc] = sp[k];
-    }
-    for (int b = wave; b < nb; b += kWaves) {
-      const double* src = srcB + (size_t)b * ldb;
-      double accb[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) accb[k] = 0.0;
-      for (int c = lane; c < n; c += 64) {
-        const double pv = src[c];
-#pragma unroll
-        for (int k = 0; k < D; ++k) accb[k] = fma(pv, Hs[c * DE + k], accb[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < D; ++k) {
-        const double sb = wave_sum(accb[k]);
-        if (lane == 0) PHt[(size_t)k * ldx + b] = sb;
-      }
-    }
-    __syncthreads();
-  } else {
+  {
   // ---- D: stream the stored tiles once ----
   const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
   const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
@@ -748,7 +711,7 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
     }
   }
   __syncthreads();
-  }                                                            // (!PX)
+  }
   if (!WR && NS > 0) {
     // read-only step: PHt holds P_base * H'; subtract sum_s KS_s * (K_s' * H')
     constexpr int NG = NS * D * DE > 0 ? NS * D * DE : 1;
@@ -962,32 +925,13 @@ __global__ __launch_bounds__(kThreads, PX ? (NS > 3 ? 2 : 5) : ((!WR && E == 0) 
   RBPF_SYM_KSTAMP(6);
 }
 
-template <int D, int NS, bool WR, int E, int CH, bool PX = false>
+template <int D, int NS, bool WR, int E, int CH>
 static hipError_t launch_sym_kc(const StepArgs& a, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH, PX>), 160 * 1024, attr_done)) return e;
-  const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E, PX ? 1 : 0);
-  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E, CH, PX>), dim3(a.N), dim3(kThreads), lds, s, a);
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH>), 160 * 1024, attr_done)) return e;
+  const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E);
+  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E, CH>), dim3(a.N), dim3(kThreads), lds, s, a);
   return hipGetLastError();
-}
-
-// read-only filter step through the family products (rbpf_family.hip): index + measModel + GEMM, then the per-particle rest
-bool sym_family_step(const StepArgs& a) {
-  return a.fam_PHt != nullptr && a.fam_H != nullptr && a.fam_idx != nullptr && a.lay.sym && a.lay.CH64 == 8 && a.mdl.d == 3 && !a.write_base &&
-         !a.info && !a.fp32 && a.phase < 0 && a.H_ext == nullptr && a.n_sets >= 1 && a.n_sets <= 7;
-}
-static hipError_t launch_sym_family(const StepArgs& a, hipStream_t s) {
-  if (hipError_t e = launch_family_products(a, s)) return e;
-  switch (a.n_sets) {
-    case 1: return launch_sym_kc<3, 1, false, 0, 8, true>(a, s);
-    case 2: return launch_sym_kc<3, 2, false, 0, 8, true>(a, s);
-    case 3: return launch_sym_kc<3, 3, false, 0, 8, true>(a, s);
-    case 4: return launch_sym_kc<3, 4, false, 0, 8, true>(a, s);
-    case 5: return launch_sym_kc<3, 5, false, 0, 8, true>(a, s);
-    case 6: return launch_sym_kc<3, 6, false, 0, 8, true>(a, s);
-    case 7: return launch_sym_kc<3, 7, false, 0, 8, true>(a, s);
-    default: return hipErrorInvalidValue;
-  }
 }
 
 template <int D, int NS, bool WR, int E>
@@ -999,7 +943,6 @@ static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
 
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
   if (!a.lay.sym || a.mdl.d != 3 || (a.lay.CH64 != 8 && a.lay.CH64 != 4) || a.fp32) return hipErrorInvalidValue;
-  if (sym_family_step(a)) return launch_sym_family(a, s);
   if (a.info) {                                            // information form: lazy_depth <= 3
     if (a.write_base) {
       switch (a.n_sets) {

@@ -509,7 +509,7 @@ def _raise_callback_error(model, exc):
 def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt,
                    sparseFeatures=False, makePlots: Optional[Callable] = None, *, rng=None, trace=False,
                    want_xn_traj=True, extras=False, lazy_depth=0, inplace=0, storage="fp64", fix_p_mean=False, n_devices=0,
-                   device_ids=None, family_products=0):
+                   device_ids=None):
     """Mirror of src/particleFilter.m:1-3.  Returns the reference's 8 outputs
     (traj_max, traj_mean, xl_max, xl_mean, P_max, P_mean, traj_sample_iwmax, xn_traj); with
     extras=True a 9th element (dict of traces / final particle banks) is appended.
@@ -525,10 +525,7 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     n_devices = W > 1 (rbpf_options.n_devices): the library shards the N_P particles over W GPUs itself -- one host thread per
     device, RCCL collectives -- and returns the reference's eight outputs (xn_traj from the replicated state history; None with
     want_xn_traj=False); device_ids names the HIP devices
-    (a device named twice makes its ranks share it over a host-staged transport: tests on one GPU).
-    family_products = 1 (rbpf_options.family_products): read-only steps of storage="fp64sym" with lazy_depth >= 2 form
-    P_base * [H_1' ... H_f'] per family of particles that share a stored matrix on the matrix cores instead of streaming the matrix
-    per particle (default)."""
+    (a device named twice makes its ranks share it over a host-staged transport: tests on one GPU)."""
     model, _ = _recognise(dynModel, measModel, model_dyn_res_norm(dynModel))
     generic = model is None
     if generic:
@@ -544,7 +541,7 @@ def particleFilter(dynModel, measModel, odometry, y, x0_nonLin, x0_lin, P0_lin, 
     blk, _keep = _rng_block(rng, N, T, model.nw, 1)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if (trace or extras) else 0, fix_p_mean=1 if fix_p_mean else 0,
                             lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
-                            storage=_storage_code(storage), family_products=int(family_products))
+                            storage=_storage_code(storage))
     mdesc = model.descriptor()
     multi = int(n_devices) > 1 or (int(n_devices) == 1 and device_ids is not None)
     if multi:
@@ -762,12 +759,21 @@ def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y
                                     exchange_capacity=0):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
     covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
-    chol_refresh = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1 up/down-dates and
-    recomputed every K-th step (rbpf_options.chol_refresh; ancestor probabilities to ~1e-10 of the default).
+    chol_refresh (rbpf_options.chol_refresh) = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1
+    up/down-dates and recomputed every K-th step (every index identical, ancestor probabilities within 2e-9, outputs 1e-9 of the
+    from-scratch factorisation); 1: chol(Imat_i + ImatAddt) from scratch at every step, the reference's own arithmetic; 0 (default):
+    automatic -- K = 32 for the recognised dense families from nLin = 128 on, 1 elsewhere (`chol_refresh_in_use` tells).
     n_devices = W > 1: the particles of every iteration are sharded over W GPUs inside the library (rbpf_options.n_devices)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
                      dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids, storage,
                      exchange_capacity)
+
+
+def chol_refresh_in_use(model, chol_refresh=0):
+    """The K rbpf_options.chol_refresh = `chol_refresh` stands for with this model (rbpf_chol_refresh_resolve): > 1 carried
+    ancestor-weight factors refreshed every K-th step, 1 the from-scratch factorisation of every step."""
+    lib = load_library()
+    return int(lib.rbpf_chol_refresh_resolve(int(model.descriptor().kind), int(model.nLin), int(model.ny), int(chol_refresh)))
 
 
 def sample(w, u):
@@ -845,14 +851,14 @@ class FilterSession:
     """Thin RAII wrapper over rbpf_filter_create / advance / sync / timing / destroy."""
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng=None, keep_history=False,
-                 trace=False, lazy_depth=0, inplace=0, storage="fp64", family_products=0):
+                 trace=False, lazy_depth=0, inplace=0, storage="fp64"):
         self.lib = load_library()
         self.model = model
         self.prob = _Problem(model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt)
         self.blk, self._rng = _rng_block(rng, self.prob.N_P, self.prob.N_T, model.nw, 1)
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=1 if trace else 0, fix_p_mean=0,
                                      lazy_depth=int(lazy_depth), jitter=0.0, inplace=int(inplace),
-                                     storage=_storage_code(storage), family_products=int(family_products))
+                                     storage=_storage_code(storage))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         check(self.lib.rbpf_filter_create(C.byref(self.mdesc), C.byref(self.prob.c), C.byref(self.blk),

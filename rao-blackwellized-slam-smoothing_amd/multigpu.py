@@ -168,7 +168,7 @@ class ShardedFilterSession:
 
     def __init__(self, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_local, dt, rng=None, rank=0, world=1,
                  transport="device", planner="device", lazy_depth=0, storage="fp64", keep_history=False, exchange_capacity=0,
-                 sync_phases=False, force_collectives=False, family_products=0):
+                 sync_phases=False, force_collectives=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -205,7 +205,7 @@ class ShardedFilterSession:
             raise ValueError("lazy_depth >= 2 needs planner='device'")
         self.opt = _ffi.rbpf_options(keep_history=1 if keep_history else 0, trace=0, fix_p_mean=0, lazy_depth=int(lazy_depth),
                                      jitter=0.0, storage=_storage_code(storage), exchange_capacity=int(exchange_capacity),
-                                     chol_refresh=int(getattr(self, "chol_refresh", 0)), family_products=int(family_products))
+                                     chol_refresh=int(getattr(self, "chol_refresh_requested", 0)))
         self.mdesc = model.descriptor()
         self.ctx = C.c_void_p()
         self._create()
@@ -539,8 +539,10 @@ class ShardedSmootherSession(ShardedFilterSession):
                  transport="device", exchange_capacity=0, sync_phases=False, lazy_depth=0, chol_refresh=0, force_collectives=False,
                  storage="fp64"):
         self.N_K = int(N_K)
-        self.chol_refresh = int(chol_refresh)
+        self.chol_refresh_requested = int(chol_refresh)
         lib = load_library()
+        # the K in use (0 = automatic): the step loop below issues the refresh exchange at the steps the library refreshes at
+        self.chol_refresh = int(lib.rbpf_chol_refresh_resolve(int(model.descriptor().kind), int(model.nLin), int(model.ny), int(chol_refresh)))
         for name, argt in (("rbpf_shard_smoother_create", [C.POINTER(_ffi.rbpf_model), C.POINTER(_ffi.rbpf_problem),
                                                            C.POINTER(_ffi.rbpf_rng), C.POINTER(_ffi.rbpf_options), C.c_int32,
                                                            C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),

@@ -24,6 +24,14 @@ def build(native_dir=None):
     return LIB
 
 
+def build_arbiter():
+    """The extended-precision build (-DRBPF_ORACLE_LONG_DOUBLE, x87 long double: see the header of oracle/rbpf_oracle_c.c)."""
+    out = os.path.join(ORACLE_DIR, "_build", "librbpf_oracle_c_ld.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(ORACLE_DIR, "rbpf_oracle_c.c")):
+        subprocess.run(["make", "-C", ORACLE_DIR, "arbiter"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return out
+
+
 def particle_filter(rbpf, model, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, dt, rng, n_threads=0,
                     want_full=True, lib_path=None):
     """Runs the C restatement with the product package's marshalling (same structs as include/rbpf.h).

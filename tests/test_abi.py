@@ -26,14 +26,58 @@ def test_library_exports_every_declared_symbol(rbpf):
     lib = rbpf.load_library()
     for name in declared_functions():
         assert hasattr(lib, name), name
-    assert lib.rbpf_abi_version() == 8
     import ctypes as C
     ffi = __import__("importlib").import_module(rbpf.__name__ + "._ffi")
+    src = open(os.path.join(ROOT, "include", "rbpf.h")).read()
+    assert lib.rbpf_abi_version() == ffi.ABI_VERSION == int(re.search(r"#define RBPF_ABI_VERSION (\d+)", src).group(1))
     for which, mirror in enumerate(ffi.ABI_STRUCTS):                       # the ctypes mirror against the library's own sizeof
         assert lib.rbpf_abi_sizeof(which) == C.sizeof(mirror), mirror.__name__
     assert lib.rbpf_abi_sizeof(99) == -1
     assert lib.rbpf_status_string(0) == b"ok"
     assert b"positive definite" in lib.rbpf_status_string(rbpf.RBPF_ERR_CHOL_FAILED)
+
+
+def test_options_of_another_layout_are_refused(rbpf):
+    """rbpf_options.struct_size (ABI 9): an entry point handed options of another size refuses them BEFORE reading a field -- a
+    binding compiled against an older header cannot make the library read past its struct (no device needed: the check comes first)."""
+    import ctypes as C
+    ffi = __import__("importlib").import_module(rbpf.__name__ + "._ffi")
+    host = __import__("importlib").import_module(rbpf.__name__ + ".host")
+    lib = rbpf.load_library()
+    c = cases.radio_case(4, 3, 8, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    prob = host._Problem(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"])
+    blk, _keep = host._rng_block(cases.device_rng(rbpf, c), prob.N_P, prob.N_T, mdl.nw, 1)
+    mdesc = mdl.descriptor()
+    good = ffi.rbpf_options(keep_history=1)
+    assert good.struct_size == C.sizeof(ffi.rbpf_options) == lib.rbpf_abi_sizeof(3)
+    nbytes = C.c_size_t(0)
+    assert lib.rbpf_filter_workspace_bytes(C.byref(mdesc), C.byref(prob.c), C.byref(good), C.byref(nbytes)) == rbpf.RBPF_OK
+    stale = ffi.rbpf_options(keep_history=1)
+    stale.struct_size = C.sizeof(ffi.rbpf_options) - 8
+    ctx = C.c_void_p()
+    out = ffi.rbpf_filter_out()
+    sm = ffi.rbpf_smoother_out()
+    for call in (lambda: lib.rbpf_filter_workspace_bytes(C.byref(mdesc), C.byref(prob.c), C.byref(stale), C.byref(nbytes)),
+                 lambda: lib.rbpf_filter_create(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(stale), C.byref(ctx)),
+                 lambda: lib.rbpf_particle_filter(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(stale), C.byref(out)),
+                 lambda: lib.rbpf_particle_smoother(C.byref(mdesc), C.byref(prob.c), C.byref(blk), C.byref(stale), 1, 1, C.byref(sm))):
+        assert call() == rbpf.RBPF_ERR_INVALID_ARG
+        assert b"struct_size" in lib.rbpf_last_error()
+
+
+def test_chol_refresh_resolution(rbpf):
+    """rbpf_options.chol_refresh = 0 is automatic: carried factors (K = 32) for the recognised dense families from nLin = 128 on,
+    the from-scratch factorisation elsewhere; explicit values are kept (rbpf_chol_refresh_resolve, no device needed)."""
+    lib = rbpf.load_library()
+    MAG, RADIO, SPARSE, GENERIC = 1, 2, 3, 4
+    assert lib.rbpf_chol_refresh_resolve(MAG, 515, 3, 0) == 32 and lib.rbpf_chol_refresh_resolve(MAG, 259, 3, 0) == 32
+    assert lib.rbpf_chol_refresh_resolve(RADIO, 128, 1, 0) == 32
+    assert lib.rbpf_chol_refresh_resolve(MAG, 19, 3, 0) == 1 and lib.rbpf_chol_refresh_resolve(RADIO, 127, 1, 0) == 1
+    assert lib.rbpf_chol_refresh_resolve(MAG, 1027, 3, 0) == 1                    # the sweep holds nLin <= 575
+    assert lib.rbpf_chol_refresh_resolve(GENERIC, 515, 3, 0) == 1 and lib.rbpf_chol_refresh_resolve(SPARSE, 200, 3, 0) == 1
+    assert lib.rbpf_chol_refresh_resolve(MAG, 515, 3, 1) == 1 and lib.rbpf_chol_refresh_resolve(MAG, 515, 3, 16) == 16
+    assert lib.rbpf_chol_refresh_resolve(MAG, 19, 3, 4) == 4
 
 
 def test_no_cpu_fallback_without_a_device(rbpf):

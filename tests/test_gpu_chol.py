@@ -43,7 +43,7 @@ def numpy_logw(S, e, jitter=None):
     return out
 
 
-@pytest.mark.parametrize("variant", [16, 648, 644, 649])
+@pytest.mark.parametrize("variant", [16, 648, 644])
 @pytest.mark.parametrize("M", [5, 16, 63, 64, 65, 130, 259, 515, 516, 576, 640])
 def test_batched_factorisation_matches_numpy(rbpf, M, variant):
     B = 9 if M > 300 else 21
@@ -85,7 +85,7 @@ def test_jitter_retry_and_failure_flag(rbpf, M, variant):
 
 def test_largest_supported_size(rbpf):
     S, e = spd_batch(3, 1023, seed=11)
-    for variant in (16, 648, 644, 649):
+    for variant in (16, 648, 644):
         got, status, _ = rbpf.chol_weights(S, e, variant=variant)
         assert status == 0
         np.testing.assert_allclose(got, numpy_logw(S, e), rtol=1e-11, atol=1e-9)
@@ -112,7 +112,7 @@ def test_smoother_with_the_16_column_kernel_forced(rbpf):
         ts.run_both(rbpf, c, info_form=True, chol_variant=7)
 
 
-@pytest.mark.parametrize("kind,m,variant", [("mag", 256, 16), ("mag", 200, 16), ("mag", 256, 644), ("mag", 256, 648), ("mag", 256, 649), ("mag", 173, 16)])
+@pytest.mark.parametrize("kind,m,variant", [("mag", 256, 16), ("mag", 200, 16), ("mag", 256, 644), ("mag", 256, 648), ("mag", 173, 16)])
 def test_packed_information_matrices_through_every_loader(rbpf, kind, m, variant):
     """nLin >= 176: the banks, Imat0, ImatAddt hold the information matrices in packed block-lower storage (imat_packed_index).
     The 16-column kernel reads them through the general loader (chol_aug_elems), the 64-column kernel through its call-free strip /
@@ -121,19 +121,6 @@ def test_packed_information_matrices_through_every_loader(rbpf, kind, m, variant
     import test_gpu_smoother as ts
     c = cases.mag_case(7, 6, m, seed=23, N_K=3)
     ref, out = ts.run_both(rbpf, c, info_form=True, chol_variant=variant)
-    ts.check(ref, out, 3)
-
-
-@pytest.mark.parametrize("m,storage", [(512, "fp64sym"), (512, "fp64"), (445, "fp64"), (600, "fp64")])
-def test_information_form_smoother_through_the_128_column_kernel(rbpf, m, storage):
-    """rbpf_options.chol_variant = 128: particleSmootherInformationForm.m:224-236 through rbpf_chol128.hpp inside the smoother -- packed
-    information matrices, the pending H' R^-1 H of the last update folded into the element load, Imat(:,:,ai) written on the way
-    (nLin = 515: 33 row tiles, the metric's size; 448 = 29 row tiles, a right-hand-side row alone in its tile; 603 = 38 row tiles)
-    -- against the numpy oracle, N_K = 3."""
-    import test_gpu_smoother as ts
-    c = cases.mag_case(7, 6, m, seed=29, N_K=3)
-    kw = dict(storage=storage, lazy_depth=3) if storage == "fp64sym" else {}
-    ref, out = ts.run_both(rbpf, c, info_form=True, chol_variant=128, **kw)
     ts.check(ref, out, 3)
 
 
@@ -180,36 +167,6 @@ def test_information_form_factorisation_of_small_matrices(rbpf, M, variant):
     np.testing.assert_allclose(got, numpy_logw_info(S, e), rtol=1e-11, atol=1e-9)
 
 
-@pytest.mark.parametrize("M", [432, 433, 447, 448, 449, 463, 464, 465, 500, 511, 512, 513, 515, 516, 527, 528, 529, 559, 560, 561, 575, 576, 577, 600,
-                               639, 640, 641, 700])
-def test_128_column_kernel_matches_numpy(rbpf, M):
-    """rbpf_chol128.hpp (28 .. 44 row tiles: every residue of the row-tile count modulo 8 -- the last super-block holds 1 .. 8 diagonal
-    tiles -- and matrix sizes around the tile boundaries; one, two and three passes per super-block) against numpy and the
-    64-column kernel, badly scaled rows included."""
-    S, e = spd_batch(5, M, seed=300 + M, scale_spread=1.0 if M % 2 else 0.0)
-    got, status, _ = rbpf.chol_weights(S, e, variant=128, info_form=True)
-    assert status == 0
-    want = numpy_logw_info(S, e)
-    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-9)
-    got64, status, _ = rbpf.chol_weights(S, e, variant=648, info_form=True)
-    np.testing.assert_allclose(got, got64, rtol=1e-11, atol=1e-9)
-
-
-def test_128_column_kernel_flags_a_failed_factorisation(rbpf):
-    S, e = spd_batch(4, 515, seed=19)
-    w, V = np.linalg.eigh(S[1])
-    w[0] = -1.0
-    S[1] = (V * w) @ V.T
-    got, status, _ = rbpf.chol_weights(S, e, variant=128, info_form=True)
-    assert status & 2 and np.isnan(got[1])
-    ok = [0, 2, 3]
-    np.testing.assert_allclose(got[ok], numpy_logw_info(S[ok], e[ok]), rtol=1e-11, atol=1e-9)
-    with pytest.raises(rbpf.RBPFError):                                     # not an information-form launch / too few row tiles
-        rbpf.chol_weights(S, e, variant=128)
-    with pytest.raises(rbpf.RBPFError):
-        rbpf.chol_weights(S[:, :300, :300], e[:, :300], variant=128, info_form=True)
-
-
 def test_information_form_failure_is_flagged(rbpf):
     """particleSmootherInformationForm.m:224-236 has no usable retry (quirk Q4): a failed factorisation is an error."""
     S, e = spd_batch(5, 128, seed=9)
@@ -231,7 +188,7 @@ def test_every_kernel_over_a_sweep_of_sizes(rbpf):
         S, e = spd_batch(3, M, seed=1000 + M)
         want0, want1 = numpy_logw(S, e), numpy_logw_info(S, e)
         rt = (M + 16) // 16
-        for variant in (0, 16, 644, 648, 649):
+        for variant in (0, 16, 644, 648):
             got, status, _ = rbpf.chol_weights(S, e, jitter=1e-2, variant=variant)
             assert status == 0, (M, variant)
             np.testing.assert_allclose(got, want0, rtol=1e-11, atol=1e-9, err_msg=f"M={M} variant={variant}")

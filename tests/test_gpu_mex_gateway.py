@@ -72,7 +72,7 @@ def test_gateway_compiles_and_fails_loudly_without_a_device(rbpf, tmp_path):
     r = subprocess.run([exe, tmp, "--no-device"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     rep = report(tmp)
-    assert float(rep["version"]) == 8
+    assert float(rep["version"]) == 9
     assert rep["nodevice_error"].startswith("rbpf:status") and "no HIP device" in rep["nodevice_error"]
 
 
