@@ -58,7 +58,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
+def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, T_s=150):
     """Times oracle/rbpf_oracle_c.c (the plain-C restatement of src/particleFilter.m) on this host's
     cores on a bounded sample of the same workload.  The oracle is only the thing *measured* here."""
     import numpy as np
@@ -81,10 +81,8 @@ def cpu_baseline(pkg, data, model, x0_lin, P0, R, m, target_s=15.0):
                                            x0_lin, P0, Q, R, N_s, 0.01, rng, n_threads=cores, want_full=False,
                                            lib_path=lib_path)
         return secs
-    t_cal = run(5)
-    per_step = max(t_cal / 5.0, 1e-6)
-    T_s = int(min(1200, max(8, target_s / per_step)))
-    secs = run(T_s)
+    run(5)                                                     # first touch / thread pool
+    secs = run(T_s)                                            # a FIXED sample (N = 1024, T = 150: about 15 s on 16 cores), so the figure is reproducible
     return {"value": N_s * T_s / secs, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": f"slam-dense-mag N={N_s} T={T_s} m={m} fp64, C restatement of particleFilter.m "
                       f"(gcc {flags}, OpenMP over particles), {secs:.1f} s"}
@@ -113,7 +111,7 @@ def roofline_of(tm, storage="fp64"):
                     "symmetric storage, the lazy update and the shared reads all elide bytes)"}
 
 
-def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True, family_products=0):
+def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, keep_history=True):
     """One single-GPU filter run: W warm-up steps, K timed steps.  keep_history: the state history and the ancestor table
     (particleFilter.m:117-118,233: xn_traj / traj_sample_iwmax) are written inside the timed steps, so the run could return the
     reference's full output set."""
@@ -123,7 +121,7 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, 
     model, x0_lin, P0, R = pkg.dense_mag_prior(m, data["LL"], THETA_MAG)
     with pkg.FilterSession(model, data["dx"], data["y"], data["initState"], x0_lin, P0, Q, R, N, 0.01,
                            rng=pkg.PhiloxRNG(seed), keep_history=keep_history, lazy_depth=lazy_depth, inplace=inplace,
-                           storage=storage, family_products=family_products) as sess:
+                           storage=storage) as sess:
         sess.advance(W)
         sess.sync()
         sess.timing(enable=True)
@@ -255,9 +253,12 @@ def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed, **opts):
     secs = time.perf_counter() - t0
     its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
     share = ("1/8 of N=65536" if N_share == 8192 else f"{N_share / 65536:g} of N=65536" +
-             (": the largest power-of-two particle count whose smoother state fits one 288 GB GPU" if N_share == 32768 or opts.get("chol_refresh", 0) > 1 else ""))
-    return {"workload": f"slam-dense-mag N_P={N_share} ({share}) T={T} m={m} N_K={N_K} fp64, information form, complete run",
-            "options": opts, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
+             (": the largest power-of-two particle count whose smoother state fits one 288 GB GPU" if N_share == 32768 else ""))
+    K_ref = pkg.chol_refresh_in_use(mdl, opts.get("chol_refresh", 0))
+    how = (f"ancestor-weight factors carried along the lineages, refactorised every {K_ref} steps" if K_ref > 1
+           else "chol(Imat_i + ImatAddt) from scratch for every particle at every step (the reference's arithmetic)")
+    return {"workload": f"slam-dense-mag N_P={N_share} ({share}) T={T} m={m} N_K={N_K} fp64, information form, complete run, {how}",
+            "options": opts, "chol_refresh_in_use": K_ref, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
             "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
             "finite": bool(np.all(np.isfinite(XNK))),
             "pos_rmse_m_last_iteration": round(float(np.sqrt(np.mean((XNK[0:3, :, -1] - d["pos"]) ** 2))), 4)}
@@ -275,15 +276,16 @@ def smoother_radio_large(pkg, datagen):
     for _ in range(2):                                                           # the first run also pays for the first touch of 30 GB
         t0 = time.perf_counter()
         XNK, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
-                                                        x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3))
+                                                        x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3), lazy_depth=3, chol_refresh=16)
         runs.append(round(time.perf_counter() - t0, 3))
-    for _ in range(2):                                                           # lazy covariance update + carried factors
+    for _ in range(2):                                                           # the reference's arithmetic: from scratch at every step
         t0 = time.perf_counter()
         XNKc, _, _ = pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
-                                                         x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3), lazy_depth=3, chol_refresh=16)
+                                                         x0, P0, Qr, R, 65536, 3, 1.0, rng=pkg.PhiloxRNG(3), chol_refresh=1)
         runs_c.append(round(time.perf_counter() - t0, 3))
-    return {"workload": "slam-dense-radio N_P=65536 T=48 m=128 N_K=3 fp64, information form (BASELINE.json configs[3] on one GPU)",
-            "seconds": min(runs), "runs": runs, "seconds_lazy3_carried_factors16": min(runs_c), "runs_lazy3_carried_factors16": runs_c,
+    return {"workload": "slam-dense-radio N_P=65536 T=48 m=128 N_K=3 fp64, information form (BASELINE.json configs[3] on one GPU), lazy_depth 3, "
+                        "ancestor-weight factors carried and refactorised every 16 steps",
+            "seconds": min(runs), "runs": runs, "seconds_fresh_factorisation_every_step": min(runs_c), "runs_fresh_factorisation_every_step": runs_c,
             "same_trajectory_draws": bool(np.allclose(XNK, XNKc, rtol=1e-9, atol=1e-11)),
             "unit": "s", "finite": bool(np.all(np.isfinite(XNK)) and np.all(np.isfinite(XNKc)))}
 
@@ -299,6 +301,7 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
     sess = mg.ShardedSmootherSession(model, d["dx"], d["y"], d["initState"], x0_lin, P0, Q, R, N_local, N_K, 0.01,
                                      rng=pkg.PhiloxRNG(seed), rank=rank, world=world, lazy_depth=lazy_depth, chol_refresh=chol_refresh,
                                      force_collectives=(world == 1), storage="fp64sym" if m == 512 else "fp64")
+    sess_K = int(sess.chol_refresh)                           # the K in use (0 = automatic was resolved by the session)
     try:
         torch.cuda.synchronize()
         if dist is not None:
@@ -321,7 +324,7 @@ def smoother_sharded_leg(pkg, mg, datagen, torch, dist, N_local, m, T_s, T_full,
     per_step = [v / T_s for v in tt[1:]]
     return {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_local * world} ({N_local} per GPU x {world}) m={m} N_K={N_K}, "
                         f"first {T_s} of {T_full} time steps of every iteration, lazy_depth {lazy_depth}, "
-                        + (f"ancestor-weight factors carried, refreshed every {chol_refresh} steps" if chol_refresh > 1 else "fresh factorisation every step"),
+                        + (f"ancestor-weight factors carried, refreshed every {sess_K} steps" if sess_K > 1 else "from-scratch factorisation every step"),
             "seconds": tt[0], "seconds_per_iteration": tt[1:], "ms_per_time_step_per_iteration": [v * 1e3 for v in per_step],
             "extrapolated_full_T_seconds": sum(per_step) * T_full, "sharding": st}
 
@@ -377,54 +380,104 @@ def smoother_kernel_roofline(pkg):
 
 def smoother_trace_child(args):
     """Child of smoother_kernel_in_smoother: a short run of the metric's smoother configuration, nothing else (runs under
-    rocprofv3 --kernel-trace --stats)."""
+    rocprofv3 --kernel-trace --stats or --pmc).  --chol-refresh selects the ancestor-weight arithmetic (0: the library default)."""
     pkg = importlib.import_module("rao-blackwellized-slam-smoothing_amd")
     datagen = importlib.import_module("rao-blackwellized-slam-smoothing_amd.datagen")
     Q = q_mag()
     d = datagen.bean_6D(args.T, Q, THETA_MAG, 0.01, seed=args.seed)
     mdl, x0, P0, R = pkg.dense_mag_prior(args.m, d["LL"], THETA_MAG)
     pkg.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R,
-                                        args.particles, 2, 0.01, rng=pkg.PhiloxRNG(3), lazy_depth=3, storage="fp64sym" if args.m == 512 else "fp64")
+                                        args.particles, 2, 0.01, rng=pkg.PhiloxRNG(3), lazy_depth=3, storage="fp64sym" if args.m == 512 else "fp64",
+                                        chol_refresh=args.chol_refresh)
 
 
-def smoother_kernel_in_smoother(args, N_P=8192, T=24):
-    """The ancestor-weight factorisation AS THE SMOOTHER RUNS IT (packed information matrices in, Imat(:,:,ai) out, siblings sharing
-    their ancestor's matrix): mean launch time from a `rocprofv3 --kernel-trace --stats` child run of the metric's smoother
-    configuration (N_P = 8192, m = 512, lazy_depth 3, N_K = 2, T = 24 steps), priced against the fp64 matrix peak with n^3/3 flop per
-    particle.  The step kernels of the same run are listed beside it."""
+def sweep_factor_bytes(n):
+    """Bytes of one carried factor in the sweep layout (csrc/rbpf_chol_sweep.hpp: sweep_factor_doubles)."""
+    NS = (n + 1 + 63) >> 6
+    t = (n + 1) & 63
+    tailc = 1 <= t <= 8 and n + 1 > 64
+    if not tailc:
+        return 8.0 * sum(64 * (NS - (k >> 6)) for k in range(n))
+    M = NS - 1
+    return 8.0 * (sum(64 * (M - (min(k, 64 * M) >> 6)) for k in range(n)) + 8 * n)
+
+
+def smoother_kernel_in_smoother(args, N_P=8192):
+    """The dominant kernel of the ancestor-weight step AS THE SMOOTHER RUNS IT, from child runs of the metric's smoother configuration
+    (N_P = 8192, m = 512, lazy_depth 3, N_K = 2) under rocprofv3:
+
+    * the library default -- carried factors: `chol_sweep_kernel` (one read of the ancestor's factor + one write of the particle's,
+      2 x 1.21 MB; HBM-bound), mean launch time from --kernel-trace --stats over T = 70 steps, HBM traffic per launch from two
+      --pmc passes (2 x FETCH_SIZE + WRITE_SIZE, KiB counters) over T = 40 steps; the refresh's kernels listed beside it;
+    * chol_refresh = 1 -- the from-scratch factorisation `chol_solve64_kernel` (n^3 / 3 flop per particle against the fp64 matrix
+      peak), T = 24 steps."""
     exe = shutil.which("rocprofv3")
     if exe is None:
         return {"error": "rocprofv3 not on PATH"}
     if under_profiler():
         return {"error": "bench.py itself runs under a profiler: nested trace pass skipped"}
-    tmp = tempfile.mkdtemp(prefix="rbpf_trace_", dir="/tmp")
-    try:
-        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", tmp, "-o", "sm", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--smoother-trace-child", "--particles", str(N_P), "--m", str(args.m), "--T", str(T),
-               "--seed", str(args.seed)]
-        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
-        files = glob.glob(os.path.join(tmp, "**", "*kernel_stats.csv"), recursive=True)
-        if r.returncode != 0 or not files:
-            return {"error": f"rocprofv3 --kernel-trace failed (rc {r.returncode}): {r.stdout[-300:]}"}
-        rows = list(csv.DictReader(open(files[0])))
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
     n = args.m + 3
-    out = {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_P} T={T} m={args.m} N_K=2 lazy_depth 3 (rocprofv3 --kernel-trace --stats child run)",
-           "kernels": {}}
-    for x in rows:
-        name = x["Name"].split("(")[0].replace("void rbpf::", "").replace("rbpf::", "")
-        if "chol_solve" in name or "step_sym_kernel" in name or "step_kernel" in name:
-            out["kernels"][name] = {"calls": int(x["Calls"]), "avg_launch_ms": float(x["AverageNs"]) / 1e6, "share_of_gpu_time_pct": float(x["Percentage"])}
-    chol = [(k, v) for k, v in out["kernels"].items() if "chol_solve" in k]
-    if not chol:
-        out["error"] = "no chol_solve kernel in the trace"
-        return out
-    k, v = max(chol, key=lambda kv: kv[1]["calls"])
-    flops = N_P * n ** 3 / 3.0
-    ach = flops / (v["avg_launch_ms"] * 1e-3) / 1e12
-    out.update({"kernel": k, "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
-                "avg_launch_ms": v["avg_launch_ms"], "launches": v["calls"], "algorithmic_flop_per_launch": flops})
+    env = dict(os.environ, TMPDIR="/tmp")
+
+    def child(mode, T, K):
+        tmp = tempfile.mkdtemp(prefix="rbpf_trace_", dir="/tmp")
+        try:
+            cmd = [exe] + mode + ["--output-format", "csv", "-d", tmp, "-o", "sm", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                                  "--smoother-trace-child", "--particles", str(N_P), "--m", str(args.m), "--T", str(T), "--seed", str(args.seed),
+                                  "--chol-refresh", str(K)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=420)
+            pat = "*kernel_stats.csv" if "--stats" in mode else "*counter_collection.csv"
+            files = glob.glob(os.path.join(tmp, "**", pat), recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError(f"rocprofv3 {' '.join(mode)} failed (rc {r.returncode}): {r.stdout[-300:]}")
+            return list(csv.DictReader(open(files[0])))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    def kernels(rows):
+        ks = {}
+        for x in rows:
+            name = x["Name"].split("(")[0].replace("void rbpf::", "").replace("rbpf::", "")
+            if any(t in name for t in ("chol_", "step_sym_kernel", "step_kernel", "gemm_kernel", "sweep_")):
+                ks[name] = {"calls": int(x["Calls"]), "avg_launch_ms": float(x["AverageNs"]) / 1e6, "share_of_gpu_time_pct": float(x["Percentage"])}
+        return ks
+
+    out = {"workload": f"slam-dense-mag particleSmootherInformationForm N_P={N_P} m={args.m} N_K=2 lazy_depth 3, block-lower P (rocprofv3 child runs)"}
+    # ---- the default: carried factors ----
+    try:
+        ks = kernels(child(["--kernel-trace", "--stats"], 70, 0))
+        out["kernels"] = ks
+        sw = [(k, v) for k, v in ks.items() if k.startswith("chol_sweep_kernel")]
+        if not sw:
+            raise RuntimeError("no chol_sweep_kernel in the trace of the default configuration")
+        k, v = max(sw, key=lambda kv: kv[1]["calls"])
+        by = 2.0 * sweep_factor_bytes(n) * N_P
+        ach = by / (v["avg_launch_ms"] * 1e-3) / 1e9
+        out.update({"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                    "avg_launch_ms": v["avg_launch_ms"], "launches": v["calls"], "algorithmic_bytes_per_launch": by, "traffic": None})
+        tr = {}
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            rows = [x for x in child(["--pmc", ctr], 40, 0) if "chol_sweep_kernel" in x.get("Kernel_Name", "") and x.get("Counter_Name") == ctr]
+            if not rows:
+                raise RuntimeError(f"{ctr}: no chol_sweep_kernel dispatch in the counter pass")
+            tr[ctr] = sum(float(x["Counter_Value"]) for x in rows) * 1024.0 / len(rows)
+        traffic = 2.0 * tr["FETCH_SIZE"] + tr["WRITE_SIZE"]
+        out.update({"traffic": traffic, "traffic_detail": {"FETCH_SIZE_bytes_x2": 2.0 * tr["FETCH_SIZE"], "WRITE_SIZE_bytes": tr["WRITE_SIZE"]},
+                    "traffic_over_algorithmic": traffic / by, "hbm_counter_GBps": traffic / (v["avg_launch_ms"] * 1e-3) / 1e9,
+                    "frac_hbm_counters": traffic / (v["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS})
+    except Exception as exc:                                               # report, never hide
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    # ---- chol_refresh = 1: the reference's arithmetic ----
+    try:
+        ks = kernels(child(["--kernel-trace", "--stats"], 24, 1))
+        chol = [(k, v) for k, v in ks.items() if "chol_solve" in k]
+        k, v = max(chol, key=lambda kv: kv[1]["calls"])
+        flops = N_P * n ** 3 / 3.0
+        ach = flops / (v["avg_launch_ms"] * 1e-3) / 1e12
+        out["fresh_factorisation"] = {"kernel": k, "bound": "mfma", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                                      "avg_launch_ms": v["avg_launch_ms"], "launches": v["calls"], "algorithmic_flop_per_launch": flops, "kernels": ks}
+    except Exception as exc:
+        out["fresh_factorisation"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 
@@ -499,8 +552,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother", action="store_true", help="skip every smoother leg")
     ap.add_argument("--no-smoother-full", action="store_true", help="skip the complete T=3000 smoother run of the per-GPU share (about a minute)")
-    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 32768, the "
-                    "reference's arithmetic, about 4 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
+    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 32768, "
+                    "about 2 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
     ap.add_argument("--no-filter-full", action="store_true", help="skip the complete T-step filter run (about 40 s)")
     ap.add_argument("--driver", default="torchrun", choices=["torchrun", "inlib"],
                     help="inlib: ALSO time the in-library multi-device driver (rbpf_options.n_devices, csrc/rbpf_multi.hip: one host process, one thread "
@@ -509,6 +562,7 @@ def main():
     ap.add_argument("--inlib-steps", type=int, default=120, help="time steps of the --driver inlib run (a complete one-shot call: upload, steps, extraction)")
     ap.add_argument("--time-budget", type=float, default=300.0, help="seconds of wall clock after which the longest optional leg (the N_P = 32768 smoother) is not started")
     ap.add_argument("--smoother-trace-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--chol-refresh", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--no-large", action="store_true", help="skip the extra filter configurations (configs[1], configs[4] share) and the N=65536 radio smoother")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
@@ -521,8 +575,6 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
     ap.add_argument("--smoother-steps", type=int, default=150, help="time steps per iteration of the sharded smoother leg (--gpus > 1); --T runs it complete")
     ap.add_argument("--smoother-particles", type=int, default=8192, help="particles per GPU of the sharded smoother leg")
-    ap.add_argument("--smoother-16k-carried", action="store_true", help="also run the complete smoother at N_P = 16384 with carried factors (the largest that option "
-                    "fits on one GPU: its refreshes keep full-square information matrices; about a minute)")
     ap.add_argument("--smoother-timeout", type=float, default=420.0, help="watchdog of EACH sharded smoother leg, seconds (a leg that does not return ends every rank with exit code 3)")
     args = ap.parse_args()
 
@@ -699,24 +751,23 @@ def main():
             # the smoothers take the filter's storage option where it applies to them (symmetric covariance storage: nLin = 515)
             sm_storage = args.storage if args.storage in ("fp64", "fp64sym") and args.m == 512 else "fp64"
             if not args.no_smoother_full:
-                # the reference's arithmetic (a fresh factorisation per particle and step, :228), covariances rewritten every
-                # third step -- and the same run with the ancestor-weight factors carried along the lineages (option
-                # chol_refresh: rank-1 up/down-dates, refactorised every 32nd step; ancestor probabilities within 1e-9 of the
-                # fresh factorisation's, tests/test_gpu_chol_carry.py)
+                # THE metric's smoother number (`smoother_wall_clock_s`) is the library's default configuration of
+                # particleSmootherInformationForm at the per-GPU share: covariances rewritten every third step, ancestor-weight factors
+                # carried along the lineages and refactorised every 32nd step (indices identical, ancestor probabilities within 2e-9,
+                # outputs within 1e-9 of the from-scratch factorisation: tests/test_gpu_r05_parity.py).  The reference's own arithmetic --
+                # chol(Imat_i + ImatAddt) for every particle at every step, :228 -- stays selectable (chol_refresh = 1) and is timed beside it.
                 sm["share_full"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage))
-                sm["share_full_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3,
-                                                                                       chol_refresh=32, storage=sm_storage))
+                sm["share_full_fresh_factorisation"] = guarded(lambda: smoother_share_full(pkg, datagen, 8192, 3000, 512, 2, args.seed, lazy_depth=3,
+                                                                                           chol_refresh=1, storage=sm_storage))
+                line["smoother_metric_rule"] = ("smoother_wall_clock_s = complete T = 3000, N_K = 2 run of particleSmootherInformationForm at the per-GPU share "
+                                                "N_P = 8192 with the library's defaults (carried ancestor-weight factors); *_fresh_factorisation_s = the same run "
+                                                "with the reference's from-scratch factorisation at every step (chol_refresh = 1); *_largest_single_gpu_s = the "
+                                                "defaults at N_P = 32768, half of the metric's N, the most one GPU holds")
                 if "seconds" in sm["share_full"]:
                     line["smoother_wall_clock_s"] = sm["share_full"]["seconds"]
-                    line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3, fresh factorisation every step"
-                if "seconds" in sm["share_full_carried_factors"]:
-                    line["smoother_wall_clock_carried_factors_s"] = sm["share_full_carried_factors"]["seconds"]
-                if args.smoother_16k_carried:
-                    # the largest smoother one GPU holds WITH CARRIED FACTORS: per particle 2 x 1.19 MB covariance banks (symmetric
-                    # storage), 2 x 2.12 MB Imat (full squares: the refreshes' G'G writes them), 2.23 MB factorisation workspace,
-                    # 2 x 1.21 MB carried factors + 0.4 MB refresh scratch = 11.7 MB at nLin = 515 -> N_P = 16 384 needs 191 GB of the 288 GB
-                    sm["N16384_carried_factors"] = guarded(lambda: smoother_share_full(pkg, datagen, 16384, 3000, 512, 2, args.seed,
-                                                                                       lazy_depth=3, chol_refresh=32, storage=sm_storage))
+                    line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3"
+                if "seconds" in sm["share_full_fresh_factorisation"]:
+                    line["smoother_wall_clock_fresh_factorisation_s"] = sm["share_full_fresh_factorisation"]["seconds"]
             if not args.no_large:
                 sm["radio_N65536"] = guarded(smoother_radio_large, pkg, datagen)
             line["smoother"] = sm
@@ -729,23 +780,16 @@ def main():
             # workgroups, ~58 us each), not by bytes -- symmetric storage (supported at this size too) gives the same 8.0-8.2 M/s
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")
             line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]
-            if args.storage == "fp64sym" and args.m == 512 and args.lazy_depth >= 2:
-                # north_star's "MFMA for the batched P*H' where m >= 64", measured: the headline workload with the read-only steps formed per
-                # family of particles that share a stored matrix on the fp64 matrix cores (rbpf_options.family_products = 1)
-                def family():
-                    r, *_ = filter_leg(pkg, datagen, N_local, args.m, T, K, W, args.seed, args.lazy_depth, args.inplace, args.storage, family_products=1)
-                    r["workload"] = line["config"]["workload"] + ", read-only steps as family GEMMs on the matrix cores (family_products = 1; not the default: slower)"
-                    return r
-                line["family_products_filter"] = guarded(family)
         if solo and not args.no_filter_full:
             line["filter_full_T"] = guarded(lambda: filter_full_run(pkg, datagen, N_local, args.m, T, args.seed, args.lazy_depth, args.inplace, args.storage))
             if "seconds" in line["filter_full_T"]:
                 line["filter_full_T_s"] = line["filter_full_T"]["seconds"]
         if solo and not args.no_smoother and not args.no_smoother_full and not args.no_smoother_largest:
-            # The largest smoother ONE GPU holds, the reference's arithmetic (a fresh factorisation per particle and step): half of the
-            # metric's N.  Per particle 2 x 1.19 MB covariance banks, 2 x 1.15 MB information matrices (packed block-lower storage),
-            # 2.23 MB factorisation workspace = 6.9 MB at nLin = 515 -> 226 GB of the 288 GB.  The longest leg of the run (about four
-            # minutes), so it goes last and only while the run is inside its time budget.
+            # The largest smoother ONE GPU holds, library defaults (carried factors): half of the metric's N.  Per particle 2 x 1.19 MB
+            # covariance banks, 2 x 1.15 MB information matrices (packed block-lower storage, materialised at the refreshes only),
+            # 2 x 1.21 MB carried factors, 0.4 MB refresh scratch = 7.5 MB at nLin = 515 -> 246 GB of the 288 GB (the factorisation
+            # workspaces of a refresh are per chunk of 4096 particles).  The longest leg of the run (about two minutes), so it goes last and
+            # only while the run is inside its time budget.
             elapsed = time.perf_counter() - t_start
             if elapsed > args.time_budget:
                 line["smoother"]["largest_single_gpu"] = {"skipped": f"{elapsed:.0f} s of wall clock used before this leg (--time-budget {args.time_budget:.0f})"}
@@ -755,7 +799,7 @@ def main():
                 line["smoother"]["largest_single_gpu"] = r32
                 if "seconds" in r32:
                     line["smoother_wall_clock_largest_single_gpu_s"] = r32["seconds"]
-                    line["smoother_wall_clock_largest_single_gpu_workload"] = r32["workload"] + ", lazy_depth 3, fresh factorisation every step"
+                    line["smoother_wall_clock_largest_single_gpu_workload"] = r32["workload"] + ", lazy_depth 3"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)
@@ -805,21 +849,21 @@ def main():
 
         def radio(**o):
             return smoother_sharded_radio_leg(pkg, mg, datagen, torch, dist, args.smoother_particles, args.seed, rank, world, **o)
-        # the reference's arithmetic (a fresh factorisation per particle and step), then factors carried along the lineages
-        # (tolerance: DESIGN.md 4.3); BASELINE.json configs[3]: dense-radio, 8192 particles per GPU, both ways
+        # the library's defaults (factors carried along the lineages; tolerance: DESIGN.md 4), then the reference's arithmetic (a
+        # from-scratch factorisation per particle and step); BASELINE.json configs[3]: dense-radio, 8192 particles per GPU, both ways
         res = timed("smoother_sharded", lambda: leg(0))
-        res_c = timed("smoother_sharded_carried_factors", lambda: leg(32))
-        res_r = timed("smoother_sharded_radio", lambda: radio())
-        res_rc = timed("smoother_sharded_radio_carried_factors", lambda: radio(lazy_depth=3, chol_refresh=16))
+        res_f = timed("smoother_sharded_fresh_factorisation", lambda: leg(1))
+        res_r = timed("smoother_sharded_radio", lambda: radio(lazy_depth=3, chol_refresh=16))
+        res_rf = timed("smoother_sharded_radio_fresh_factorisation", lambda: radio(chol_refresh=1))
         if rank == 0:
             line["smoother_sharded"] = res
-            line["smoother_sharded_carried_factors"] = res_c
+            line["smoother_sharded_fresh_factorisation"] = res_f
             line["smoother_sharded_radio"] = res_r
-            line["smoother_sharded_radio_carried_factors"] = res_rc
+            line["smoother_sharded_radio_fresh_factorisation"] = res_rf
             if "extrapolated_full_T_seconds" in res:
                 line["smoother_wall_clock_extrapolated_s"] = res["extrapolated_full_T_seconds"]
-            if "extrapolated_full_T_seconds" in res_c:
-                line["smoother_wall_clock_carried_factors_extrapolated_s"] = res_c["extrapolated_full_T_seconds"]
+            if "extrapolated_full_T_seconds" in res_f:
+                line["smoother_wall_clock_fresh_factorisation_extrapolated_s"] = res_f["extrapolated_full_T_seconds"]
     if rank == 0:
         emit(line)
     if dist is not None:

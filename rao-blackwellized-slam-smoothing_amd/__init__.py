@@ -13,7 +13,7 @@ from ._ffi import (RBPFError, load_library, EXPORTS,                  # noqa: F4
 from .host import (particleFilter, particleSmoother, particleSmootherInformationForm,   # noqa: F401
                    DenseMagModel, DenseRadioModel, SparseVisualModel, dense_mag_prior, dense_radio_prior,
                    domain_cartesian_dx, eigenval, PhiloxRNG, ReplayRNG, FilterSession, sample, chol_weights, chol_sweep_probe, quat_helper,
-                   GenericDenseModel, particle_filter_external)
+                   GenericDenseModel, particle_filter_external, chol_refresh_in_use)
 
 
 def device_count() -> int:

@@ -1,0 +1,175 @@
+"""GPU parity, round 5 (VERDICT r04 "Next round" item 1): the four holes that were still open under the metric.
+
+(i)   Near-ties of the importance weights.  `iw_max` / `traj_max` are index work (particleFilter.m:159 takes the FIRST maximum), and
+      in dense-radio siblings tie STRUCTURALLY (measModel sees the position only, run_dense2D_withHeading.m:168, which propagates
+      without noise, :75-76).  Two statements are tested: siblings' log-weights are bit-identical on the device whatever slot computed
+      them, so exact ties resolve as in the reference; and where two DIFFERENT particles' weights differ by less than fp64 evaluation
+      noise (profiles/r04_size_scan.txt's "FAIL": radio m = 512, t = 3) the extended-precision arbiter decides -- it sides with the
+      device and the C restatement, against the numpy oracle's rounding.
+(ii)  The filter over the metric's horizon T = 3000 against the ARBITER (oracle/rbpf_oracle_c.c built with -DRBPF_ORACLE_LONG_DOUBLE;
+      fixture tests/golden/arbiter_filter_N64_T3000_m512.npz, generated on the CPU by tests/golden/make_arbiter_fixture.py): every
+      index identical, 1e-9 up to t = 500, and over the whole horizon err(HIP, arbiter) <= 1.25 x err(C fp64, arbiter) per quantity --
+      the product is no further from the exact result of the reference's formulas than a correctly rounded fp64 restatement is.
+(iii) particleSmootherInformationForm over a long horizon (T = 1000, m = 512, N_P = 64, N_K = 2, block-lower P, lazy_depth 3) with the
+      from-scratch factorisation (chol_refresh 1) and with carried factors (32, the default): every ancestor, every draw, weights /
+      ancestor probabilities / outputs by the same rule against the arbiter (particleSmootherInformationForm.m:186-335).
+(iv)  N = 65 536, 10 steps, the same Philox streams: the bench's schedule (block-lower storage, lazy_depth 4, two banks, shared flush)
+      against the reference's literal schedule (full-square storage rewritten every step): identical resampling indices, outputs 1e-10.
+
+Tolerances: indices bit-exact; fp64 quantities 1e-9 relative where the problem's conditioning allows, otherwise the arbiter rule."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_c
+from test_gpu_configs import check_filter_properties, mag_inputs, rel, run_session
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+SLACK = 1.25                                # err(HIP, arbiter) <= SLACK x err(C fp64, arbiter)
+
+
+def test_radio_siblings_tie_exactly_and_near_ties_follow_the_arbiter(rbpf):
+    """(i) dense-radio, m = 512, N_P = 6, T = 7, seed 41 -- the case profiles/r04_size_scan.txt recorded as FAIL."""
+    c = cases.radio_case(6, 7, 512, seed=41, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    arb, _ = oracle_c.particle_filter(rbpf, mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                                      cases.device_rng(rbpf, c), lib_path=oracle_c.build_arbiter())
+    c64, _ = oracle_c.particle_filter(rbpf, mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                                      cases.device_rng(rbpf, c))
+    for kw in ({}, dict(lazy_depth=3)):
+        out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"],
+                                  rng=cases.device_rng(rbpf, c), extras=True, **kw)
+        ex = out[8]
+        ai, logw, w = ex["ai"], ex["logw"], ex["w"]
+        np.testing.assert_array_equal(ai[1:], arb["trace_ai"].T[1:])
+        # siblings: same ancestor => same position (noise-free) => same H, same prior => the same weight, BIT FOR BIT
+        n_sib = 0
+        for t in range(1, ai.shape[0]):
+            for a in np.unique(ai[t]):
+                sib = np.flatnonzero(ai[t] == a)
+                n_sib += len(sib) > 1
+                assert len(set(float(v).hex() for v in logw[t, sib])) == 1, (t, a, [float(v).hex() for v in logw[t, sib]])
+        assert n_sib >= 5
+        # the arg-max of every step is the arbiter's (first maximum among exact ties); the device agrees with the C restatement too
+        np.testing.assert_array_equal(np.argmax(w, axis=1), np.argmax(arb["trace_w"], axis=0))
+        np.testing.assert_array_equal(np.argmax(w, axis=1), np.argmax(c64["trace_w"], axis=0))
+        assert int(ex["iw_max"]) == int(arb["iw_max"][0])
+        assert rel(out[0], arb["traj_max"]) <= RTOL and rel(out[1], arb["traj_mean"]) <= RTOL
+        assert rel(w, arb["trace_w"].T) <= RTOL
+    # what the r04 scan tripped over: at t = 3 particles 0 and 3 -- different lineages -- differ by less than the evaluations' noise
+    tr = cases.oracle_filter(c)["trace"]
+    gap_true = abs(arb["trace_logw"][0, 3] - arb["trace_logw"][3, 3])
+    noise_numpy = np.max(np.abs(tr["logw"][3] - arb["trace_logw"][:, 3]))
+    assert gap_true < noise_numpy                                    # the numpy oracle's order of the two is decided by its rounding
+    assert int(np.argmax(arb["trace_w"][:, 3])) == 3 and int(np.argmax(tr["w"][3])) == 0
+
+
+def load_fixture(name, d, *more):
+    """The fixture and its measurements: y is taken from the fixture (the generator's BLAS product rounds differently on another host
+    CPU, and one ulp on an input is 1e-9 on an output over these horizons); every other input is regenerated and checked."""
+    import make_arbiter_fixture as maf
+    fx = np.load(os.path.join(GOLDEN, name))
+    assert np.max(np.abs(d["y"] - fx["y"])) <= 1e-12 * np.max(np.abs(fx["y"]))       # the same problem, up to the generator's rounding
+    d["y"] = fx["y"]
+    assert str(fx["inputs_sha256"]) == maf.checksum(d["dx"], d["y"], d["initState"], *more), "the generators no longer produce the fixture's inputs: regenerate it"
+    return fx
+
+
+def test_filter_over_the_full_horizon_against_the_arbiter(rbpf):
+    """(ii) m = 512, N = 64, T = 3000 (750 lazy cycles, the bean trajectory three times round): block-lower storage with lazy_depth 4
+    in both bank schedules, and full-square storage rewritten every step (the reference's own schedule)."""
+    import make_arbiter_fixture as maf
+    N, T = 64, 3000
+    d, mdl, x0, P0, R, rng = maf.filter_inputs()
+    fx = load_fixture("arbiter_filter_N64_T3000_m512.npz", d, x0, P0, R, rng.U, rng.Z)
+    rows = fx["P_rows"]
+    ai_ref = fx["trace_ai"].astype(np.int32).T
+    keys = ("trace_w", "traj_max", "traj_mean", "xl_max", "xl_mean", "final_xl", "traj_sample_iwmax", "P_max_rows", "P_mean_rows", "P_max_diag")
+    report = {}
+    for tag, kw in (("sym_lazy4_two_banks", dict(lazy_depth=4, inplace=-1, storage="fp64sym")),
+                    ("sym_lazy4_in_place", dict(lazy_depth=4, inplace=1, storage="fp64sym")),
+                    ("full_square_every_step", dict())):
+        out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                                  extras=True, **kw)
+        ex = out[8]
+        np.testing.assert_array_equal(ex["ai"][1:], ai_ref[1:])                  # 2999 x 64 resampling indices
+        assert int(ex["iw_max"]) == int(fx["iw_max"][0])
+        got = dict(trace_w=ex["w"].T, traj_max=out[0], traj_mean=out[1], xl_max=out[2], xl_mean=out[3], final_xl=ex["xl"],
+                   traj_sample_iwmax=out[6], P_max_rows=out[4][rows, :], P_mean_rows=out[5][rows, :], P_max_diag=np.diag(out[4]))
+        assert rel(got["trace_w"][:, :500], fx["trace_w"][:, :500]) <= RTOL      # the well-conditioned stretch: north_star's 1e-9
+        assert rel(out[0][:, :500], fx["traj_max"][:, :500]) <= RTOL and rel(out[1][:, :500], fx["traj_mean"][:, :500]) <= RTOL
+        for k in keys:
+            e_hip, e_c = rel(got[k], fx[k]), float(fx["err_c64_nofma__" + k])
+            report[(tag, k)] = (e_hip, e_c)
+            assert e_hip <= max(RTOL, SLACK * e_c), (tag, k, e_hip, e_c)
+            # block-lower storage keeps P exactly symmetric -- the plain form's drift is the growth of its asymmetric part -- and holds
+            # north_star's 1e-9 against the arbiter over the WHOLE horizon (measured 1e-11 on the weights, where fp64 C is at 7.6e-9)
+            if tag.startswith("sym_"):
+                assert e_hip <= RTOL, (tag, k, e_hip)
+    print({f"{t}:{k}": f"{a:.2e} (C {b:.2e})" for (t, k), (a, b) in report.items()})
+
+
+@pytest.mark.parametrize("chol_refresh", [1, 32])
+def test_information_form_smoother_over_a_long_horizon_against_the_arbiter(rbpf, chol_refresh):
+    """(iii) T = 1000, m = 512, N_P = 64, N_K = 2, block-lower P, lazy_depth 3; chol_refresh 1 = chol(Imat_i + ImatAddt) at every step
+    (the reference's arithmetic), 32 = carried factors with 31 refreshes along the run (the default)."""
+    import make_arbiter_fixture as maf
+    N, T, N_K = 64, 1000, 2
+    d, mdl, x0, P0, R, rng = maf.smoother_inputs()
+    fx = load_fixture("arbiter_info_smoother_N64_T1000_m512.npz", d, x0, P0, R, rng.U, rng.Z, rng.Ufin)
+    assert rbpf.chol_refresh_in_use(mdl, 0) == 32
+    XNK, XLK, PK, ex = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
+                                                            x0, P0, cases.Q_MAG, R, N, N_K, 0.01, rng=rng, extras=True, storage="fp64sym",
+                                                            lazy_depth=3, chol_refresh=chol_refresh)
+    np.testing.assert_array_equal(ex["ak"], fx["ak"])                            # the trajectory draws
+    np.testing.assert_array_equal(ex["ai"][:, 1:], fx["ai"].astype(np.int32)[:, 1:])   # every ancestor incl. slot N_P's (:241)
+    rows = fx["P_rows"]
+    got = dict(w=ex["w"], paNt=ex["paNt"][1, 1:], XNK=XNK, XLK=XLK, PK_rows=PK[rows, :, :],
+               PK_diag=np.stack([np.diag(PK[:, :, k]) for k in range(N_K)], axis=1))
+    report = {}
+    for k, v in got.items():
+        ref = fx[k]
+        if k == "paNt" and ref.shape[0] == T:                                    # stored with the (undefined) row of t = 0
+            ref = ref[1:]
+        e_hip = float(np.max(np.abs(v - ref))) if k == "paNt" else rel(v, ref)
+        e_c = float(fx["err_c64_nofma__" + k])
+        report[k] = (e_hip, e_c)
+        # carried factors: the stated tolerance of the option on the ancestor probabilities (2e-9 absolute) next to the arbiter rule
+        tol = max(RTOL, SLACK * e_c)
+        if chol_refresh > 1 and k == "paNt":
+            tol = max(tol, 2e-9)
+        assert e_hip <= tol, (k, e_hip, e_c)
+    print({k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
+
+
+def test_bench_schedule_equals_the_literal_schedule_at_configs2_size(rbpf):
+    """(iv) N = 65 536, m = 512, 10 steps on the same Philox streams: block-lower storage / lazy_depth 4 / two banks / shared flush (what
+    bench.py times; 2.96 x fewer bytes than SURVEY 8(d)'s formula) against full-square storage rewritten at every step
+    (particleFilter.m:112-113,198 as written: 139 GB per bank).  Two full-square banks are 282 GB -- where they do not fit the single
+    bank rewritten at every second step (lazy_depth 2, in place) stands in."""
+    N, steps = 65536, 10
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 512)
+    want = ("traj_max", "traj_mean", "xl_max", "xl_mean", "P_max", "trace_w", "trace_ai")
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=0, storage="fp64sym")
+    check_filter_properties(a, N, steps, P0)
+    literal = "full-square, every step, two banks"
+    try:
+        b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=0, inplace=-1, storage="fp64")
+    except rbpf.RBPFError as e:
+        if e.status != rbpf.RBPF_ERR_OUT_OF_MEMORY:
+            raise
+        literal = "full-square, every second step, one bank in place"
+        b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=2, inplace=1, storage="fp64")
+    print("literal schedule:", literal)
+    np.testing.assert_array_equal(a["trace_ai"], b["trace_ai"])
+    for k in want:
+        if k != "trace_ai":
+            sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
+            assert rel(a[k][sl], b[k][sl]) <= 1e-10, (k, rel(a[k][sl], b[k][sl]))
