@@ -250,7 +250,7 @@ hipError_t launch_unpack_P_sets(const Layout& lay, int d, const double* Pt, cons
 hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, const double* w, double* out,
                                    hipStream_t s);
 hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,
-                            int n_paths, double* out, hipStream_t s);
+                            int n_paths, double* out, hipStream_t s, int path0 = 0);
 hipError_t launch_philox_fill(unsigned long long seed, int k_iter, int N, int T, int nw, double* U, double* Z,
                               double* Ufin, hipStream_t s);
 // layout 0: dy[p][c][k] (MATLAB [ny x nLin x Npred]); layout 1: dy[p][k][c] (rows of H contiguous)

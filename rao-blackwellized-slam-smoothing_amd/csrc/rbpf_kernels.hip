@@ -154,7 +154,7 @@ bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_set
   // (CPL <= 2: the blocked variants are only instantiated for one or two row chunks per wave -- launch_step_t; with three chunks,
   //  384 <= nLin < 512, the plain plan stays whatever its size.  r04: this function used to say "blocked" there, the launch sized
   //  the LDS for the blocked plan and then ran the plain kernel over it: wrong results for nLin 441..511 and for the information
-  //  form from nLin = 384 on, sizes no test had touched; tests/test_gpu_filter.py test_three_row_chunks)
+  //  form from nLin = 384 on, sizes no test had touched; tests/test_gpu_filter.py test_every_row_chunk_count)
   if (n_sets < 1 || lay.mc == 0 || lay.CPL < 1 || lay.CPL > 2 || lay.CH != lay.CPL * lay.RS || lay.RS * lay.CS != kWaves) return false;
   return (size_t)lds_plan(lay.n, m.d, extra, n_sets, lay.ldx, lay.CS, lay.mc, m.ktot, 0).total * sizeof(double) > (size_t)RBPF_KB_THRESHOLD_KB * 1024;
 }
@@ -1548,10 +1548,10 @@ hipError_t launch_weighted_mean_xl(int N, int n, int ldx, const double* xl, cons
 // Ancestral paths: the lazily evaluated equivalent of the eager history permutation
 // xn_traj(:,:,1:t-1) = xn_traj(:,ai,1:t-1)  (particleFilter.m:118).  X: [T][nN][N], A: [T][N].
 __global__ void backtrace_kernel(int N, int nN, int T, const double* __restrict__ X, const int* __restrict__ A,
-                                 const int* __restrict__ start_index, int n_paths, double* __restrict__ out) {
+                                 const int* __restrict__ start_index, int n_paths, double* __restrict__ out, int path0) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_paths) return;
-  int j = start_index ? start_index[p] : p;
+  int j = start_index ? start_index[p] : path0 + p;          // (path0: first path of a chunk of all paths)
   for (int t = T - 1; t >= 0; --t) {
     for (int c = 0; c < nN; ++c)
       out[c + (size_t)nN * (p + (size_t)n_paths * t)] = X[((size_t)t * nN + c) * N + j];
@@ -1560,9 +1560,9 @@ __global__ void backtrace_kernel(int N, int nN, int T, const double* __restrict_
 }
 
 hipError_t launch_backtrace(int N, int nN, int T, const double* X, const int* A, const int* start_index,
-                            int n_paths, double* out, hipStream_t s) {
+                            int n_paths, double* out, hipStream_t s, int path0) {
   hipLaunchKernelGGL(backtrace_kernel, dim3((n_paths + 63) / 64), dim3(64), 0, s, N, nN, T, X, A, start_index,
-                     n_paths, out);
+                     n_paths, out, path0);
   return hipGetLastError();
 }
 

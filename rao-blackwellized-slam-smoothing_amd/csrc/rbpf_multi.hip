@@ -94,15 +94,18 @@ struct Multi {
   long long migrated = 0, sent_records = 0;
   // RCCL transport: a rank that fails between collectives aborts EVERY communicator of this process (ncclCommAbort makes the
   // collective kernels its peers wait behind give up), so that the peers' stream synchronisations return, their threads join and the
-  // entry point reports the first failure instead of hanging; communicators are never destroyed after that, only aborted.
+  // entry point reports the first failure instead of hanging.  The handles stay where they are (peers read comm[r] concurrently: no
+  // write to the vector after creation); `comms_aborted` is checked before every collective and keeps the destructor from destroying
+  // aborted communicators; the rank that failed FIRST is recorded by a compare-exchange, not recovered from message texts.
   std::mutex abort_m;
-  bool comms_aborted = false;
+  std::atomic<bool> comms_aborted{false};
+  std::atomic<int> first_failed{-1};
   int home_device = -1;                            // the caller's current device, restored when the call returns
   void abort_comms() {
     std::lock_guard<std::mutex> lk(abort_m);
-    if (comms_aborted || host_staged || !g_rccl.CommAbort) return;
-    comms_aborted = true;
-    for (auto& c : comm) if (c) { g_rccl.CommAbort(c); c = nullptr; }
+    if (comms_aborted.load() || host_staged || !g_rccl.CommAbort) return;
+    comms_aborted.store(true);
+    for (auto c : comm) if (c) g_rccl.CommAbort(c);
   }
   Multi() { if (hipGetDevice(&home_device) != hipSuccess) home_device = -1; }
   ~Multi() {
@@ -111,7 +114,7 @@ struct Multi {
       hipSetDevice(devs[r]);
       rbpf_destroy(ctx[r]);
     }
-    for (auto c : comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
+    if (!comms_aborted.load()) for (auto c : comm) if (c && g_rccl.CommDestroy) g_rccl.CommDestroy(c);
     if (home_device >= 0) hipSetDevice(home_device);
   }
 };
@@ -127,7 +130,11 @@ int run_ranks(Multi& M, F fn) {
     int s = (hipSetDevice(M.devs[r]) == hipSuccess) ? RBPF_OK : RBPF_ERR_HIP;
     if (s == RBPF_OK) s = fn(r);
     M.status[r] = s;
-    if (s != RBPF_OK) { const char* e = rbpf_last_error(); M.msg[r] = e ? e : ""; M.bar.abort(); M.abort_comms(); }
+    if (s != RBPF_OK) {
+      int none = -1;
+      M.first_failed.compare_exchange_strong(none, r);         // the first rank to get here failed on its own
+      const char* e = rbpf_last_error(); M.msg[r] = e ? e : ""; M.bar.abort(); M.abort_comms();
+    }
   };
   if (M.W == 1) body(0);
   else {
@@ -135,15 +142,19 @@ int run_ranks(Multi& M, F fn) {
     for (int r = 0; r < M.W; ++r) th.emplace_back(body, r);
     for (auto& t : th) t.join();
   }
-  int first = -1;                                  // the rank that failed on its own, not one released by its abort
-  for (int r = 0; r < M.W; ++r)
-    if (M.status[r] != RBPF_OK && (first < 0 || (M.msg[first].find("another rank failed") != std::string::npos && M.msg[r].find("another rank failed") == std::string::npos))) first = r;
+  int first = M.first_failed.load();               // the rank that failed on its own, not one released by its abort
+  if (first < 0) for (int r = 0; r < M.W && first < 0; ++r) if (M.status[r] != RBPF_OK) first = r;
+  M.first_failed.store(-1);
   if (first >= 0) { set_error("device " + std::to_string(M.devs[first]) + " (rank " + std::to_string(first) + "): " + M.msg[first]); return M.status[first]; }
   return RBPF_OK;
 }
 
 int gather_rows(Multi& M, int r, const double* local, double* gathered, size_t count) {
-  if (!M.host_staged) { MT_NCCL(g_rccl.AllGather(local, gathered, count, ncclDouble, M.comm[r], M.stream[r])); return RBPF_OK; }
+  if (!M.host_staged) {
+    if (M.comms_aborted.load()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
+    MT_NCCL(g_rccl.AllGather(local, gathered, count, ncclDouble, M.comm[r], M.stream[r]));
+    return RBPF_OK;
+  }
   HIPCHK(hipStreamSynchronize(M.stream[r]));
   if (M.h_fwd.size() < (size_t)M.W * count) { set_error("host staging buffer too small"); return RBPF_ERR_STATE; }
   HIPCHK(hipMemcpy(M.h_fwd.data() + (size_t)r * count, local, count * sizeof(double), hipMemcpyDeviceToHost));
@@ -165,6 +176,7 @@ int exchange_rows(Multi& M, int r, const double* send, double* recv, const long 
   long long ns = 0;
   for (int q = 0; q < W; ++q) ns += snd[q];
   if (!M.host_staged) {
+    if (M.comms_aborted.load()) { set_error("another rank failed"); return RBPF_ERR_STATE; }
     MT_NCCL(g_rccl.GroupStart());
     size_t so = 0, ro = recv_off;
     for (int q = 0; q < W; ++q) {

@@ -674,11 +674,21 @@ int rbpf_shard_xn_traj(rbpf_ctx* c, double* xn_traj) {
   if (c->t < 1) { set_error("xn_traj needs at least one finished step"); return RBPF_ERR_STATE; }
   RB_TRY(ctx_check_flags(c));
   const int nN = c->mdl.nN, N = s->Nglob, Td = c->t;
+  // The output is nN * N * T doubles (9.4 GB at N = 65 536, T = 3000, nN = 6) and the banks may have left little of the device: the
+  // paths are traced in chunks through a scratch buffer of at most 256 MB (rows of the host array are nN * N doubles apart, a
+  // chunk's are nN * cnt: one strided copy per chunk)
+  const size_t budget = (size_t)256 << 20;
+  const int chunk = (int)std::max<size_t>(64, std::min<size_t>((size_t)N, budget / ((size_t)nN * Td * sizeof(double))));
   double* dout = nullptr;
-  RB_TRY(dmalloc(&dout, (size_t)nN * N * Td));
-  hipError_t e = launch_backtrace(N, nN, Td, s->Xhist, s->Ahist, nullptr, N, dout, c->stream);   // particleFilter.m:117-118
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess) e = hipMemcpy(xn_traj, dout, (size_t)nN * N * Td * sizeof(double), hipMemcpyDeviceToHost);
+  RB_TRY(dmalloc(&dout, (size_t)nN * chunk * Td));
+  hipError_t e = hipSuccess;
+  for (int p0 = 0; p0 < N && e == hipSuccess; p0 += chunk) {
+    const int cnt = std::min(chunk, N - p0);
+    e = launch_backtrace(N, nN, Td, s->Xhist, s->Ahist, nullptr, cnt, dout, c->stream, p0);      // particleFilter.m:117-118
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy2D(xn_traj + (size_t)nN * p0, (size_t)nN * N * sizeof(double), dout, (size_t)nN * cnt * sizeof(double),
+                                         (size_t)nN * cnt * sizeof(double), (size_t)Td, hipMemcpyDeviceToHost);
+  }
   hipFree(dout);
   HIPCHK(e);
   return RBPF_OK;

@@ -48,6 +48,20 @@ def test_multi_device_filter_equals_single_gpu(rbpf, m, N, ids):
     np.testing.assert_array_equal(multi[7], full[7])                         # xn_traj from the replicated state history
 
 
+def test_xn_traj_is_traced_in_chunks(rbpf):
+    """rbpf_shard_xn_traj traces the ancestral paths through a scratch buffer of at most 256 MB: N = 8192, T = 600, nN = 7 is 275 MB of
+    output, i.e. two chunks of paths, each copied into its columns of the host array; equal to the single-GPU xn_traj
+    (particleFilter.m:117-118)."""
+    d, mdl, x0, P0, R = _mag(rbpf, 600, 16)
+    N = 8192
+    full = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01,
+                               rng=rbpf.PhiloxRNG(11))
+    multi = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01,
+                                rng=rbpf.PhiloxRNG(11), n_devices=1, device_ids=[0])
+    assert multi[7].shape == (7, N, 600) and multi[7].nbytes > 256 << 20
+    np.testing.assert_array_equal(multi[7], full[7])
+
+
 @pytest.mark.parametrize("storage,lazy_depth,m", [("fp64", 3, 130), ("fp64sym", 4, 512), ("fp64sym", 0, 512)])
 def test_multi_device_filter_with_lazy_update_and_symmetric_storage(rbpf, storage, lazy_depth, m):
     d, mdl, x0, P0, R = _mag(rbpf, 11, m)
