@@ -1114,6 +1114,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         HIPCHK(hipGetLastError());
       }
     }
+    bool sweep_in_flight = false;                  // (RBPF_SWEEP_OVERLAP_PROBE, diagnostic builds)
     for (int t = 0; t < T; ++t) {
       const double* xref = (k > 0) ? s->d_xnk + (size_t)t * nN : nullptr;
       int n_draw = N;
@@ -1191,6 +1192,27 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             sw.W = s->d_W; sw.yt = c->d_y + (size_t)(t - 1) * d; sw.qf = s->d_qf[s->icur]; sw.hld = s->d_hld[s->icur];
             sw.pant_log = s->d_pant_log; sw.status = c->d_flags;
             sw.order = (c->order_step == t - 1) ? c->d_order : nullptr;     // generation t-1 in the order its step ran in
+            // TIMING PROBE (diagnostic builds; WRONG RESULTS by design: slot N_P's ancestor is drawn before the sweep has added
+            // logwMeas): the sweep on a second stream BESIDE the normalisation and the step kernels of the same time step -- what an
+            // implementation that defers only slot N_P's work behind the sweep could gain
+            static const int ovl = tuning_env("RBPF_SWEEP_OVERLAP_PROBE") ? 1 : 0;
+            if (ovl) {
+              if (!c->stream2) {
+                HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+              }
+              if (sw.order) {                                 // the step kernels of this time step rewrite the order while the sweep reads it
+                if (!s->d_base_loc) RB_TRY(dmalloc(&s->d_base_loc, (size_t)N));      // (a buffer the single-GPU smoother does not use)
+                HIPCHK(hipMemcpyAsync(s->d_base_loc, sw.order, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
+                sw.order = s->d_base_loc;
+              }
+              HIPCHK(hipEventRecord(c->ev_fork, st));
+              HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+              HIPCHK(launch_chol_sweep(sw, c->stream2));
+              HIPCHK(hipEventRecord(c->ev_join, c->stream2));
+              sweep_in_flight = true;
+            } else
             HIPCHK(launch_chol_sweep(sw, st));
             s->sw_cur ^= 1;
             skip_chol = true;
@@ -1234,6 +1256,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       }
       if (generic) RB_TRY(generic_finish_inputs(c, k > 0 ? xnk_h.data() + (size_t)t * nN : nullptr));
       const int st_step = info_form ? info_step(c, k, t, xref, n_draw, d_Rinv) : ctx_step(c, k, xref, n_draw, nullptr);
+      if (sweep_in_flight) { HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0)); sweep_in_flight = false; }   // (timing probe only)
       if (generic) { c->ext_xn = nullptr; c->ext_H = nullptr; }
       RB_TRY(st_step);
     }

@@ -130,7 +130,7 @@ def test_information_form_smoother_at_the_benchmark_basis_sizes(rbpf, m):
     64-column kernel (two workgroups per CU)."""
     import test_gpu_smoother as ts
     c = cases.mag_case(6, 5, m, seed=23, N_K=2)
-    ref, out = ts.run_both(rbpf, c, info_form=True)
+    ref, out = ts.run_both(rbpf, c, info_form=True, chol_refresh=1)          # the factorisation at every step (0 = automatic carries the factors)
     ts.check(ref, out, 2)
 
 

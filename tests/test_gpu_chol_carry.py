@@ -32,11 +32,11 @@ def test_carried_factors_match_the_oracle(rbpf, kind, N_P, N_T, m, K):
 
 @pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 64, 60, 130), ("radio", 96, 80, 128)])
 def test_drift_of_the_carried_factors_over_a_long_run(rbpf, kind, N_P, N_T, m):
-    """60 / 80 steps without a refresh against the default (fresh factorisation every step) on the same random numbers: the
+    """60 / 80 steps without a refresh against the fresh factorisation of every step (chol_refresh = 1) on the same random numbers: the
     ancestor probabilities stay within 1e-9, so every index and every output is identical or within 1e-9."""
     mk = cases.mag_case if kind == "mag" else cases.radio_case
     c = mk(N_P, N_T, m, seed=73, N_K=2)
-    a = run(rbpf, c)
+    a = run(rbpf, c, chol_refresh=1)                      # from scratch at every step (the r04 default; 0 is automatic since r05)
     b = run(rbpf, c, chol_refresh=1000)
     pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
     drift = float(np.max(np.abs(pa - pb)))
@@ -53,6 +53,28 @@ def test_carried_factors_with_the_lazy_covariance_update(rbpf):
     ts.check(ref, out, 3)
 
 
+def test_refresh_in_chunks_of_factor_workspaces(rbpf):
+    """r05: with carried factors the refresh factorises in chunks of 4096 particles over one set of workspaces (the 2.2 MB per
+    particle N_P = 32 768 has no room for).  N_P = 4100 = one full chunk + 4: the default (K = 32, refreshes at t = 1 and t = 33)
+    against the from-scratch factorisation of every step on the same Philox streams -- same ancestors and draws, paNt 1e-9."""
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    T, N = 36, 4100
+    Q = dg.radio_Q(T, "square_3D")
+    th = [0.25, 2.0, 0.01]
+    d = dg.planar_heading(T, Q, th, 1.0, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = rbpf.dense_radio_prior(128, d["LL"], th)
+    assert rbpf.chol_refresh_in_use(mdl, 0) == 32
+    go = lambda **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
+                                                           x0, P0, Q, R, N, 2, 1.0, rng=rbpf.PhiloxRNG(9), extras=True, **kw)
+    a = go(chol_refresh=1)
+    b = go()
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert np.max(np.abs(a[3]["paNt"][1, 1:] - b[3]["paNt"][1, 1:])) <= 1e-9
+    assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[1], a[1]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
+
+
 def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
     c = cases.mag_case(4, 4, 600, seed=1, N_K=2)             # nLin = 603 > 575
     with pytest.raises(rbpf.RBPFError) as ei:
@@ -61,7 +83,7 @@ def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
 
 
 def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf):
-    """The options of bench.py's second smoother number (lazy_depth = 3, chol_refresh = 32) at the metric's matrix size
+    """The options of the metric's smoother number (lazy_depth = 3, chol_refresh = 32 = what 0 resolves to) at the metric's matrix size
     (slam-dense-mag m = 512, nLin = 515) over the metric's T = 3000 time steps -- 94 refresh cycles, device Philox, the product's own data
     generator -- against the fresh factorisation on the same streams: ancestor probabilities within the stated 2e-9 at every
     step (measured 8.8e-10; it does not grow with the refresh period, tools/drift_study.py), every ancestor index and trajectory
@@ -77,7 +99,7 @@ def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf):
     def go(**kw):
         return rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R,
                                                     N, N_K, 0.01, rng=rbpf.PhiloxRNG(17), extras=True, **kw)
-    a = go(lazy_depth=3)
+    a = go(lazy_depth=3, chol_refresh=1)
     b = go(lazy_depth=3, chol_refresh=32)
     pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
     assert np.all(np.isfinite(pb))

@@ -115,12 +115,14 @@ def test_m1024_filter_matches_oracle(rbpf, storage, lazy_depth, tol):
             assert rel(got, want_) <= tol
 
 
-def test_information_form_smoother_matches_oracle_at_m512(rbpf):
+@pytest.mark.parametrize("chol_refresh", [1, 0])
+def test_information_form_smoother_matches_oracle_at_m512(rbpf, chol_refresh):
     """particleSmootherInformationForm at the metric's matrix size nLin = 515 (33 row tiles: the 8-wave shape of the
-    64-column factorisation, the step kernel's 4-chunk layout) against the numpy oracle, N_K = 3."""
+    64-column factorisation, the step kernel's 4-chunk layout) against the numpy oracle, N_K = 3 -- the reference's arithmetic
+    (chol_refresh = 1: a factorisation per particle and step) and the library default (0: carried factors)."""
     import test_gpu_smoother as ts
     c = cases.mag_case(6, 5, 512, seed=37, N_K=3)
-    ref, out = ts.run_both(rbpf, c, info_form=True)
+    ref, out = ts.run_both(rbpf, c, info_form=True, chol_refresh=chol_refresh)
     ts.check(ref, out, 3)
 
 
@@ -208,7 +210,7 @@ def test_radio_filter_against_the_c_restatement(rbpf):
 @pytest.mark.parametrize("kind,N,T,m", [("radio", 65536, 8, 128), ("mag", 8192, 8, 512)])
 def test_carried_factors_and_lazy_update_at_the_configuration_sizes(rbpf, kind, N, T, m):
     """The options the bench's second smoother number uses (lazy_depth = 3, chol_refresh) at configs[3]'s size and at the
-    per-GPU share of configs[2] (N_P = 8192, nLin = 515) against the default arithmetic on the same Philox streams: same
+    per-GPU share of configs[2] (N_P = 8192, nLin = 515) against the reference's arithmetic (chol_refresh = 1) on the same Philox streams: same
     ancestors and trajectory draws, ancestor probabilities within 1e-9, outputs within 1e-9."""
     dg = importlib.import_module(rbpf.__name__ + ".datagen")
     if kind == "radio":
@@ -223,7 +225,7 @@ def test_carried_factors_and_lazy_update_at_the_configuration_sizes(rbpf, kind, 
         mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
     run = lambda **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
                                                             x0, P0, Q, R, N, 2, dt, rng=rbpf.PhiloxRNG(9), extras=True, **kw)
-    a = run()
+    a = run(chol_refresh=1)                               # from scratch at every step (0 is automatic since r05)
     b = run(lazy_depth=3, chol_refresh=3)
     np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
     np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])

@@ -45,12 +45,15 @@ def test_covariance_form_smoother_matches_oracle(rbpf, kind, N_P, N_T, m):
     check(ref, out, 3)
 
 
+@pytest.mark.parametrize("chol_refresh", [1, 0])
 @pytest.mark.parametrize("kind,N_P,N_T,m", [("mag", 8, 6, 16), ("mag", 6, 5, 130), ("radio", 10, 8, 32),
                                             ("radio", 9, 7, 128)])
-def test_information_form_smoother_matches_oracle(rbpf, kind, N_P, N_T, m):
+def test_information_form_smoother_matches_oracle(rbpf, kind, N_P, N_T, m, chol_refresh):
+    """chol_refresh = 1: the reference's arithmetic (chol(Imat_i + ImatAddt) at every step, :228); 0: the library default (carried
+    factors from nLin = 128 on, the same as 1 below)."""
     mk = cases.mag_case if kind == "mag" else cases.radio_case
     c = mk(N_P, N_T, m, seed=9, N_K=3)
-    ref, out = run_both(rbpf, c, info_form=True)
+    ref, out = run_both(rbpf, c, info_form=True, chol_refresh=chol_refresh)
     check(ref, out, 3)
 
 
