@@ -259,7 +259,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   if (sparse) {
     if (c->lay.mc != 0 || sparse_step_lds_bytes(prob->n_lin, prob->n_y) > 150 * 1024) { set_error("sparse-visual-2D supports nLin <= 96"); return RBPF_ERR_UNSUPPORTED; }
     if (ex) { set_error("the sparseFeatures branch is not sharded"); return RBPF_ERR_UNSUPPORTED; }
-  } else if (step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
+  } else if (step_lds_bytes(c->mdl, c->lay, smoother ? 1 : 0) > 160 * 1024) { set_error("nLin too large for the LDS plan of the step kernel"); return RBPF_ERR_UNSUPPORTED; }
   c->N = prob->N_P; c->T = prob->N_T; c->smoother = smoother; c->N_K = smoother ? N_K : 1;
   c->bank_cap = (size_t)prob->N_P + (ex ? ex->bank_extra : 0);
   c->rng_slots = (ex && ex->rng_slots) ? ex->rng_slots : (size_t)prob->N_P;
@@ -381,7 +381,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   if (c->lazy_depth >= 2) {
     if (L.CH < 1 || L.CPL < 1 || L.CPL > 2) { set_error("lazy_depth >= 2 needs 128 <= nLin with at most two row chunks per wave"); return RBPF_ERR_UNSUPPORTED; }
-    if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 2 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
+    if (!L.sym && step_lds_bytes(c->mdl, c->lay, smoother ? 1 : 0, c->lazy_depth) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
     if (L.sym && step_sym_lds_bytes(c->mdl, c->lay, c->lazy_depth, 1, smoother ? 1 : 0) > 160 * 1024) { set_error("lazy_depth too large for the LDS plan"); return RBPF_ERR_UNSUPPORTED; }
     for (int b = 0; b <= c->lazy_depth; ++b) {            // entry N of every bank stays zero (fresh lineages)
       RB_TRY(dmalloc(&c->Fb[b], (size_t)(N + 1) * 2 * d * L.ldx));

@@ -483,8 +483,12 @@ hipError_t launch_propagate(const StepArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // THE step kernel: one workgroup (4 wave64) per particle slot.
 //   E = 0 : particleFilter.m:100-204 / particleSmoother.m:124-340 (covariance-form weights)
-//   E = 2 : particleSmootherInformationForm.m:274-335 -- additionally streams P*ivec and P*ivecPlus so
-//           the importance weight can be formed exactly as the reference writes it (:292-304)
+//   E = 1 : particleSmootherInformationForm.m:274-335 -- additionally streams P*ivec.  The reference also needs P*ivecPlus with
+//           ivecPlus = ivec + H' R^-1 y (:292): that is P*ivec + (P H')(R^-1 y), formed from the accumulated columns instead of
+//           streamed (r05; as rbpf_step_sym.hip does).  Same algebra, one right-hand side less in the stream -- and the two
+//           quadratic forms of the importance weight (:301-303) then SHARE the rounding of P*ivec, which cancels in their difference:
+//           against the extended-precision arbiter the weights of dense-radio went from 4.5e-9 (both products streamed; the fp64
+//           C restatement: 2.9e-9) to the level of the block-lower kernel
 // ---------------------------------------------------------------------------------------------
 #ifndef RBPF_MINWAVES
 #define RBPF_MINWAVES 1     // min waves per SIMD requested from the register allocator (tuning)
@@ -595,17 +599,17 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 
   RBPF_KSTAMP(2);
   // ---- C: measurement Jacobian H_i, column per thread (+ ivecPlus = ivec + dyi'/R*yt', :292) ----
-  {
-    double Riy[D];
-    if (E > 0) {
+  double Riy[D];                                               // R^-1 y
+  if (E > 0) {
 #pragma unroll
-      for (int aa = 0; aa < D; ++aa) {
-        double s = 0.0;
+    for (int aa = 0; aa < D; ++aa) {
+      double s = 0.0;
 #pragma unroll
-        for (int bb = 0; bb < D; ++bb) s = fma(M.Rinv[aa + D * bb], a.y[bb], s);
-        Riy[aa] = s;
-      }
+      for (int bb = 0; bb < D; ++bb) s = fma(M.Rinv[aa + D * bb], a.y[bb], s);
+      Riy[aa] = s;
     }
+  }
+  {
     for (int c = tid; c < n; c += kThreads) {
       double h[D];
       if (a.H_ext != nullptr) {
@@ -617,13 +621,12 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 #pragma unroll
       for (int k = 0; k < D; ++k) HK[c * REC + k] = h[k];
       if (E > 0) {
-        double s = HK[c * REC + D];
+        double s = HK[c * REC + D];                                          // ivecPlus (:292), the new information vector (:333)
 #pragma unroll
         for (int k = 0; k < D; ++k) s = fma(h[k], Riy[k], s);
-        HK[c * REC + D + 1] = s;
 #pragma unroll
         for (int k = 0; k < D; ++k) a.Hb_new[((size_t)i * D + k) * ldx + c] = h[k];
-        a.ivec_new[(size_t)i * ldx + c] = s;                                 // :333
+        a.ivec_new[(size_t)i * ldx + c] = s;
       }
     }
   }
@@ -712,7 +715,7 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 
   RBPF_KSTAMP(4);
   // ---- E: innovation covariance S = H (P H') + R, innovation e = y - H xl (+ quadratic forms) ----
-  constexpr int NRED = D * D + D + E;
+  constexpr int NRED = D * D + D + 2 * E;
   {
     double part[NRED];
 #pragma unroll
@@ -729,9 +732,13 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
 #pragma unroll
       for (int aa = 0; aa < D; ++aa) part[D * D + aa] = fma(h[aa], x, part[D * D + aa]);
       if (E > 0) {
-        // ivec'*P*ivec and ivecPlus'*P*ivecPlus (:301-303) with P = the (downdated) prior covariance
-        part[D * D + D] = fma(HK[r * REC + D], PHt[(size_t)D * ldx + r], part[D * D + D]);
-        part[D * D + D + 1] = fma(HK[r * REC + D + 1], PHt[(size_t)(D + 1) * ldx + r], part[D * D + D + 1]);
+        // ivec'*P*ivec and ivecPlus'*P*ivecPlus (:301-303) with P = the (downdated) prior covariance; P*ivecPlus = P*ivec + (P H')(R^-1 y)
+        const double iv = HK[r * REC + D], piv = PHt[(size_t)D * ldx + r];
+        double ivp = iv, pivp = piv;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { ivp = fma(h[k], Riy[k], ivp); pivp = fma(ph[k], Riy[k], pivp); }
+        part[D * D + D] = fma(iv, piv, part[D * D + D]);
+        part[D * D + D + 1] = fma(ivp, pivp, part[D * D + D + 1]);
       }
     }
 #pragma unroll
@@ -827,7 +834,9 @@ __global__ __launch_bounds__(kThreads, RBPF_MINWAVES) void step_kernel(const Ste
         Kn[(size_t)j * ldx + r] = kk[j];
       }
       if (E > 0) {
-        const double ip = HK[r * REC + D + 1];
+        double ip = HK[r * REC + D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) ip = fma(HK[r * REC + k], Riy[k], ip);
 #pragma unroll
         for (int k = 0; k < D; ++k) uK[k] = fma(ip, kk[k], uK[k]);          // ivecPlus' * K
       }
@@ -908,7 +917,7 @@ static hipError_t launch_step_cpl(const StepArgs& a, hipStream_t s) {
   }
 }
 
-// multi-step lazy variants: up to kMaxSets pending sets (3 for the information form, E = 2), light (read-only) or flush
+// multi-step lazy variants: up to kMaxSets pending sets (3 for the information form, E = 1), light (read-only) or flush
 template <typename TS, int D, int E>
 static hipError_t launch_step_lazy(const StepArgs& a, hipStream_t s) {
   if (a.lay.CPL < 1 || a.lay.CPL > 2) return hipErrorInvalidValue;
@@ -940,8 +949,8 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s) {
   }
   if (!legacy) {
     if (a.info) {                                          // information form: lazy_depth <= 3 (flush with 2 or 3 sets)
-      if (D == 3) return launch_step_lazy<double, 3, 2>(a, s);
-      if (D == 1) return launch_step_lazy<double, 1, 2>(a, s);
+      if (D == 3) return launch_step_lazy<double, 3, 1>(a, s);
+      if (D == 1) return launch_step_lazy<double, 1, 1>(a, s);
       return hipErrorInvalidValue;
     }
     if (D == 3) return launch_step_lazy<double, 3, 0>(a, s);
@@ -949,8 +958,8 @@ hipError_t launch_step(const StepArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   }
   if (a.info) {
-    if (D == 3) return a.n_sets ? launch_step_cpl<double, 3, 2, 1, true>(a, s) : launch_step_cpl<double, 3, 2, 0, true>(a, s);
-    if (D == 1) return a.n_sets ? launch_step_cpl<double, 1, 2, 1, true>(a, s) : launch_step_cpl<double, 1, 2, 0, true>(a, s);
+    if (D == 3) return a.n_sets ? launch_step_cpl<double, 3, 1, 1, true>(a, s) : launch_step_cpl<double, 3, 1, 0, true>(a, s);
+    if (D == 1) return a.n_sets ? launch_step_cpl<double, 1, 1, 1, true>(a, s) : launch_step_cpl<double, 1, 1, 0, true>(a, s);
     return hipErrorInvalidValue;
   }
   if (D == 3) return a.n_sets ? launch_step_cpl<double, 3, 0, 1, true>(a, s) : launch_step_cpl<double, 3, 0, 0, true>(a, s);

@@ -173,3 +173,63 @@ def test_bench_schedule_equals_the_literal_schedule_at_configs2_size(rbpf):
         if k != "trace_ai":
             sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
             assert rel(a[k][sl], b[k][sl]) <= 1e-10, (k, rel(a[k][sl], b[k][sl]))
+
+
+@pytest.mark.parametrize("form,opts", [("info", dict(chol_refresh=1)), ("info", dict()), ("info", dict(lazy_depth=3, chol_refresh=16)), ("cov", dict())])
+def test_radio_smoothers_against_the_arbiter(rbpf, form, opts):
+    """dense-radio (BASELINE.json configs[3]'s family and basis size, m = 128), N_P = 64, T = 200, N_K = 3: particleSmootherInformationForm
+    -- from scratch, library default (carried factors), and the bench's configs[3] options -- and particleSmoother against the
+    arbiter: every ancestor and draw identical, weights / ancestor probabilities / outputs by the arbiter rule
+    (run_dense2D_withHeading.m:75-77,168; particleSmoother.m:159-241; particleSmootherInformationForm.m:186-335)."""
+    import make_arbiter_fixture as maf
+    N, T, N_K = 64, 200, 3
+    d, mdl, x0, P0, R, Q, rng = maf.radio_inputs()
+    fx = load_fixture("arbiter_radio_smoothers_N64_T200_m128.npz", d, x0, P0, R, Q, rng.U, rng.Z, rng.Ufin)
+    f = rbpf.particleSmootherInformationForm if form == "info" else rbpf.particleSmoother
+    XNK, XLK, PK, ex = f(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R, N, N_K, 1.0, rng=rng,
+                         extras=True, **opts)
+    np.testing.assert_array_equal(ex["ak"], fx[form + "__ak"])
+    np.testing.assert_array_equal(ex["ai"][:, 1:], fx[form + "__ai"].astype(np.int32)[:, 1:])
+    got = dict(w=ex["w"], paNt=ex["paNt"][1:, 1:], XNK=XNK, XLK=XLK, PK=PK)
+    carried = form == "info" and rbpf.chol_refresh_in_use(mdl, opts.get("chol_refresh", 0)) > 1
+    report = {}
+    for k, v in got.items():
+        ref = fx[f"{form}__{k}"]
+        e_hip = float(np.max(np.abs(v - ref))) if k == "paNt" else rel(v, ref)
+        e_c = float(fx[f"{form}__err_c64_nofma__{k}"])
+        report[k] = (e_hip, e_c)
+        # The information form's ancestor weight is -qf/2 + v'v/2 + ... (:234-236): two quadratic forms of size ~1e5 whose difference is
+        # O(1), one from the covariance (carried through the update algebraically on the device, a fresh P*ivec product in the
+        # restatement), one from the factorisation.  Every fp64 evaluation of it sits at ~1e-9 absolute here (C: 8.6e-10, device
+        # 1.3e-9): "no further from the exact result than twice a correctly rounded restatement" is the rule for this quantity.
+        tol = max(RTOL, (2.0 if (form == "info" and k == "paNt") else SLACK) * e_c)
+        if carried and k == "paNt":
+            tol = max(tol, 2e-9)
+        assert e_hip <= tol, (k, e_hip, e_c)
+    print(form, opts, {k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(lazy_depth=3), dict(lazy_depth=4, storage="fp64sym")])
+def test_filter_at_configs1_basis_size_over_the_full_horizon_against_the_arbiter(rbpf, opts):
+    """m = 256 (nLin = 259: BASELINE.json configs[1]'s basis size), N = 64, T = 3000: full-square storage rewritten every step, configs[1]'s
+    own options (lazy_depth 3) and block-lower storage with four tile rows, against the arbiter: all indices, 1e-9 up to t = 500, the
+    arbiter rule over the whole horizon."""
+    import make_arbiter_fixture as maf
+    N, T = 64, 3000
+    d, mdl, x0, P0, R, rng = maf.filter_m256_inputs()
+    fx = load_fixture("arbiter_filter_N64_T3000_m256.npz", d, x0, P0, R, rng.U, rng.Z)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                              extras=True, **opts)
+    ex = out[8]
+    np.testing.assert_array_equal(ex["ai"][1:], fx["trace_ai"].astype(np.int32).T[1:])
+    assert int(ex["iw_max"]) == int(fx["iw_max"][0])
+    st = int(fx["trace_w_stride"])
+    got = dict(trace_w=ex["w"].T[:, ::st], traj_mean=out[1], xl_max=out[2], xl_mean=out[3], final_xl=ex["xl"], P_max_diag=np.diag(out[4]),
+               traj_max=out[0])
+    assert rel(got["trace_w"][:, :500 // st], fx["trace_w"][:, :500 // st]) <= RTOL
+    report = {}
+    for k, v in got.items():
+        e_hip, e_c = rel(v, fx[k]), float(fx["err_c64_nofma__" + k])
+        report[k] = (e_hip, e_c)
+        assert e_hip <= max(RTOL, SLACK * e_c), (k, e_hip, e_c)
+    print(opts, {k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
