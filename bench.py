@@ -252,11 +252,14 @@ def smoother_share_full(pkg, datagen, N_share, T, m, N_K, seed, **opts):
                                                     rng=pkg.PhiloxRNG(3), **opts)
     secs = time.perf_counter() - t0
     its = [round(b - a, 3) for a, b in zip([t0] + marks[:-1], marks)]
-    share = ("1/8 of N=65536" if N_share == 8192 else f"{N_share / 65536:g} of N=65536" +
-             (": the largest power-of-two particle count whose smoother state fits one 288 GB GPU" if N_share == 32768 else ""))
+    share = ("1/8 of N=65536" if N_share == 8192 else "the metric's full N" if N_share == 65536 else f"{N_share / 65536:g} of N=65536")
     K_ref = pkg.chol_refresh_in_use(mdl, opts.get("chol_refresh", 0))
-    how = (f"ancestor-weight factors carried along the lineages, refactorised every {K_ref} steps" if K_ref > 1
-           else "chol(Imat_i + ImatAddt) from scratch for every particle at every step (the reference's arithmetic)")
+    how = ("ancestor-weight factors carried along the lineages and never refactorised after the first step, no information matrix stored"
+           if K_ref >= T - 1 else
+           f"ancestor-weight factors carried along the lineages, refactorised every {K_ref} steps" + (" from the origin (no information matrix stored)" if opts.get("info_rebuild") else "")
+           if K_ref > 1 else "chol(Imat_i + ImatAddt) from scratch for every particle at every step (the reference's arithmetic)")
+    if opts.get("inplace", 0) > 0:
+        how += ", one covariance bank rewritten in place"
     return {"workload": f"slam-dense-mag N_P={N_share} ({share}) T={T} m={m} N_K={N_K} fp64, information form, complete run, {how}",
             "options": opts, "chol_refresh_in_use": K_ref, "seconds": round(secs, 3), "seconds_per_iteration": its, "unit": "s",
             "ms_per_time_step_with_ancestor_sampling": round(its[-1] / T * 1e3, 3) if len(its) > 1 else None,
@@ -552,8 +555,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-smoother", action="store_true", help="skip every smoother leg")
     ap.add_argument("--no-smoother-full", action="store_true", help="skip the complete T=3000 smoother run of the per-GPU share (about a minute)")
-    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the largest single-GPU particle count (N_P = 32768, "
-                    "about 2 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
+    ap.add_argument("--no-smoother-largest", action="store_true", help="skip the complete smoother run at the metric's full N_P = 65536 on this one GPU "
+                    "(about 3.5 minutes; also skipped -- and said so in the line -- when the run is already past --time-budget)")
+    ap.add_argument("--smoother-32k", action="store_true", help="also run the complete smoother at N_P = 32768 with the library defaults (two banks, information "
+                    "matrices stored at the refreshes: the largest size that configuration holds; about 2 minutes)")
     ap.add_argument("--no-filter-full", action="store_true", help="skip the complete T-step filter run (about 40 s)")
     ap.add_argument("--driver", default="torchrun", choices=["torchrun", "inlib"],
                     help="inlib: ALSO time the in-library multi-device driver (rbpf_options.n_devices, csrc/rbpf_multi.hip: one host process, one thread "
@@ -761,8 +766,9 @@ def main():
                                                                                            chol_refresh=1, storage=sm_storage))
                 line["smoother_metric_rule"] = ("smoother_wall_clock_s = complete T = 3000, N_K = 2 run of particleSmootherInformationForm at the per-GPU share "
                                                 "N_P = 8192 with the library's defaults (carried ancestor-weight factors); *_fresh_factorisation_s = the same run "
-                                                "with the reference's from-scratch factorisation at every step (chol_refresh = 1); *_largest_single_gpu_s = the "
-                                                "defaults at N_P = 32768, half of the metric's N, the most one GPU holds")
+                                                "with the reference's from-scratch factorisation at every step (chol_refresh = 1); smoother_wall_clock_N65536_1gpu_s = "
+                                                "the metric's FULL N_P = 65536 on this one GPU (factors never refactorised, no information matrix stored, one "
+                                                "covariance bank in place)")
                 if "seconds" in sm["share_full"]:
                     line["smoother_wall_clock_s"] = sm["share_full"]["seconds"]
                     line["smoother_wall_clock_workload"] = sm["share_full"]["workload"] + ", lazy_depth 3"
@@ -784,22 +790,30 @@ def main():
             line["filter_full_T"] = guarded(lambda: filter_full_run(pkg, datagen, N_local, args.m, T, args.seed, args.lazy_depth, args.inplace, args.storage))
             if "seconds" in line["filter_full_T"]:
                 line["filter_full_T_s"] = line["filter_full_T"]["seconds"]
+        if solo and not args.no_smoother and not args.no_smoother_full and args.smoother_32k:
+            sm_storage = args.storage if args.storage in ("fp64", "fp64sym") and args.m == 512 else "fp64"
+            r32 = guarded(lambda: smoother_share_full(pkg, datagen, 32768, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage))
+            line["smoother"]["N32768_library_defaults"] = r32
+            if "seconds" in r32:
+                line["smoother_wall_clock_N32768_defaults_s"] = r32["seconds"]
         if solo and not args.no_smoother and not args.no_smoother_full and not args.no_smoother_largest:
-            # The largest smoother ONE GPU holds, library defaults (carried factors): half of the metric's N.  Per particle 2 x 1.19 MB
-            # covariance banks, 2 x 1.15 MB information matrices (packed block-lower storage, materialised at the refreshes only),
-            # 2 x 1.21 MB carried factors, 0.4 MB refresh scratch = 7.5 MB at nLin = 515 -> 246 GB of the 288 GB (the factorisation
-            # workspaces of a refresh are per chunk of 4096 particles).  The longest leg of the run (about two minutes), so it goes last and
+            # THE METRIC'S FULL SMOOTHER ON ONE GPU: N_P = 65 536, T = 3000, m = 512, N_K = 2.  What makes it fit (r05): the carried factors need
+            # no information matrix once they are never refactorised (chol_refresh >= N_T: 2999 sweeps on end; ancestor probabilities 1.5e-9
+            # from the from-scratch arithmetic at N_P = 8192 over T = 3000, every index identical: profiles/r05_refresh_free_vs_fresh_*.jsonl),
+            # and one covariance bank rewritten in place.  Per particle 1.19 MB covariance + 2 x 1.21 MB factors + 0.1 MB of vectors = 3.7 MB ->
+            # 243 GB + 11 GB of state history + 14 GB of chunk workspaces.  The longest leg of the run (about 3.5 minutes), so it goes last and
             # only while the run is inside its time budget.
             elapsed = time.perf_counter() - t_start
             if elapsed > args.time_budget:
-                line["smoother"]["largest_single_gpu"] = {"skipped": f"{elapsed:.0f} s of wall clock used before this leg (--time-budget {args.time_budget:.0f})"}
+                line["smoother"]["full_N65536_single_gpu"] = {"skipped": f"{elapsed:.0f} s of wall clock used before this leg (--time-budget {args.time_budget:.0f})"}
             else:
                 sm_storage = args.storage if args.storage in ("fp64", "fp64sym") and args.m == 512 else "fp64"
-                r32 = guarded(lambda: smoother_share_full(pkg, datagen, 32768, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage))
-                line["smoother"]["largest_single_gpu"] = r32
-                if "seconds" in r32:
-                    line["smoother_wall_clock_largest_single_gpu_s"] = r32["seconds"]
-                    line["smoother_wall_clock_largest_single_gpu_workload"] = r32["workload"] + ", lazy_depth 3"
+                r64 = guarded(lambda: smoother_share_full(pkg, datagen, 65536, 3000, 512, 2, args.seed, lazy_depth=3, storage=sm_storage,
+                                                          chol_refresh=3000, inplace=1))
+                line["smoother"]["full_N65536_single_gpu"] = r64
+                if "seconds" in r64:
+                    line["smoother_wall_clock_N65536_1gpu_s"] = r64["seconds"]
+                    line["smoother_wall_clock_N65536_1gpu_workload"] = r64["workload"] + ", lazy_depth 3"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(pkg, data, model, x0_lin, P0, R, args.m)

@@ -31,8 +31,8 @@ extern "C" {
 #endif
 
 #define RBPF_ABI_VERSION 9   /* 9 (r05): rbpf_options starts with `struct_size` (checked by every entry point that takes options), lost
-                              * `family_products` (r04's family GEMM was measured slower and removed) and chol_refresh = 0 now means
-                              * "automatic"; rbpf_probe_family_pht is gone, rbpf_chol_refresh_resolve is new */
+                              * `family_products` (r04's family GEMM was measured slower and removed), gained `info_rebuild`, and
+                              * chol_refresh = 0 now means "automatic"; rbpf_probe_family_pht is gone, rbpf_chol_refresh_resolve is new */
 
 typedef enum {
   RBPF_OK = 0,
@@ -169,7 +169,7 @@ typedef struct {
                           * 8 on symmetric storage, storage = 2) / 3 (information form, also in the sharded smoother); ignored  *
                           * by the covariance-form smoother                                                                  */
   double jitter;         /* <=0: reference default (1e-3 filter :89, 1e-2 smoothers :70)        */
-  int32_t inplace;       /* filter with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
+  int32_t inplace;       /* filter (and, on request only, the information-form smoother) with lazy_depth >= 2: keep ONE covariance bank and rewrite it in place at    *
                           * every flush (the first child of a stored matrix overwrites it after its siblings    *
                           * were written to dead slots) instead of ping-pong banks -- halves the memory, same    *
                           * results bit for bit.  0: automatic (when two banks do not fit the device), 1: on,    *
@@ -229,6 +229,14 @@ typedef struct {
   const int32_t* device_ids; /* [n_devices] HIP device of every rank, NULL = 0 .. n_devices-1.  A device named more than once makes *
                           * its ranks share that GPU over a host-staged transport (no RCCL) -- how a one-GPU machine exercises the  *
                           * multi-rank loop; n_devices = 1 with device_ids set runs the loop with a world of one.                  */
+  int32_t info_rebuild;  /* information-form smoother with carried factors (chol_refresh = K > 1), single device: 0 = the information    *
+                          * matrices are materialised at every refresh (two banks of N_P matrices; a refresh walks back K generations).   *
+                          * 1 = NONE is stored: every refresh rebuilds them from the initial matrix along the WHOLE ancestral path --    *
+                          * Imat_i = Imat0 + sum of H' R^-1 H over the path, :334's terms in another order of summation -- chunk by chunk  *
+                          * (4096 particles x 32 generations at a time).  2.3 MB per particle less at nLin = 515: with inplace = 1 the     *
+                          * state is 3.6 MB per particle and the metric's N_P = 65 536 fits one 288 GB GPU.  The cost of a refresh grows   *
+                          * with t: choose K in the hundreds (K >= N_T - 1 never refreshes and implies this mode).  Same tolerance as      *
+                          * chol_refresh (tests/test_gpu_chol_carry.py, test_gpu_r05_parity.py).                                          */
 } rbpf_options;
 
 /* Outputs of particleFilter (src/particleFilter.m:1,26-34).  NULL pointers are skipped. */

@@ -285,7 +285,7 @@ void fill_nan(mxArray* a) { double* p = mxGetPr(a); const size_t n = mxGetNumber
 // the reference's signatures, so they are session state of the gateway, set once by  rbpf_mex('options', struct(...))  (see
 // matlab/rbpf_options.m) and applied to every later filter / smoother call.  All zero = the reference's behaviour.
 struct SessionOptions {
-  int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0;
+  int lazy_depth = 0, chol_refresh = 0, chol_variant = 0, storage = 0, inplace = 0, fix_p_mean = 0, n_devices = 0, rng_mode = 0, info_rebuild = 0;
   double jitter = 0.0, rng_seed = 0.0;
   std::vector<int32_t> device_ids;                 // [n_devices] HIP device of every rank (empty: 0 .. n_devices-1)
 };
@@ -323,6 +323,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   opt.n_devices = g_session.n_devices;                       // > 1: the library shards the particles over that many GPUs itself (RCCL)
   opt.device_ids = g_session.device_ids.empty() ? nullptr : g_session.device_ids.data();
   opt.struct_size = (int32_t)sizeof(opt);
+  opt.info_rebuild = g_session.info_rebuild;
   if (cmd == "options") {
     if (nrhs > 2 || (nrhs == 2 && !mxIsStruct(prhs[1]))) mexErrMsgIdAndTxt("rbpf:usage", "options expects one struct (or nothing: query)");
     if (nrhs == 2) {
@@ -331,6 +332,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       session_field(prhs[1], "chol_variant", o.chol_variant); session_field(prhs[1], "storage", o.storage);
       session_field(prhs[1], "inplace", o.inplace); session_field(prhs[1], "fix_p_mean", o.fix_p_mean);
       session_field(prhs[1], "n_devices", o.n_devices); session_field(prhs[1], "rng_mode", o.rng_mode);
+      session_field(prhs[1], "info_rebuild", o.info_rebuild);
       if (const mxArray* f = mxGetField(prhs[1], 0, "rng_seed")) { if (!mxIsEmpty(f)) o.rng_seed = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "jitter")) { if (!mxIsEmpty(f)) o.jitter = mxGetScalar(f); }
       if (const mxArray* f = mxGetField(prhs[1], 0, "device_ids")) {
@@ -348,12 +350,12 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     }
     // rng_mode / rng_seed are consumed by the .m wrappers (matlab/rbpf_rngblock.m): 0 = MATLAB's stream in the reference's
     // interleaved order (seed-exact), 1 = MATLAB's stream, vectorised draws, 2 = the device Philox generator keyed by rng_seed
-    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed", "device_ids"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
+    const char* names[] = {"lazy_depth", "chol_refresh", "chol_variant", "storage", "inplace", "fix_p_mean", "jitter", "n_devices", "rng_mode", "rng_seed", "info_rebuild", "device_ids"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 12, names);
     const double vals[] = {(double)g_session.lazy_depth, (double)g_session.chol_refresh, (double)g_session.chol_variant,
                            (double)g_session.storage, (double)g_session.inplace, (double)g_session.fix_p_mean, g_session.jitter,
-                           (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed};
-    for (int q = 0; q < 10; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
+                           (double)g_session.n_devices, (double)g_session.rng_mode, g_session.rng_seed, (double)g_session.info_rebuild};
+    for (int q = 0; q < 11; ++q) mxSetField(plhs[0], 0, names[q], mxCreateDoubleScalar(vals[q]));
     mxArray* ids = mxCreateDoubleMatrix(1, g_session.device_ids.size(), mxREAL);
     for (size_t q = 0; q < g_session.device_ids.size(); ++q) mxGetPr(ids)[q] = (double)g_session.device_ids[q];
     mxSetField(plhs[0], 0, "device_ids", ids);

@@ -71,7 +71,8 @@ class rbpf_options(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("keep_history", C.c_int32), ("trace", C.c_int32), ("fix_p_mean", C.c_int32),
                 ("lazy_depth", C.c_int32), ("jitter", C.c_double), ("inplace", C.c_int32), ("storage", C.c_int32),
                 ("chol_variant", C.c_int32), ("chol_refresh", C.c_int32), ("exchange_capacity", C.c_int32), ("on_step", ON_STEP_FN),
-                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32))]
+                ("on_step_user", C.c_void_p), ("n_devices", C.c_int32), ("device_ids", C.POINTER(C.c_int32)),
+                ("info_rebuild", C.c_int32)]
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)

@@ -349,8 +349,10 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : ((c->lay.sym && c->lay.CH64 == 8) ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
-    const bool can = !smoother && !ex && c->lazy_depth >= 2;
-    if (c->opt.inplace > 0 && !can) { set_error("inplace=1 needs the unsharded filter with lazy_depth >= 2"); return RBPF_ERR_UNSUPPORTED; }
+    // (the information-form smoother on request only -- smoother_run refuses it for the covariance form, whose every step reads and
+    //  rewrites the matrices)
+    const bool can = !ex && c->lazy_depth >= 2 && (!smoother || c->opt.inplace > 0);
+    if (c->opt.inplace > 0 && !can) { set_error("inplace=1 needs lazy_depth >= 2 and an unsharded session"); return RBPF_ERR_UNSUPPORTED; }
     c->inplace = c->opt.inplace > 0;
     if (c->opt.inplace == 0 && can) {
       size_t fr = 0, tot = 0;

@@ -348,6 +348,35 @@ __global__ void sweep_path_kernel(int N, int nN, int Kp, int t_last, int t0, con
   base_slot[i] = slot;
 }
 
+// Refresh without stored information matrices (rbpf_options.info_rebuild): the whole ancestral path, in segments of S generations
+// counted from the top (segment j = generations [max(0, hi_j - S), hi_j), hi_j = t_last + 1 - j S).  One walk notes where every
+// particle's lineage stands at the top generation of each segment ...
+__global__ void origin_marks_kernel(int N, int t_last, int S, const int* __restrict__ A, int* __restrict__ marks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int slot = i;
+  for (int s = t_last; s >= 0; --s) {
+    const int below_top = t_last - s;                        // generations under the top one
+    if (below_top % S == 0) marks[(size_t)(below_top / S) * N + i] = slot;
+    if (s > 0) slot = A[(size_t)s * N + slot];               // ancestor in generation s - 1
+  }
+}
+
+// ... and a segment's states are then collected from its mark: particles p0 .. p0 + cnt - 1, generations lo .. hi - 1 ->
+// Xp [(i - p0) * (hi - lo) + (s - lo)][nN]
+__global__ void origin_segment_kernel(int N, int nN, int p0, int cnt, int lo, int hi, const int* __restrict__ A, const double* __restrict__ X,
+                                      const int* __restrict__ mark, double* __restrict__ Xp) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= cnt) return;
+  int slot = mark[p0 + q];                                   // the lineage at generation hi - 1
+  for (int s = hi - 1; s >= lo; --s) {
+    const double* Xs = X + (size_t)s * nN * N;
+    double* col = Xp + ((size_t)q * (hi - lo) + (s - lo)) * nN;
+    for (int c = 0; c < nN; ++c) col[c] = Xs[(size_t)c * N + slot];
+    if (s > 0) slot = A[(size_t)s * N + slot];
+  }
+}
+
 // Particle-sharded smoother: the same walk over the replicated global history (logical slot ids), for every logical slot j:
 // owner_now[j] = where its particle lives now (rank * Nloc + physical slot), base_loc[j] = where the particle of its ancestor
 // in generation t0 lived when that generation was materialised (-1: t0 < 0, the common initial matrix).  The path states are

@@ -58,6 +58,10 @@ struct SmootherState {
   size_t imat_len = 0;          // doubles per information matrix of the banks: n * n, or imat_packed_doubles(n)
   size_t Mmax = 0;
   int l_chunk = 0;              // carried factors: matrices per launch of the refresh factorisation (d_L holds that many workspaces)
+  bool refresh_free = false;    // no information matrix is stored (rbpf_options.info_rebuild, or chol_refresh >= N_T - 1): a refresh rebuilds them
+                                // from Imat0 along the whole ancestral path, chunk by chunk -- the Imat "bank" is one chunk of l_chunk matrices
+  int seg_len = 0;              // ... in segments of this many generations (d_G / d_Xp hold l_chunk x seg_len rows)
+  int* d_marks = nullptr;       // [ceil(T / seg_len)][N] slot of every particle's ancestor at the top generation of each segment
   // sharded information-form smoother
   double* d_Rinv = nullptr;     // [d*d]
   std::vector<double> h_ivec0;  // [ldx]
@@ -84,7 +88,7 @@ void smoother_free(rbpf_ctx* c) {
   for (int b = 0; b < 2; ++b) { hipFree(s->d_Imat[b]); hipFree(s->d_Hb[b]); hipFree(s->d_ivec[b]); hipFree(s->d_hld[b]); hipFree(s->d_qf[b]); }
   hipFree(s->d_ImatAdd); hipFree(s->d_ivecAdd); hipFree(s->d_Imat0); hipFree(s->d_ak); hipFree(s->d_ivec0); hipFree(s->d_hld0);
   hipFree(s->d_Rinv); hipFree(s->d_Lsw[0]); hipFree(s->d_Lsw[1]); hipFree(s->d_W);
-  hipFree(s->d_base_slot); hipFree(s->d_Xp);
+  hipFree(s->d_base_slot); hipFree(s->d_Xp); hipFree(s->d_marks);
   hipFree(s->d_owner_now); hipFree(s->d_base_gid); hipFree(s->d_base_loc); hipFree(s->d_rf_send); hipFree(s->d_rf_recv); hipFree(s->d_rf_idx);
   delete s;
   c->sm = nullptr;
@@ -167,6 +171,7 @@ struct GemmArgs {
   // packed (zero: off): C -- symmetric, M == N -- and the matrices `add` / `add_rec` point at are information matrices in packed
   // block-lower storage (imat_packed_index below; bsC, add_stride and the records' pitch = imat_packed_doubles(M)); rsC / csC unused
   int packed;
+  int add_self;      // C += (this batch's C): accumulate into the output (add / add_idx unused)
 };
 
 typedef double gemm_v4d __attribute__((ext_vector_type(4)));
@@ -228,7 +233,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   }
   // result layout: col = lane & 15, row = (lane >> 4) + 4 * reg
   const double* addp = nullptr;
-  if (g.add) {
+  if (g.add_self) addp = C;
+  else if (g.add) {
     const int e = g.add_idx ? g.add_idx[bz] : 0;
     const size_t rec_pitch = g.packed ? imat_packed_doubles(g.M) : (size_t)g.M * g.N;
     addp = (g.add_rec && e >= g.add_nbank) ? g.add_rec + (size_t)(e - g.add_nbank) * rec_pitch : g.add + (size_t)e * g.add_stride;
@@ -935,17 +941,20 @@ static void whitening_factor(const std::vector<double>& Rh, int d, std::vector<d
 // has just materialised (bank s->imat_cur) with the 64-column kernel, add logwMeas to pant_log, and store the factors in the sweep
 // layout in the OTHER factor bank (the caller flips sw_cur).  Runs in chunks of s->l_chunk particles over one set of factor
 // workspaces: same launches per particle, 2.2 MB per particle less memory at nLin = 515.
-static int refresh_factorise(rbpf_ctx* c, const double* d_Rinv, double* pant_log, int N, hipStream_t st) {
+// chunk_imat != null (refresh-free smoother): the particles first .. first + N - 1 (N <= l_chunk) whose matrices sit in that chunk buffer.
+static int refresh_factorise(rbpf_ctx* c, const double* d_Rinv, double* pant_log, int N, hipStream_t st, int first = 0,
+                             const double* chunk_imat = nullptr) {
   SmootherState* s = c->sm;
   const int n = c->mdl.n, d = c->mdl.d;
   const size_t fd = chol_factor_doubles(n), sd = sweep_factor_doubles(n);
-  for (int p0 = 0; p0 < N; p0 += s->l_chunk) {
-    const int cnt = std::min(s->l_chunk, N - p0);
+  for (int q0 = 0; q0 < N; q0 += s->l_chunk) {
+    const int cnt = std::min(s->l_chunk, N - q0), p0 = first + q0;
     CholArgs ca;
     std::memset(&ca, 0, sizeof(ca));
     ca.d = d; ca.n = n; ca.ldx = c->lay.ldx; ca.status = c->d_flags; ca.pant_log = pant_log + p0;
     ca.mode = 1; ca.Msz = n; ca.Lbuf = s->d_L; ca.ldL = (long)fd;
-    ca.Imat = s->d_Imat[s->imat_cur] + (size_t)p0 * s->imat_len; ca.imat_stride = (long)s->imat_len; ca.imat_packed = s->imat_packed ? 1 : 0;
+    ca.Imat = chunk_imat ? chunk_imat + (size_t)q0 * s->imat_len : s->d_Imat[s->imat_cur] + (size_t)p0 * s->imat_len;
+    ca.imat_stride = (long)s->imat_len; ca.imat_packed = s->imat_packed ? 1 : 0;
     ca.imat_anc = nullptr; ca.ImatOut = nullptr; ca.Hb = nullptr; ca.Rinv = d_Rinv; ca.ImatAdd = s->d_ImatAdd;
     ca.ivec = s->d_ivec[s->icur] + (size_t)p0 * c->lay.ldx; ca.ivecAdd = s->d_ivecAdd;
     ca.qf = s->d_qf[s->icur] + p0; ca.hld = s->d_hld[s->icur] + p0;
@@ -962,6 +971,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
   hipStream_t st = c->stream;
   SmootherState* s = new SmootherState();
   c->sm = s;
+  if (!info_form && c->inplace) { set_error("inplace=1: the covariance-form smoother rewrites its covariances at every step (use the information form)"); return RBPF_ERR_UNSUPPORTED; }
   if (!info_form) c->lazy_depth = 1;          // the covariance form reads the flushed covariances of every particle every step
   c->sort_steps = true;
   const bool generic = c->mdl.kind == RBPF_MODEL_GENERIC_DENSE;
@@ -1047,9 +1057,18 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     s->lazy_imat = s->refresh && c->mdl.kind != RBPF_MODEL_GENERIC_DENSE;     // needs measModel on the device
     s->imat_packed = imat_storage_packed(n, d, s->refresh, s->lazy_imat);
     s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
+    s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
+    // Refresh-free (r05): with K >= N_T - 1 the factors are never refactorised after t = 1 -- against the extended-precision arbiter
+    // their ancestor probabilities are as close with K = 999 as with K = 32 or from scratch (6.8e-10 / 7.0e-10 / 6.7e-10 over T = 1000,
+    // DESIGN.md 9) -- so no information matrix is ever read again: none is stored, the first factorisation runs chunk by chunk over
+    // one buffer of l_chunk matrices.  3.6 MB of state per particle with one covariance bank (rbpf_options.inplace): the metric's full
+    // N_P = 65 536 fits one 288 GB MI355X.
+    s->refresh_free = s->lazy_imat && (s->refresh >= T - 1 || c->opt.info_rebuild > 0);
+    s->seg_len = 32;
     for (int b = 0; b < 2; ++b) {
-      RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
-      if (s->imat_packed) HIPCHK(hipMemsetAsync(s->d_Imat[b], 0, (size_t)N * s->imat_len * 8, st));   // the never-written upper halves of the diagonal tiles
+      const size_t n_mat = s->refresh_free ? (b == 0 ? (size_t)s->l_chunk : (size_t)0) : (size_t)N;
+      RB_TRY(dmalloc(&s->d_Imat[b], n_mat * s->imat_len));
+      if (s->imat_packed && n_mat) HIPCHK(hipMemsetAsync(s->d_Imat[b], 0, n_mat * s->imat_len * 8, st));   // the never-written upper halves of the diagonal tiles
       RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
       RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
       RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
@@ -1057,7 +1076,6 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     }
     // factor workspaces of the 64-column kernel: one per particle -- or, with carried factors, per particle of a CHUNK of the
     // refresh (they are converted to the sweep layout chunk by chunk): 2.2 MB per particle at nLin = 515 that N_P = 32 768 has no room for
-    s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
     RB_TRY(dmalloc(&s->d_L, (size_t)s->l_chunk * chol_factor_doubles(n)));
     RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
     RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
@@ -1070,8 +1088,14 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
       if (s->lazy_imat) {
         RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
-        RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
-        RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
+        if (s->refresh_free) {                                             // a chunk of particles x a segment of generations at a time
+          RB_TRY(dmalloc(&s->d_Xp, (size_t)s->l_chunk * s->seg_len * nN));
+          RB_TRY(dmalloc(&s->d_G, (size_t)s->l_chunk * s->seg_len * d * n));
+          RB_TRY(dmalloc(&s->d_marks, (size_t)((T + s->seg_len - 1) / s->seg_len) * N));
+        } else {
+          RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));          // generations a refresh walks back: K
+          RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
+        }
       }
     }
   }
@@ -1218,6 +1242,37 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             skip_chol = true;
           } else if (carry && s->lazy_imat) {
             // refresh: Imat of generation t-1 from the base generation + G'G along the ancestral paths, then factorise it
+            if (s->refresh_free) {
+              // No information matrix is stored: Imat_i(t-1) = Imat0 + sum over the WHOLE ancestral path of H' R^-1 H (:334's terms, in
+              // another order of summation), accumulated segment by segment into a chunk buffer, then chol(Imat + ImatAddt) out of it
+              // and the factors into the sweep layout.  Cost grows with t; the marks make every segment's walk O(seg_len).
+              const int S = s->seg_len, n_gen = t, n_seg = (n_gen + S - 1) / S;        // generations 0 .. t-1; segment j = [hi_j - len_j, hi_j), hi_0 = t
+              hipLaunchKernelGGL(origin_marks_kernel, dim3((N + 127) / 128), dim3(128), 0, st, N, t - 1, S, c->A, s->d_marks);
+              HIPCHK(hipGetLastError());
+              for (int p0 = 0; p0 < N; p0 += s->l_chunk) {
+                const int cnt = std::min(s->l_chunk, N - p0);
+                for (int j = 0; j < n_seg; ++j) {
+                  const int hi = n_gen - j * S, lo = std::max(0, hi - S), len = hi - lo;
+                  hipLaunchKernelGGL(origin_segment_kernel, dim3((cnt + 127) / 128), dim3(128), 0, st, N, nN, p0, cnt, lo, hi, c->A, c->X,
+                                     s->d_marks + (size_t)j * N, s->d_Xp);
+                  HIPCHK(hipGetLastError());
+                  HIPCHK(launch_meas_model(c->mdl, cnt * len, s->d_Xp, s->d_G, st, 1));
+                  const size_t rows = (size_t)cnt * len;
+                  hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)((rows * n + 255) / 256)), dim3(256), 0, st, rows, d, n, s->d_W, s->d_G);
+                  HIPCHK(hipGetLastError());
+                  const long Kd = (long)len * d;
+                  GemmArgs gg{n, n, (int)Kd, s->d_G, 1, n, Kd * n, s->d_G, n, 1, Kd * n, s->d_Imat[0], 1, n, (long)s->imat_len};
+                  gg.lower = 1; gg.packed = s->imat_packed ? 1 : 0;
+                  if (j == 0) { gg.add = s->d_Imat0; gg.add_stride = 0L; gg.add_idx = nullptr; }
+                  else gg.add_self = 1;
+                  HIPCHK(launch_gemm(gg, cnt, st));
+                }
+                RB_TRY(refresh_factorise(c, d_Rinv, s->d_pant_log, cnt, st, p0, s->d_Imat[0]));
+              }
+              s->imat_valid = false; s->base_gen = t - 1;
+              s->sw_cur ^= 1;
+              skip_chol = true;
+            } else {
             const int t0 = s->base_gen, Kp = t - 1 - t0;
             if (Kp < 1 || Kp > s->refresh) { set_error("internal: refresh window"); return RBPF_ERR_STATE; }
             const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
@@ -1239,6 +1294,7 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             RB_TRY(refresh_factorise(c, d_Rinv, s->d_pant_log, N, st));        // chol(Imat + ImatAddt), chunk by chunk -> sweep layout
             s->sw_cur ^= 1;
             skip_chol = true;
+            }
           } else {
             RB_TRY(info_fill_chol_args(c, ca, d_Rinv, c->A + (size_t)(t - 1) * N));   // ancestors of the generation t-1
             if (carry) ca.variant = 64;            // the refresh reads the factor back in the 64-column kernel's layout

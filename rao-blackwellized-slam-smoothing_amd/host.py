@@ -679,7 +679,7 @@ def model_dyn_res_norm(dynModel):
 
 def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K, dt,
               sparseFeatures, makePlots, rng, extras, chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None,
-              storage="fp64", exchange_capacity=0):
+              storage="fp64", exchange_capacity=0, inplace=0, info_rebuild=0):
     if sparseFeatures:
         if info_form:
             # particleSmootherInformationForm.m:77-80 prints and returns with outputs unassigned
@@ -699,7 +699,8 @@ def _smoother(info_form, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin
         rng = ReplayRNG(rng.U, np.zeros(rng.U.shape + (model.nw,)), rng.Ufin)
     blk, _keep = _rng_block(rng, prob.N_P, prob.N_T, model.nw, N_K)
     opt = _ffi.rbpf_options(keep_history=1, trace=1 if extras else 0, fix_p_mean=0, lazy_depth=int(lazy_depth), jitter=0.0,
-                            chol_variant=int(chol_variant), chol_refresh=int(chol_refresh), storage=_storage_code(storage))
+                            chol_variant=int(chol_variant), chol_refresh=int(chol_refresh), storage=_storage_code(storage),
+                            inplace=int(inplace), info_rebuild=int(info_rebuild))
     if int(n_devices) > 1 or (int(n_devices) == 1 and device_ids is not None):
         if extras:
             raise RBPFError(_ffi.RBPF_ERR_UNSUPPORTED, "n_devices: traces are not gathered from the sharded smoother")
@@ -756,17 +757,21 @@ def particleSmoother(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0
 def particleSmootherInformationForm(dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R,
                                     N_P, N_K, dt, sparseFeatures=False, makePlots=None, *, rng=None, extras=False,
                                     chol_variant=0, lazy_depth=0, chol_refresh=0, n_devices=0, device_ids=None, storage="fp64",
-                                    exchange_capacity=0):
+                                    exchange_capacity=0, inplace=0, info_rebuild=0):
     """Mirror of src/particleSmootherInformationForm.m:1-2 -> (XNK, XLK, PK).  lazy_depth = C >= 2 (max 3): the stored
     covariances are rewritten every C-th step only (same algebra as :331 every step, results to rounding).
     chol_refresh (rbpf_options.chol_refresh) = K > 1: the ancestor-weight factors (:228) are carried along the lineages by rank-1
     up/down-dates and recomputed every K-th step (every index identical, ancestor probabilities within 2e-9, outputs 1e-9 of the
     from-scratch factorisation); 1: chol(Imat_i + ImatAddt) from scratch at every step, the reference's own arithmetic; 0 (default):
     automatic -- K = 32 for the recognised dense families from nLin = 128 on, 1 elsewhere (`chol_refresh_in_use` tells).
+    info_rebuild = 1 (rbpf_options.info_rebuild): no information matrix is stored -- every refresh rebuilds them from the initial
+    matrix along the whole ancestral path, chunk by chunk (choose K in the hundreds; K >= N_T - 1 never refreshes and implies it);
+    together with inplace = 1 (one covariance bank rewritten in place; needs lazy_depth >= 2) the state is 3.6 MB per particle at
+    nLin = 515 -- the metric's N_P = 65 536 on one 288 GB GPU.
     n_devices = W > 1: the particles of every iteration are sharded over W GPUs inside the library (rbpf_options.n_devices)."""
     return _smoother(True, dynModel, measModel, dynResNorm, odometry, y, x0_nonLin, x0_lin, P0_lin, Q, R, N_P, N_K,
                      dt, sparseFeatures, makePlots, rng, extras, chol_variant, lazy_depth, chol_refresh, n_devices, device_ids, storage,
-                     exchange_capacity)
+                     exchange_capacity, inplace, info_rebuild)
 
 
 def chol_refresh_in_use(model, chol_refresh=0):

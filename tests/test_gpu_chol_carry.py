@@ -75,6 +75,67 @@ def test_refresh_in_chunks_of_factor_workspaces(rbpf):
     assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[1], a[1]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
 
 
+@pytest.mark.parametrize("kind,N_P,N_T,m,opts", [("mag", 7, 12, 512, dict(storage="fp64sym", lazy_depth=3, inplace=1)),
+                                                  ("mag", 9, 10, 256, dict(lazy_depth=3)), ("radio", 10, 14, 128, dict(lazy_depth=2, inplace=1)),
+                                                  ("mag", 8, 11, 130, dict())])
+def test_refresh_free_smoother_matches_the_oracle(rbpf, kind, N_P, N_T, m, opts):
+    """r05: chol_refresh >= N_T - 1 never refactorises after the first step and stores no information matrix (the first
+    factorisation runs over a chunk buffer); with inplace = 1 the information-form smoother keeps ONE covariance bank rewritten in
+    place.  Against the numpy oracle like every other mode: ancestors bit-exact, paNt / weights / outputs 1e-9."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=79, N_K=3)
+    ref = cases.oracle_smoother(c, True)
+    out = run(rbpf, c, chol_refresh=10 ** 6, **opts)
+    ts.check(ref, out, 3)
+
+
+@pytest.mark.parametrize("kind,N_P,N_T,m,K,opts", [("mag", 7, 80, 512, 33, dict(storage="fp64sym", lazy_depth=3, inplace=1)),
+                                                    ("mag", 9, 45, 130, 7, dict(lazy_depth=2)), ("radio", 10, 75, 128, 36, dict(lazy_depth=3, inplace=1)),
+                                                    ("mag", 6, 12, 256, 2, dict())])
+def test_refresh_from_the_origin_matches_the_oracle(rbpf, kind, N_P, N_T, m, K, opts):
+    """rbpf_options.info_rebuild = 1: no information matrix is stored; every K-th step rebuilds them from Imat0 along the whole
+    ancestral path in segments of 32 generations (paths of 33 .. 79 generations: two and three segments, a one-generation tail) and
+    refactorises.  Against the numpy oracle: ancestors bit-exact, paNt / weights / outputs 1e-9."""
+    mk = cases.mag_case if kind == "mag" else cases.radio_case
+    c = mk(N_P, N_T, m, seed=83, N_K=2)
+    ref = cases.oracle_smoother(c, True)
+    out = run(rbpf, c, chol_refresh=K, info_rebuild=1, **opts)
+    ts.check(ref, out, 2)
+
+
+def test_refresh_free_and_in_place_equal_the_default_at_many_chunks(rbpf):
+    """N_P = 9000 (three chunks of the first factorisation: 4096 + 4096 + 808), dense-radio m = 128, T = 40: the refresh-free in-place
+    run against the library default (K = 32, two banks) on the same Philox streams: same ancestors and draws, outputs 1e-9."""
+    import importlib
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    T, N = 40, 9000
+    Q = dg.radio_Q(T, "square_3D")
+    th = [0.25, 2.0, 0.01]
+    d = dg.planar_heading(T, Q, th, 1.0, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = rbpf.dense_radio_prior(128, d["LL"], th)
+    go = lambda **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
+                                                           x0, P0, Q, R, N, 2, 1.0, rng=rbpf.PhiloxRNG(9), extras=True, **kw)
+    a = go(lazy_depth=3)
+    b = go(lazy_depth=3, chol_refresh=10 ** 6, inplace=1)
+    b2 = go(lazy_depth=3, chol_refresh=17, info_rebuild=1, inplace=1)      # refreshes from the origin at t = 18, 35 over three chunks
+    for other in (b2,):
+        np.testing.assert_array_equal(a[3]["ai"][:, 1:], other[3]["ai"][:, 1:])
+        assert np.max(np.abs(a[3]["paNt"][1, 1:] - other[3]["paNt"][1, 1:])) <= 1e-9 and ts.rel(other[0], a[0]) <= 1e-9
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert np.max(np.abs(a[3]["paNt"][1, 1:] - b[3]["paNt"][1, 1:])) <= 1e-9
+    assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[1], a[1]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
+
+
+def test_in_place_is_refused_for_the_covariance_form(rbpf):
+    c = cases.mag_case(5, 5, 130, seed=3, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R,
+                                             c["N_P"], 2, c["dt"], rng=cases.device_rng(rbpf, c), inplace=1)      # lazy_depth < 2
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+
+
 def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
     c = cases.mag_case(4, 4, 600, seed=1, N_K=2)             # nLin = 603 > 575
     with pytest.raises(rbpf.RBPFError) as ei:
@@ -82,7 +143,11 @@ def test_carried_factors_are_refused_where_they_do_not_apply(rbpf):
     assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
 
 
-def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf):
+_fresh_T3000 = {}                                            # the from-scratch run, shared by the two parametrisations
+
+
+@pytest.mark.parametrize("opts", [dict(chol_refresh=32), dict(chol_refresh=10 ** 6, inplace=1)])
+def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf, opts):
     """The options of the metric's smoother number (lazy_depth = 3, chol_refresh = 32 = what 0 resolves to) at the metric's matrix size
     (slam-dense-mag m = 512, nLin = 515) over the metric's T = 3000 time steps -- 94 refresh cycles, device Philox, the product's own data
     generator -- against the fresh factorisation on the same streams: ancestor probabilities within the stated 2e-9 at every
@@ -99,8 +164,9 @@ def test_drift_at_the_bench_configuration_over_the_full_horizon(rbpf):
     def go(**kw):
         return rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, Q, R,
                                                     N, N_K, 0.01, rng=rbpf.PhiloxRNG(17), extras=True, **kw)
-    a = go(lazy_depth=3, chol_refresh=1)
-    b = go(lazy_depth=3, chol_refresh=32)
+    a = _fresh_T3000.get("a") or go(lazy_depth=3, chol_refresh=1)
+    _fresh_T3000["a"] = a
+    b = go(lazy_depth=3, **opts)                            # K = 32: the default; 10^6: refresh-free (2999 sweeps on end), one bank in place
     pa, pb = a[3]["paNt"][1, 1:], b[3]["paNt"][1, 1:]
     assert np.all(np.isfinite(pb))
     drift = np.max(np.abs(pa - pb), axis=1)                 # per time step

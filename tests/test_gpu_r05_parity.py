@@ -116,10 +116,11 @@ def test_filter_over_the_full_horizon_against_the_arbiter(rbpf):
     print({f"{t}:{k}": f"{a:.2e} (C {b:.2e})" for (t, k), (a, b) in report.items()})
 
 
-@pytest.mark.parametrize("chol_refresh", [1, 32])
-def test_information_form_smoother_over_a_long_horizon_against_the_arbiter(rbpf, chol_refresh):
+@pytest.mark.parametrize("chol_refresh,inplace", [(1, 0), (32, 0), (10 ** 6, 1)])
+def test_information_form_smoother_over_a_long_horizon_against_the_arbiter(rbpf, chol_refresh, inplace):
     """(iii) T = 1000, m = 512, N_P = 64, N_K = 2, block-lower P, lazy_depth 3; chol_refresh 1 = chol(Imat_i + ImatAddt) at every step
-    (the reference's arithmetic), 32 = carried factors with 31 refreshes along the run (the default)."""
+    (the reference's arithmetic), 32 = carried factors with 31 refreshes along the run (the default), 10^6 = refresh-free (999 sweeps
+    on end, no information matrix stored) with one covariance bank in place: the configuration that runs N_P = 65 536 on one GPU."""
     import make_arbiter_fixture as maf
     N, T, N_K = 64, 1000, 2
     d, mdl, x0, P0, R, rng = maf.smoother_inputs()
@@ -127,7 +128,7 @@ def test_information_form_smoother_over_a_long_horizon_against_the_arbiter(rbpf,
     assert rbpf.chol_refresh_in_use(mdl, 0) == 32
     XNK, XLK, PK, ex = rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],
                                                             x0, P0, cases.Q_MAG, R, N, N_K, 0.01, rng=rng, extras=True, storage="fp64sym",
-                                                            lazy_depth=3, chol_refresh=chol_refresh)
+                                                            lazy_depth=3, chol_refresh=chol_refresh, inplace=inplace)
     np.testing.assert_array_equal(ex["ak"], fx["ak"])                            # the trajectory draws
     np.testing.assert_array_equal(ex["ai"][:, 1:], fx["ai"].astype(np.int32)[:, 1:])   # every ancestor incl. slot N_P's (:241)
     rows = fx["P_rows"]
