@@ -234,3 +234,35 @@ def test_filter_at_configs1_basis_size_over_the_full_horizon_against_the_arbiter
         report[k] = (e_hip, e_c)
         assert e_hip <= max(RTOL, SLACK * e_c), (k, e_hip, e_c)
     print(opts, {k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
+
+
+def test_smoother_at_the_metrics_full_particle_count_on_one_gpu(rbpf):
+    """particleSmootherInformationForm at the metric's N_P = 65 536, m = 512 on ONE GPU: factors carried and never refactorised (no
+    information matrix stored: chol_refresh >= N_T), one block-lower covariance bank rewritten in place, lazy_depth 3 -- 3.7 MB of state
+    per particle.  T = 8, N_K = 2: finite outputs, normalised weights and ancestor probabilities (particleSmootherInformationForm.m:243-245),
+    ancestors in range, symmetric positive-definite PK; and the same run at N_P = 4096 equals the library default there (two banks,
+    refreshes) in every index and to 1e-9 -- the full-size configuration is the small one's arithmetic."""
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    T, N_K = 8, 2
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(512, d["LL"], cases.THETA_MAG)
+    go = lambda N, **kw: rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"],   # noqa: E731
+                                                              x0, P0, cases.Q_MAG, R, N, N_K, 0.01, rng=rbpf.PhiloxRNG(9), extras=True,
+                                                              storage="fp64sym", lazy_depth=3, **kw)
+    a = go(4096)
+    b = go(4096, chol_refresh=T, inplace=1)
+    np.testing.assert_array_equal(a[3]["ai"][:, 1:], b[3]["ai"][:, 1:])
+    np.testing.assert_array_equal(a[3]["ak"], b[3]["ak"])
+    assert np.max(np.abs(a[3]["paNt"][1, 1:] - b[3]["paNt"][1, 1:])) <= 1e-9
+    assert rel(b[0], a[0]) <= RTOL and rel(b[1], a[1]) <= RTOL and rel(b[2], a[2]) <= RTOL
+    del a, b
+    N = 65536
+    XNK, XLK, PK, ex = go(N, chol_refresh=T, inplace=1)
+    assert np.all(np.isfinite(XNK)) and np.all(np.isfinite(XLK)) and np.all(np.isfinite(PK))
+    np.testing.assert_allclose(ex["w"].sum(axis=2), 1.0, rtol=0, atol=1e-12)
+    assert ex["ai"][:, 1:].min() >= 0 and ex["ai"][:, 1:].max() < N
+    np.testing.assert_allclose(ex["paNt"][1, 1:].sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    for k in range(N_K):
+        P = PK[:, :, k]
+        assert rel(P, P.T) < 1e-12 and np.linalg.eigvalsh(0.5 * (P + P.T)).min() > 0
+        assert np.all(np.diag(P) <= np.diag(P0) * (1 + 1e-12))
