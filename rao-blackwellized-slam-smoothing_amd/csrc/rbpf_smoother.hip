@@ -1063,6 +1063,10 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
     // DESIGN.md 9) -- so no information matrix is ever read again: none is stored, the first factorisation runs chunk by chunk over
     // one buffer of l_chunk matrices.  3.6 MB of state per particle with one covariance bank (rbpf_options.inplace): the metric's full
     // N_P = 65 536 fits one 288 GB MI355X.
+    if (c->opt.info_rebuild > 0 && !s->lazy_imat) {
+      set_error("info_rebuild = 1 needs carried factors (chol_refresh != 1) and a recognised model family: the information matrices are rebuilt from measModel along the state history");
+      return RBPF_ERR_UNSUPPORTED;
+    }
     s->refresh_free = s->lazy_imat && (s->refresh >= T - 1 || c->opt.info_rebuild > 0);
     s->seg_len = 32;
     for (int b = 0; b < 2; ++b) {
@@ -1495,6 +1499,7 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     s->refresh = K > 1 ? K : 0;
   }
   if (s->refresh && c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) { set_error("chol_refresh > 1 in the sharded smoother needs measModel on the device"); return RBPF_ERR_UNSUPPORTED; }
+  if (c->opt.info_rebuild > 0) { set_error("info_rebuild = 1 is a single-device option (the sharded smoother exchanges stored information matrices at its refreshes)"); return RBPF_ERR_UNSUPPORTED; }
   s->lazy_imat = s->refresh > 1;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
   RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));

@@ -127,7 +127,14 @@ def test_refresh_free_and_in_place_equal_the_default_at_many_chunks(rbpf):
     assert ts.rel(b[0], a[0]) <= 1e-9 and ts.rel(b[1], a[1]) <= 1e-9 and ts.rel(b[2], a[2]) <= 1e-9
 
 
-def test_in_place_is_refused_for_the_covariance_form(rbpf):
+def test_info_rebuild_is_refused_without_carried_factors(rbpf):
+    c = cases.mag_case(5, 5, 130, seed=3, N_K=2)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        run(rbpf, c, chol_refresh=1, info_rebuild=1)
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+
+
+def test_in_place_needs_the_lazy_update(rbpf):
     c = cases.mag_case(5, 5, 130, seed=3, N_K=2)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     with pytest.raises(rbpf.RBPFError) as ei:
