@@ -199,7 +199,10 @@ typedef struct {
                           * every ancestor index and trajectory draw identical, ancestor probabilities within 2e-9 absolute, outputs *
                           * within 1e-9 of the from-scratch factorisation (measured 8.8e-10 over T = 3000 at nLin = 515;             *
                           * tests/test_gpu_chol_carry.py, test_gpu_r05_parity.py).  nLin <= 575, n_y = 1 or 3; also in *
-                          * the sharded smoother (rbpf_shard_smoother_refresh_*).                                                     *
+                          * the sharded smoother (rbpf_shard_smoother_refresh_*).  K >= N_T - 1 never refactorises after the first    *
+                          * step: no information matrix is stored (or, sharded, exchanged) at all -- see info_rebuild; 256 < K <       *
+                          * N_T - 1 (single device only) rebuilds the matrices from the origin at every refresh likewise, since a        *
+                          * window that long would need N_P x K x n_y x n_lin doubles of Jacobians.                                      *
                           * 1: factorise from scratch at every step, the reference's own arithmetic.                                  *
                           * 0 (default): AUTOMATIC = 32 where the carried factors apply and pay (recognised dense family, 128 <=      *
                           * nLin <= 575), 1 elsewhere; rbpf_chol_refresh_resolve tells which.                                        *

@@ -1067,7 +1067,9 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       set_error("info_rebuild = 1 needs carried factors (chol_refresh != 1) and a recognised model family: the information matrices are rebuilt from measModel along the state history");
       return RBPF_ERR_UNSUPPORTED;
     }
-    s->refresh_free = s->lazy_imat && (s->refresh >= T - 1 || c->opt.info_rebuild > 0);
+    // (a window of more than 256 generations would need N_P x K x n_y x n doubles of Jacobians per refresh: such periods take the
+    //  rebuild from the origin as well, whose scratch is one chunk x one segment)
+    s->refresh_free = s->lazy_imat && (s->refresh >= T - 1 || c->opt.info_rebuild > 0 || s->refresh > 256);
     s->seg_len = 32;
     for (int b = 0; b < 2; ++b) {
       const size_t n_mat = s->refresh_free ? (b == 0 ? (size_t)s->l_chunk : (size_t)0) : (size_t)N;
@@ -1499,22 +1501,28 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     s->refresh = K > 1 ? K : 0;
   }
   if (s->refresh && c->mdl.kind == RBPF_MODEL_GENERIC_DENSE) { set_error("chol_refresh > 1 in the sharded smoother needs measModel on the device"); return RBPF_ERR_UNSUPPORTED; }
-  if (c->opt.info_rebuild > 0) { set_error("info_rebuild = 1 is a single-device option (the sharded smoother exchanges stored information matrices at its refreshes)"); return RBPF_ERR_UNSUPPORTED; }
+  if (c->opt.info_rebuild > 0 && s->refresh < T - 1) { set_error("info_rebuild = 1 with refreshes is a single-device option (the sharded smoother exchanges stored information matrices at its refreshes; chol_refresh >= N_T - 1 never refreshes and stores none)"); return RBPF_ERR_UNSUPPORTED; }
+  if (s->refresh > 256 && s->refresh < T - 1) { set_error("sharded smoother: chol_refresh between 257 and N_T - 2 is not supported (choose <= 256, or >= N_T - 1: never refresh)"); return RBPF_ERR_UNSUPPORTED; }
   s->lazy_imat = s->refresh > 1;
+  // chol_refresh >= N_T - 1: the factors are never refactorised after t = 1 -- no information matrix is stored or exchanged, the first
+  // factorisation runs chunk by chunk (as in the single-device smoother, smoother_run)
+  s->refresh_free = s->lazy_imat && s->refresh >= T - 1;
+  s->seg_len = 32;
   RB_TRY(dmalloc(&s->d_xnk, (size_t)T * nN));
   RB_TRY(dmalloc(&s->d_dyref, (size_t)T * d * n));
   RB_TRY(dmalloc(&s->d_ak, 4));
   s->imat_packed = imat_storage_packed(n, d, s->refresh, true);
   s->imat_len = s->imat_packed ? imat_packed_doubles(n) : (size_t)n * n;
+  s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
   for (int b = 0; b < 2; ++b) {
-    RB_TRY(dmalloc(&s->d_Imat[b], (size_t)N * s->imat_len));
-    if (s->imat_packed) HIPCHK(hipMemset(s->d_Imat[b], 0, (size_t)N * s->imat_len * 8));
+    const size_t n_mat = s->refresh_free ? (b == 0 ? (size_t)s->l_chunk : (size_t)0) : (size_t)N;
+    RB_TRY(dmalloc(&s->d_Imat[b], n_mat * s->imat_len));
+    if (s->imat_packed && n_mat) HIPCHK(hipMemset(s->d_Imat[b], 0, n_mat * s->imat_len * 8));
     RB_TRY(dmalloc(&s->d_Hb[b], (size_t)N * d * L.ldx));
     RB_TRY(dmalloc(&s->d_ivec[b], (size_t)N * L.ldx));
     RB_TRY(dmalloc(&s->d_hld[b], (size_t)N));
     RB_TRY(dmalloc(&s->d_qf[b], (size_t)N));
   }
-  s->l_chunk = s->lazy_imat ? std::min(N, 4096) : N;
   RB_TRY(dmalloc(&s->d_L, (size_t)s->l_chunk * chol_factor_doubles(n)));
   RB_TRY(dmalloc(&s->d_ImatAdd, (size_t)n * n));
   RB_TRY(dmalloc(&s->d_ivecAdd, (size_t)n));
@@ -1541,8 +1549,9 @@ int rbpf_shard_smoother_create(const rbpf_model* model, const rbpf_problem* prob
     whitening_factor(c->h_R, d, Wm);
     HIPCHK(hipMemcpy(s->d_W, Wm.data(), (size_t)d * d * 8, hipMemcpyHostToDevice));
     RB_TRY(dmalloc(&s->d_base_slot, (size_t)N));
-    RB_TRY(dmalloc(&s->d_Xp, (size_t)N * s->refresh * nN));
-    RB_TRY(dmalloc(&s->d_G, (size_t)N * s->refresh * d * n));
+    const size_t Kwin = s->refresh_free ? 1 : (size_t)s->refresh;        // generations a refresh walks back
+    RB_TRY(dmalloc(&s->d_Xp, (size_t)N * Kwin * nN));
+    RB_TRY(dmalloc(&s->d_G, (s->refresh_free ? (size_t)s->l_chunk : (size_t)N) * Kwin * d * n));
     RB_TRY(dmalloc(&s->d_owner_now, (size_t)sh->Nglob));
     RB_TRY(dmalloc(&s->d_base_gid, (size_t)sh->Nglob));
     RB_TRY(dmalloc(&s->d_base_loc, (size_t)sh->Nglob));
@@ -1758,6 +1767,27 @@ int rbpf_shard_smoother_refresh_end(rbpf_ctx* c, const int32_t* base_index, int3
     if (!base_index || n_recv < 0 || (size_t)n_recv > s->rf_cap) { set_error("refresh_end: base_index / n_recv"); return RBPF_ERR_INVALID_ARG; }
     for (int p = 0; p < N; ++p) if (base_index[p] < 0 || base_index[p] >= N + n_recv) { set_error("refresh_end: base_index out of range"); return RBPF_ERR_INVALID_ARG; }
     HIPCHK(hipMemcpyAsync(s->d_base_slot, base_index, (size_t)N * sizeof(int), hipMemcpyHostToDevice, st));
+  }
+  if (s->refresh_free) {
+    // the first (and only) factorisation, chunk by chunk: Imat = Imat0 + H' R^-1 H of generation 0 into the chunk buffer,
+    // chol(Imat + ImatAddt) out of it, factors into the sweep layout; nothing was fetched from other ranks
+    if (t != 1 || t0 >= 0 || Kp != 1) { set_error("internal: refresh-free sharded smoother refreshed after t = 1"); return RBPF_ERR_STATE; }
+    for (int p0 = 0; p0 < N; p0 += s->l_chunk) {
+      const int cnt = std::min(s->l_chunk, N - p0);
+      HIPCHK(launch_meas_model(c->mdl, cnt, s->d_Xp + (size_t)p0 * c->mdl.nN, s->d_G, st, 1));
+      hipLaunchKernelGGL(sweep_whiten_kernel, dim3((unsigned)(((size_t)cnt * n + 255) / 256)), dim3(256), 0, st, (size_t)cnt, d, n, s->d_W, s->d_G);
+      HIPCHK(hipGetLastError());
+      GemmArgs g1{n, n, d, s->d_G, 1, n, (long)d * n, s->d_G, n, 1, (long)d * n, s->d_Imat[0], 1, n, (long)s->imat_len};
+      g1.lower = 1; g1.packed = s->imat_packed ? 1 : 0;
+      g1.add = s->d_Imat0; g1.add_stride = 0L; g1.add_idx = nullptr;
+      HIPCHK(launch_gemm(g1, cnt, st));
+      RB_TRY(refresh_factorise(c, s->d_Rinv, sh->anc_local, cnt, st, p0, s->d_Imat[0]));
+    }
+    s->imat_valid = false; s->base_gen = t - 1;
+    HIPCHK(hipMemcpyAsync(s->d_base_gid, s->d_owner_now, (size_t)sh->Nglob * sizeof(int), hipMemcpyDeviceToDevice, st));
+    s->sw_cur ^= 1; s->sw_valid = true; s->rf_stage = 0;
+    HIPCHK(hipStreamSynchronize(st));
+    return RBPF_OK;
   }
   const int ni = s->imat_valid ? (s->imat_cur ^ 1) : 0;
   HIPCHK(launch_meas_model(c->mdl, N * Kp, s->d_Xp, s->d_G, st, 1));

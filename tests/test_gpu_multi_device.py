@@ -132,9 +132,10 @@ def test_multi_device_smoother_with_carried_factors(rbpf, kind, ids, cap):
     else:
         d, mdl, x0, P0, R = _mag(rbpf, 14, 130)
         args = (mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, 36, 3, 0.01)
-    kw = dict(lazy_depth=3, chol_refresh=4)
-    ref = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), **kw)
-    # exchange_capacity = -1: record AND refresh buffers start at one / two entries and grow on demand (every rank by the same rule)
-    out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), n_devices=len(ids), device_ids=ids, exchange_capacity=cap, **kw)
-    for a, b in zip(out, ref):
-        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+    for kw in (dict(lazy_depth=3, chol_refresh=4),
+               dict(lazy_depth=3, chol_refresh=10 ** 6)):           # never refreshed after t = 1: no information matrix stored or exchanged
+        ref = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), **kw)
+        # exchange_capacity = -1: record AND refresh buffers start at one / two entries and grow on demand (every rank by the same rule)
+        out = rbpf.particleSmootherInformationForm(*args, rng=rbpf.PhiloxRNG(9), n_devices=len(ids), device_ids=ids, exchange_capacity=cap, **kw)
+        for a, b in zip(out, ref):
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
