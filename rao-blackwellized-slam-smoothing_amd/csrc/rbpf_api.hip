@@ -465,9 +465,6 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->traj_max); hipFree(c->traj_mean); hipFree(c->d_scal); hipFree(c->d_flags); hipFree(c->d_order); hipFree(c->d_counts); hipFree(c->d_pre_i); hipFree(c->d_pre_d); hipFree(c->d_unext); hipFree(c->d_rs);
   smoother_free(c);
   shard_free(c);
-  if (c->ev_fork) hipEventDestroy(c->ev_fork);
-  if (c->ev_join) hipEventDestroy(c->ev_join);
-  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -753,12 +750,6 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     int* lead = c->d_share; int* dst = c->d_share + N; int* ph = c->d_share + 2 * (size_t)N;
     HIPCHK(launch_share_plan(N, N, A_t, lead, dst, ph, c->timing_on ? c->d_share_writers : nullptr, c->stream));
     a.dst_slot = dst; a.phase_of = ph; a.share_flush = 1;
-    if (tuning_env("RBPF_STAGGER_PROBE") && c->timing_on && a.n_sets == 4 && !info) HIPCHK(launch_stagger_probe(N, A_t, ph, c->stream));
-    if ((tuning_env("RBPF_STAGGER_PROBE") || tuning_env("RBPF_SHARE_CONCURRENT")) && !c->stream2) {     // (diagnostic builds: outside the timed bracket)
-      HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-      HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
   }
   RB_TRY(ctx_arm_distinct(c, a, (size_t)N + 1));
   HIPCHK(launch_propagate(a, c->stream));
@@ -772,37 +763,13 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     a.phase = 1; HIPCHK(launch_step(a, c->stream));
   } else if (share) {
     // Writers (the flush variant, one per parent with children) first, then their read-only siblings (the same pending sets; they
-    // point at their writer's new entry), one after the other on the context's stream.  Measured r05 (diagnostic build,
-    // RBPF_SHARE_CONCURRENT = 1: both on two streams, side by side): 11.39 against 11.24 ms per step at N = 65 536 -- the flush step is
-    // at its byte floor (writers at the copy ceiling), the siblings' reads add to the same memory path, nothing is idle to fill.
-    static const int serial = tuning_env("RBPF_SHARE_CONCURRENT") ? 0 : 1;
-    // TIMING PROBE of a staggered flush (diagnostic builds; WRONG RESULTS by design, one step only): a quarter of the families flush,
-    // the rest run the read-only variant with two sets -- the mix a step would see if every lineage flushed at its own phase
-    // (VERDICT r04 item 4).  1: the three launches one after the other; 2: writers + siblings beside the read-only particles.
-    static const int probe = tuning_env("RBPF_STAGGER_PROBE") ? atoi(tuning_env("RBPF_STAGGER_PROBE")) : 0;
-    const bool probing = probe && c->timing_on && a.n_sets == 4 && !info;
+    // point at their writer's new entry), one after the other.  (Measured r05 with diagnostic builds of commit 31144f4: both side by side on
+    // two streams 11.39 against 11.24 ms per step; one step of a STAGGERED flush -- a quarter of the families flushing beside three
+    // quarters of read-only particles -- 12.2 ms whether serial or concurrent, against the lock-step schedule's 11.66: DESIGN.md 9.)
+    a.phase = 1; HIPCHK(launch_step(a, c->stream));                 // writers: the flush variant
     StepArgs rd = a;
-    rd.phase = 0; rd.write_base = 0;
-    a.phase = 1;
-    if (probing) {
-      StepArgs lt = a;
-      lt.phase = 2; lt.write_base = 0; lt.n_sets = 2; lt.share_flush = 0;
-      hipStream_t s2 = (probe == 2) ? c->stream2 : c->stream;
-      if (probe == 2) { HIPCHK(hipEventRecord(c->ev_fork, c->stream)); HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
-      if (probe != 4) HIPCHK(launch_step(lt, s2));                     // (3: the read-only particles alone; 4: the flushing quarter alone)
-      if (probe != 3) { HIPCHK(launch_step(a, c->stream)); HIPCHK(launch_step(rd, c->stream)); }
-      if (probe == 2) { HIPCHK(hipEventRecord(c->ev_join, c->stream2)); HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0)); }
-    } else if (serial) {
-      HIPCHK(launch_step(a, c->stream));
-      HIPCHK(launch_step(rd, c->stream));
-    } else {
-      HIPCHK(hipEventRecord(c->ev_fork, c->stream));
-      HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-      HIPCHK(launch_step(a, c->stream));
-      HIPCHK(launch_step(rd, c->stream2));
-      HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-      HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    }
+    rd.phase = 0; rd.write_base = 0;                                // readers: the read-only variant with the same pending sets
+    HIPCHK(launch_step(rd, c->stream));
     if (c->timing_on) c->share_flush_particles += N;
   } else {
     HIPCHK(launch_step(a, c->stream));

@@ -183,41 +183,20 @@ __device__ __forceinline__ bool sweep_block(const SweepArgs& a, const double* __
     if (q == NS - 1 && tailc) dst_[q] = (lane < 8) ? (base_)[(size_t)(q - B) * 64 + lane] : 0.0;            \
     else dst_[q] = (base_)[(size_t)(q - B) * 64 + lane];                                                   \
   }
-#ifndef RBPF_SWEEP_DEPTH
-#define RBPF_SWEEP_DEPTH 1                       // columns requested ahead of the one being rotated (2: measured r05)
-#endif
-#if RBPF_SWEEP_DEPTH >= 2
-  double nx2[NS];
-#pragma unroll
-  for (int q = 0; q < NS; ++q) nx2[q] = 0.0;
-#endif
+  // (two columns requested ahead instead of one -- a register move per slot -- measured r05, commit 31144f4: 4.36-4.44 against 4.38-4.56 ms,
+  //  noise: the sweep is bound by the memory system, not by the depth of its prefetch)
   {
     const double* c0 = src + sweep_col_offset(k0, NS, a.tailc);
     RBPF_SW_LOAD(nxt, c0)
-#if RBPF_SWEEP_DEPTH >= 2
-    if (k0 + 1 < k1) {
-      const double* c1 = src + sweep_col_offset(k0 + 1, NS, a.tailc);
-      RBPF_SW_LOAD(nx2, c1)
-    }
-#endif
   }
   for (int k = k0; k < k1; ++k) {
     const int r_lane = k - k0;
 #pragma unroll
     for (int q = B; q < NS; ++q) col[q] = nxt[q];
-#if RBPF_SWEEP_DEPTH >= 2
-#pragma unroll
-    for (int q = B; q < NS; ++q) nxt[q] = nx2[q];
-    if (k + 2 < k1) {                                     // two columns ahead (same slot range): a register move per slot instead of an unrolled ring
-      const double* cn = src + sweep_col_offset(k + 2, NS, a.tailc);
-      RBPF_SW_LOAD(nx2, cn)
-    }
-#else
     if (k + 1 < k1) {                                     // the next column of this block (same slot range)
       const double* cn = src + sweep_col_offset(k + 1, NS, a.tailc);
       RBPF_SW_LOAD(nxt, cn)
     }
-#endif
 
     double Lkk = readlane_f64(col[B], r_lane);
     if (!plain_copy) {

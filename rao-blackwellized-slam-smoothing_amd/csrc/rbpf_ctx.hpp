@@ -40,10 +40,6 @@ struct InfoStep {
 struct rbpf_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  // shared flush: the read-only siblings of a flush step run BESIDE the writers (they read the same stored matrices and write
-  // disjoint outputs): a second stream forked from / joined to `stream` by two events
-  hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   rbpf::ModelDev mdl;
   rbpf::Layout lay;
   rbpf::Layout lay_low;     // same HBM layout, 2 x 2 wave decomposition (lazy variants with >= 3 pending sets)

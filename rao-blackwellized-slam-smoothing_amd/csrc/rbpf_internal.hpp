@@ -225,7 +225,6 @@ hipError_t launch_order_large(int n_slots, int range, const int* key, const int*
 hipError_t launch_order(int n_slots, int range, const int* key, int* order, int* counts, hipStream_t s, const int* remap = nullptr);
 // plan of a single-bank flush: order [N] lists the slots sorted by the entry base[ai[.]] of their ancestor's stored
 // matrix.  dst [N] / phase [N] out; scratch: 3 N ints.
-hipError_t launch_stagger_probe(int N, const int* ai, int* phase, hipStream_t s);
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase,
                                int* scratch, hipStream_t s);
 hipError_t launch_share_plan(int N, int nkeys, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s);

@@ -289,17 +289,6 @@ hipError_t launch_share_plan(int N, int nkeys, const int* ai, int* lead, int* ds
   return hipGetLastError();
 }
 
-// TIMING PROBE of a staggered flush (diagnostic builds, rbpf_api.hip ctx_step; wrong results by design): three of four families --
-// by parent index -- leave the flush (phase 2: they will run a read-only variant instead)
-__global__ void stagger_probe_kernel(int N, const int* __restrict__ ai, int* __restrict__ phase) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N && (ai[i] & 3) != 0) phase[i] = 2;
-}
-hipError_t launch_stagger_probe(int N, const int* ai, int* phase, hipStream_t s) {
-  hipLaunchKernelGGL(stagger_probe_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, ai, phase);
-  return hipGetLastError();
-}
-
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
                                hipStream_t s) {
   int* has = scratch; int* nzp = scratch + N; int* freelist = scratch + 2 * (size_t)N;

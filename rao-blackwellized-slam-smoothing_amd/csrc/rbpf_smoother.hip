@@ -1144,7 +1144,6 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
         HIPCHK(hipGetLastError());
       }
     }
-    bool sweep_in_flight = false;                  // (RBPF_SWEEP_OVERLAP_PROBE, diagnostic builds)
     for (int t = 0; t < T; ++t) {
       const double* xref = (k > 0) ? s->d_xnk + (size_t)t * nN : nullptr;
       int n_draw = N;
@@ -1222,27 +1221,8 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
             sw.W = s->d_W; sw.yt = c->d_y + (size_t)(t - 1) * d; sw.qf = s->d_qf[s->icur]; sw.hld = s->d_hld[s->icur];
             sw.pant_log = s->d_pant_log; sw.status = c->d_flags;
             sw.order = (c->order_step == t - 1) ? c->d_order : nullptr;     // generation t-1 in the order its step ran in
-            // TIMING PROBE (diagnostic builds; WRONG RESULTS by design: slot N_P's ancestor is drawn before the sweep has added
-            // logwMeas): the sweep on a second stream BESIDE the normalisation and the step kernels of the same time step -- what an
-            // implementation that defers only slot N_P's work behind the sweep could gain
-            static const int ovl = tuning_env("RBPF_SWEEP_OVERLAP_PROBE") ? 1 : 0;
-            if (ovl) {
-              if (!c->stream2) {
-                HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-                HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-              }
-              if (sw.order) {                                 // the step kernels of this time step rewrite the order while the sweep reads it
-                if (!s->d_base_loc) RB_TRY(dmalloc(&s->d_base_loc, (size_t)N));      // (a buffer the single-GPU smoother does not use)
-                HIPCHK(hipMemcpyAsync(s->d_base_loc, sw.order, (size_t)N * sizeof(int), hipMemcpyDeviceToDevice, st));
-                sw.order = s->d_base_loc;
-              }
-              HIPCHK(hipEventRecord(c->ev_fork, st));
-              HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-              HIPCHK(launch_chol_sweep(sw, c->stream2));
-              HIPCHK(hipEventRecord(c->ev_join, c->stream2));
-              sweep_in_flight = true;
-            } else
+            // (measured r05, diagnostic build of commit 31144f4: the sweep on a second stream beside the step kernels of the same time
+            //  step -- only slot N_P's ancestor depends on it -- 7.39 -> 7.15 ms per step: not worth splitting that slot out)
             HIPCHK(launch_chol_sweep(sw, st));
             s->sw_cur ^= 1;
             skip_chol = true;
@@ -1318,7 +1298,6 @@ static int smoother_run(rbpf_ctx* c, int N_K, int info_form, rbpf_smoother_out* 
       }
       if (generic) RB_TRY(generic_finish_inputs(c, k > 0 ? xnk_h.data() + (size_t)t * nN : nullptr));
       const int st_step = info_form ? info_step(c, k, t, xref, n_draw, d_Rinv) : ctx_step(c, k, xref, n_draw, nullptr);
-      if (sweep_in_flight) { HIPCHK(hipStreamWaitEvent(st, c->ev_join, 0)); sweep_in_flight = false; }   // (timing probe only)
       if (generic) { c->ext_xn = nullptr; c->ext_H = nullptr; }
       RB_TRY(st_step);
     }
@@ -1437,8 +1416,16 @@ extern "C" int rbpf_particle_smoother(const rbpf_model* model, const rbpf_proble
   if (wants_multi(opt)) return multi_particle_smoother(model, prob, rng, opt, N_K, info_form, out);   // sharded over several GPUs
   rbpf_ctx* c = nullptr;
   int st = ctx_create(model, prob, rng, opt, true, N_K, &c);
-  if (st != RBPF_OK) return st;
-  st = smoother_run(c, N_K, info_form, out);
+  if (st == RBPF_OK) st = smoother_run(c, N_K, info_form, out);
+  if (st == RBPF_ERR_OUT_OF_MEMORY && info_form && prob) {
+    // say what would fit: the information-form state without stored information matrices and with one covariance bank
+    const double n = (double)prob->n_lin, mb = (8.0 * (0.57 * n * n + 2.0 * 0.52 * (n + 1) * (n + 1))) / 1e6;
+    set_error(std::string(rbpf_last_error()) + " -- the information-form smoother did not fit this device with these options.  Its smallest "
+              "footprint: storage = 2 (where supported), lazy_depth >= 2, inplace = 1 and chol_refresh >= N_T (or info_rebuild = 1): about " +
+              std::to_string((int)(mb * 10) / 10.0).substr(0, 4) + " MB of state per particle at this nLin (include/rbpf.h, rbpf_options)");
+  }
+  if (!c) return st;
+  if (st != RBPF_OK) { ctx_free(c); return st; }
   if (st == RBPF_OK) {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) st = hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__);

@@ -266,3 +266,17 @@ def test_smoother_at_the_metrics_full_particle_count_on_one_gpu(rbpf):
         P = PK[:, :, k]
         assert rel(P, P.T) < 1e-12 and np.linalg.eigvalsh(0.5 * (P + P.T)).min() > 0
         assert np.all(np.diag(P) <= np.diag(P0) * (1 + 1e-12))
+
+
+def test_out_of_memory_names_the_configuration_that_fits(rbpf):
+    """N_P = 65 536 at m = 512 with the default layout (two covariance banks, information matrices stored at the refreshes: 7.5 MB per
+    particle = 490 GB) does not fit one GPU: RBPF_ERR_OUT_OF_MEMORY, and the message names the options that do
+    (test_smoother_at_the_metrics_full_particle_count_on_one_gpu runs them)."""
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    d = dg.bean_6D(6, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(512, d["LL"], cases.THETA_MAG)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R,
+                                             65536, 2, 0.01, rng=rbpf.PhiloxRNG(9), storage="fp64sym", lazy_depth=3)
+    assert ei.value.status == rbpf.RBPF_ERR_OUT_OF_MEMORY
+    assert "inplace = 1" in str(ei.value) and "chol_refresh >= N_T" in str(ei.value)
