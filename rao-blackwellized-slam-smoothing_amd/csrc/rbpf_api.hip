@@ -24,6 +24,9 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   char buf[512];
   snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
   g_last_error = buf;
+  // the runtime keeps the failure as its thread's "last error" until somebody reads it: left there, the hipGetLastError() after the next
+  // kernel launch of ANOTHER call would report this one again (seen as "out of memory" in a filter created after a refused smoother)
+  (void)hipGetLastError();
   return (e == hipErrorOutOfMemory) ? RBPF_ERR_OUT_OF_MEMORY : RBPF_ERR_HIP;
 }
 

@@ -271,7 +271,7 @@ def test_smoother_at_the_metrics_full_particle_count_on_one_gpu(rbpf):
 def test_out_of_memory_names_the_configuration_that_fits(rbpf):
     """N_P = 65 536 at m = 512 with the default layout (two covariance banks, information matrices stored at the refreshes: 7.5 MB per
     particle = 490 GB) does not fit one GPU: RBPF_ERR_OUT_OF_MEMORY, and the message names the options that do
-    (test_smoother_at_the_metrics_full_particle_count_on_one_gpu runs them)."""
+    (test_smoother_at_the_metrics_full_particle_count_on_one_gpu runs them).  A call made after the refusal works."""
     dg = importlib.import_module(rbpf.__name__ + ".datagen")
     d = dg.bean_6D(6, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
     mdl, x0, P0, R = rbpf.dense_mag_prior(512, d["LL"], cases.THETA_MAG)
@@ -280,3 +280,6 @@ def test_out_of_memory_names_the_configuration_that_fits(rbpf):
                                              65536, 2, 0.01, rng=rbpf.PhiloxRNG(9), storage="fp64sym", lazy_depth=3)
     assert ei.value.status == rbpf.RBPF_ERR_OUT_OF_MEMORY
     assert "inplace = 1" in str(ei.value) and "chol_refresh >= N_T" in str(ei.value)
+    # ... and the refusal leaves nothing behind: neither memory nor the runtime's sticky error (the next call's launches succeed)
+    out = run_session(rbpf, d, mdl, x0, P0, R, 256, 5, ("traj_max", "trace_w"), lazy_depth=3, storage="fp64sym")
+    assert np.all(np.isfinite(out["trace_w"][:, :5]))
