@@ -97,7 +97,7 @@ def roofline_of(tm, storage="fp64"):
     ach = sched / (avg_ms * 1e-3) / 1e9
     alg = tm["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
-            "kernel": "step_sym_kernel (all variants of a lazy cycle; a flush step = its two launches)" if storage == "fp64sym" else "step_kernel",
+            "kernel": "step_sym_kernel (all variants of a lazy cycle; a flush step = its two launches)" if storage in ("fp64sym", "fp32sym") else "step_kernel",
             "avg_launch_ms": avg_ms, "launches": tm["launches"],
             "scheduled_bytes_per_launch": sched,
             "algorithmic_bytes_per_launch": tm["bytes_per_launch"], "algorithmic_GBps": alg,
@@ -141,15 +141,16 @@ def filter_leg(pkg, datagen, N, m, T, K, W, seed, lazy_depth, inplace, storage, 
 
 def bank_bytes_per_particle(n, storage):
     """Bytes of one stored covariance (include/rbpf.h rbpf_options.storage)."""
-    if storage == "fp64sym":                                       # lower block triangle in 64 x 64 tiles + border rows
+    if storage in ("fp64sym", "fp32sym"):                          # lower block triangle in 64 x 64 tiles + border rows
         mc = (n // 128) * 128
         ch = mc // 64
-        return 8.0 * (ch * (ch + 1) // 2 * 4096 + (n - mc) * ((n + 1) // 2 * 2))
+        return (8.0 if storage == "fp64sym" else 4.0) * (ch * (ch + 1) // 2 * 4096 + (n - mc) * ((n + 1) // 2 * 2))
     return n * n * (8.0 if storage == "fp64" else 4.0)
 
 
 def workload_string(N_total, T, m, n, storage, lazy_depth, world, single_bank):
-    prec = {"fp64": "fp64", "fp64sym": "fp64, symmetric storage (lower block triangle)"}.get(storage, "fp64 arithmetic / fp32 covariance storage")
+    prec = {"fp64": "fp64", "fp64sym": "fp64, symmetric storage (lower block triangle)",
+            "fp32sym": "fp64 arithmetic / fp32 covariance storage, lower block triangle"}.get(storage, "fp64 arithmetic / fp32 covariance storage")
     bank = "single covariance bank rewritten in place" if single_bank else "ping-pong covariance banks"
     return (f"slam-dense-mag N={N_total} T={T} m={m} (nLin={n}) {prec}, forward filter, {world} GPU, lazy_depth {lazy_depth}, "
             f"{bank}")
@@ -574,7 +575,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--lazy-depth", type=int, default=4, help="rewrite the covariances every C-th step only (0/1: every step)")
     ap.add_argument("--inplace", type=int, default=0, help="single covariance bank rewritten in place: 1 on, -1 off, 0 automatic (when two banks do not fit)")
-    ap.add_argument("--storage", default="fp64sym", choices=["fp64", "fp32", "fp64sym"],
+    ap.add_argument("--storage", default="fp64sym", choices=["fp64", "fp32", "fp64sym", "fp32sym"],
                     help="how the covariance banks are STORED (arithmetic is fp64): fp64sym = fp64, lower block triangle only (default; results within 1e-9 "
                          "of fp64), fp64 = full square as the reference holds them, fp32 = full square in float")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded session even at --gpus 1 (testing)")
@@ -785,7 +786,10 @@ def main():
             # BASELINE.json configs[1].  Full-square storage: at N = 8192, nLin = 259 a step is bound by the fixed per-workgroup work (16 rounds of
             # workgroups, ~58 us each), not by bytes -- symmetric storage (supported at this size too) gives the same 8.0-8.2 M/s
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")
-            line["configs4_share_filter"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")       # 1/8 of configs[4]
+            # 1/8 of BASELINE.json configs[4] (fp32 storage is the config's own dtype): block-lower fp32 tiles at sixteen tile rows (r05), and the
+            # full-square fp32 storage it replaces
+            line["configs4_share_filter"] = guarded(extra, 32768, 1024, 32, 4, 4, "fp32sym")
+            line["configs4_share_filter_full_square"] = guarded(extra, 32768, 1024, 30, 4, 2, "fp32")
         if solo and not args.no_filter_full:
             line["filter_full_T"] = guarded(lambda: filter_full_run(pkg, datagen, N_local, args.m, T, args.seed, args.lazy_depth, args.inplace, args.storage))
             if "seconds" in line["filter_full_T"]:

@@ -183,8 +183,12 @@ typedef struct {
                           * 515, i.e. 0.56 x the HBM traffic and memory of storage 0; read-only steps of lazy_depth apply the  *
                           * pending sets as P H' - KS (K' H') instead of element-wise.  Same algebra: results within 1e-9 of  *
                           * storage 0 (P(r,c) and P(c,r), which differ by rounding in the reference's plain form, are one     *
-                          * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]): filter *
-                          * and both smoothers, single-GPU and sharded; RBPF_ERR_UNSUPPORTED elsewhere.                         */
+                          * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]) or      *
+                          * 259 <= n_lin <= 383: filter and both smoothers, single-GPU and sharded; 1027 <= n_lin <= 1151       *
+                          * (sixteen tile rows, BASELINE.json configs[4]'s basis size): the filter; RBPF_ERR_UNSUPPORTED         *
+                          * elsewhere.                                                                                          *
+                          * 3 = fp32 tiles of the lower block triangle (storage 1's rounding on storage 2's layout: 0.28 x the   *
+                          * bytes of storage 0): the filter with 515 <= n_lin <= 639 or 1027 <= n_lin <= 1151, lazy_depth <= 4.  */
   int32_t chol_variant;  /* smoothers: kernel of the ancestor-weight factorisation (particleSmoother.m:221,                   *
                           * particleSmootherInformationForm.m:228).  0: by matrix size (default); 16 / 64 / 648 / 644 / 1 /             *
                           * (a non-zero value with chol_refresh = 0 selects the from-scratch factorisation, chol_refresh = 1)           *

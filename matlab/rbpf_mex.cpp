@@ -345,7 +345,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
           }
         }
       }
-      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 2 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
+      if (o.lazy_depth < 0 || o.chol_refresh < 0 || o.storage < 0 || o.storage > 3 || o.n_devices < 0 || o.rng_mode < 0 || o.rng_mode > 2 || o.rng_seed < 0) mexErrMsgIdAndTxt("rbpf:usage", "options: value out of range");
       g_session = o;
     }
     // rng_mode / rng_seed are consumed by the .m wrappers (matlab/rbpf_rngblock.m): 0 = MATLAB's stream in the reference's

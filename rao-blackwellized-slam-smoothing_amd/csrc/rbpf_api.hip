@@ -227,16 +227,18 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   c->lay = make_layout(prob->n_lin, prob->n_y);
   c->lay_low = make_layout_low_regs(prob->n_lin, prob->n_y);
   const bool sparse = model->kind == RBPF_MODEL_SPARSE_VISUAL_2D;
-  c->fp32 = c->opt.storage == 1;
-  if (c->opt.storage < 0 || c->opt.storage > 2) { set_error("options.storage must be 0 (fp64), 1 (fp32) or 2 (fp64, symmetric)"); return RBPF_ERR_INVALID_ARG; }
-  if (c->opt.storage == 2) {
+  c->fp32 = c->opt.storage == 1 || c->opt.storage == 3;
+  if (c->opt.storage < 0 || c->opt.storage > 3) { set_error("options.storage must be 0 (fp64), 1 (fp32), 2 (fp64, symmetric) or 3 (fp32, symmetric)"); return RBPF_ERR_INVALID_ARG; }
+  if (c->opt.storage == 2 || c->opt.storage == 3) {
     // symmetric storage (lower block triangle, rbpf_step_sym.hip): the filter of the ny = 3 dense families at the
     // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
     if (sparse || !sym_supported(prob->n_lin, prob->n_y)) {
-      set_error("symmetric storage (options.storage = 2): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639 only"); return RBPF_ERR_UNSUPPORTED;
+      set_error("symmetric storage (options.storage = 2 / 3): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639, dense filter with nLin in 1027..1151 only"); return RBPF_ERR_UNSUPPORTED;
     }
     c->lay = make_layout_sym(prob->n_lin, prob->n_y);
     c->lay_low = c->lay;
+    if (c->lay.CH64 == 16 && smoother) { set_error("symmetric storage at sixteen tile rows (nLin >= 1027): the filter only"); return RBPF_ERR_UNSUPPORTED; }
+    if (c->fp32 && c->lay.CH64 == 4) { set_error("fp32 tiles (options.storage = 3): nLin in 515..639 or 1027..1151"); return RBPF_ERR_UNSUPPORTED; }
   }
   if (c->fp32 && (smoother || sparse || prob->n_y != 3)) {
     set_error("fp32 storage of the covariance banks: dense-mag filter only"); return RBPF_ERR_UNSUPPORTED;
@@ -349,7 +351,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   // ---- particle banks ----
   // multi-step lazy update: the filter (up to kMaxSets pending sets) and the information-form smoother (up to 3: its step
   // kernel carries two more right-hand sides); the covariance-form smoother switches it off (smoother_run)
-  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : ((c->lay.sym && c->lay.CH64 == 8) ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
+  c->lazy_depth = (!sparse && c->opt.lazy_depth >= 2) ? std::min(c->opt.lazy_depth, smoother ? 3 : ((c->lay.sym && c->lay.CH64 == 8 && !c->fp32) ? (int)kMaxSets : (int)kMaxSetsFull)) : 1;
   {
     // one covariance bank rewritten in place instead of ping-pong banks: on request, or when two do not fit
     // (the information-form smoother on request only -- smoother_run refuses it for the covariance form, whose every step reads and
@@ -378,7 +380,11 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
   // shared flush: with ping-pong banks the children of one parent store ONE copy of their (identical) flushed matrix
-  c->share_flush = c->lazy_depth >= 2 && !c->inplace && !ex && c->lay.sym && c->lay.CH64 == 8 && !c->fp32;   // (smoothers: the information form)
+  c->share_flush = c->lazy_depth >= 2 && !c->inplace && !ex && c->lay.sym && (c->lay.CH64 == 8 || c->lay.CH64 == 16);   // (smoothers: the information form)
+  if (const size_t sd = sym_strip_doubles(c->lay, d)) {     // sixteen tile rows: the step kernel's column strips live in global memory
+    RB_TRY(dmalloc(&c->d_strip_ws, (size_t)N * sd));
+    c->strip_ws_stride = sd;
+  }
   if (c->share_flush) {
     RB_TRY(dmalloc(&c->d_share, (size_t)3 * N));
     RB_TRY(dmalloc(&c->d_share_writers, 1));
@@ -460,6 +466,7 @@ void ctx_free(rbpf_ctx* c) {
   hipFree(c->d_NN); hipFree(c->d_y); hipFree(c->d_odo); hipFree(c->d_cholQ); hipFree(c->d_cholQfull);
   hipFree(c->d_x0l); hipFree(c->d_P0t); hipFree(c->d_P0b); hipFree(c->d_U); hipFree(c->d_Z);
   if (c->inplace) { c->Pt[1] = nullptr; c->Pb[1] = nullptr; }     // aliases of bank 0
+  hipFree(c->d_strip_ws);
   hipFree(c->d_ip); hipFree(c->d_share); hipFree(c->d_share_writers); hipFree(c->d_distinct_mark); hipFree(c->d_distinct_counter);
   for (int b = 0; b < 2; ++b) { hipFree(c->Pt[b]); hipFree(c->Pb[b]); hipFree(c->F[b]); hipFree(c->xl[b]); }
   hipFree(c->X); hipFree(c->A); hipFree(c->logw); hipFree(c->w); hipFree(c->wc);
@@ -684,6 +691,7 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
   a.fself_idx_new = nullptr; a.base_old = nullptr; a.base_new = nullptr;
   a.dst_slot = nullptr; a.phase_of = nullptr; a.phase = -1; a.share_flush = 0;
   a.fp32 = c->fp32 ? 1 : 0;
+  a.strip_ws = c->d_strip_ws; a.strip_ws_stride = c->strip_ws_stride;
   a.xn_ext = c->ext_xn; a.H_ext = c->ext_H;
   if (c->mdl.kind == RBPF_MODEL_GENERIC_DENSE && (!a.xn_ext || !a.H_ext)) {
     set_error("generic (host-callback) model: advance with rbpf_filter_step_external"); return RBPF_ERR_STATE;
@@ -946,12 +954,14 @@ int rbpf_device_count(void) {
 int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, const rbpf_options* opt, size_t* bytes) {
   if (!model || !p || !bytes) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
   RB_TRY(options_ok(opt));
-  const Layout L = (opt && opt->storage == 2 && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y) : make_layout(p->n_lin, p->n_y);
+  const Layout L = (opt && (opt->storage == 2 || opt->storage == 3) && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y) : make_layout(p->n_lin, p->n_y);
+  const bool f32 = opt && (opt->storage == 1 || opt->storage == 3);
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;
   size_t b = 2 * bank_bytes(L, p->n_y, p->N_P);
-  if (opt && opt->storage == 1) b -= (size_t)p->N_P * (L.szT + L.szB) * sizeof(double);  // float banks: half of two double banks
-  if (opt && opt->inplace > 0) b -= (size_t)p->N_P * (L.szT + L.szB) * (opt->storage == 1 ? sizeof(float) : sizeof(double));   // one bank
+  if (f32) b -= (size_t)p->N_P * (L.szT + L.szB) * sizeof(double);  // float banks: half of two double banks
+  if (opt && opt->inplace > 0) b -= (size_t)p->N_P * (L.szT + L.szB) * (f32 ? sizeof(float) : sizeof(double));   // one bank
+  b += (size_t)p->N_P * sym_strip_doubles(L, p->n_y) * sizeof(double);
   b += (size_t)(hist ? p->N_T : 2) * p->n_nonlin * p->N_P * sizeof(double);
   b += (size_t)(hist ? p->N_T : 1) * p->N_P * sizeof(int);
   b += (size_t)(trace ? 2 * p->N_T : 2) * p->N_P * sizeof(double) + (size_t)p->N_P * sizeof(double);

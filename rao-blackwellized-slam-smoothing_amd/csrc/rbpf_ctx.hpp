@@ -89,6 +89,7 @@ struct rbpf_ctx {
   // shared flush (filter, ping-pong banks, symmetric storage at eight tile rows): one child per parent stores the flushed matrix
   bool share_flush = false;
   int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)
+  double* d_strip_ws = nullptr; size_t strip_ws_stride = 0;   // symmetric storage at sixteen tile rows: the step kernel's column strips ([N][stride])
   unsigned long long* d_share_writers = nullptr;   // writers of the timed shared flushes (device counter)
   long long share_flush_particles = 0;          // particles of the timed shared flushes (N per flush step)
   // timed launches: reads of stored matrices counted per particle (nominal) and per DISTINCT matrix (device counter)

@@ -129,6 +129,7 @@ struct StepArgs {
   // to a dead entry, phase 1 = the first child of every stored matrix, which overwrites it after its siblings read it.
   const int* dst_slot; const int* phase_of; int phase;
   int fp32;                      // 1: the covariance banks (Pt / Pb) hold float; strides stay in elements
+  double* strip_ws; size_t strip_ws_stride;   // symmetric storage at sixteen tile rows: column-strip workspace, [workgroup][sym_strip_doubles]
   // generic model family (arbitrary host callbacks): the propagated states and the measurement Jacobians of this step
   // were evaluated on the host and uploaded
   const double* xn_ext;          // SoA [nN][N] new non-linear states (null: dynModel runs on the device)
@@ -206,6 +207,7 @@ Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
 Layout make_layout_sym(int n, int d);            // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
 bool sym_supported(int n, int d);
+size_t sym_strip_doubles(const Layout& lay, int d);   // per workgroup, 0 unless sixteen tile rows
 size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra = 0);   // extra = 1: information form
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s);
 // wave-level reduction primitives of the symmetric step kernel on their own (tests): in [4][64] -> out [4] lane sums

@@ -347,6 +347,7 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.xl_new = c->xl[xn]; a.F_new = lazy ? c->Fb[t % (c->lazy_depth + 1)] : c->F[nb];
   a.Pt_new = c->Pt[nb]; a.Pb_new = c->Pb[nb];
   a.fp32 = c->fp32 ? 1 : 0;
+  a.strip_ws = c->d_strip_ws; a.strip_ws_stride = c->strip_ws_stride;
   a.rng_mode = c->rng_mode; a.k_iter = k_iter; a.seed = c->seed;
   a.Z = (c->d_Z && t > 0) ? c->d_Z + ((size_t)k_iter * std::max(c->T - 1, 0) + (size_t)(t - 1)) * s->Nglob * nw : nullptr;
   a.xref = xref_t; a.xref_gslot = s->Nglob - 1;

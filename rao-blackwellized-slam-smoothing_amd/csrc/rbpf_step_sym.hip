@@ -25,8 +25,17 @@
 // * At a flush step of the filter with two banks only one child per parent runs the flush variant; its siblings run the read-only
 //   variant over the same source and point at the writer's new entry (shared flush: launch_share_plan, StepArgs::share_flush).
 //
-// Supported: dense families with ny = 3, fp64, 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]) or four tile rows
-// (nLin = 259), filter and both smoothers, single-GPU and sharded.
+// * Sixteen tile rows (nLin = 1027: BASELINE.json configs[4]; r05): a wave owns the rows {w, 15 - w} (17 tiles each).  Its column strip
+//   would be 64 (15 - w) columns -- 118 KB for the seven strips, more than the CU has next to H and P H' -- so a wave keeps the
+//   column sums of ONE block column in a 1.5 KB LDS stage and copies them out to its strip in a global workspace (StepArgs::strip_ws,
+//   118 KB per workgroup, three coalesced 512-byte stores per block column); the combine after the stream reads them back in the
+//   same fixed order.  3 % more bytes than the stored matrix, all of them L2 hits in practice.
+// * TS = float (rbpf_options.storage = 3): the tiles hold fp32 (same element order, 8-byte loads per lane), all arithmetic fp64, a
+//   flush rounds once on the way out -- as storage = 1 does for the full square.  Filter only.
+//
+// Supported: dense families with ny = 3; fp64: 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]) or four tile rows
+// (nLin = 259), filter and both smoothers, single-GPU and sharded; sixteen tile rows (nLin = 1027) and fp32 tiles: the filter.
+#include <type_traits>
 #include "rbpf_internal.hpp"
 #include "rbpf_device.hpp"
 #include "rbpf_model_dev.hpp"
@@ -43,6 +52,22 @@
 namespace rbpf {
 
 typedef double dbl2s __attribute__((ext_vector_type(2)));
+typedef float flt2s __attribute__((ext_vector_type(2)));
+
+// a column pair of one stored row: TS = double (16 bytes per lane) or float (fp32 tiles, 8 bytes per lane; arithmetic stays fp64)
+template <typename TS> __device__ __forceinline__ dbl2s ld_tile(const TS* p);
+template <> __device__ __forceinline__ dbl2s ld_tile<double>(const double* p) { return *reinterpret_cast<const dbl2s*>(p); }
+template <> __device__ __forceinline__ dbl2s ld_tile<float>(const float* p) {
+  const flt2s v = *reinterpret_cast<const flt2s*>(p);
+  dbl2s o; o.x = (double)v.x; o.y = (double)v.y;
+  return o;
+}
+template <typename TS> __device__ __forceinline__ void st_tile(TS* p, dbl2s v);
+template <> __device__ __forceinline__ void st_tile<double>(double* p, dbl2s v) { __builtin_nontemporal_store(v, reinterpret_cast<dbl2s*>(p)); }
+template <> __device__ __forceinline__ void st_tile<float>(float* p, dbl2s v) {
+  flt2s o; o.x = (float)v.x; o.y = (float)v.y;
+  __builtin_nontemporal_store(o, reinterpret_cast<flt2s*>(p));
+}
 
 constexpr int kSymRows = 2;            // tile rows per wave: rows rp and CH - 1 - rp (CH + 1 tiles whatever rp: balanced)
 // CH = 8 tile rows (nLin = 515): wave w owns the row pair rp = w and every column pair.  CH = 4 (nLin = 259): two waves share a row
@@ -53,7 +78,15 @@ constexpr int kSymStage = 32;          // columns of pending column factors a wa
 
 bool sym_supported(int n, int d) {
   const int mc = (n / kChunkRows) * kChunkRows;
-  return d == 3 && (mc / kSymChunk == 8 || mc / kSymChunk == 4);
+  return d == 3 && (mc / kSymChunk == 8 || mc / kSymChunk == 4 || mc / kSymChunk == 16);
+}
+
+// sixteen tile rows: doubles of the global column-strip workspace per workgroup (the seven strips of row pairs 1..7)
+size_t sym_strip_doubles(const Layout& lay, int d) {
+  if (!lay.sym || lay.CH64 != 16) return 0;
+  size_t o = 0;
+  for (int rp = 1; rp < lay.CH64 / 2; ++rp) o += (size_t)d * kSymChunk * (lay.CH64 - 1 - rp);
+  return o;
 }
 
 Layout make_layout_sym(int n, int d) {
@@ -73,26 +106,30 @@ __host__ __device__ inline int sym_ld_col(int ch, int rp) { return kSymChunk * (
 __host__ __device__ inline int sym_off_col(int off_col1, int D, int ch, int rp) { return off_col1 + D * kSymChunk * ((rp - 1) * (ch - 1) - (rp - 1) * rp / 2); }
 
 __host__ __device__ inline int sym_even(int x) { return (x + 1) & ~1; }
+// waves of a workgroup = row pairs x column phases: four (CH = 8: four row pairs; CH = 4: two row pairs x two phases), eight at CH = 16
+__host__ __device__ constexpr int sym_waves(int ch) { return ch == 16 ? 8 : kWaves; }
 
 __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage, int ch, int xl_lds = 1) {
   SymPlan p;
+  const int waves = sym_waves(ch);
   int o = 0;
   p.off_H = o;   o += sym_even(n * D + 2);           // + pad so that the first core column pair is 16-byte aligned
   p.off_xl = o;  o += xl_lds ? ldx : 0;
   p.off_PHt = o; o += D * ldx;
   p.off_col1 = o;
-  for (int rp = 1; rp < ch / 2; ++rp) o += D * sym_ld_col(ch, rp);
+  if (ch == 16) o += waves * D * kSymChunk;        // sixteen tile rows: one block column of column sums per wave (the strips are global)
+  else for (int rp = 1; rp < ch / 2; ++rp) o += D * sym_ld_col(ch, rp);
   p.off_row = o;  o += (ch == 4) ? D * ch * kSymChunk : 0;
   p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o; o += 64;
-  p.off_red = o;  o += kWaves * kSymRed;
-  p.off_kst = o;  o += kWaves * kSymStage * nd_stage;
+  p.off_red = o;  o += waves * kSymRed;
+  p.off_kst = o;  o += waves * kSymStage * nd_stage;
   p.total = o;
   return p;
 }
 
 size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra) {
-  const int xl_lds = (RBPF_SYM_LIGHT_WGS > 2 && !write_base && extra == 0) ? 0 : 1;
+  const int xl_lds = ((RBPF_SYM_LIGHT_WGS > 2 && !write_base && extra == 0) || lay.CH64 == 16) ? 0 : 1;
   return (size_t)sym_plan(lay.n, m.d + extra, lay.ldx, m.ktot, write_base ? n_sets * m.d : 0, lay.CH64, xl_lds).total * sizeof(double);
 }
 
@@ -166,8 +203,8 @@ hipError_t launch_probe_wave_reduce(const double* in, double* out, hipStream_t s
 // Q0: index of the first active row in ks / hown / accr (default: the last NACT rows); ADD: the strip entries of these columns already
 // hold the other row's contribution of this block column (split flush) -- add to them.
 // NPH column phases: this wave takes the pairs pbeg + cp, pbeg + cp + NPH, ... of the stage.
-template <int D, int DE, int NS, bool WR, int NACT, bool DIAG, int Q0 = kSymRows - NACT, bool ADD = false, int KR = kSymRows, int NPH = 1>
-__device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], double* const (&dst)[kSymRows],
+template <typename TS, int D, int DE, int NS, bool WR, int NACT, bool DIAG, int Q0 = kSymRows - NACT, bool ADD = false, int KR = kSymRows, int NPH = 1>
+__device__ __forceinline__ void sym_block(const TS* const (&src)[kSymRows], TS* const (&dst)[kSymRows],
                                           const double* __restrict__ Hc, const double* __restrict__ kst, int pbeg, int cp,
                                           const double (&ks)[KR][NS * D > 0 ? NS * D : 1], const double (&hown)[kSymRows][DE],
                                           double (&accr)[kSymRows][DE], double* __restrict__ colp, int ldc, int lane) {
@@ -189,7 +226,7 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #pragma unroll
     for (int u = 0; u < UP; ++u)
 #pragma unroll
-      for (int q = 0; q < NACT; ++q) v[u][q] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(p0 + u * NPH) * (2 * kSymChunk));
+      for (int q = 0; q < NACT; ++q) v[u][q] = ld_tile<TS>(src[Q0 + q] + (size_t)(p0 + u * NPH) * (2 * kSymChunk));
 #pragma unroll
     for (int hh = 0; hh < UP / PB; ++hh) {
       double pc[PB][2][DE];
@@ -278,7 +315,7 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
               }
             }
             dbl2s o; o.x = p0v; o.y = p1v;
-            __builtin_nontemporal_store(o, reinterpret_cast<dbl2s*>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk)));
+            st_tile<TS>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk), o);
           }
 #pragma unroll
           for (int k = 0; k < DE; ++k) accr[Q0 + q][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][k]));
@@ -328,8 +365,8 @@ __device__ __forceinline__ void sym_block(const double* const (&src)[kSymRows], 
 #ifndef RBPF_SYM_BUTTERFLY
 #define RBPF_SYM_BUTTERFLY 1
 #endif
-template <int D, int DE, int NACT, bool DIAG, int Q0>
-__device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRows], const double* __restrict__ Hc,
+template <typename TS, int D, int DE, int NACT, bool DIAG, int Q0>
+__device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows], const double* __restrict__ Hc,
                                                const double (&hown)[kSymRows][4][DE], double (&accr)[kSymRows][4][DE],
                                                double* __restrict__ colp, int ldc, int lane) {
   const int r16 = lane & 15, g = lane >> 4;
@@ -345,7 +382,7 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
       for (int q = 0; q < NACT; ++q)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq)
-          v[u][q][rq] = *reinterpret_cast<const dbl2s*>(src[Q0 + q] + (size_t)(t0 + u) * (8 * kSymChunk) + rq * 32);
+          v[u][q][rq] = ld_tile<TS>(src[Q0 + q] + (size_t)(t0 + u) * (8 * kSymChunk) + rq * 32);
 #pragma unroll
     for (int u = 0; u < TQ; ++u) {
       const int t = t0 + u;
@@ -415,9 +452,11 @@ __device__ __forceinline__ void sym_block_quad(const double* const (&src)[kSymRo
 // (r04 also built the read-only filter step as a family GEMM on the matrix cores -- P_base * [H_1' ... H_f'] per family of particles
 // sharing a stored matrix -- and measured it 0.4-0.8 ms per step SLOWER than this kernel: removed in r05, see commit 4711b84 and
 // DESIGN_NOTEBOOK.md 10.)
-template <int D, int NS, bool WR, int E, int CH>
-__global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2) void step_sym_kernel(const StepArgs a) {
-  constexpr int NPH = (CH == 8) ? 1 : 2;                       // column phases (waves per row pair)
+template <typename TS, int D, int NS, bool WR, int E, int CH>
+__global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)) void step_sym_kernel(const StepArgs a) {
+  constexpr int NW = sym_waves(CH), NT = 64 * NW;              // CH = 16: eight waves, one workgroup per CU (the same eight waves per CU as 2 x 4)
+  constexpr int NPH = (CH == 4) ? 2 : 1;                       // column phases (waves per row pair)
+  constexpr bool kGStrip = (CH == 16);                         // column strips in the global workspace, one block column staged in LDS
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
   // more than four pending sets in a flush: the wave's two tile rows go through every block column one after the other, so that
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   const int i = pre_i[0];
   const int dslot = WR ? pre_i[4] : i;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH, (RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0) ? 0 : 1);
+  const SymPlan lp = sym_plan(n, DE, ldx, M.ktot, WR ? ND : 0, CH, ((RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0) || CH == 16) ? 0 : 1);
   double* Hs = smem + lp.off_H + ((nb * DE) & 1);             // [H | ivec] of column c at Hs[c * DE ..): core pairs 16-byte aligned
   double* xls = smem + lp.off_xl;
   double* PHt = smem + lp.off_PHt;                            // [DE][ldx]
@@ -450,8 +489,8 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   const double* recp = remote ? a.rec + (size_t)(ancb - a.n_bank_local) * a.rec_stride : nullptr;
   const bool remoteP = a.rec != nullptr && baseb >= a.n_bank_local;
   const double* recP = remoteP ? a.rec + (size_t)(baseb - a.n_bank_local) * a.rec_stride : nullptr;
-  const double* srcT = remoteP ? recP : a.Pt_old + (size_t)baseb * a.Pt_old_stride;
-  const double* srcB = remoteP ? recP + a.rec_off_B : a.Pb_old + (size_t)baseb * a.Pb_old_stride;
+  const TS* srcT = remoteP ? reinterpret_cast<const TS*>(recP) : reinterpret_cast<const TS*>(a.Pt_old) + (size_t)baseb * a.Pt_old_stride;
+  const TS* srcB = remoteP ? reinterpret_cast<const TS*>(recP + a.rec_off_B) : reinterpret_cast<const TS*>(a.Pb_old) + (size_t)baseb * a.Pb_old_stride;
   const double* srcX = remote ? recp + a.rec_off_X : a.xl_old + (size_t)ancb * a.xl_old_stride;
   const double* Fs[NSA];
 #pragma unroll
@@ -465,12 +504,12 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   RBPF_SYM_KSTAMP(0);
   // ---- A: propagated state (propagate_kernel ran first), prior mean ----
   if (tid < kPreDoubles) misc[tid] = a.pre_d[(size_t)pos * kPreDoubles + tid];
-  constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0);   // three workgroups per CU: no room for the prior mean in LDS
-  if (kXlLds) for (int c = tid; c < n; c += kThreads) xls[c] = srcX[c];
+  constexpr bool kXlLds = !(RBPF_SYM_LIGHT_WGS > 2 && !WR && E == 0) && CH != 16;   // three workgroups per CU: no room for the prior mean in LDS
+  if (kXlLds) for (int c = tid; c < n; c += NT) xls[c] = srcX[c];
   double Riy[D];                                               // R^-1 y (:292)
   if (E > 0) {
     const double* iv = remote ? recp + a.rec_off_I : a.ivec_old + (size_t)ancb * a.ivec_old_stride;
-    for (int c = tid; c < n; c += kThreads) Hs[c * DE + D] = iv[c];
+    for (int c = tid; c < n; c += NT) Hs[c * DE + D] = iv[c];
 #pragma unroll
     for (int aa = 0; aa < D; ++aa) {
       double sacc = 0.0;
@@ -482,11 +521,11 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   __syncthreads();
   RBPF_SYM_KSTAMP(1);
   // ---- B: per-axis sin / cos tables ----
-  for (int q = tid; q < M.ktot; q += kThreads) basis_table_entry(M, q, misc, tabS, tabC);
+  for (int q = tid; q < M.ktot; q += NT) basis_table_entry(M, q, misc, tabS, tabC);
   __syncthreads();
   RBPF_SYM_KSTAMP(2);
   // ---- C: measurement Jacobian, one column per thread ----
-  for (int c = tid; c < n; c += kThreads) {
+  for (int c = tid; c < n; c += NT) {
     double h[D];
     if (a.H_ext != nullptr) {
 #pragma unroll
@@ -535,7 +574,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     // the border COLUMNS of this row, P(r, b) = B(b, r), downdated like the border phase does when this is a flush.  Read here,
     // before anything is stored: in the second launch of a single-bank flush the border phase overwrites these very values.
     for (int b = 0; b < nb && cp == 0 && !kQuad; ++b) {        // (once per row: the first column phase; quad mapping: after the stream)
-      double pv = srcB[(size_t)b * ldb + r];
+      double pv = (double)srcB[(size_t)b * ldb + r];
       if (WR) {
 #pragma unroll
         for (int sset = 0; sset < NS; ++sset)
@@ -548,10 +587,12 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   }
   if (WR) __syncthreads();                                     // every wave has read the old border block before any wave stores it
   {
-    double* dT = a.Pt_new + (size_t)dslot * Ly.szT;
+    TS* dT = reinterpret_cast<TS*>(a.Pt_new) + (size_t)dslot * Ly.szT;
     double* kst = smem + lp.off_kst + (size_t)wave * kSymStage * ND;
-    double* colw = (rp == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, CH, rp);
-    const int ldc = (rp == 0) ? ldx : sym_ld_col(CH, rp);
+    double* colw = (rp == 0) ? PHt + nb : (kGStrip ? smem + lp.off_col1 + (size_t)wave * DE * kSymChunk : smem + sym_off_col(lp.off_col1, DE, CH, rp));
+    const int ldc = (rp == 0) ? ldx : (kGStrip ? kSymChunk : sym_ld_col(CH, rp));
+    // sixteen tile rows: this wave's strip in the global workspace
+    double* gstrip = kGStrip ? a.strip_ws + (size_t)blockIdx.x * a.strip_ws_stride + sym_off_col(0, DE, CH, rp) : nullptr;
     const double* Hcore = Hs + (size_t)nb * DE;
     // column factors K(c, .) of kSymStage columns of every pending set -> the wave's LDS stage [pair][k][e] (lane = column;
     // wave-private: program order is the only synchronisation; the fetch latency is paid once per 32 columns and hidden by the
@@ -571,30 +612,30 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     };
     const int last = rows[kSymRows - 1];
     for (int J = 0; J <= last; ++J) {
-      const double* src[kSymRows]; double* dst[kSymRows];
+      const TS* src[kSymRows]; TS* dst[kSymRows];
 #pragma unroll
       for (int q = 0; q < kSymRows; ++q) {
         const size_t off = ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * lane;
         src[q] = srcT + off; dst[q] = dT + off;
       }
       const double* Hc = Hcore + (size_t)J * kSymChunk * DE;
-      double* colp = colw + (size_t)J * kSymChunk;
+      double* colp = (kGStrip && rp > 0) ? colw : colw + (size_t)J * kSymChunk;
       if constexpr (kQuad) {
-        const double* srq[kSymRows];
+        const TS* srq[kSymRows];
 #pragma unroll
         for (int q = 0; q < kSymRows; ++q)
           srq[q] = srcT + ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * kSymChunk * (lane >> 4) + 2 * (lane & 15);
-        if (J < rows[0]) sym_block_quad<D, DE, 2, false, 0>(srq, Hc, hq, accq, colp, ldc, lane);
-        else if (J == rows[0]) sym_block_quad<D, DE, 2, true, 0>(srq, Hc, hq, accq, colp, ldc, lane);
-        else if (J < last) sym_block_quad<D, DE, 1, false, 1>(srq, Hc, hq, accq, colp, ldc, lane);
-        else sym_block_quad<D, DE, 1, true, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+        if (J < rows[0]) sym_block_quad<TS, D, DE, 2, false, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+        else if (J == rows[0]) sym_block_quad<TS, D, DE, 2, true, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+        else if (J < last) sym_block_quad<TS, D, DE, 1, false, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+        else sym_block_quad<TS, D, DE, 1, true, 1>(srq, Hc, hq, accq, colp, ldc, lane);
       } else if constexpr (!kSplit) {
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
-          if (J < rows[0]) sym_block<D, DE, NS, WR, 2, false, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
-          else if (J == rows[0]) sym_block<D, DE, NS, WR, 2, true, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
-          else if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
-          else sym_block<D, DE, NS, WR, 1, true, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          if (J < rows[0]) sym_block<TS, D, DE, NS, WR, 2, false, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else if (J == rows[0]) sym_block<TS, D, DE, NS, WR, 2, true, 0, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else if (J < last) sym_block<TS, D, DE, NS, WR, 1, false, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else sym_block<TS, D, DE, NS, WR, 1, true, 1, false, kSymRows, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
         }
       } else {
         // row 1 (always active), then row 0 where it reaches this block column; row 0's column sums are added to row 1's
@@ -604,8 +645,8 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
           for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[1] * kSymChunk + lane];
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           fetch(nb + J * kSymChunk + 2 * pbeg); park();
-          if (J < last) sym_block<D, DE, NS, WR, 1, false, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
-          else sym_block<D, DE, NS, WR, 1, true, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          if (J < last) sym_block<TS, D, DE, NS, WR, 1, false, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+          else sym_block<TS, D, DE, NS, WR, 1, true, 1, false, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
         }
         if (J <= rows[0]) {
 #pragma unroll
@@ -614,17 +655,23 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
             for (int k = 0; k < D; ++k) ks[0][s * D + k] = Fs[s][(size_t)k * ldx + nb + rows[0] * kSymChunk + lane];
           for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
             fetch(nb + J * kSymChunk + 2 * pbeg); park();
-            if (J < rows[0]) sym_block<D, DE, NS, WR, 1, false, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
-            else sym_block<D, DE, NS, WR, 1, true, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+            if (J < rows[0]) sym_block<TS, D, DE, NS, WR, 1, false, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
+            else sym_block<TS, D, DE, NS, WR, 1, true, 0, true, 1, NPH>(src, dst, Hc, kst, pbeg, cp, ks, hown, accr, colp, ldc, lane);
           }
         }
+      }
+      if (kGStrip && rp > 0 && J < last) {
+        // the block column's sums leave the stage: rows k of the strip, 64 consecutive columns each (the stage is wave-private: program
+        // order is the only synchronisation, as for kst)
+#pragma unroll
+        for (int k = 0; k < DE; ++k) gstrip[(size_t)k * sym_ld_col(CH, rp) + J * kSymChunk + lane] = colw[k * kSymChunk + lane];
       }
     }
   }
   // border rows (row-major block B, all n columns): lanes walk columns, wave-reduce per row (as in step_kernel)
-  for (int b = wave; b < nb; b += kWaves) {
-    const double* src = srcB + (size_t)b * ldb;
-    double* dstb = a.Pb_new + (size_t)dslot * Ly.szB + (size_t)b * ldb;
+  for (int b = wave; b < nb; b += NW) {
+    const TS* src = srcB + (size_t)b * ldb;
+    TS* dstb = reinterpret_cast<TS*>(a.Pb_new) + (size_t)dslot * Ly.szB + (size_t)b * ldb;
     double ksb[NDA];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -634,7 +681,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 #pragma unroll
     for (int k = 0; k < DE; ++k) accb[k] = 0.0;
     for (int c = 2 * lane; c < ldb; c += 128) {
-      const dbl2s vv = *reinterpret_cast<const dbl2s*>(src + c);
+      const dbl2s vv = ld_tile<TS>(src + c);
       double p[2] = {vv.x, vv.y};
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -650,7 +697,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
           for (int k = 0; k < DE; ++k) accb[k] = fma(p[e], Hs[cc * DE + k], accb[k]);
         }
       }
-      if (WR) { dbl2s o; o.x = p[0]; o.y = p[1]; *reinterpret_cast<dbl2s*>(dstb + c) = o; }
+      if (WR) { dbl2s o; o.x = p[0]; o.y = p[1]; st_tile<TS>(dstb + c, o); }
     }
 #pragma unroll
     for (int k = 0; k < DE; ++k) {
@@ -684,7 +731,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 #pragma unroll
         for (int k = 0; k < DE; ++k) s[k] = 0.0;
         for (int b = 0; b < nb; ++b) {
-          const double pv = srcB[(size_t)b * ldb + nb + rc];
+          const double pv = (double)srcB[(size_t)b * ldb + nb + rc];
 #pragma unroll
           for (int k = 0; k < DE; ++k) s[k] = fma(pv, Hs[b * DE + k], s[k]);
         }
@@ -700,7 +747,8 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 #pragma unroll
       for (int w = 0; w < CH / 2; ++w) {
         if (rows[q] < CH - 1 - w) {                           // row pair w holds off-diagonal tiles in this block column
-          const double* cw = (w == 0) ? PHt + nb : smem + sym_off_col(lp.off_col1, DE, CH, w);
+          const double* cw = (w == 0) ? PHt + nb : (kGStrip ? a.strip_ws + (size_t)blockIdx.x * a.strip_ws_stride + sym_off_col(0, DE, CH, w)
+                                                            : smem + sym_off_col(lp.off_col1, DE, CH, w));
           const int ldw = (w == 0) ? ldx : sym_ld_col(CH, w);
 #pragma unroll
           for (int k = 0; k < DE; ++k) s[k] += cw[(size_t)k * ldw + rc];
@@ -718,7 +766,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     double g[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) g[q] = 0.0;
-    for (int c = tid; c < n; c += kThreads) {
+    for (int c = tid; c < n; c += NT) {
       double h[DE];
 #pragma unroll
       for (int k = 0; k < DE; ++k) h[k] = Hs[c * DE + k];
@@ -740,10 +788,10 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
       double s = red[q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + q];
+      for (int w = 1; w < NW; ++w) s += red[w * kSymRed + q];
       g[q] = s;
     }
-    for (int r = tid; r < n; r += kThreads) {
+    for (int r = tid; r < n; r += NT) {
       double ph[DE];
 #pragma unroll
       for (int j = 0; j < DE; ++j) ph[j] = PHt[(size_t)j * ldx + r];
@@ -768,7 +816,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     double part[NRED];
 #pragma unroll
     for (int q = 0; q < NRED; ++q) part[q] = 0.0;
-    for (int r = tid; r < n; r += kThreads) {
+    for (int r = tid; r < n; r += NT) {
       double h[D], ph[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) { h[k] = Hs[r * DE + k]; ph[k] = PHt[(size_t)k * ldx + r]; }
@@ -800,12 +848,12 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     double SS[D * D], e[D], cS[D * D], v[D];
     for (int q = 0; q < D * D; ++q) {
       double s = red[q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + q];
+      for (int w = 1; w < NW; ++w) s += red[w * kSymRed + q];
       SS[q] = s + M.R[q];                                                   // particleFilter.m:141
     }
     for (int q = 0; q < D; ++q) {
       double s = red[D * D + q];
-      for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + D * D + q];
+      for (int w = 1; w < NW; ++w) s += red[w * kSymRed + D * D + q];
       e[q] = a.y[q] - s;                                                    // :140
     }
     bool ok = chol_lower_small<D>(SS, cS);                                  // :145
@@ -832,7 +880,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     for (int q = 0; q < D; ++q) misc[40 + q] = e[q];
     if (E > 0) {
       double qa = red[D * D + D], qb = red[D * D + D + 1];
-      for (int w = 1; w < kWaves; ++w) { qa += red[w * kSymRed + D * D + D]; qb += red[w * kSymRed + D * D + D + 1]; }
+      for (int w = 1; w < NW; ++w) { qa += red[w * kSymRed + D * D + D]; qb += red[w * kSymRed + D * D + D + 1]; }
       double sl2 = 0.0;
       for (int q = 0; q < D; ++q) sl2 += log(cS[q + D * q]);
       misc[44] = qa; misc[45] = qb; misc[46] = ok ? sl2 : nan("");
@@ -863,7 +911,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
     double uK[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) uK[k] = 0.0;
-    for (int r = tid; r < n; r += kThreads) {
+    for (int r = tid; r < n; r += NT) {
       double ph[D], u[D], kk[D];
 #pragma unroll
       for (int k = 0; k < D; ++k) ph[k] = PHt[(size_t)k * ldx + r];
@@ -899,7 +947,7 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
       __syncthreads();
       if (tid == 0) {
         double u[D];
-        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < kWaves; ++w) s += red[w * kSymRed + k]; u[k] = s; }
+        for (int k = 0; k < D; ++k) { double s = red[k]; for (int w = 1; w < NW; ++w) s += red[w * kSymRed + k]; u[k] = s; }
         double corr = 0.0;                                                  // ivecPlus' * (K*SS*K') * ivecPlus
         for (int bb = 0; bb < D; ++bb) {
           double t = 0.0;
@@ -925,65 +973,79 @@ __global__ __launch_bounds__(kThreads, (!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)
   RBPF_SYM_KSTAMP(6);
 }
 
-template <int D, int NS, bool WR, int E, int CH>
+template <typename TS, int D, int NS, bool WR, int E, int CH>
 static hipError_t launch_sym_kc(const StepArgs& a, hipStream_t s) {
   static std::atomic<uint64_t> attr_done{0};
-  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_sym_kernel<D, NS, WR, E, CH>), 160 * 1024, attr_done)) return e;
+  if (hipError_t e = lds_opt_in(reinterpret_cast<const void*>(&step_sym_kernel<TS, D, NS, WR, E, CH>), 160 * 1024, attr_done)) return e;
   const size_t lds = step_sym_lds_bytes(a.mdl, a.lay, NS, WR ? 1 : 0, E);
-  hipLaunchKernelGGL((step_sym_kernel<D, NS, WR, E, CH>), dim3(a.N), dim3(kThreads), lds, s, a);
+  if (CH == 16 && (!a.strip_ws || lds > 160 * 1024)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((step_sym_kernel<TS, D, NS, WR, E, CH>), dim3(a.N), dim3(64 * sym_waves(CH)), lds, s, a);
   return hipGetLastError();
 }
 
-template <int D, int NS, bool WR, int E>
+template <typename TS, int D, int NS, bool WR, int E>
 static hipError_t launch_sym_k(const StepArgs& a, hipStream_t s) {
-  if (a.lay.CH64 == 8) return launch_sym_kc<D, NS, WR, E, 8>(a, s);
-  if constexpr (NS <= 4) { if (a.lay.CH64 == 4) return launch_sym_kc<D, NS, WR, E, 4>(a, s); }      // four tile rows: lazy_depth <= 4
+  if constexpr (std::is_same<TS, double>::value) {
+    if (a.lay.CH64 == 8) return launch_sym_kc<TS, D, NS, WR, E, 8>(a, s);
+    if constexpr (NS <= 4) { if (a.lay.CH64 == 4) return launch_sym_kc<TS, D, NS, WR, E, 4>(a, s); }      // four tile rows: lazy_depth <= 4
+  }
+  // sixteen tile rows (fp64 and fp32 tiles) and fp32 tiles at eight: the filter, lazy_depth <= 4
+  if constexpr (NS <= 4 && E == 0) {
+    if (a.lay.CH64 == 16) return launch_sym_kc<TS, D, NS, WR, E, 16>(a, s);
+    if constexpr (std::is_same<TS, float>::value) { if (a.lay.CH64 == 8) return launch_sym_kc<TS, D, NS, WR, E, 8>(a, s); }
+  }
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
-  if (!a.lay.sym || a.mdl.d != 3 || (a.lay.CH64 != 8 && a.lay.CH64 != 4) || a.fp32) return hipErrorInvalidValue;
-  if (a.info) {                                            // information form: lazy_depth <= 3
-    if (a.write_base) {
-      switch (a.n_sets) {
-        case 0: return launch_sym_k<3, 0, true, 1>(a, s);
-        case 1: return launch_sym_k<3, 1, true, 1>(a, s);
-        case 2: return launch_sym_k<3, 2, true, 1>(a, s);
-        case 3: return launch_sym_k<3, 3, true, 1>(a, s);
-        default: return hipErrorInvalidValue;
-      }
-    }
-    switch (a.n_sets) {
-      case 1: return launch_sym_k<3, 1, false, 1>(a, s);
-      case 2: return launch_sym_k<3, 2, false, 1>(a, s);
-      case 3: return launch_sym_k<3, 3, false, 1>(a, s);     // the readers of a shared flush at lazy_depth 3
-      default: return hipErrorInvalidValue;
-    }
-  }
+template <typename TS>
+static hipError_t launch_step_sym_filter(const StepArgs& a, hipStream_t s) {
   if (a.write_base) {
     switch (a.n_sets) {
-      case 0: return launch_sym_k<3, 0, true, 0>(a, s);
-      case 1: return launch_sym_k<3, 1, true, 0>(a, s);
-      case 2: return launch_sym_k<3, 2, true, 0>(a, s);
-      case 3: return launch_sym_k<3, 3, true, 0>(a, s);
-      case 4: return launch_sym_k<3, 4, true, 0>(a, s);
-      case 5: return launch_sym_k<3, 5, true, 0>(a, s);
-      case 6: return launch_sym_k<3, 6, true, 0>(a, s);
-      case 7: return launch_sym_k<3, 7, true, 0>(a, s);
-      case 8: return launch_sym_k<3, 8, true, 0>(a, s);
+      case 0: return launch_sym_k<TS, 3, 0, true, 0>(a, s);
+      case 1: return launch_sym_k<TS, 3, 1, true, 0>(a, s);
+      case 2: return launch_sym_k<TS, 3, 2, true, 0>(a, s);
+      case 3: return launch_sym_k<TS, 3, 3, true, 0>(a, s);
+      case 4: return launch_sym_k<TS, 3, 4, true, 0>(a, s);
+      case 5: return launch_sym_k<TS, 3, 5, true, 0>(a, s);
+      case 6: return launch_sym_k<TS, 3, 6, true, 0>(a, s);
+      case 7: return launch_sym_k<TS, 3, 7, true, 0>(a, s);
+      case 8: return launch_sym_k<TS, 3, 8, true, 0>(a, s);
       default: return hipErrorInvalidValue;
     }
   }
   switch (a.n_sets) {
-    case 1: return launch_sym_k<3, 1, false, 0>(a, s);
-    case 2: return launch_sym_k<3, 2, false, 0>(a, s);
-    case 3: return launch_sym_k<3, 3, false, 0>(a, s);
-    case 4: return launch_sym_k<3, 4, false, 0>(a, s);
-    case 5: return launch_sym_k<3, 5, false, 0>(a, s);
-    case 6: return launch_sym_k<3, 6, false, 0>(a, s);
-    case 7: return launch_sym_k<3, 7, false, 0>(a, s);
+    case 1: return launch_sym_k<TS, 3, 1, false, 0>(a, s);
+    case 2: return launch_sym_k<TS, 3, 2, false, 0>(a, s);
+    case 3: return launch_sym_k<TS, 3, 3, false, 0>(a, s);
+    case 4: return launch_sym_k<TS, 3, 4, false, 0>(a, s);
+    case 5: return launch_sym_k<TS, 3, 5, false, 0>(a, s);
+    case 6: return launch_sym_k<TS, 3, 6, false, 0>(a, s);
+    case 7: return launch_sym_k<TS, 3, 7, false, 0>(a, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
+  if (!a.lay.sym || a.mdl.d != 3 || (a.lay.CH64 != 8 && a.lay.CH64 != 4 && a.lay.CH64 != 16)) return hipErrorInvalidValue;
+  if (a.fp32) return a.info ? hipErrorInvalidValue : launch_step_sym_filter<float>(a, s);
+  if (a.info) {                                            // information form: lazy_depth <= 3
+    if (a.write_base) {
+      switch (a.n_sets) {
+        case 0: return launch_sym_k<double, 3, 0, true, 1>(a, s);
+        case 1: return launch_sym_k<double, 3, 1, true, 1>(a, s);
+        case 2: return launch_sym_k<double, 3, 2, true, 1>(a, s);
+        case 3: return launch_sym_k<double, 3, 3, true, 1>(a, s);
+        default: return hipErrorInvalidValue;
+      }
+    }
+    switch (a.n_sets) {
+      case 1: return launch_sym_k<double, 3, 1, false, 1>(a, s);
+      case 2: return launch_sym_k<double, 3, 2, false, 1>(a, s);
+      case 3: return launch_sym_k<double, 3, 3, false, 1>(a, s);     // the readers of a shared flush at lazy_depth 3
+      default: return hipErrorInvalidValue;
+    }
+  }
+  return launch_step_sym_filter<double>(a, s);
 }
 
 }  // namespace rbpf

@@ -442,14 +442,17 @@ class _Problem:
 
 def _storage_code(storage):
     """rbpf_options.storage: "fp64" (default, the reference's precision), "fp32" storage of the covariance banks, or
-    "fp64sym" (fp64, lower block triangle only: particleFilter.m:198 keeps the covariances symmetric)."""
+    "fp64sym" (fp64, lower block triangle only: particleFilter.m:198 keeps the covariances symmetric), or "fp32sym" (the lower block
+    triangle in fp32; arithmetic stays fp64)."""
     if storage in ("fp64", 0, None):
         return 0
     if storage in ("fp32", 1):
         return 1
     if storage in ("fp64sym", "sym", 2):
         return 2
-    raise ValueError("storage must be 'fp64', 'fp32' or 'fp64sym'")
+    if storage in ("fp32sym", 3):
+        return 3
+    raise ValueError("storage must be 'fp64', 'fp32', 'fp64sym' or 'fp32sym'")
 
 
 def _check_sparse_flag(model, sparseFeatures):

@@ -156,6 +156,24 @@ def test_two_ranks_with_symmetric_storage(lazy_depth):
     np.testing.assert_allclose(tx, full["traj_max"], rtol=1e-9, atol=1e-11)
 
 
+@pytest.mark.parametrize("storage,m,lazy_depth", [("fp64sym", 1024, 0), ("fp64sym", 1024, 3), ("fp32sym", 512, 0), ("fp32sym", 1024, 3)])
+def test_two_ranks_with_sixteen_tile_rows_and_fp32_tiles(storage, m, lazy_depth):
+    """The r05 block-lower variants in the sharded filter -- sixteen tile rows (nLin = 1027) and fp32 tiles: without the lazy update a
+    migrating record is a verbatim copy (bit-identical to the single-GPU run on the same storage), with it the packer applies the
+    pending sets over the block-lower layout (1e-9; 2e-5 where it rounds to fp32 at another point)."""
+    T, n_local = 9, 16
+    tm, tx, stats = _run(2, "gloo", "host", T, m, n_local, "device", lazy_depth, storage)
+    ref = _single(T, m, 2 * n_local, storage)
+    assert stats["steps"] == T and stats["sent_records"] >= 0
+    if lazy_depth == 0:
+        np.testing.assert_array_equal(tm, ref["traj_mean"])
+        np.testing.assert_array_equal(tx, ref["traj_max"])
+    else:
+        tol = dict(rtol=1e-9, atol=1e-11) if storage == "fp64sym" else dict(rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(tm, ref["traj_mean"], **tol)
+        np.testing.assert_allclose(tx, ref["traj_max"], **tol)
+
+
 @pytest.mark.parametrize("lazy_depth", [0, 3])
 def test_world_size_one_rccl_device_transport(lazy_depth):
     """World 1 over RCCL with force_collectives: the real all_gather_into_tensor / all_to_all_single calls on the library's

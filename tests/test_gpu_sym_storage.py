@@ -254,3 +254,112 @@ def test_scheduled_bytes_count_distinct_matrices_and_shared_flush_writers(rbpf):
     assert tm["launches"] == K
     assert (reads + writes) * stored_lo + fixed <= total <= (reads + writes) * stored_hi + 6.0 * fixed
     assert reads < 0.8 * N * K and writes < 0.8 * N * (K // C + 1)   # the sharing is real on this workload
+
+
+# ---- sixteen tile rows (nLin = 1027, BASELINE.json configs[4]'s basis size) and fp32 tiles (rbpf_options.storage = 3), r05 ------------
+@pytest.fixture(scope="module")
+def oracle_m1024():
+    c = cases.mag_case(6, 9, 1024, seed=29)
+    return c, cases.oracle_filter(c)
+
+
+@pytest.fixture(scope="module")
+def oracle_m512_short():
+    c = cases.mag_case(6, 9, 512, seed=29)
+    return c, cases.oracle_filter(c)
+
+
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, 1), (4, -1), (4, 1)])
+def test_symmetric_storage_filter_at_m1024_matches_oracle(rbpf, oracle_m1024, lazy_depth, inplace):
+    """nLin = 1027: sixteen tile rows -- eight waves, rows {w, 15 - w}, the column sums of one block column staged in LDS and kept in
+    the global strip workspace (rbpf_step_sym.hip) -- every variant of a lazy cycle, both bank schedules (shared flush with two banks),
+    against the numpy oracle (particleFilter.m:100-218): indices bit-exact, fp64 quantities 1e-9."""
+    c, ref = oracle_m1024
+    check_filter(ref, run_sym(rbpf, c, lazy_depth, inplace))
+
+
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, 1), (4, -1), (4, 1)])
+@pytest.mark.parametrize("m", [512, 1024])
+def test_fp32_tiles_match_oracle_to_storage_precision(rbpf, oracle_m512_short, oracle_m1024, m, lazy_depth, inplace):
+    """storage = "fp32sym": the lower block triangle in fp32, arithmetic fp64 -- the rounding of storage = "fp32" (6e-8 per stored
+    element and rewrite) on the layout of "fp64sym".  Against the numpy oracle: tolerance 2e-5 as for "fp32"
+    (tests/test_gpu_filter.py), the same resampling indices for this seed, and it really is another storage precision."""
+    c, ref = oracle_m512_short if m == 512 else oracle_m1024
+    out = run_sym(rbpf, c, lazy_depth, inplace, storage="fp32sym")
+    ex, tr = out[8], ref["trace"]
+    np.testing.assert_array_equal(ex["ai"][1:], tr["ai"][1:])
+    TOL = 2e-5
+    assert rel(ex["w"], tr["w"]) <= TOL
+    assert rel(out[1], ref["traj_mean"]) <= TOL and rel(out[2], ref["xl_max"]) <= TOL and rel(out[4], ref["P_max"]) <= TOL
+    assert rel(ex["xl"], tr["xl"]) <= TOL and rel(ex["P"], tr["P"]) <= TOL
+    assert rel(ex["P"], tr["P"]) > 1e-12
+    assert rel(out[4], out[4].T) < 1e-13                                        # one stored value per (r, c) / (c, r) pair
+
+
+@pytest.mark.parametrize("storage,tol_banks", [("fp64sym", 1e-11), ("fp32sym", 2e-6)])
+def test_sixteen_tile_rows_on_philox_streams(rbpf, storage, tol_banks):
+    """N = 2048, m = 1024, 13 steps on the device generator, lazy_depth 4: the shared flush (two banks) and the single bank rewritten
+    in place give the same indices and the same outputs to rounding (fp32 tiles: a last-bit difference of an fp64 value can move its
+    fp32 rounding -- isolated elements differ by one fp32 ulp); two runs are bit-identical; "fp64sym" equals the full square to 1e-9
+    with identical indices."""
+    from test_gpu_configs import check_filter_properties, mag_inputs, run_session
+    N, steps = 2048, 13
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 1024)
+    want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean")
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=-1, storage=storage)
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=1, storage=storage)
+    a2 = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=-1, storage=storage)
+    check_filter_properties(a, N, steps, P0)
+    np.testing.assert_array_equal(a["trace_ai"], b["trace_ai"])
+    for k in want:
+        sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
+        if k != "trace_ai":
+            assert rel(a[k][sl], b[k][sl]) <= tol_banks, k
+        np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
+    full = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=-1, storage="fp64" if storage == "fp64sym" else "fp32")
+    if storage == "fp64sym":
+        np.testing.assert_array_equal(a["trace_ai"], full["trace_ai"])
+    if np.array_equal(a["trace_ai"], full["trace_ai"]):
+        for k in ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "xl_mean"):
+            sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
+            assert rel(a[k][sl], full[k][sl]) <= (RTOL if storage == "fp64sym" else 2e-5), k
+
+
+def test_configs4_share_on_fp32_tiles(rbpf):
+    """Per-GPU share of BASELINE.json configs[4] on the block-lower layout: N = 32 768, m = 1024, fp32 tiles (73 GB per bank, two banks,
+    shared flush), lazy_depth 4: properties hold, two runs are bit-identical, and the session reports the schedule it chose."""
+    from test_gpu_configs import check_filter_properties, mag_inputs, run_session
+    N, steps = 32768, 7
+    d, mdl, x0, P0, R = mag_inputs(rbpf, 40, 1024)
+    want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai")
+    a = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=0, storage="fp32sym")
+    check_filter_properties(a, N, steps, P0)
+    b = run_session(rbpf, d, mdl, x0, P0, R, N, steps, want, lazy_depth=4, inplace=0, storage="fp32sym")
+    for k in want:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    with rbpf.FilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rbpf.PhiloxRNG(5),
+                            lazy_depth=4, inplace=0, storage="fp32sym") as s:
+        assert s.schedule() == (2, True)                                         # two banks, shared flush
+
+
+def test_block_lower_storage_is_refused_where_it_is_not_built(rbpf):
+    """fp32 tiles and sixteen tile rows serve the filter; the smoothers, four tile rows in fp32 and dense-radio are refused by name."""
+    c = cases.mag_case(6, 5, 1024, seed=29, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    for storage in ("fp64sym", "fp32sym"):
+        with pytest.raises(rbpf.RBPFError) as ei:
+            rbpf.particleSmoother(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 2, c["dt"],
+                                  rng=cases.device_rng(rbpf, c), storage=storage)
+        assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+    c = cases.mag_case(6, 5, 256, seed=29)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, c["dt"],
+                            rng=cases.device_rng(rbpf, c), storage="fp32sym")
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+    c = cases.mag_case(6, 5, 512, seed=29, N_K=2)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 2,
+                                             c["dt"], rng=cases.device_rng(rbpf, c), storage="fp32sym")
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
