@@ -235,7 +235,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     if (sparse || !sym_supported(prob->n_lin, prob->n_y)) {
       set_error("symmetric storage (options.storage = 2 / 3): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639, dense filter with nLin in 1027..1151 only"); return RBPF_ERR_UNSUPPORTED;
     }
-    c->lay = make_layout_sym(prob->n_lin, prob->n_y);
+    c->lay = make_layout_sym(prob->n_lin, prob->n_y, c->fp32 ? 1 : 0);
     c->lay_low = c->lay;
     if (c->lay.CH64 == 16 && smoother) { set_error("symmetric storage at sixteen tile rows (nLin >= 1027): the filter only"); return RBPF_ERR_UNSUPPORTED; }
     if (c->fp32 && c->lay.CH64 == 4) { set_error("fp32 tiles (options.storage = 3): nLin in 515..639 or 1027..1151"); return RBPF_ERR_UNSUPPORTED; }
@@ -954,7 +954,7 @@ int rbpf_device_count(void) {
 int rbpf_filter_workspace_bytes(const rbpf_model* model, const rbpf_problem* p, const rbpf_options* opt, size_t* bytes) {
   if (!model || !p || !bytes) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
   RB_TRY(options_ok(opt));
-  const Layout L = (opt && (opt->storage == 2 || opt->storage == 3) && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y) : make_layout(p->n_lin, p->n_y);
+  const Layout L = (opt && (opt->storage == 2 || opt->storage == 3) && sym_supported(p->n_lin, p->n_y)) ? make_layout_sym(p->n_lin, p->n_y, opt->storage == 3 ? 1 : 0) : make_layout(p->n_lin, p->n_y);
   const bool f32 = opt && (opt->storage == 1 || opt->storage == 3);
   const bool hist = !opt || opt->keep_history;
   const bool trace = opt && opt->trace;

@@ -93,17 +93,21 @@ struct Layout {
   int n, nb, mc, ldb, ldx;   // ldx: padded length of per-particle vectors (xl, K, KS)
   int CH;                    // mc / 128
   int RS, CS, CPL;           // wave decomposition of the core stream (rows x column phases)
-  int sym, CH64;             // symmetric storage: mc / 64 tile rows
+  int sym, CH64;             // symmetric storage (1: fp64 tiles, column PAIRS; 2: fp32 tiles, column QUADS -- 16 bytes per lane either way): mc / 64 tile rows
   size_t szT, szB;           // elements per particle
 };
 
 // offset of core element (r, c) (core coordinates, r, c in [0, mc)) inside block T of the symmetric layout; (r, c) above the
 // block diagonal is read from its mirror image
-__host__ __device__ inline size_t sym_t_index(int r, int c) {
+// (cg: columns a lane's 16-byte load covers -- 2 in fp64 tiles, 4 in fp32 tiles: Layout::sym = 1 / 2)
+__host__ __device__ inline size_t sym_t_index(int r, int c, int cg = 2) {
   int I = r / kSymChunk, J = c / kSymChunk;
   if (J > I) { const int t = r; r = c; c = t; I = r / kSymChunk; J = c / kSymChunk; }
-  return ((size_t)I * (I + 1) / 2 + J) * kSymTile + (size_t)((c % kSymChunk) / 2) * (2 * kSymChunk) + (size_t)(r % kSymChunk) * 2 + (c & 1);
+  return ((size_t)I * (I + 1) / 2 + J) * kSymTile + (size_t)((c % kSymChunk) / cg) * (cg * kSymChunk) + (size_t)(r % kSymChunk) * cg + (c % cg);
 }
+
+
+__host__ __device__ inline int sym_cg(const Layout& L) { return L.sym == 2 ? 4 : 2; }
 
 struct StepArgs {
   ModelDev mdl;
@@ -205,7 +209,7 @@ size_t step_lds_bytes(const ModelDev& m, const Layout& lay, int extra = 0, int n
 bool step_use_blocked(const ModelDev& m, const Layout& lay, int extra, int n_sets);
 Layout make_layout(int n, int d);
 Layout make_layout_low_regs(int n, int d);
-Layout make_layout_sym(int n, int d);            // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
+Layout make_layout_sym(int n, int d, int fp32 = 0);   // symmetric storage (see Layout); sym_supported: the sizes the step kernel takes
 bool sym_supported(int n, int d);
 size_t sym_strip_doubles(const Layout& lay, int d);   // per workgroup, 0 unless sixteen tile rows
 size_t step_sym_lds_bytes(const ModelDev& m, const Layout& lay, int n_sets, int write_base, int extra = 0);   // extra = 1: information form

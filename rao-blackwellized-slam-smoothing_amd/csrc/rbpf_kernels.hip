@@ -1459,7 +1459,7 @@ __global__ void pack_P_kernel(Layout L, const double* __restrict__ P, size_t src
     const double v = src[q];
     if (r < L.nb) b[(size_t)r * L.ldb + c] = (TS)v;
     else if (!L.sym) t[(size_t)c * L.mc + (r - L.nb)] = (TS)v;
-    else if (c >= L.nb && (r - L.nb) / kSymChunk >= (c - L.nb) / kSymChunk) t[sym_t_index(r - L.nb, c - L.nb)] = (TS)v;   // lower block triangle
+    else if (c >= L.nb && (r - L.nb) / kSymChunk >= (c - L.nb) / kSymChunk) t[sym_t_index(r - L.nb, c - L.nb, sym_cg(L))] = (TS)v;   // lower block triangle
   }
   // zero the pad column of the border block
   if (L.ldb > L.n)
@@ -1503,7 +1503,7 @@ __global__ __launch_bounds__(256) void unpack_P_kernel(Layout L, int d, const TS
       double v;
       if (r < L.nb) v = (double)b[(size_t)r * L.ldb + c];
       else if (!L.sym) v = (double)t[(size_t)c * L.mc + (r - L.nb)];
-      else v = (c < L.nb) ? (double)b[(size_t)c * L.ldb + r] : (double)t[sym_t_index(r - L.nb, c - L.nb)];   // mirror image where not stored
+      else v = (c < L.nb) ? (double)b[(size_t)c * L.ldb + r] : (double)t[sym_t_index(r - L.nb, c - L.nb, sym_cg(L))];   // mirror image where not stored
       for (int sset = 0; sset < us.n_sets; ++sset)
         for (int k = 0; k < d; ++k) v = fma(-F[sset][(size_t)k * L.ldx + r], F[sset][(size_t)(d + k) * L.ldx + c], v);
       dst[(size_t)c * L.n + r] = v;
@@ -1834,8 +1834,9 @@ __global__ void pack_records_flushed_kernel(Layout L, int d, const int* __restri
       while ((I + 1) * (I + 2) / 2 <= tile) ++I;
       while (I * (I + 1) / 2 > tile) --I;
       const int J = tile - I * (I + 1) / 2;
-      rr = L.nb + I * kSymChunk + (within % (2 * kSymChunk)) / 2;
-      c = L.nb + J * kSymChunk + 2 * (within / (2 * kSymChunk)) + (within & 1);
+      const int cg = sym_cg(L);
+      rr = L.nb + I * kSymChunk + (within % (cg * kSymChunk)) / cg;
+      c = L.nb + J * kSymChunk + cg * (within / (cg * kSymChunk)) + (within % cg);
     }
     double v = (double)t[q];
     for (int s = 0; s < ps.n_sets; ++s)

@@ -30,8 +30,10 @@
 //   column sums of ONE block column in a 1.5 KB LDS stage and copies them out to its strip in a global workspace (StepArgs::strip_ws,
 //   118 KB per workgroup, three coalesced 512-byte stores per block column); the combine after the stream reads them back in the
 //   same fixed order.  3 % more bytes than the stored matrix, all of them L2 hits in practice.
-// * TS = float (rbpf_options.storage = 3): the tiles hold fp32 (same element order, 8-byte loads per lane), all arithmetic fp64, a
-//   flush rounds once on the way out -- as storage = 1 does for the full square.  Filter only.
+// * TS = float (rbpf_options.storage = 3): the tiles hold fp32 in column QUADS (Layout::sym = 2: a lane's 16-byte load is four columns
+//   of its row -- with the pair order and 8-byte loads the read-only step moved 5.6 TB/s out of the L2s against the fp64 kernel's 9.2:
+//   the vector memory path is bound by load instructions, not bytes), all arithmetic fp64, a flush rounds once on the way out -- as
+//   storage = 1 does for the full square.  Filter only.
 //
 // Supported: dense families with ny = 3; fp64: 512 <= mc < 640 core rows (nLin = 515: BASELINE.json configs[2]) or four tile rows
 // (nLin = 259), filter and both smoothers, single-GPU and sharded; sixteen tile rows (nLin = 1027) and fp32 tiles: the filter.
@@ -53,6 +55,9 @@ namespace rbpf {
 
 typedef double dbl2s __attribute__((ext_vector_type(2)));
 typedef float flt2s __attribute__((ext_vector_type(2)));
+typedef float flt4s __attribute__((ext_vector_type(4)));
+template <typename TS> struct SymTile { static constexpr int cg = 2; };       // columns per 16-byte lane load: fp64 tiles hold column pairs,
+template <> struct SymTile<float> { static constexpr int cg = 4; };           // fp32 tiles column quads (Layout::sym = 2, sym_t_index)
 
 // a column pair of one stored row: TS = double (16 bytes per lane) or float (fp32 tiles, 8 bytes per lane; arithmetic stays fp64)
 template <typename TS> __device__ __forceinline__ dbl2s ld_tile(const TS* p);
@@ -89,9 +94,9 @@ size_t sym_strip_doubles(const Layout& lay, int d) {
   return o;
 }
 
-Layout make_layout_sym(int n, int d) {
+Layout make_layout_sym(int n, int d, int fp32) {
   Layout L = make_layout(n, d);
-  L.sym = 1;
+  L.sym = fp32 ? 2 : 1;
   L.CH64 = L.mc / kSymChunk;
   L.szT = (size_t)L.CH64 * (L.CH64 + 1) / 2 * kSymTile;
   return L;
@@ -218,18 +223,36 @@ __device__ __forceinline__ void sym_block(const TS* const (&src)[kSymRows], TS* 
   // column pairs per round = wave-wide 1 KB loads in flight / active rows: 8 loads in the read-only steps, 4 in a flush (with 8 the
   // three- and four-set flushes kept 28-85 registers in scratch inside the block-column loop: 10 % more HBM writes, flush 29.1 ->
   // 26.1 ms at N = 65 536 with 4)
-  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : RBPF_SYM_LIGHT_LOADS) / NACT;
+  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : RBPF_SYM_LIGHT_LOADS) / NACT;   // (fp32 tiles: UP / 2 loads of a column quad)
   constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
+  constexpr bool kF4 = std::is_same<TS, float>::value;     // fp32 tiles: one 16-byte load = two column pairs of a row (pairs 2 j, 2 j + 1)
+  static_assert(!kF4 || (NPH == 1 && UP % 2 == 0 && PB == 2), "fp32 tiles: whole column quads per round");
   for (int p0 = pbeg + cp; p0 < pbeg + kSymStage / 2; p0 += UP * NPH) {   // the kSymStage columns whose pending factors are staged
     dbl2s v[UP][NACT];
+    if constexpr (kF4) {
+      flt4s raw[UP / 2][NACT];
+#pragma unroll
+      for (int j = 0; j < UP / 2; ++j)
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) raw[j][q] = *reinterpret_cast<const flt4s*>(src[Q0 + q] + (size_t)((p0 >> 1) + j) * (4 * kSymChunk));
+#pragma unroll
+      for (int j = 0; j < UP / 2; ++j)
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) {
+          v[2 * j][q].x = (double)raw[j][q].x; v[2 * j][q].y = (double)raw[j][q].y;
+          v[2 * j + 1][q].x = (double)raw[j][q].z; v[2 * j + 1][q].y = (double)raw[j][q].w;
+        }
+    } else {
 #pragma unroll
     for (int u = 0; u < UP; ++u)
 #pragma unroll
       for (int q = 0; q < NACT; ++q) v[u][q] = ld_tile<TS>(src[Q0 + q] + (size_t)(p0 + u * NPH) * (2 * kSymChunk));
+    }
 #pragma unroll
     for (int hh = 0; hh < UP / PB; ++hh) {
       double pc[PB][2][DE];
+      dbl2s outv[kF4 && WR ? PB : 1][NACT];                  // fp32 tiles: the two pairs of a column quad leave in one 16-byte store
 #pragma unroll
       for (int uu = 0; uu < PB; ++uu) {
         const int u = hh * PB + uu, p = p0 + u * NPH;
@@ -315,7 +338,8 @@ __device__ __forceinline__ void sym_block(const TS* const (&src)[kSymRows], TS* 
               }
             }
             dbl2s o; o.x = p0v; o.y = p1v;
-            st_tile<TS>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk), o);
+            if constexpr (kF4) outv[uu][q] = o;
+            else st_tile<TS>(dst[Q0 + q] + (size_t)p * (2 * kSymChunk), o);
           }
 #pragma unroll
           for (int k = 0; k < DE; ++k) accr[Q0 + q][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][k]));
@@ -323,6 +347,13 @@ __device__ __forceinline__ void sym_block(const TS* const (&src)[kSymRows], TS* 
 #pragma unroll
             for (int k = 0; k < DE; ++k) { pc[uu][0][k] = fma(p0v, hown[Q0 + q][k], pc[uu][0][k]); pc[uu][1][k] = fma(p1v, hown[Q0 + q][k], pc[uu][1][k]); }
           }
+        }
+      }
+      if constexpr (kF4 && WR) {
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) {
+          flt4s o4; o4.x = (float)outv[0][q].x; o4.y = (float)outv[0][q].y; o4.z = (float)outv[1][q].x; o4.w = (float)outv[1][q].y;
+          __builtin_nontemporal_store(o4, reinterpret_cast<flt4s*>(dst[Q0 + q] + (size_t)((p0 + hh * PB) >> 1) * (4 * kSymChunk)));
         }
       }
       if (kCol) {
@@ -443,6 +474,81 @@ __device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows],
         }
       }
     }
+  }
+}
+
+// The same mapping on fp32 tiles (column quads): the lane's 16-byte load brings the column quad 4 t + g of row r16 + 16 rq, i.e. the column
+// pairs 2 (4 t + g) and 2 (4 t + g) + 1; each goes through the arithmetic of sym_block_quad.  src[q]: the tile's base + 256 g + 4 r16.
+template <int D, int DE, int NACT, bool DIAG, int Q0>
+__device__ __forceinline__ void sym_block_quad_f4(const float* const (&src)[kSymRows], const double* __restrict__ Hc,
+                                                  const double (&hown)[kSymRows][4][DE], double (&accr)[kSymRows][4][DE],
+                                                  double* __restrict__ colp, int ldc, int lane) {
+  static_assert(DE == 3 && RBPF_SYM_BUTTERFLY, "fp32 tiles: the filter");
+  const int r16 = lane & 15, g = lane >> 4;
+  constexpr bool kCol = !(DIAG && NACT == 1);
+#ifndef RBPF_SYM_QUAD_LOADS_F4
+#define RBPF_SYM_QUAD_LOADS_F4 8   // wave loads in flight per round: each is worth two of the fp64 kernel's (sixteen: 145 spilled registers)
+#endif
+  constexpr int TQ = (RBPF_SYM_QUAD_LOADS_F4 / 4) / NACT;   // groups of four column quads per round
+#pragma unroll 1
+  for (int t0 = 0; t0 < kSymChunk / 16; t0 += TQ) {
+    flt4s v[TQ][NACT][4];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+      for (int q = 0; q < NACT; ++q)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          v[u][q][rq] = *reinterpret_cast<const flt4s*>(src[Q0 + q] + (size_t)(t0 + u) * (16 * kSymChunk) + rq * 64);
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pi = 2 * (4 * (t0 + u) + g) + h;            // column pair of the tile
+        __builtin_amdgcn_sched_barrier(0);                    // one pair at a time (conversions and H reads of later pairs hoisted: 140 spilled registers)
+        double h0[DE], h1[DE];
+        {
+          double hb[2 * DE + 2];
+#pragma unroll
+          for (int k2 = 0; k2 < (2 * DE + 1) / 2; ++k2) {
+            const dbl2s tt = *reinterpret_cast<const dbl2s*>(Hc + (size_t)pi * 2 * DE + 2 * k2);
+            hb[2 * k2] = tt.x; hb[2 * k2 + 1] = tt.y;
+          }
+#pragma unroll
+          for (int k = 0; k < DE; ++k) { h0[k] = hb[k]; h1[k] = hb[DE + k]; }
+        }
+        double pc[2][DE];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int k = 0; k < DE; ++k) pc[e][k] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NACT; ++q)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const double p0v = (double)(h ? v[u][q][rq].z : v[u][q][rq].x), p1v = (double)(h ? v[u][q][rq].w : v[u][q][rq].y);
+#pragma unroll
+            for (int k = 0; k < DE; ++k) accr[Q0 + q][rq][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][rq][k]));
+            if (!(DIAG && q == 0)) {
+#pragma unroll
+              for (int k = 0; k < DE; ++k) { pc[0][k] = fma(p0v, hown[Q0 + q][rq][k], pc[0][k]); pc[1][k] = fma(p1v, hown[Q0 + q][rq][k], pc[1][k]); }
+            }
+          }
+        if (kCol) {
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned b0 = 0u - (unsigned)(lane & 1), b1 = 0u - (unsigned)((lane >> 1) & 1);
+          const double r0 = bfly_pair<0x121>(pc[0][0], pc[0][1], b0), r1 = bfly_pair<0x121>(pc[0][2], pc[1][0], b0);
+          double w = bfly_pair<0x121>(pc[1][1], pc[1][2], b0);
+          double q = bfly_pair<0x122>(r0, r1, b1);
+          w += dpp_mov<0x122>(w);
+          q += dpp_mov<0x124>(q); w += dpp_mov<0x124>(w);
+          q += dpp_mov<0x128>(q); w += dpp_mov<0x128>(w);
+          const int col = 2 * pi;
+          if (r16 < 4) colp[(size_t)(r16 == 3 ? 0 : r16) * ldc + col + (r16 == 3 ? 1 : 0)] = q;
+          if (r16 < 2) colp[(size_t)(1 + r16) * ldc + col + 1] = w;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
   }
 }
 
@@ -615,7 +721,7 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
       const TS* src[kSymRows]; TS* dst[kSymRows];
 #pragma unroll
       for (int q = 0; q < kSymRows; ++q) {
-        const size_t off = ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * lane;
+        const size_t off = ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + SymTile<TS>::cg * lane;
         src[q] = srcT + off; dst[q] = dT + off;
       }
       const double* Hc = Hcore + (size_t)J * kSymChunk * DE;
@@ -624,11 +730,18 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
         const TS* srq[kSymRows];
 #pragma unroll
         for (int q = 0; q < kSymRows; ++q)
-          srq[q] = srcT + ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + 2 * kSymChunk * (lane >> 4) + 2 * (lane & 15);
+          srq[q] = srcT + ((size_t)rows[q] * (rows[q] + 1) / 2 + J) * kSymTile + SymTile<TS>::cg * (kSymChunk * (lane >> 4) + (lane & 15));
+        if constexpr (std::is_same<TS, float>::value) {
+          if (J < rows[0]) sym_block_quad_f4<D, DE, 2, false, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+          else if (J == rows[0]) sym_block_quad_f4<D, DE, 2, true, 0>(srq, Hc, hq, accq, colp, ldc, lane);
+          else if (J < last) sym_block_quad_f4<D, DE, 1, false, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+          else sym_block_quad_f4<D, DE, 1, true, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+        } else {
         if (J < rows[0]) sym_block_quad<TS, D, DE, 2, false, 0>(srq, Hc, hq, accq, colp, ldc, lane);
         else if (J == rows[0]) sym_block_quad<TS, D, DE, 2, true, 0>(srq, Hc, hq, accq, colp, ldc, lane);
         else if (J < last) sym_block_quad<TS, D, DE, 1, false, 1>(srq, Hc, hq, accq, colp, ldc, lane);
         else sym_block_quad<TS, D, DE, 1, true, 1>(srq, Hc, hq, accq, colp, ldc, lane);
+        }
       } else if constexpr (!kSplit) {
         for (int pbeg = 0; pbeg < kSymChunk / 2; pbeg += kSymStage / 2) {
           if (WR && ND > 0) { fetch(nb + J * kSymChunk + 2 * pbeg); park(); }
