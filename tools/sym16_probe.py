@@ -39,7 +39,10 @@ def parity(pkg):
 
 def timing(pkg, N):
     dg = importlib.import_module(pkg.__name__ + ".datagen")
-    for storage, lazy, inplace in (("fp32", 2, 0), ("fp32sym", 2, 0), ("fp32sym", 3, 0), ("fp32sym", 4, 0), ("fp32sym", 4, 1), ("fp64sym", 4, 0), ("fp64", 2, 0)):
+    legs = (("fp32", 2, 0), ("fp32sym", 2, 0), ("fp32sym", 3, 0), ("fp32sym", 4, 0), ("fp32sym", 4, 1), ("fp64sym", 4, 0), ("fp64", 2, 0))
+    if "deep" in sys.argv[1:]:
+        legs = (("fp32sym", 4, 0), ("fp32sym", 5, 0), ("fp32sym", 6, 0), ("fp32sym", 8, 0), ("fp64sym", 6, 0), ("fp64sym", 8, 0))
+    for storage, lazy, inplace in legs:
         try:
             r, *_ = bench.filter_leg(pkg, dg, N, 1024, 3000, 24, 4, 1, lazy, inplace, storage)
             print(json.dumps({"storage": storage, "lazy_depth": lazy, "inplace": inplace, "N": N, "Mps": r["value"] / 1e6, "ms_per_step": r["ms_per_step"],
@@ -56,5 +59,5 @@ if __name__ == "__main__":
             N = int(a[2:])
     if "parity" in sys.argv[1:] or len(sys.argv) == 1:
         parity(pkg)
-    if "time" in sys.argv[1:] or len(sys.argv) == 1:
+    if "time" in sys.argv[1:] or "deep" in sys.argv[1:] or len(sys.argv) == 1:
         timing(pkg, N)
