@@ -157,11 +157,36 @@ __device__ __forceinline__ double fold16(double a, double b) {
   const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
   return __hiloint2double((int)r1[0], (int)r0[0]) + __hiloint2double((int)r1[1], (int)r0[1]);
 }
+#ifndef RBPF_SYM_DPP_NOINIT
+#define RBPF_SYM_DPP_NOINIT 1
+#endif
+#ifndef RBPF_SYM_BFI
+#define RBPF_SYM_BFI 1
+#endif
+// a row rotation reads a valid lane everywhere, so the destination needs no initial value (bound_ctrl: no v_mov_b32 dst, 0 before every v_mov_b32_dpp)
+template <int CTRL>
+__device__ __forceinline__ int dpp_rot32(int x) {
+#if RBPF_SYM_DPP_NOINIT
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, true);
+#else
+  return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, false);
+#endif
+}
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double x) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+  const int lo = dpp_rot32<CTRL>(__double2loint(x));
+  const int hi = dpp_rot32<CTRL>(__double2hiint(x));
   return __hiloint2double(hi, lo);
+}
+// (a & m) | (b & ~m) in one instruction
+__device__ __forceinline__ unsigned blend32(unsigned m, unsigned a, unsigned b) {
+#if RBPF_SYM_BFI
+  unsigned r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
+#else
+  return (a & m) | (b & ~m);
+#endif
 }
 // one butterfly stage: the lane keeps u (sel = false) or v (sel = true), passes the other one on by the row rotation CTRL and adds what arrives
 // (bit blends of the 32-bit halves, m = 0 or ~0: with selects on a lane predicate the register allocation of the whole kernel fell
@@ -170,10 +195,10 @@ template <int CTRL>
 __device__ __forceinline__ double bfly_pair(double u, double v, unsigned m) {
   const unsigned ulo = (unsigned)__double2loint(u), uhi = (unsigned)__double2hiint(u);
   const unsigned vlo = (unsigned)__double2loint(v), vhi = (unsigned)__double2hiint(v);
-  const unsigned klo = (vlo & m) | (ulo & ~m), khi = (vhi & m) | (uhi & ~m);
-  const unsigned slo = (ulo & m) | (vlo & ~m), shi = (uhi & m) | (vhi & ~m);
-  const int rlo = __builtin_amdgcn_update_dpp(0, (int)slo, CTRL, 0xf, 0xf, false);
-  const int rhi = __builtin_amdgcn_update_dpp(0, (int)shi, CTRL, 0xf, 0xf, false);
+  const unsigned klo = blend32(m, vlo, ulo), khi = blend32(m, vhi, uhi);
+  const unsigned slo = blend32(m, ulo, vlo), shi = blend32(m, uhi, vhi);
+  const int rlo = dpp_rot32<CTRL>((int)slo);
+  const int rhi = dpp_rot32<CTRL>((int)shi);
   return __hiloint2double((int)khi, (int)klo) + __hiloint2double(rhi, rlo);
 }
 // every lane of a 16-lane row gets the row's sum (rotations by 8, 4, 2, 1: a fixed order)
