@@ -365,7 +365,7 @@ int rbpf::shard_step_impl(rbpf_ctx* c, const int32_t* anc_bank_host, const int32
   a.pre_i = c->d_pre_i; a.pre_d = c->d_pre_d; a.u_next = nullptr;
   a.phase = -1;                                            // (every slot; the shared flush below launches by phase)
   // shared flush (see ctx_step): the children of one parent -- one bank entry or one received record -- store ONE flushed matrix
-  const bool share = lazy && flush && t > 0 && dev_plan && L.sym && L.CH64 == 8 && !c->fp32 && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
+  const bool share = lazy && flush && t > 0 && dev_plan && L.sym && (L.CH64 == 8 || L.CH64 == 16) && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
   if (share) {
     const size_t keys = (size_t)N + s->recv_cap;
     if (s->share_keys < keys) {

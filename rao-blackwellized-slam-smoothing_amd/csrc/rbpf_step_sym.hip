@@ -430,18 +430,8 @@ __device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows],
   // quads per round: RBPF_SYM_QUAD_LOADS wave loads in flight whatever the active rows (information form, DE = 4: eight -- its
   // four more row-sum and four more H registers per row do not leave room for sixteen)
   constexpr int TQ = ((DE > 3 ? 8 : RBPF_SYM_QUAD_LOADS) / 4) / NACT;
-  for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
-    dbl2s v[TQ][NACT][4];
-#pragma unroll
-    for (int u = 0; u < TQ; ++u)
-#pragma unroll
-      for (int q = 0; q < NACT; ++q)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq)
-          v[u][q][rq] = ld_tile<TS>(src[Q0 + q] + (size_t)(t0 + u) * (8 * kSymChunk) + rq * 32);
-#pragma unroll
-    for (int u = 0; u < TQ; ++u) {
-      const int t = t0 + u;
+  // one quad of column pairs (4 t .. 4 t + 3; this lane: pair 4 t + g), vq: its rows r16 + 16 rq of the active tile rows
+  auto quad = [&](const dbl2s (&vq)[NACT][4], const int t) {
       double h0[DE], h1[DE];
       {
         double hb[2 * DE + 2];                          // the pair's 2 * DE values of [H | ivec] sit contiguously
@@ -462,7 +452,7 @@ __device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows],
       for (int q = 0; q < NACT; ++q)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-          const double p0v = v[u][q][rq].x, p1v = v[u][q][rq].y;
+          const double p0v = vq[q][rq].x, p1v = vq[q][rq].y;
 #pragma unroll
           for (int k = 0; k < DE; ++k) accr[Q0 + q][rq][k] = fma(p1v, h1[k], fma(p0v, h0[k], accr[Q0 + q][rq][k]));
           if (!(DIAG && q == 0)) {
@@ -498,7 +488,22 @@ __device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows],
             }
         }
       }
-    }
+  };
+  // (a round = TQ quads loaded, then consumed.  r05 tried to keep loads in flight all the time -- half rounds double-buffered, or every
+  //  quad's registers reloaded right after their use: both forms spilled 120 registers, 2.8 instead of 5.7 M particle-steps/s.  The
+  //  loop must not be unrolled either: the compiler then hoists the next rounds' loads and spills.)
+#pragma unroll 1
+  for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
+    dbl2s v[TQ][NACT][4];
+#pragma unroll
+    for (int u = 0; u < TQ; ++u)
+#pragma unroll
+      for (int q = 0; q < NACT; ++q)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+          v[u][q][rq] = ld_tile<TS>(src[Q0 + q] + (size_t)(t0 + u) * (8 * kSymChunk) + rq * 32);
+#pragma unroll
+    for (int u = 0; u < TQ; ++u) quad(v[u], t0 + u);
   }
 }
 
