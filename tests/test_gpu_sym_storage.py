@@ -296,6 +296,33 @@ def test_fp32_tiles_match_oracle_to_storage_precision(rbpf, oracle_m512_short, o
     assert rel(out[4], out[4].T) < 1e-13                                        # one stored value per (r, c) / (c, r) pair
 
 
+def test_sixteen_tile_rows_against_the_c_restatement(rbpf, tmp_path_factory):
+    """N = 256, T = 40, m = 1024 on replayed random numbers: block-lower storage at sixteen tile rows, lazy_depth 4 with two banks
+    (shared flush) and in place, lazy_depth 2, against the plain-C restatement -- every resampling index, weights, final maps and
+    covariances of all particles (particleFilter.m:100-218)."""
+    import bench
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    N, T, m = 256, 40, 1024
+    d = dg.bean_6D(T, cases.Q_MAG, cases.THETA_MAG, 0.01, seed=1)
+    mdl, x0, P0, R = rbpf.dense_mag_prior(m, d["LL"], cases.THETA_MAG)
+    rs = np.random.RandomState(93)
+    rng = rbpf.ReplayRNG(rs.random_sample((1, T - 1, N)), rs.standard_normal((1, T - 1, N, 6)))
+    lib = oracle_c.build(native_dir=str(tmp_path_factory.mktemp("oracle_native_sym16")))
+    ref, _ = oracle_c.particle_filter(rbpf, mdl, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng,
+                                      n_threads=bench.usable_cores(), want_full=True, lib_path=lib)
+    for lazy_depth, inplace in ((4, -1), (4, 1), (2, -1)):
+        out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                                  extras=True, lazy_depth=lazy_depth, inplace=inplace, storage="fp64sym")
+        ex = out[8]
+        np.testing.assert_array_equal(ex["ai"][1:], ref["trace_ai"].T[1:])
+        assert rel(ex["w"], ref["trace_w"].T) <= RTOL
+        assert rel(out[0], ref["traj_max"]) <= RTOL and rel(out[1], ref["traj_mean"]) <= RTOL
+        assert rel(out[2], ref["xl_max"]) <= RTOL and rel(out[3], ref["xl_mean"]) <= RTOL
+        assert rel(out[4], ref["P_max"]) <= RTOL and rel(out[5], ref["P_mean"]) <= RTOL
+        assert rel(ex["xl"], ref["final_xl"]) <= RTOL and rel(ex["P"], ref["final_P"]) <= RTOL
+        assert rel(out[4], out[4].T) < 1e-13
+
+
 @pytest.mark.parametrize("storage,tol_banks", [("fp64sym", 1e-11), ("fp32sym", 2e-6)])
 def test_sixteen_tile_rows_on_philox_streams(rbpf, storage, tol_banks):
     """N = 2048, m = 1024, 13 steps on the device generator, lazy_depth 4: the shared flush (two banks) and the single bank rewritten
