@@ -185,7 +185,8 @@ typedef struct {
                           * storage 0 (P(r,c) and P(c,r), which differ by rounding in the reference's plain form, are one     *
                           * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]) or      *
                           * 259 <= n_lin <= 383: filter and both smoothers, single-GPU and sharded; 1027 <= n_lin <= 1151       *
-                          * (sixteen tile rows, BASELINE.json configs[4]'s basis size): the filter; RBPF_ERR_UNSUPPORTED         *
+                          * (sixteen tile rows, BASELINE.json configs[4]'s basis size): the filter; dense-radio (n_y = 1) with   *
+                          * n_lin = 128 (two tile rows: 0.75 x the bytes): filter and both smoothers; RBPF_ERR_UNSUPPORTED       *
                           * elsewhere.                                                                                          *
                           * 3 = fp32 tiles of the lower block triangle (storage 1's rounding on storage 2's layout: 0.28 x the   *
                           * bytes of storage 0): the filter with 515 <= n_lin <= 639 or 1027 <= n_lin <= 1151, lazy_depth <= 4.  */

@@ -233,7 +233,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     // symmetric storage (lower block triangle, rbpf_step_sym.hip): the filter of the ny = 3 dense families at the
     // sizes its wave decomposition takes (eight 64-row tile rows: 512 <= nLin - nb < 640)
     if (sparse || !sym_supported(prob->n_lin, prob->n_y)) {
-      set_error("symmetric storage (options.storage = 2 / 3): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639, dense filter with nLin in 1027..1151 only"); return RBPF_ERR_UNSUPPORTED;
+      set_error("symmetric storage (options.storage = 2 / 3): dense filter / smoothers (single-GPU or sharded) with ny = 3 and nLin in 259..383 or 515..639, dense filter with nLin in 1027..1151, dense-radio (ny = 1) with nLin = 128 only"); return RBPF_ERR_UNSUPPORTED;
     }
     c->lay = make_layout_sym(prob->n_lin, prob->n_y, c->fp32 ? 1 : 0);
     c->lay_low = c->lay;

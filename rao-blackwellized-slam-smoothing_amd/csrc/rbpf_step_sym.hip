@@ -83,7 +83,9 @@ constexpr int kSymStage = 32;          // columns of pending column factors a wa
 
 bool sym_supported(int n, int d) {
   const int mc = (n / kChunkRows) * kChunkRows;
-  return d == 3 && (mc / kSymChunk == 8 || mc / kSymChunk == 4 || mc / kSymChunk == 16);
+  const int ch = mc / kSymChunk;
+  if (d == 1) return ch == 2 && n == mc;             // dense-radio (n_y = 1, nLin = m = 128: two tile rows, no border rows)
+  return d == 3 && (ch == 8 || ch == 4 || ch == 16);
 }
 
 // sixteen tile rows: doubles of the global column-strip workspace per workgroup (the seven strips of row pairs 1..7)
@@ -103,7 +105,7 @@ Layout make_layout_sym(int n, int d, int fp32) {
 }
 
 // LDS plan (doubles).  Column strips: row pair rp > 0 keeps its column contributions for core columns [0, 64 (CH - 1 - rp)); row
-// pair 0's go straight into PHt.  off_row: the row sums of the second column phase (CH = 4 only).
+// pair 0's go straight into PHt.  off_row: the row sums of the column phases 1 .. NPH - 1 (CH = 4: two phases; CH = 2: four).
 struct SymPlan { int off_H, off_xl, off_PHt, off_col1, off_row, off_tab, off_misc, off_red, off_kst, total; };
 // strip of row pair rp (rp >= 1): D x ld_col(rp) doubles at off_col1 + D * 64 * sum_{v=1}^{rp-1} (CH - 1 - v)   (closed forms: no
 // indexed arrays, which would live in scratch memory)
@@ -113,6 +115,8 @@ __host__ __device__ inline int sym_off_col(int off_col1, int D, int ch, int rp) 
 __host__ __device__ inline int sym_even(int x) { return (x + 1) & ~1; }
 // waves of a workgroup = row pairs x column phases: four (CH = 8: four row pairs; CH = 4: two row pairs x two phases), eight at CH = 16
 __host__ __device__ constexpr int sym_waves(int ch) { return ch == 16 ? 8 : kWaves; }
+// column phases = waves that share a row pair and split its column pairs: CH / 2 row pairs x phases = waves
+__host__ __device__ constexpr int sym_phases(int ch) { return ch == 4 ? 2 : (ch == 2 ? 4 : 1); }
 
 __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int nd_stage, int ch, int xl_lds = 1) {
   SymPlan p;
@@ -124,7 +128,7 @@ __host__ __device__ inline SymPlan sym_plan(int n, int D, int ldx, int ktot, int
   p.off_col1 = o;
   if (ch == 16) o += waves * D * kSymChunk;        // sixteen tile rows: one block column of column sums per wave (the strips are global)
   else for (int rp = 1; rp < ch / 2; ++rp) o += D * sym_ld_col(ch, rp);
-  p.off_row = o;  o += (ch == 4) ? D * ch * kSymChunk : 0;
+  p.off_row = o;  o += (sym_phases(ch) - 1) * D * ch * kSymChunk;
   p.off_tab = o;  o += sym_even(2 * (ktot > 0 ? ktot : 1));
   p.off_misc = o; o += 64;
   p.off_red = o;  o += waves * kSymRed;
@@ -248,8 +252,9 @@ __device__ __forceinline__ void sym_block(const TS* const (&src)[kSymRows], TS* 
   // column pairs per round = wave-wide 1 KB loads in flight / active rows: 8 loads in the read-only steps, 4 in a flush (with 8 the
   // three- and four-set flushes kept 28-85 registers in scratch inside the block-column loop: 10 % more HBM writes, flush 29.1 ->
   // 26.1 ms at N = 65 536 with 4)
-  constexpr int UP = (WR ? RBPF_SYM_FLUSH_LOADS : RBPF_SYM_LIGHT_LOADS) / NACT;   // (fp32 tiles: UP / 2 loads of a column quad)
-  constexpr int PB = WR ? 2 : 4;                        // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
+  constexpr int UP0 = (WR ? RBPF_SYM_FLUSH_LOADS : RBPF_SYM_LIGHT_LOADS) / NACT;   // (fp32 tiles: UP / 2 loads of a column quad)
+  constexpr int UP = UP0 * NPH > kSymStage / 2 ? kSymStage / 2 / NPH : UP0;          // a round stays inside the stage of kSymStage / 2 pairs
+  constexpr int PB = (WR || UP < 4) ? 2 : 4;            // pairs per compute / reduction batch (a flush carries 2 * ND factor values per pair)
   constexpr bool kCol = !(DIAG && NACT == 1);           // any off-diagonal tile in this block column?
   constexpr bool kF4 = std::is_same<TS, float>::value;     // fp32 tiles: one 16-byte load = two column pairs of a row (pairs 2 j, 2 j + 1)
   static_assert(!kF4 || (NPH == 1 && UP % 2 == 0 && PB == 2), "fp32 tiles: whole column quads per round");
@@ -591,7 +596,7 @@ __device__ __forceinline__ void sym_block_quad_f4(const float* const (&src)[kSym
 template <typename TS, int D, int NS, bool WR, int E, int CH>
 __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0) ? RBPF_SYM_LIGHT_WGS : 2)) void step_sym_kernel(const StepArgs a) {
   constexpr int NW = sym_waves(CH), NT = 64 * NW;              // CH = 16: eight waves, one workgroup per CU (the same eight waves per CU as 2 x 4)
-  constexpr int NPH = (CH == 4) ? 2 : 1;                       // column phases (waves per row pair)
+  constexpr int NPH = sym_phases(CH);                          // column phases (waves per row pair)
   constexpr bool kGStrip = (CH == 16);                         // column strips in the global workspace, one block column staged in LDS
   extern __shared__ double smem[];
   constexpr int DE = D + E, ND = NS * D, NDA = ND > 0 ? ND : 1, NSA = NS > 0 ? NS : 1;
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
   RBPF_SYM_KSTAMP(3);
   {
   // ---- D: stream the stored tiles once ----
-  const int rp = (NPH == 1) ? wave : (wave & 1), cp = (NPH == 1) ? 0 : (wave >> 1);   // row pair, column phase
+  const int rp = (NPH == 1) ? wave : (wave % (CH / 2)), cp = (NPH == 1) ? 0 : (wave / (CH / 2));   // row pair, column phase
   const int rows[kSymRows] = {rp, CH - 1 - rp};                // ascending
   constexpr bool kQuad = RBPF_SYM_QUAD && !WR && NPH == 1 && E <= RBPF_SYM_QUAD_EMAX;   // read-only steps at CH = 8: sym_block_quad
   double accr[kSymRows][DE], hown[kSymRows][DE], ks[kSplit ? 1 : kSymRows][NDA];
@@ -741,10 +746,14 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
         for (int k = 0; k < D; ++k) kpre[s * D + k] = Fs[s][(size_t)(D + k) * ldx + col0 + (lane & (kSymStage - 1))];
     };
     auto park = [&]() {
+      // the stage is written as doubles and read as 16-byte pairs: the compiler barriers keep the two kinds of access in program order
+      // (type-based alias analysis sees them as unrelated; seen to go wrong in the one-set flush at two tile rows)
+      asm volatile("" ::: "memory");
       if (lane < kSymStage) {
 #pragma unroll
         for (int k = 0; k < ND; ++k) kst[((size_t)(lane >> 1) * ND + k) * 2 + (lane & 1)] = kpre[k];
       }
+      asm volatile("" ::: "memory");
     };
     const int last = rows[kSymRows - 1];
     for (int J = 0; J <= last; ++J) {
@@ -848,8 +857,8 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
       if (lane == 0) PHt[(size_t)k * ldx + b] = s;
     }
   }
-  if (NPH > 1 && cp > 0) {                                     // second column phase: its row sums go through LDS
-    double* rowp = smem + lp.off_row;
+  if (NPH > 1 && cp > 0) {                                     // the other column phases: their row sums go through LDS
+    double* rowp = smem + lp.off_row + (size_t)(cp - 1) * DE * CH * kSymChunk;
 #pragma unroll
     for (int q = 0; q < kSymRows; ++q)
 #pragma unroll
@@ -883,9 +892,12 @@ __global__ __launch_bounds__(64 * sym_waves(CH), CH == 16 ? 1 : ((!WR && E == 0)
           s[k] = fold16(fold32(accq[q][0][k], accq[q][1][k]), fold32(accq[q][2][k], accq[q][3][k])) + s[k];
       }
       if (NPH > 1) {
-        const double* rowp = smem + lp.off_row;
 #pragma unroll
-        for (int k = 0; k < DE; ++k) s[k] += rowp[(size_t)k * (CH * kSymChunk) + rc];
+        for (int ph = 1; ph < NPH; ++ph) {                     // phases in order: a fixed summation order
+          const double* rowp = smem + lp.off_row + (size_t)(ph - 1) * DE * CH * kSymChunk;
+#pragma unroll
+          for (int k = 0; k < DE; ++k) s[k] += rowp[(size_t)k * (CH * kSymChunk) + rc];
+        }
       }
 #pragma unroll
       for (int w = 0; w < CH / 2; ++w) {
@@ -1168,7 +1180,48 @@ static hipError_t launch_step_sym_filter(const StepArgs& a, hipStream_t s) {
   }
 }
 
+// dense-radio (n_y = 1, nLin = 128): two tile rows, four waves share the one row pair; filter and information form, lazy_depth <= 3
+template <int NS, bool WR, int E>
+static hipError_t launch_sym_radio(const StepArgs& a, hipStream_t s) { return launch_sym_kc<double, 1, NS, WR, E, 2>(a, s); }
+
+static hipError_t launch_step_sym_radio(const StepArgs& a, hipStream_t s) {
+  if (a.lay.CH64 != 2 || a.fp32 || a.lay.nb != 0) return hipErrorInvalidValue;
+  if (a.info) {
+    if (a.write_base) {
+      switch (a.n_sets) {
+        case 0: return launch_sym_radio<0, true, 1>(a, s);
+        case 1: return launch_sym_radio<1, true, 1>(a, s);
+        case 2: return launch_sym_radio<2, true, 1>(a, s);
+        case 3: return launch_sym_radio<3, true, 1>(a, s);
+        default: return hipErrorInvalidValue;
+      }
+    }
+    switch (a.n_sets) {
+      case 1: return launch_sym_radio<1, false, 1>(a, s);
+      case 2: return launch_sym_radio<2, false, 1>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (a.write_base) {
+    switch (a.n_sets) {
+      case 0: return launch_sym_radio<0, true, 0>(a, s);
+      case 1: return launch_sym_radio<1, true, 0>(a, s);
+      case 2: return launch_sym_radio<2, true, 0>(a, s);
+      case 3: return launch_sym_radio<3, true, 0>(a, s);
+      case 4: return launch_sym_radio<4, true, 0>(a, s);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  switch (a.n_sets) {
+    case 1: return launch_sym_radio<1, false, 0>(a, s);
+    case 2: return launch_sym_radio<2, false, 0>(a, s);
+    case 3: return launch_sym_radio<3, false, 0>(a, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 hipError_t launch_step_sym(const StepArgs& a, hipStream_t s) {
+  if (a.lay.sym && a.mdl.d == 1) return launch_step_sym_radio(a, s);
   if (!a.lay.sym || a.mdl.d != 3 || (a.lay.CH64 != 8 && a.lay.CH64 != 4 && a.lay.CH64 != 16)) return hipErrorInvalidValue;
   if (a.fp32) return a.info ? hipErrorInvalidValue : launch_step_sym_filter<float>(a, s);
   if (a.info) {                                            // information form: lazy_depth <= 3

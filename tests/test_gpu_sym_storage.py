@@ -390,3 +390,59 @@ def test_block_lower_storage_is_refused_where_it_is_not_built(rbpf):
         rbpf.particleSmootherInformationForm(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 2,
                                              c["dt"], rng=cases.device_rng(rbpf, c), storage="fp32sym")
     assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+
+
+# ---- dense-radio (n_y = 1, nLin = m = 128: two tile rows, four waves share the one row pair), r05 ---------------------------------------
+@pytest.mark.parametrize("lazy_depth,inplace", [(0, -1), (2, -1), (3, -1), (3, 1), (4, -1), (4, 1)])
+def test_symmetric_storage_radio_filter_matches_oracle(rbpf, lazy_depth, inplace):
+    """slam-dense-radio (run_dense2D_withHeading.m:75-76,168) on block-lower storage: three of the four 64 x 64 tiles, the four waves
+    split the column pairs of the one row pair (four column phases), their row sums meet in LDS in a fixed order.  lazy_depth 0 is the
+    one-set flush whose wave-private LDS stage needed compiler barriers (written as doubles, read as 16-byte pairs)."""
+    c = cases.radio_case(8, 11, 128, seed=5)
+    ref = cases.oracle_filter(c)
+    check_filter(ref, run_sym(rbpf, c, lazy_depth, inplace))
+
+
+@pytest.mark.parametrize("info_form,kw", [(False, {}), (True, {}), (True, dict(lazy_depth=3)), (True, dict(lazy_depth=3, chol_refresh=1))])
+def test_symmetric_storage_radio_smoothers_match_oracle(rbpf, info_form, kw):
+    """Both smoothers of dense-radio on block-lower storage, N_K = 3, against the numpy oracle (particleSmoother.m:124-341,
+    particleSmootherInformationForm.m:98-362): carried factors (default) and the from-scratch factorisation."""
+    import test_gpu_smoother as ts
+    c = cases.radio_case(8, 9, 128, seed=7, N_K=3)
+    ref, out = ts.run_both(rbpf, c, info_form=info_form, storage="fp64sym", **kw)
+    ts.check(ref, out, 3)
+
+
+def test_symmetric_storage_radio_at_configs3_size(rbpf):
+    """N = 65 536 dense-radio particles on block-lower storage, lazy_depth 3, 12 steps on the device generator: the same resampling
+    indices as the full square, outputs to 1e-9, two runs bit-identical."""
+    dg = importlib.import_module(rbpf.__name__ + ".datagen")
+    T, N, steps = 24, 65536, 12
+    Qr = dg.radio_Q(T, "square_3D")
+    th = [0.25, 2.0, 0.01]
+    d = dg.planar_heading(T, Qr, th, 1.0, seed=1, nLL=4, traj="square_3D")
+    mdl, x0, P0, R = rbpf.dense_radio_prior(128, d["LL"], th)
+    want = ("traj_max", "traj_mean", "xl_max", "P_max", "trace_w", "trace_ai", "xl_mean")
+
+    def go(storage):
+        with rbpf.FilterSession(mdl, d["dx"], d["y"], d["initState"], x0, P0, Qr, R, N, 1.0, rng=rbpf.PhiloxRNG(5), keep_history=True, trace=True,
+                                lazy_depth=3, storage=storage) as s:
+            s.advance(steps)
+            s.sync()
+            return s.finish(want=want)
+    a, a2, full = go("fp64sym"), go("fp64sym"), go("fp64")
+    np.testing.assert_array_equal(a["trace_ai"], full["trace_ai"])
+    for k in want:
+        np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
+        if k != "trace_ai":
+            sl = (slice(None), slice(0, steps)) if k in ("traj_max", "traj_mean", "trace_w") else Ellipsis
+            assert rel(a[k][sl], full[k][sl]) <= RTOL, k
+
+
+def test_symmetric_storage_radio_is_refused_at_other_sizes(rbpf):
+    c = cases.radio_case(6, 5, 16, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with pytest.raises(rbpf.RBPFError) as ei:
+        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, c["dt"],
+                            rng=cases.device_rng(rbpf, c), storage="fp64sym")
+    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
