@@ -16,7 +16,8 @@ function o = rbpf_options(varargin)
 %   chol_variant  which kernel factorises (0 automatic); same arithmetic
 %   storage       1: covariance banks stored in single precision (arithmetic stays double; 2e-5 instead of 1e-9);
 %                 2: double precision, lower block triangle only (particleFilter keeps P symmetric: 0.56 x the memory and
-%                 traffic, results within 1e-9; dense-mag filter with 256 / 512 / 1024 basis functions, smoothers with 256 / 512);
+%                 traffic, results within 1e-9; dense-mag filter with 256 / 512 / 1024 basis functions, smoothers with 256 / 512;
+%                 dense-radio with 128 basis functions: 0.75 x, pays only without lazy_depth);
 %                 3: the lower block triangle in single precision (filter with 512 / 1024 basis functions)
 %   n_devices     W > 1: particleFilter / particleSmootherInformationForm shard their N_P particles over W GPUs of this
 %                 machine inside the library (one thread per GPU, RCCL collectives); N_P must be a multiple of W; all of the

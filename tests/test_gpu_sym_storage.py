@@ -160,7 +160,7 @@ def test_symmetric_storage_is_rejected_where_it_is_not_implemented(rbpf):
     c = cases.mag_case(6, 5, 125, seed=1)                                       # nLin = 128: two tile rows
     with pytest.raises(rbpf.RBPFError):
         run_sym(rbpf, c, 3, -1)
-    c = cases.radio_case(6, 5, 128, seed=1, N_K=2)
+    c = cases.radio_case(6, 5, 256, seed=1, N_K=2)                              # dense-radio: nLin = 128 only (r05)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     with pytest.raises(rbpf.RBPFError):
         rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 1.0,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# r05 profiles, run on the GPU box via gpurun: rocprofv3 kernel stats of (1) the DEFAULT headline path (the filter leg of bench.py),
+# r05 profiles, run on the GPU box via gpurun: rocprofv3 kernel stats of (1) the DEFAULT headline path (the filter leg of bench.py), (1b) configs[4]'s share on fp32 block-lower tiles,
 # (2) the information-form smoother at the per-GPU share with the library defaults (carried factors) and with chol_refresh = 1, and
 # (3) HBM counters of the default smoother (separate --pmc passes; no trace domains with --pmc).  Summaries -> gpurun_out/summ/.
 set -u
@@ -9,6 +9,7 @@ mkdir -p $OUT $REPO/gpurun_out/summ
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/filter -o t -- python3 $REPO/bench.py --steps 200 --no-smoother --no-large --no-cpu-baseline --no-filter-full > $OUT/filter.json 2> $OUT/filter.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4 -o t -- python3 $REPO/tools/sym16_trace.py fp32sym 4 32768 60 > $OUT/c4.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sm_default -o sm -- python3 $REPO/tools/smoother_bench.py mag 8192 130 512 2 info lazy_depth=3 storage=2 > $OUT/sm_default.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sm_fresh -o sm -- python3 $REPO/tools/smoother_bench.py mag 8192 40 512 2 info lazy_depth=3 storage=2 chol_refresh=1 > $OUT/sm_fresh.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $REPO/tools/smoother_bench.py mag 8192 40 512 2 info lazy_depth=3 storage=2 > $OUT/pmc_fetch.log 2>&1
@@ -36,6 +37,13 @@ try:
 except Exception as exc:
     lines.append(f"bench line not parsed: {exc}")
 open(os.path.join(summ, "r05_filter_sym_N65536_m512_summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
+lines = stats("c4", "tools/sym16_trace.py fp32sym 4 32768 60 (BASELINE.json configs[4]'s per-GPU share: N = 32768, m = 1024, fp32 block-lower tiles, lazy_depth 4)", 8)
+try:
+    lines.append("the run's own line: " + [l for l in open(os.path.join(out, "c4.log")) if "particle-steps/s" in l][-1].strip())
+except Exception as exc:
+    lines.append(f"run line not found: {exc}")
+open(os.path.join(summ, "r05_filter_fp32sym_N32768_m1024_summary.txt"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 lines = stats("sm_default", "tools/smoother_bench.py mag 8192 130 512 2 info lazy_depth=3 storage=2 (library defaults: carried factors, K = 32)")
 lines += stats("sm_fresh", "tools/smoother_bench.py mag 8192 40 512 2 info lazy_depth=3 storage=2 chol_refresh=1 (the reference's arithmetic)", 8)
