@@ -495,8 +495,9 @@ __device__ __forceinline__ void sym_block_quad(const TS* const (&src)[kSymRows],
       }
   };
   // (a round = TQ quads loaded, then consumed.  r05 tried to keep loads in flight all the time -- half rounds double-buffered, or every
-  //  quad's registers reloaded right after their use: both forms spilled 120 registers, 2.8 instead of 5.7 M particle-steps/s.  The
-  //  loop must not be unrolled either: the compiler then hoists the next rounds' loads and spills.)
+  //  quad's registers reloaded right after their use: both forms spilled 120 registers, 2.8 instead of 5.7 M particle-steps/s; the second
+  //  form without a peeled last round and only where two tile rows are active: 11 spilled registers, 5.47 against 5.76 M.  The loop must
+  //  not be unrolled either: the compiler then hoists the next rounds' loads and spills.)
 #pragma unroll 1
   for (int t0 = 0; t0 < kSymChunk / 8; t0 += TQ) {      // quads of column pairs
     dbl2s v[TQ][NACT][4];
