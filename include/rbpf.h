@@ -184,7 +184,7 @@ typedef struct {
                           * pending sets as P H' - KS (K' H') instead of element-wise.  Same algebra: results within 1e-9 of  *
                           * storage 0 (P(r,c) and P(c,r), which differ by rounding in the reference's plain form, are one     *
                           * stored value).  Dense families with n_y = 3 and 515 <= n_lin <= 639 (BASELINE.json configs[2]) or      *
-                          * 259 <= n_lin <= 383: filter and both smoothers, single-GPU and sharded; 1027 <= n_lin <= 1151       *
+                          * 259 <= n_lin <= 383: filter and both smoothers, single-GPU and sharded; 1024 <= n_lin <= 1151       *
                           * (sixteen tile rows, BASELINE.json configs[4]'s basis size): the filter; dense-radio (n_y = 1) with   *
                           * n_lin = 128 (two tile rows: 0.75 x the bytes): filter and both smoothers; RBPF_ERR_UNSUPPORTED       *
                           * elsewhere.                                                                                          *

@@ -296,6 +296,19 @@ def test_fp32_tiles_match_oracle_to_storage_precision(rbpf, oracle_m512_short, o
     assert rel(out[4], out[4].T) < 1e-13                                        # one stored value per (r, c) / (c, r) pair
 
 
+@pytest.mark.parametrize("m", [1021, 1148])
+def test_sixteen_tile_rows_at_the_ends_of_the_supported_range(rbpf, m):
+    """nLin = 1024 (no border row) and nLin = 1151 (127 border rows): the ends of the range the sixteen-tile-row kernel takes, fp64 tiles
+    against the numpy oracle at 1e-9 and fp32 tiles at storage precision; nLin = 1152 is refused (tested with the other refusals)."""
+    c = cases.mag_case(6, 6, m, seed=31)
+    ref = cases.oracle_filter(c)
+    for lazy_depth, inplace in ((0, -1), (3, -1), (4, 1)):
+        check_filter(ref, run_sym(rbpf, c, lazy_depth, inplace))
+    out = run_sym(rbpf, c, 3, -1, storage="fp32sym")
+    np.testing.assert_array_equal(out[8]["ai"][1:], ref["trace"]["ai"][1:])
+    assert rel(out[8]["P"], ref["trace"]["P"]) <= 2e-5 and rel(out[8]["w"], ref["trace"]["w"]) <= 2e-5
+
+
 def test_sixteen_tile_rows_against_the_c_restatement(rbpf, tmp_path_factory):
     """N = 256, T = 40, m = 1024 on replayed random numbers: block-lower storage at sixteen tile rows, lazy_depth 4 with two banks
     (shared flush) and in place, lazy_depth 2, against the plain-C restatement -- every resampling index, weights, final maps and
@@ -378,12 +391,13 @@ def test_block_lower_storage_is_refused_where_it_is_not_built(rbpf):
             rbpf.particleSmoother(mdl.dynModel, mdl.measModel, mdl.dynResNorm, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, 2, c["dt"],
                                   rng=cases.device_rng(rbpf, c), storage=storage)
         assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
-    c = cases.mag_case(6, 5, 256, seed=29)
-    mdl, x0, P0, R = cases.device_model(rbpf, c)
-    with pytest.raises(rbpf.RBPFError) as ei:
-        rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, c["dt"],
-                            rng=cases.device_rng(rbpf, c), storage="fp32sym")
-    assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+    for m, storage in ((256, "fp32sym"), (1149, "fp64sym")):                    # fp32 tiles at four tile rows; nLin = 1152: eighteen tile rows
+        c = cases.mag_case(6, 5, m, seed=29)
+        mdl, x0, P0, R = cases.device_model(rbpf, c)
+        with pytest.raises(rbpf.RBPFError) as ei:
+            rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, c["dt"],
+                                rng=cases.device_rng(rbpf, c), storage=storage)
+        assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
     c = cases.mag_case(6, 5, 512, seed=29, N_K=2)
     mdl, x0, P0, R = cases.device_model(rbpf, c)
     with pytest.raises(rbpf.RBPFError) as ei:
