@@ -236,6 +236,33 @@ def test_filter_at_configs1_basis_size_over_the_full_horizon_against_the_arbiter
     print(opts, {k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
 
 
+@pytest.mark.parametrize("opts", [dict(lazy_depth=4, inplace=-1, storage="fp64sym"), dict(lazy_depth=4, inplace=1, storage="fp64sym"),
+                                  dict(lazy_depth=2, storage="fp64sym"), dict()])
+def test_filter_at_sixteen_tile_rows_over_a_long_horizon_against_the_arbiter(rbpf, opts):
+    """m = 1024 (nLin = 1027: BASELINE.json configs[4]'s basis size, sixteen tile rows of the block-lower storage, r05), N = 32, T = 1000:
+    block-lower storage in both bank schedules and at lazy_depth 2, and the full square rewritten every step (the reference's own
+    schedule), against the extended-precision arbiter: every index, 1e-9 up to t = 500, the arbiter rule over the whole horizon."""
+    import make_arbiter_fixture as maf
+    N, T = 32, 1000
+    d, mdl, x0, P0, R, rng = maf.filter_m1024_inputs()
+    fx = load_fixture("arbiter_filter_N32_T1000_m1024.npz", d, x0, P0, R, rng.U, rng.Z)
+    out = rbpf.particleFilter(mdl.dynModel, mdl.measModel, d["dx"], d["y"], d["initState"], x0, P0, cases.Q_MAG, R, N, 0.01, rng=rng,
+                              extras=True, **opts)
+    ex = out[8]
+    np.testing.assert_array_equal(ex["ai"][1:], fx["trace_ai"].astype(np.int32).T[1:])
+    assert int(ex["iw_max"]) == int(fx["iw_max"][0])
+    st = int(fx["trace_w_stride"])
+    got = dict(trace_w=ex["w"].T[:, ::st], traj_mean=out[1], xl_max=out[2], xl_mean=out[3], final_xl=ex["xl"], P_max_diag=np.diag(out[4]),
+               traj_max=out[0])
+    assert rel(got["trace_w"][:, :500 // st], fx["trace_w"][:, :500 // st]) <= RTOL
+    report = {}
+    for k, v in got.items():
+        e_hip, e_c = rel(v, fx[k]), float(fx["err_c64_nofma__" + k])
+        report[k] = (e_hip, e_c)
+        assert e_hip <= max(RTOL, SLACK * e_c), (k, e_hip, e_c)
+    print(opts, {k: f"{a:.2e} (C {b:.2e})" for k, (a, b) in report.items()})
+
+
 def test_smoother_at_the_metrics_full_particle_count_on_one_gpu(rbpf):
     """particleSmootherInformationForm at the metric's N_P = 65 536, m = 512 on ONE GPU: factors carried and never refactorised (no
     information matrix stored: chol_refresh >= N_T), one block-lower covariance bank rewritten in place, lazy_depth 3 -- 3.7 MB of state

@@ -85,6 +85,7 @@ def test_arbiter_fixtures_are_complete():
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     need = {"arbiter_filter_N64_T3000_m512.npz": ("y", "inputs_sha256", "trace_ai", "trace_w", "xl_max", "err_c64_nofma__trace_w", "err_c64_fma__trace_w"),
             "arbiter_filter_N64_T3000_m256.npz": ("y", "inputs_sha256", "trace_ai", "trace_w", "trace_w_stride", "err_c64_nofma__trace_w"),
+            "arbiter_filter_N32_T1000_m1024.npz": ("y", "inputs_sha256", "trace_ai", "trace_w", "trace_w_stride", "err_c64_nofma__trace_w"),
             "arbiter_info_smoother_N64_T1000_m512.npz": ("y", "inputs_sha256", "ai", "ak", "w", "paNt", "XNK", "PK_rows", "err_c64_nofma__paNt"),
             "arbiter_radio_smoothers_N64_T200_m128.npz": ("y", "inputs_sha256", "info__ai", "cov__ai", "info__paNt", "cov__w", "info__err_c64_nofma__w")}
     for name, keys in need.items():
