@@ -378,7 +378,13 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
     HIPCHK(hipMemsetAsync(c->F[b], 0, c->bank_cap * 2 * d * L.ldx * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->xl[b], 0, c->bank_cap * L.ldx * sizeof(double), c->stream));
   }
-  if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)5 * N));
+  if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)8 * N));
+  c->share_inplace = c->inplace && c->lazy_depth >= 2 && !ex && c->lay.sym && (c->lay.CH64 == 8 || c->lay.CH64 == 16);
+  if (const char* e = getenv("RBPF_SHARE_INPLACE")) c->share_inplace = c->share_inplace && atoi(e) != 0;
+  if (c->share_inplace) {
+    RB_TRY(dmalloc(&c->d_share_writers, 1));
+    HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));
+  }
   // shared flush: with ping-pong banks the children of one parent store ONE copy of their (identical) flushed matrix
   c->share_flush = c->lazy_depth >= 2 && !c->inplace && !ex && c->lay.sym && (c->lay.CH64 == 8 || c->lay.CH64 == 16);   // (smoothers: the information form)
   if (const size_t sd = sym_strip_doubles(c->lay, d)) {     // sixteen tile rows: the step kernel's column strips live in global memory
@@ -747,7 +753,15 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     a.qf_new = info->qf_new; a.Hb_new = info->Hb_new;
   }
   const bool two_phase = c->inplace && lazy && flush && t > 0;
-  if (two_phase) {
+  const bool sip = two_phase && c->share_inplace && a.n_sets >= 1 && a.n_sets <= (info ? 3 : 7);
+  if (sip) {
+    // single bank, shared flush: one writer per parent with children; the first writer of a stored matrix overwrites it in place
+    // after everything else has read it (launch_share_inplace_plan)
+    if (!a.order) { set_error("in-place flush without a processing order"); return RBPF_ERR_STATE; }
+    int* dst = c->d_ip; int* ph = c->d_ip + N;
+    HIPCHK(launch_share_inplace_plan(N, a.order, A_t, c->base[told], dst, ph, c->d_ip + 2 * (size_t)N, c->timing_on ? c->d_share_writers : nullptr, c->stream));
+    a.dst_slot = dst; a.phase_of = ph; a.share_flush = 1;
+  } else if (two_phase) {
     // single-bank flush: siblings move to dead entries first (launch 0), then the first child of every stored
     // matrix overwrites it (launch 1); the plan comes from the ancestor-sorted order of the fused resample kernel
     if (!a.order) { set_error("in-place flush without a processing order"); return RBPF_ERR_STATE; }
@@ -769,7 +783,13 @@ int ctx_step(rbpf_ctx* c, int k_iter, const double* xref_t, int n_draw, const In
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, c->stream));
   }
-  if (two_phase) {
+  if (sip) {
+    StepArgs rd = a;
+    rd.phase = 0; rd.write_base = 0; HIPCHK(launch_step(rd, c->stream));   // readers over the old matrices
+    a.phase = 1; HIPCHK(launch_step(a, c->stream));                        // writers into entries nobody refers to
+    a.phase = 2; HIPCHK(launch_step(a, c->stream));                        // first writers, in place
+    if (c->timing_on) c->share_flush_particles += N;
+  } else if (two_phase) {
     a.phase = 0; HIPCHK(launch_step(a, c->stream));
     a.phase = 1; HIPCHK(launch_step(a, c->stream));
   } else if (share) {
@@ -1051,7 +1071,7 @@ int rbpf_filter_tell(const rbpf_ctx* c, int32_t* t) {
 int rbpf_filter_schedule(const rbpf_ctx* c, int32_t* banks, int32_t* shared_flush) {
   if (!c || !banks || !shared_flush) { set_error("NULL argument"); return RBPF_ERR_INVALID_ARG; }
   *banks = c->inplace ? 1 : 2;
-  *shared_flush = c->share_flush ? 1 : 0;
+  *shared_flush = (c->share_flush || c->share_inplace) ? 1 : 0;
   return RBPF_OK;
 }
 
@@ -1076,7 +1096,7 @@ int rbpf_timing_read(rbpf_ctx* c, rbpf_timing* out, int32_t reset) {
   const double n = c->mdl.n, nN = c->mdl.nN;
   out->algorithmic_bytes_per_launch = (double)c->N * (2.0 * n * n + 2.0 * n + 2.0 * nN) * (c->fp32 ? 4.0 : 8.0);   // SURVEY 8d, s = 4 | 8
   double sched = c->sched_bytes;
-  if (c->share_flush && c->share_flush_particles > 0) {
+  if ((c->share_flush || c->share_inplace) && c->share_flush_particles > 0) {
     // shared flushes: only the writers stored a matrix (the accounting above charged every particle of a flush step with one)
     unsigned long long wr = 0;
     HIPCHK(hipMemcpy(&wr, c->d_share_writers, sizeof(wr), hipMemcpyDeviceToHost));

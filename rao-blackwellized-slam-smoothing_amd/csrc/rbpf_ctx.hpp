@@ -85,7 +85,8 @@ struct rbpf_ctx {
   int drawn_step = -1;           // step whose ordinary ancestors were already drawn by generic_draw_propagate
   bool fp32 = false;        // the covariance banks hold float (rbpf_options.storage = 1)
   bool inplace = false;     // single covariance bank, rewritten in place at every flush (rbpf_options.inplace)
-  int* d_ip = nullptr;      // [5][N] in-place flush plan: destination entry, phase, scratch
+  int* d_ip = nullptr;      // [8][N] in-place flush plan: destination entry, phase, scratch
+  bool share_inplace = false;   // single bank + block-lower storage at eight / sixteen tile rows: the children of one parent store ONE flushed matrix (launch_share_inplace_plan)
   // shared flush (filter, ping-pong banks, symmetric storage at eight tile rows): one child per parent stores the flushed matrix
   bool share_flush = false;
   int* d_share = nullptr;                       // [3][N]: smallest child per parent, destination entry, phase (1 = writer)

@@ -233,6 +233,8 @@ hipError_t launch_order(int n_slots, int range, const int* key, int* order, int*
 // matrix.  dst [N] / phase [N] out; scratch: 3 N ints.
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase,
                                int* scratch, hipStream_t s);
+hipError_t launch_share_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
+                                     unsigned long long* writers, hipStream_t s);   // scratch: 6 N ints
 hipError_t launch_share_plan(int N, int nkeys, const int* ai, int* lead, int* dst, int* phase, unsigned long long* writers, hipStream_t s);
 // multi-workgroup equivalent for large N (rbpf_resample.hip); sa may be null (normalise only)
 size_t resample_scratch_doubles(int N);

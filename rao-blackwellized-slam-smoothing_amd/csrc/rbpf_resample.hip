@@ -289,6 +289,73 @@ hipError_t launch_share_plan(int N, int nkeys, const int* ai, int* lead, int* ds
   return hipGetLastError();
 }
 
+// ---- shared flush in ONE bank (r05): the two plans above combined.  The children of one parent store ONE flushed matrix (its writer:
+// the smallest child); the first writer, in processing order, of every stored matrix with children overwrites that matrix in place
+// (phase 2: after everything that still reads it), the other writers take the entries no child refers to (phase 1), every other
+// child runs the read-only variant over the old matrices (phase 0) and points at its writer's entry.
+__global__ void sip_fill_kernel(int N, int* lead, int* leadbase, int* has, int* nzp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { lead[i] = 0x7fffffff; leadbase[i] = 0x7fffffff; has[i] = 0; nzp[i] = 0; }
+}
+__global__ void sip_mark_kernel(int N, const int* __restrict__ ai, const int* __restrict__ base, int* lead, int* __restrict__ has, int* __restrict__ nzp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { atomicMin(&lead[ai[i]], i); const int s = base[ai[i]]; has[s] = 1; nzp[s] = 1; }
+}
+__global__ void sip_first_kernel(int N, const int* __restrict__ order, const int* __restrict__ ai, const int* __restrict__ base,
+                                 const int* __restrict__ lead, int* leadbase) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int i = order[b];
+  if (lead[ai[i]] == i) atomicMin(&leadbase[base[ai[i]]], b);
+}
+__global__ void sip_flag_kernel(int N, const int* __restrict__ order, const int* __restrict__ ai, const int* __restrict__ base,
+                                const int* __restrict__ lead, const int* __restrict__ leadbase, int* __restrict__ flag) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int i = order[b];
+  flag[b] = (lead[ai[i]] == i && leadbase[base[ai[i]]] != b) ? 1 : 0;            // a writer that is not the first of its matrix
+}
+__global__ void sip_writers_kernel(int N, const int* __restrict__ order, const int* __restrict__ ai, const int* __restrict__ base,
+                                   const int* __restrict__ lead, const int* __restrict__ leadbase, const int* __restrict__ rank,
+                                   const int* __restrict__ freelist, int* __restrict__ dst, int* __restrict__ phase, unsigned long long* writers) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  bool w = false;
+  if (b < N) {
+    const int i = order[b];
+    w = lead[ai[i]] == i;
+    if (w) {
+      const int s = base[ai[i]];
+      const bool first = leadbase[s] == b;
+      dst[i] = first ? s : freelist[rank[b]];
+      phase[i] = first ? 2 : 1;
+    }
+  }
+  const unsigned long long m = __ballot(w);
+  if (writers && (threadIdx.x & 63) == 0 && m) atomicAdd(writers, (unsigned long long)__popcll(m));
+}
+__global__ void sip_readers_kernel(int N, const int* __restrict__ ai, const int* __restrict__ lead, int* __restrict__ dst, int* __restrict__ phase) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N && lead[ai[i]] != i) { dst[i] = dst[lead[ai[i]]]; phase[i] = 0; }
+}
+
+// scratch: 6 N ints
+hipError_t launch_share_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
+                                     unsigned long long* writers, hipStream_t s) {
+  int* lead = scratch; int* leadbase = scratch + N; int* has = scratch + 2 * (size_t)N; int* nzp = scratch + 3 * (size_t)N;
+  int* freelist = scratch + 4 * (size_t)N; int* flag = scratch + 5 * (size_t)N;
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(sip_fill_kernel, dim3(nb), dim3(256), 0, s, N, lead, leadbase, has, nzp);
+  hipLaunchKernelGGL(sip_mark_kernel, dim3(nb), dim3(256), 0, s, N, ai, base, lead, has, nzp);
+  hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRB), 0, s, N, nzp);          // exclusive prefix of the flags
+  hipLaunchKernelGGL(ip_free_kernel, dim3(nb), dim3(256), 0, s, N, has, nzp, freelist);
+  hipLaunchKernelGGL(sip_first_kernel, dim3(nb), dim3(256), 0, s, N, order, ai, base, lead, leadbase);
+  hipLaunchKernelGGL(sip_flag_kernel, dim3(nb), dim3(256), 0, s, N, order, ai, base, lead, leadbase, flag);
+  hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(kRB), 0, s, N, flag);         // rank among the writers that need a free entry
+  hipLaunchKernelGGL(sip_writers_kernel, dim3(nb), dim3(256), 0, s, N, order, ai, base, lead, leadbase, flag, freelist, dst, phase, writers);
+  hipLaunchKernelGGL(sip_readers_kernel, dim3(nb), dim3(256), 0, s, N, ai, lead, dst, phase);
+  return hipGetLastError();
+}
+
 hipError_t launch_inplace_plan(int N, const int* order, const int* ai, const int* base, int* dst, int* phase, int* scratch,
                                hipStream_t s) {
   int* has = scratch; int* nzp = scratch + N; int* freelist = scratch + 2 * (size_t)N;

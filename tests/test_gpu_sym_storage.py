@@ -460,3 +460,32 @@ def test_symmetric_storage_radio_is_refused_at_other_sizes(rbpf):
         rbpf.particleFilter(mdl.dynModel, mdl.measModel, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 6, c["dt"],
                             rng=cases.device_rng(rbpf, c), storage="fp64sym")
     assert ei.value.status == rbpf.RBPF_ERR_UNSUPPORTED
+
+
+# ---- one covariance bank with the shared flush (launch_share_inplace_plan), r05 ---------------------------------------------------------
+@pytest.mark.parametrize("pattern", ["one_parent", "two_parents", "identity_like"])
+@pytest.mark.parametrize("m,lazy_depth", [(512, 4), (512, 2), (1024, 3)])
+def test_single_bank_shared_flush_on_extreme_ancestries(rbpf, pattern, m, lazy_depth):
+    """The plan of the single-bank shared flush at its corners, against the numpy oracle on replayed random numbers: every particle
+    drawing the SAME ancestor at every step (one writer overwrites the one live matrix in place, everybody else reads), two ancestors
+    (two writers: one in place, one into a dead entry), and draws spread over all particles (about as many writers as particles).
+    particleFilter.m:105-113 (the gather this replaces), tools/sample.m:30-32."""
+    c = cases.mag_case(8, 10, m, seed=71)
+    U = c["rng"].U
+    if pattern == "one_parent":
+        U[...] = 0.37
+    elif pattern == "two_parents":
+        U[..., :4] = 0.21
+        U[..., 4:] = 0.83
+    else:
+        U[...] = (np.arange(8) + 0.5) / 8.0
+    ref = cases.oracle_filter(c)
+    out = run_sym(rbpf, c, lazy_depth, 1)
+    check_filter(ref, out)
+    ai = ref["trace"]["ai"][1:]
+    if pattern == "one_parent":
+        assert all(len(set(row)) == 1 for row in ai)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    with rbpf.FilterSession(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, 8, c["dt"], rng=cases.device_rng(rbpf, c),
+                            lazy_depth=lazy_depth, inplace=1, storage="fp64sym") as s:
+        assert s.schedule() == (1, True)                                         # one bank, shared flush
