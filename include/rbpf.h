@@ -173,7 +173,9 @@ typedef struct {
                           * every flush (the first child of a stored matrix overwrites it after its siblings    *
                           * were written to dead slots) instead of ping-pong banks -- halves the memory, same    *
                           * results bit for bit.  0: automatic (when two banks do not fit the device), 1: on,    *
-                          * -1: off                                                                              */
+                          * -1: off.  On block-lower storage (eight / sixteen tile rows) the single bank keeps   *
+                          * the shared flush: one writer per parent with children, the first writer of a stored  *
+                          * matrix overwrites it in place after its readers (results to rounding, as two banks). */
   int32_t storage;       /* dense-mag filter (also sharded): 0 = the covariance banks hold fp64 (the reference's precision); 1 = fp32     *
                           * STORAGE of the banks (BASELINE.json configs[4]): half the HBM traffic and memory, all     *
                           * arithmetic and every other state stay fp64.  Results then agree with the fp64 run to     *
