@@ -380,7 +380,7 @@ int ctx_create(const rbpf_model* model, const rbpf_problem* prob, const rbpf_rng
   }
   if (c->inplace) RB_TRY(dmalloc(&c->d_ip, (size_t)8 * N));
   c->share_inplace = c->inplace && c->lazy_depth >= 2 && !ex && c->lay.sym && (c->lay.CH64 == 8 || c->lay.CH64 == 16);
-  if (const char* e = getenv("RBPF_SHARE_INPLACE")) c->share_inplace = c->share_inplace && atoi(e) != 0;
+  if (const char* e = tuning_env("RBPF_SHARE_INPLACE")) c->share_inplace = c->share_inplace && atoi(e) != 0;   // diagnostic builds: the per-child in-place flush
   if (c->share_inplace) {
     RB_TRY(dmalloc(&c->d_share_writers, 1));
     HIPCHK(hipMemset(c->d_share_writers, 0, sizeof(unsigned long long)));

@@ -1,4 +1,5 @@
-"""Single covariance bank with the shared flush (r05: launch_share_inplace_plan) against the per-child in-place flush (RBPF_SHARE_INPLACE=0)
+"""Single covariance bank with the shared flush (r05: launch_share_inplace_plan) against the per-child in-place flush (RBPF_SHARE_INPLACE=0:
+read by a -DRBPF_TUNING build only -- point RBPF_LIB_PATH at one, tools/ab_env.py says how)
 and against two banks: the headline filter configuration and the per-step time of the information-form smoother at N_P = 65 536.
   python tools/inplace_share_probe.py [filter] [smoother]"""
 import importlib
