@@ -785,6 +785,13 @@ def main():
                 return r
             # BASELINE.json configs[1].  Full-square storage: at N = 8192, nLin = 259 a step is bound by the fixed per-workgroup work (16 rounds of
             # workgroups, ~58 us each), not by bytes -- symmetric storage (supported at this size too) gives the same 8.0-8.2 M/s
+            # the headline configuration in ONE covariance bank (78 GB instead of 156 GB): the shared flush in place (r05), bit-identical results
+            def single_bank():
+                r, *_ = filter_leg(pkg, datagen, N_local, args.m, T, 40, 8, args.seed, args.lazy_depth, 1, args.storage)
+                r["workload"] = workload_string(N_local, T, args.m, args.m + 3, args.storage, args.lazy_depth, 1, True)
+                return r
+            if args.inplace <= 0 and args.storage in ("fp64sym", "fp32sym"):
+                line["headline_single_bank_filter"] = guarded(single_bank)
             line["configs1_filter"] = guarded(extra, 8192, 256, 600, 30, 3, "fp64")
             # 1/8 of BASELINE.json configs[4] (fp32 storage is the config's own dtype): block-lower fp32 tiles at sixteen tile rows (r05), and the
             # full-square fp32 storage it replaces
