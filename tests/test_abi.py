@@ -66,6 +66,30 @@ def test_options_of_another_layout_are_refused(rbpf):
         assert b"struct_size" in lib.rbpf_last_error()
 
 
+def test_workspace_bytes_follow_the_storage_option(rbpf):
+    """rbpf_filter_workspace_bytes (no device needed) at BASELINE.json configs[4]'s basis size: the lower block triangle in fp32
+    (storage 3) needs less than the fp32 full square (1), which needs less than the fp64 lower block triangle (2) ... than the fp64
+    full square (0); the block-lower figures include the sixteen-tile-row kernel's column-strip workspace (118 KB per particle)."""
+    import ctypes as C
+    ffi = __import__("importlib").import_module(rbpf.__name__ + "._ffi")
+    host = __import__("importlib").import_module(rbpf.__name__ + ".host")
+    lib = rbpf.load_library()
+    c = cases.mag_case(64, 4, 1024, seed=1)
+    mdl, x0, P0, R = cases.device_model(rbpf, c)
+    prob = host._Problem(mdl, c["odometry"], c["y"], c["x0_nonLin"], x0, P0, c["Q"], R, c["N_P"], c["dt"])
+    mdesc = mdl.descriptor()
+    need = {}
+    for storage in (0, 1, 2, 3):
+        nbytes = C.c_size_t(0)
+        opt = ffi.rbpf_options(keep_history=1, storage=storage, lazy_depth=2)
+        assert lib.rbpf_filter_workspace_bytes(C.byref(mdesc), C.byref(prob.c), C.byref(opt), C.byref(nbytes)) == rbpf.RBPF_OK
+        need[storage] = nbytes.value
+    assert need[3] < need[1] < need[2] < need[0]
+    n, N = 1027, 64
+    assert need[0] - need[2] > 0.8 * N * n * n * 8                           # two banks x (n^2 - 0.53 n^2 - strips)
+    assert abs((need[2] - need[3]) - 2 * N * (136 * 4096 + 3 * 1028) * 4) <= 0.02 * need[2]   # fp32 tiles: half of two block-lower banks
+
+
 def test_chol_refresh_resolution(rbpf):
     """rbpf_options.chol_refresh = 0 is automatic: carried factors (K = 32) for the recognised dense families from nLin = 128 on,
     the from-scratch factorisation elsewhere; explicit values are kept (rbpf_chol_refresh_resolve, no device needed)."""
